@@ -1,0 +1,70 @@
+"""Shared helpers: rebuild the closed-form inputs of each golden case (same recipe as
+tests/golden/make_golden.py) and load the reference outputs stored in tests/golden/*.npz."""
+import os
+
+import numpy as np
+import torch
+
+from lgd_amd import synth
+from oracle import lgd_oracle as O
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SAMPLE_STRIDE = 37
+
+CASES = {
+    # name: (B, H, W, add_ctx, interact, box_format, coef, feat_seed)
+    "c1_ctx_stuguided": (2, 512, 512, True, "stuGuided", "x1y1x2y2", 1.0, 11),
+    "c1b_noctx_labelguided_wh": (3, 384, 512, False, "labelGuided", "x1y1wh", 1.0, 11),
+    "c1c_noctx_stuguided": (2, 320, 480, False, "stuGuided", "x1y1x2y2", 2.5, 13),
+}
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+def case_gt(name):
+    if name == "c1_ctx_stuguided":
+        gt = synth.synth_gt(2, 512, 512, 10, table=True)
+    elif name == "c1b_noctx_labelguided_wh":
+        gt = synth.synth_gt(3, 384, 512, 7, seed=9)
+        gt[1] = (np.zeros((0, 4), np.float32), np.zeros((0,), np.int64))
+        gt[2] = (gt[2][0][:4], gt[2][1][:4])
+    elif name == "c1c_noctx_stuguided":
+        gt = synth.synth_gt(2, 320, 480, 6, seed=4)
+    elif name == "c2_masks_800x1344":
+        gt = synth.synth_gt(8, 800, 1344, 10, seed=0)
+    else:
+        raise KeyError(name)
+    return [(torch.from_numpy(b.copy()), torch.from_numpy(c.copy())) for b, c in gt]
+
+
+def case_feats(name, requires_grad=False):
+    B, H, W, _, _, _, _, seed = CASES[name]
+    return {k: torch.from_numpy(v.copy()).requires_grad_(requires_grad)
+            for k, v in synth.synth_features(B, H, W, seed=seed).items()}
+
+
+def teacher_params(requires_grad=False):
+    p = synth.closed_form_params(O.teacher_param_shapes())
+    return {k: torch.from_numpy(v.copy()).requires_grad_(requires_grad) for k, v in p.items()}
+
+
+def adapter_params(requires_grad=False):
+    p = synth.closed_form_params(O.adapter_param_shapes())
+    return {k: torch.from_numpy(v.copy()).requires_grad_(requires_grad) for k, v in p.items()}
+
+
+def probes(tea):
+    return {k: torch.from_numpy(synth.det_uniform(tuple(tea[k].shape), 900 + i, -1e-3, 1e-3)) for i, k in enumerate(tea.keys())}
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().cpu().to(torch.float64).reshape(-1)
+    b = torch.as_tensor(b).detach().cpu().to(torch.float64).reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def sample(t):
+    f = t.detach().reshape(-1).double().cpu()
+    return f[::SAMPLE_STRIDE].float().numpy(), float(f.sum()), float((f * f).sum())
