@@ -1,0 +1,113 @@
+/*
+ * lgd_hip.h -- C ABI of the MI355X (gfx950) LGD hot-path kernels.
+ *
+ * The reference (megvii-research/LGD) is pure Python over detectron2 and has no
+ * FFI of its own; this header is the drop-in boundary the
+ * reference's Python call sites bind through ctypes.  Every
+ * entry point cites the reference code it replaces as
+ *     [ref: <path under /root/reference>:<lines>].
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`
+ *   - feature maps are fp32, NCHW, contiguous: (B, C, H_l, W_l) per FPN level l
+ *   - boxes of the whole mini-batch are concatenated image-major: T = sum_b N_b rows,
+ *     img_off[b] .. img_off[b+1] are image b's rows (int32, device, B+1 entries);
+ *     with ADD_CONTEXT_BOX the context box is the LAST row of each image
+ *   - per-level (T, C) tables are stored level-major: [L][T][C]
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream)
+ *   - functions never allocate, never synchronise, never throw; they return 0 on
+ *     success or a negative LGD_E* code.  Workspaces are caller-provided.
+ */
+#ifndef LGD_HIP_H
+#define LGD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGD_MAX_LEVELS 8
+
+#define LGD_OK 0
+#define LGD_EINVAL (-1)   /* bad argument (null pointer, L > LGD_MAX_LEVELS, C % 4 != 0, ...) */
+#define LGD_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
+
+/* ABI version, bumped on any signature change. */
+int lgd_abi_version(void);
+/* Name of the GPU arch the library was compiled for ("gfx950"). */
+const char* lgd_arch(void);
+/* hipGetLastError() as text for the calling thread's last failed launch ("" if none). */
+const char* lgd_last_error(void);
+
+/* ------------------------------------------------------------------ box geometry
+ * Integer pixel rectangles + row bands for every (level, box).
+ * [ref: models/customized_detectors/dynamic_teacher/utils.py:53-89  get_inside_gt_mask]
+ * The reference materialises a dense (N_b, H*W) float mask per level and image; the mask
+ * is separable and its per-axis true-set is one interval, so it is carried as
+ * rect = [x0, x1, y0, y1] (inclusive; empty box -> x1 < x0).  The inclusion predicate
+ * |centre - p| / extent <= 0.5 is evaluated in fp32 with the reference's exact operation
+ * order for every pixel coordinate p (bit-exact masks).
+ *
+ * boxes    : (T,4) fp32 x1,y1,x2,y2 in padded-image pixels, already clamped
+ *            [ref: label_encoder.py:83-85 -- the `boxlists` values]
+ * geom     : int32 workspace of lgd_geom_ints(L,B,T,max_n) entries, filled here and
+ *            consumed by the box kernels below.
+ */
+size_t lgd_geom_ints(int L, int B, int T, int max_n);
+int lgd_box_prep(const float* boxes, const int32_t* img_off, int B, int T, int max_n,
+                 int img_h, int img_w, const int32_t* level_hw_host /* L x (H,W) */, int L,
+                 int32_t* geom, void* stream);
+/* Offsets (in int32 units) of the sub-tables inside `geom`, for tests/debugging:
+ * rects [L][T][4], nbp [L][B], bands [L][B][2*max_n+2]. */
+size_t lgd_geom_rects_off(int L, int B, int T, int max_n);
+size_t lgd_geom_nbp_off(int L, int B, int T, int max_n);
+size_t lgd_geom_bands_off(int L, int B, int T, int max_n);
+
+/* ------------------------------------------------------------------ K1/K3: box reduce / box paint
+ * box_sum : out[l][t][c] = sum over pixels inside box t of feat_l[b(t)][c][y][x]
+ *           (normalize=1: divided by max(pixel count, 1))
+ *   forward of the appearance encoder (mask pooling)
+ *     [ref: dynamic_teacher.py:81-103 aggregate_per_level]
+ *   and backward of the rendering w.r.t. the projected embeddings (normalize=0).
+ * box_paint: out_l[b][c][y][x] = sum over boxes t of image b covering (y,x) of vals[l][t][c]
+ *           (normalize=1: each box's value is first divided by max(pixel count, 1))
+ *   forward of the intra-object knowledge mapping's scatter
+ *     [ref: dynamic_teacher.py:137,173  torch.mm(attn_output.T, inside_mask)]
+ *   and backward of mask pooling w.r.t. the feature map (normalize=1).
+ * skip_last=1 treats the last box of every image as empty (the context box is not
+ *   painted [ref: dynamic_teacher.py:123,131]).
+ * feats_host / outs_host: host arrays of L device pointers.
+ */
+int lgd_box_sum(const float* const* feats_host, const int32_t* level_hw_host, int L, int B, int C, int T,
+                int max_n, const int32_t* img_off, const int32_t* geom, float* out /* [L][T][C] */,
+                int normalize, int skip_last, void* stream);
+int lgd_box_paint(const float* vals /* [L][T][C] */, const int32_t* level_hw_host, int L, int B, int C, int T,
+                  int max_n, const int32_t* img_off, const int32_t* geom, float* const* outs_host,
+                  int normalize, int skip_last, void* stream);
+
+/* ------------------------------------------------------------------ K4: InstanceNorm x2 + MSE
+ * [ref: models/base_distillator.py:59-64  norm_stu / norm_tea (InstanceNorm2d(256, affine=False),
+ *  eps 1e-5, biased variance), flatten+cat over levels, coef * F.mse_loss]
+ * loss = coef / (B*C*sum_l H_l*W_l) * sum_{l,b,c,hw} (IN(a)-IN(b))^2, computed in ONE pass
+ * over a and b from per-plane fp64 moments (sum a, a^2, b, b^2, ab).
+ *   ws     : fp64 workspace of lgd_distill_ws_doubles(...) entries
+ *   stats  : fp32 [nplanes][8] per-(level,b,c) statistics kept for the backward
+ *            (mean_a, rstd_a, mean_b, rstd_b, q, 0,0,0), nplanes = L*B*C
+ *   loss   : 1 fp32
+ * backward (student side only; the teacher side is detached in the reference,
+ * base_distillator.py:55):  grad_a_l = gscale * dloss/da_l, gscale read from device
+ * (upstream gradient, 1 fp32) times coef.
+ */
+size_t lgd_distill_ws_doubles(const int32_t* level_hw_host, int L, int B, int C);
+int lgd_distill_fwd(const float* const* a_host, const float* const* b_host, const int32_t* level_hw_host,
+                    int L, int B, int C, float coef, double* ws, float* stats, float* loss, void* stream);
+int lgd_distill_bwd(const float* const* a_host, const float* const* b_host, const int32_t* level_hw_host,
+                    int L, int B, int C, float coef, const float* stats, const float* grad_loss,
+                    float* const* grad_a_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGD_HIP_H */

@@ -1,0 +1,235 @@
+// K1 / K3: box-sum (mask pooling fwd, render bwd) and box-paint (render fwd, mask pooling bwd).
+//
+// Reference arithmetic being replaced (dense fp32 GEMMs against materialised 0/1 masks):
+//   [ref: dynamic_teacher.py:95-100]   pool = mask_b (Ni,HW) @ feat_b(C,HW)^T ; / max(mask.sum(-1),1)
+//   [ref: dynamic_teacher.py:137,173]  warp = proj^T (C,Ni) @ mask_b (Ni,HW)
+//
+// MI355X design (HBM-bound: one pass over a pyramid, P = B*C*sum(HW)*4 bytes):
+//   * one wave64 per (level, image, channel) plane; lane l owns VW adjacent columns, so a row is
+//     one coalesced 16-byte-per-lane load (VW=4 when W%4==0); the row index is wave-uniform;
+//   * the masks are axis-aligned rectangles, so rows are cut into BANDS inside which the set of
+//     covering boxes is constant (box_geom.hip).  box_sum adds the rows of a band column-wise (one
+//     VALU add per element) and only then applies each active box's column interval; box_paint
+//     composes one row pattern per band and streams it to every row of the band;
+//   * lane n of the wave holds box n's rectangle/accumulator (64 boxes per pass), band activity is a
+//     single v_cmp ballot, box parameters travel by v_readlane, sums by DPP -- no LDS, no atomics,
+//     fixed reduction order (bit-reproducible run to run).
+#include "common.h"
+
+namespace lgd {
+
+struct BoxArgs {
+    const float* in[LGD_MAX_LEVELS];   // box_sum: feature maps
+    float* out[LGD_MAX_LEVELS];        // box_paint: painted maps
+    int H[LGD_MAX_LEVELS], W[LGD_MAX_LEVELS];
+    int blk0[LGD_MAX_LEVELS + 1];      // first block of each level
+    const float* vals;                 // box_paint: [L][T][C]
+    float* pooled;                     // box_sum:   [L][T][C]
+    const int32_t* img_off;
+    const int32_t* geom;
+    int L, B, C, T, max_n, normalize, skip_last;
+};
+
+struct Plane { int l, b, c, H, W, t0, n, nbp; const int32_t* rects; const int32_t* bands; };
+
+__device__ __forceinline__ Plane locate(const BoxArgs& a) {
+    Plane p;
+    int l = 0;
+    #pragma unroll
+    for (int i = 1; i < LGD_MAX_LEVELS; ++i) l += (i < a.L && (int)blockIdx.x >= a.blk0[i]) ? 1 : 0;
+    const int wave = threadIdx.x >> 6;
+    const int plane = ((int)blockIdx.x - a.blk0[l]) * 4 + wave;  // 4 waves = 4 consecutive channels
+    p.l = l; p.b = plane / a.C; p.c = plane % a.C;
+    p.H = a.H[l]; p.W = a.W[l];
+    p.t0 = a.img_off[p.b];
+    p.n = a.img_off[p.b + 1] - p.t0;
+    p.rects = a.geom + geom_rects_off() + ((size_t)l * a.T + p.t0) * 4;
+    p.nbp = a.geom[geom_nbp_off(a.L, a.T) + (size_t)l * a.B + p.b];
+    p.bands = a.geom + geom_bands_off(a.L, a.B, a.T) + ((size_t)l * a.B + p.b) * geom_maxbp(a.max_n);
+    return p;
+}
+
+struct LaneBox { int x0, x1, y0, y1; };  // lane-resident rectangle of box (pass*64 + lane); empty: x1 < x0
+
+__device__ __forceinline__ LaneBox load_lane_box(const Plane& p, int pass, int lane, int skip_last) {
+    const int n = pass * 64 + lane;
+    LaneBox r{0, -1, 0, -1};
+    if (n < p.n && !(skip_last && n == p.n - 1)) {
+        const int4 q = reinterpret_cast<const int4*>(p.rects)[n];
+        r.x0 = q.x; r.x1 = q.y; r.y0 = q.z; r.y1 = q.w;
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------- box_sum
+template <int VW>
+__device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p) {
+    const int lane = threadIdx.x & 63;
+    const float* __restrict__ src = a.in[p.l] + ((size_t)p.b * a.C + p.c) * p.H * p.W;
+    const int npass = (p.n + 63) >> 6;
+    for (int pass = 0; pass < npass; ++pass) {
+        const LaneBox bx = load_lane_box(p, pass, lane, a.skip_last);
+        float acc = 0.f;
+        for (int xc = 0; xc < p.W; xc += 64 * VW) {
+            const int xl = xc + lane * VW;
+            const bool on = xl < p.W;  // VW | W, so a lane's vector is wholly inside or outside the row
+            const float* col = src + xl;
+            for (int k = 0; k + 1 < p.nbp; ++k) {
+                const int ya = p.bands[k], yb = p.bands[k + 1];
+                unsigned long long act = __ballot(bx.x1 >= bx.x0 && bx.y0 <= ya && ya <= bx.y1 &&
+                                                  bx.x1 >= xc && bx.x0 < xc + 64 * VW);
+                if (!act) continue;  // wave-uniform: rows no box of this pass covers are never fetched
+                float cs[VW];
+                #pragma unroll
+                for (int j = 0; j < VW; ++j) cs[j] = 0.f;
+                if (on) {
+                    int y = ya;
+                    for (; y + 4 <= yb; y += 4) {
+                        const Vec<VW> v0 = vload<VW>(col + (size_t)(y + 0) * p.W);
+                        const Vec<VW> v1 = vload<VW>(col + (size_t)(y + 1) * p.W);
+                        const Vec<VW> v2 = vload<VW>(col + (size_t)(y + 2) * p.W);
+                        const Vec<VW> v3 = vload<VW>(col + (size_t)(y + 3) * p.W);
+                        #pragma unroll
+                        for (int j = 0; j < VW; ++j) cs[j] += (v0.v[j] + v1.v[j]) + (v2.v[j] + v3.v[j]);
+                    }
+                    for (; y < yb; ++y) {
+                        const Vec<VW> v0 = vload<VW>(col + (size_t)y * p.W);
+                        #pragma unroll
+                        for (int j = 0; j < VW; ++j) cs[j] += v0.v[j];
+                    }
+                }
+                while (act) {
+                    const int n = __builtin_ctzll(act);
+                    act &= act - 1;
+                    const int bx0 = __builtin_amdgcn_readlane(bx.x0, n), bx1 = __builtin_amdgcn_readlane(bx.x1, n);
+                    float part = 0.f;
+                    #pragma unroll
+                    for (int j = 0; j < VW; ++j) part += (xl + j >= bx0 && xl + j <= bx1) ? cs[j] : 0.f;
+                    const float tot = wave_sum(part);
+                    if (lane == n) acc += tot;
+                }
+            }
+        }
+        const int n = pass * 64 + lane;
+        if (n < p.n) {
+            if (a.normalize) {
+                const float cnt = (bx.x1 >= bx.x0) ? (float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)) : 0.f;
+                acc = acc / fmaxf(cnt, 1.f);  // [ref: dynamic_teacher.py:97-100]
+            }
+            a.pooled[((size_t)p.l * a.T + p.t0 + n) * a.C + p.c] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void box_sum_kernel(BoxArgs a) {
+    const Plane p = locate(a);
+    if ((p.W & 3) == 0) box_sum_plane<4>(a, p);
+    else if ((p.W & 1) == 0) box_sum_plane<2>(a, p);
+    else box_sum_plane<1>(a, p);
+}
+
+// ------------------------------------------------------------------------------------------- box_paint
+template <int VW>
+__device__ __forceinline__ void box_paint_plane(const BoxArgs& a, const Plane& p) {
+    const int lane = threadIdx.x & 63;
+    float* __restrict__ dst = a.out[p.l] + ((size_t)p.b * a.C + p.c) * p.H * p.W;
+    const float* __restrict__ vals = a.vals + ((size_t)p.l * a.T + p.t0) * a.C + p.c;
+    const int npass = (p.n + 63) >> 6;
+
+    auto lane_val = [&](const LaneBox& bx, int pass) -> float {
+        const int n = pass * 64 + lane;
+        float v = 0.f;
+        if (bx.x1 >= bx.x0) {  // only live boxes are read (the skipped context row may hold anything)
+            v = vals[(size_t)n * a.C];
+            if (a.normalize) v = v / fmaxf((float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)), 1.f);
+        }
+        return v;
+    };
+    // common case (<= 64 boxes per image): rectangles and values stay in registers for the whole plane
+    LaneBox bx0 = load_lane_box(p, 0, lane, a.skip_last);
+    float val0 = lane_val(bx0, 0);
+
+    for (int xc = 0; xc < p.W; xc += 64 * VW) {
+        const int xl = xc + lane * VW;
+        const bool on = xl < p.W;
+        float* col = dst + xl;
+        for (int k = 0; k + 1 < p.nbp; ++k) {
+            const int ya = p.bands[k], yb = p.bands[k + 1];
+            Vec<VW> pv;
+            #pragma unroll
+            for (int j = 0; j < VW; ++j) pv.v[j] = 0.f;
+            for (int pass = 0; pass < npass; ++pass) {
+                LaneBox bx = bx0;
+                float val = val0;
+                if (pass > 0) { bx = load_lane_box(p, pass, lane, a.skip_last); val = lane_val(bx, pass); }
+                unsigned long long act = __ballot(bx.x1 >= bx.x0 && bx.y0 <= ya && ya <= bx.y1);
+                while (act) {
+                    const int n = __builtin_ctzll(act);
+                    act &= act - 1;
+                    const int q0 = __builtin_amdgcn_readlane(bx.x0, n), q1 = __builtin_amdgcn_readlane(bx.x1, n);
+                    const float v = readlane_f32(val, n);
+                    #pragma unroll
+                    for (int j = 0; j < VW; ++j) pv.v[j] += (xl + j >= q0 && xl + j <= q1) ? v : 0.f;
+                }
+            }
+            if (on) {
+                for (int y = ya; y < yb; ++y) vstore<VW>(col + (size_t)y * p.W, pv);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void box_paint_kernel(BoxArgs a) {
+    const Plane p = locate(a);
+    if ((p.W & 3) == 0) box_paint_plane<4>(a, p);
+    else if ((p.W & 1) == 0) box_paint_plane<2>(a, p);
+    else box_paint_plane<1>(a, p);
+}
+
+static int fill_args(BoxArgs& a, const int32_t* level_hw_host, int L, int B, int C, int T, int max_n,
+                     const int32_t* img_off, const int32_t* geom, int normalize, int skip_last) {
+    if (!level_hw_host || !img_off || !geom || L < 1 || L > LGD_MAX_LEVELS || B < 1 || C < 4 || (C & 3) || T < 0)
+        return LGD_EINVAL;
+    a.L = L; a.B = B; a.C = C; a.T = T; a.max_n = max_n; a.normalize = normalize; a.skip_last = skip_last;
+    a.img_off = img_off; a.geom = geom; a.vals = nullptr; a.pooled = nullptr;
+    int blk = 0;
+    for (int l = 0; l < LGD_MAX_LEVELS; ++l) {
+        a.in[l] = nullptr; a.out[l] = nullptr;
+        a.H[l] = l < L ? level_hw_host[2 * l] : 0;
+        a.W[l] = l < L ? level_hw_host[2 * l + 1] : 0;
+        a.blk0[l] = blk;
+        if (l < L) blk += B * C / 4;
+    }
+    a.blk0[LGD_MAX_LEVELS] = blk;
+    return blk;
+}
+
+}  // namespace lgd
+
+extern "C" {
+
+int lgd_box_sum(const float* const* feats_host, const int32_t* level_hw_host, int L, int B, int C, int T, int max_n,
+                const int32_t* img_off, const int32_t* geom, float* out, int normalize, int skip_last, void* stream) {
+    lgd::BoxArgs a;
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last);
+    if (nblk < 0 || !feats_host || !out) return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) { if (!feats_host[l]) return LGD_EINVAL; a.in[l] = feats_host[l]; }
+    a.pooled = out;
+    if (T == 0) return LGD_OK;
+    hipLaunchKernelGGL(lgd::box_sum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    return lgd::check_launch();
+}
+
+int lgd_box_paint(const float* vals, const int32_t* level_hw_host, int L, int B, int C, int T, int max_n,
+                  const int32_t* img_off, const int32_t* geom, float* const* outs_host, int normalize, int skip_last,
+                  void* stream) {
+    lgd::BoxArgs a;
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last);
+    if (nblk < 0 || !outs_host || !vals) return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) { if (!outs_host[l]) return LGD_EINVAL; a.out[l] = outs_host[l]; }
+    a.vals = vals;
+    hipLaunchKernelGGL(lgd::box_paint_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    return lgd::check_launch();
+}
+
+}  // extern "C"

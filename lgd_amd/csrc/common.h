@@ -1,0 +1,93 @@
+// Shared device helpers for the gfx950 LGD kernels (wave64 only; no portability shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lgd_hip.h"
+
+#define LGD_WAVE 64
+
+namespace lgd {
+
+// ---- DPP cross-lane (no LDS traffic). ctrl: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Sum over the 64 lanes of a wave; result is wave-uniform. Fixed order => deterministic.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);  // row_half_mirror: 8-lane sums
+    v += dpp_f32<0x140>(v);  // row_mirror: 16-lane (row) sums in every lane
+    return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+
+// ---- vector load/store of VW consecutive floats (VW in {1,2,4}); address must be VW*4-byte aligned.
+template <int VW> struct Vec;
+template <> struct Vec<1> { float v[1]; };
+template <> struct Vec<2> { float v[2]; };
+template <> struct Vec<4> { float v[4]; };
+
+template <int VW>
+__device__ __forceinline__ Vec<VW> vload(const float* p) {
+    Vec<VW> r;
+    if constexpr (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+    else if constexpr (VW == 2) { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+    else { r.v[0] = *p; }
+    return r;
+}
+template <int VW>
+__device__ __forceinline__ void vstore(float* p, const Vec<VW>& r) {
+    if constexpr (VW == 4) { *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]); }
+    else if constexpr (VW == 2) { *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]); }
+    else { *p = r.v[0]; }
+}
+
+// ---- geometry workspace layout (int32 units): rects [L][T][4] | nbp [L][B] | bands [L][B][maxbp]
+__host__ __device__ inline int geom_maxbp(int max_n) { return 2 * max_n + 2; }
+__host__ __device__ inline size_t geom_rects_off() { return 0; }
+__host__ __device__ inline size_t geom_nbp_off(int L, int T) { return (size_t)L * T * 4; }
+__host__ __device__ inline size_t geom_bands_off(int L, int B, int T) { return geom_nbp_off(L, T) + (size_t)L * B; }
+
+// Thread-local record of the last launch failure (see lgd_last_error()).
+void set_last_error(hipError_t e);
+inline int check_launch() {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error(e); return LGD_ELAUNCH; }
+    return LGD_OK;
+}
+
+}  // namespace lgd

@@ -1,0 +1,107 @@
+"""ctypes binding of the C-ABI in include/lgd_hip.h (lgd_amd/_lib/liblgd_hip.so).
+
+There is NO CPU fallback: importing succeeds without the library (so CPU-only host
+logic stays testable) but any kernel call raises LgdHipError when the library or a
+GPU is missing -- the product path must fail loudly rather than silently compute
+elsewhere.
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
+_lib = None
+
+ABI_VERSION = 1
+
+c_fp = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/lgd_hip.h one-to-one (checked by tests/test_abi.py)
+SIGNATURES = {
+    "lgd_abi_version": (c_i, []),
+    "lgd_arch": (ctypes.c_char_p, []),
+    "lgd_last_error": (ctypes.c_char_p, []),
+    "lgd_geom_ints": (c_sz, [c_i, c_i, c_i, c_i]),
+    "lgd_geom_rects_off": (c_sz, [c_i, c_i, c_i, c_i]),
+    "lgd_geom_nbp_off": (c_sz, [c_i, c_i, c_i, c_i]),
+    "lgd_geom_bands_off": (c_sz, [c_i, c_i, c_i, c_i]),
+    "lgd_box_prep": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp, c_fp]),
+    "lgd_box_sum": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
+    "lgd_box_paint": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
+    "lgd_distill_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
+    "lgd_distill_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_distill_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
+}
+
+
+class LgdHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """dlopen the kernel library (idempotent). Raises LgdHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise LgdHipError("HIP kernel library missing: %s -- run `python -c 'import __graft_entry__ as g; g.build()'`"
+                          % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lgd_abi_version() != ABI_VERSION:
+        raise LgdHipError("liblgd_hip.so ABI %d != binding ABI %d: rebuild" % (lib.lgd_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def require_gpu(*tensors):
+    if not torch.cuda.is_available():
+        raise LgdHipError("LGD HIP kernels need a ROCm GPU (gfx950); no device is visible and there is no CPU fallback")
+    for t in tensors:
+        if not t.is_cuda:
+            raise LgdHipError("expected a device tensor, got %s" % t.device)
+
+
+def check(rc, what):
+    if rc != 0:
+        err = load().lgd_last_error().decode()
+        raise LgdHipError("%s failed with code %d %s" % (what, rc, err))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """host array of device pointers (const float* const*)."""
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def int_array(vals):
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def dense_f32(t):
+    """fp32, contiguous, 16-byte aligned view/copy of t (the kernels use dwordx4 accesses)."""
+    if t.dtype != torch.float32:
+        raise LgdHipError("LGD kernels compute in fp32, got %s" % t.dtype)
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t

@@ -1,0 +1,173 @@
+"""torch.autograd wrappers over the HIP kernels (forward AND backward are HIP; torch only owns
+device memory and the stream).  Shapes follow include/lgd_hip.h:
+  pyramids  : list of L tensors (B, C, H_l, W_l) fp32 NCHW
+  box tables: (L, T, C) fp32, boxes concatenated image-major, context box last per image
+"""
+import torch
+
+from . import hip
+
+
+class BoxGeometry:
+    """Integer rectangles + row bands of every (level, box), built once per step on the GPU.
+
+    Replaces the reference's dense masks `batchified_inside_masks` (F x B x (Ni, HiWi) floats)
+    [ref: dynamic_teacher.py:241-242, utils.py:53-89].
+    boxes: (T,4) fp32 device tensor of CLAMPED xyxy boxes in padded-image pixels
+           [ref: label_encoder.py:83-85]; counts: python list of boxes per image (host-known,
+           no device sync); level_hw: list of (H, W).
+    """
+
+    def __init__(self, boxes, counts, img_hw, level_hw):
+        hip.require_gpu(boxes)
+        lib = hip.load()
+        self.counts = [int(c) for c in counts]
+        self.B = len(self.counts)
+        self.T = int(sum(self.counts))
+        self.max_n = max(self.counts) if self.counts else 0
+        self.level_hw = [(int(h), int(w)) for h, w in level_hw]
+        self.L = len(self.level_hw)
+        self.img_hw = (int(img_hw[0]), int(img_hw[1]))
+        if boxes.shape != (self.T, 4):
+            raise hip.LgdHipError("boxes must be (T,4) with T=sum(counts)=%d, got %s" % (self.T, tuple(boxes.shape)))
+        self.boxes = hip.dense_f32(boxes.detach())
+        off = [0]
+        for c in self.counts:
+            off.append(off[-1] + c)
+        self.img_off = torch.tensor(off, dtype=torch.int32).to(boxes.device, non_blocking=True)
+        self._hw = hip.int_array([v for hw in self.level_hw for v in hw])
+        n_ints = lib.lgd_geom_ints(self.L, self.B, self.T, self.max_n)
+        self.geom = torch.empty(n_ints, dtype=torch.int32, device=boxes.device)
+        hip.check(lib.lgd_box_prep(hip.ptr(self.boxes), hip.ptr(self.img_off), self.B, self.T, self.max_n,
+                                   self.img_hw[0], self.img_hw[1], self._hw, self.L, hip.ptr(self.geom),
+                                   hip.stream_ptr()), "lgd_box_prep")
+
+    # --- debugging / tests -------------------------------------------------------------------
+    def rects(self):
+        """(L, T, 4) int32 [x0, x1, y0, y1] inclusive (empty: x1 < x0)."""
+        lib = hip.load()
+        o = lib.lgd_geom_rects_off(self.L, self.B, self.T, self.max_n)
+        return self.geom[o:o + self.L * self.T * 4].view(self.L, self.T, 4)
+
+    def bands(self):
+        """list[L][B] of python lists of row breakpoints."""
+        lib = hip.load()
+        on = lib.lgd_geom_nbp_off(self.L, self.B, self.T, self.max_n)
+        ob = lib.lgd_geom_bands_off(self.L, self.B, self.T, self.max_n)
+        mb = 2 * self.max_n + 2
+        g = self.geom.cpu()
+        nbp = g[on:on + self.L * self.B].view(self.L, self.B)
+        bands = g[ob:ob + self.L * self.B * mb].view(self.L, self.B, mb)
+        return [[bands[l, b, :int(nbp[l, b])].tolist() for b in range(self.B)] for l in range(self.L)]
+
+    def _check(self, maps):
+        if len(maps) != self.L:
+            raise hip.LgdHipError("expected %d pyramid levels, got %d" % (self.L, len(maps)))
+        for m, hw in zip(maps, self.level_hw):
+            if m.dim() != 4 or m.shape[0] != self.B or tuple(m.shape[-2:]) != hw:
+                raise hip.LgdHipError("level shape %s does not match geometry (B=%d, HW=%s)" % (tuple(m.shape), self.B, hw))
+
+
+def _box_sum(geom, maps, normalize, skip_last):
+    lib = hip.load()
+    maps = [hip.dense_f32(m) for m in maps]
+    geom._check(maps)
+    C = maps[0].shape[1]
+    out = torch.empty((geom.L, geom.T, C), dtype=torch.float32, device=maps[0].device)
+    hip.check(lib.lgd_box_sum(hip.ptr_array(maps), geom._hw, geom.L, geom.B, C, geom.T, geom.max_n,
+                              hip.ptr(geom.img_off), hip.ptr(geom.geom), hip.ptr(out), int(normalize), int(skip_last),
+                              hip.stream_ptr()), "lgd_box_sum")
+    return out
+
+
+def _box_paint(geom, vals, normalize, skip_last):
+    lib = hip.load()
+    vals = hip.dense_f32(vals)
+    C = vals.shape[2]
+    if tuple(vals.shape) != (geom.L, geom.T, C):
+        raise hip.LgdHipError("vals must be (L,T,C)=(%d,%d,C), got %s" % (geom.L, geom.T, tuple(vals.shape)))
+    outs = [torch.empty((geom.B, C, h, w), dtype=torch.float32, device=vals.device) for h, w in geom.level_hw]
+    hip.check(lib.lgd_box_paint(hip.ptr(vals), geom._hw, geom.L, geom.B, C, geom.T, geom.max_n, hip.ptr(geom.img_off),
+                                hip.ptr(geom.geom), hip.ptr_array(outs), int(normalize), int(skip_last),
+                                hip.stream_ptr()), "lgd_box_paint")
+    return outs
+
+
+class _MaskPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geom, *maps):
+        hip.require_gpu(*maps)
+        ctx.geom = geom
+        return _box_sum(geom, maps, True, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = _box_paint(ctx.geom, g, True, False)
+        return (None, *grads)
+
+
+class _RenderPaint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geom, skip_last, vals):
+        hip.require_gpu(vals)
+        ctx.geom, ctx.skip_last = geom, skip_last
+        return tuple(_box_paint(geom, vals, False, skip_last))
+
+    @staticmethod
+    def backward(ctx, *gmaps):
+        return None, None, _box_sum(ctx.geom, gmaps, False, ctx.skip_last)
+
+
+def mask_pool(geom, maps):
+    """Appearance embeddings: per-box mean of each level's map -> (L, T, C).
+    [ref: dynamic_teacher.py:81-103, 249-253]"""
+    return _MaskPool.apply(geom, *maps)
+
+
+def render_paint(geom, vals, skip_last):
+    """Per-pixel sum of the covering boxes' rows of vals (L,T,C) -> list of L maps (B,C,H_l,W_l).
+    [ref: dynamic_teacher.py:137-143 / 173-179]; skip_last: the context box is not painted."""
+    return list(_RenderPaint.apply(geom, bool(skip_last), vals))
+
+
+class _DistillInMse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coef, n_levels, *maps):
+        lib = hip.load()
+        hip.require_gpu(*maps)
+        a = [hip.dense_f32(m) for m in maps[:n_levels]]
+        b = [hip.dense_f32(m.detach()) for m in maps[n_levels:]]
+        B, C = a[0].shape[0], a[0].shape[1]
+        for x, y in zip(a, b):
+            if x.shape != y.shape or x.shape[0] != B or x.shape[1] != C:
+                raise hip.LgdHipError("student/teacher level shapes differ: %s vs %s" % (tuple(x.shape), tuple(y.shape)))
+        hw = hip.int_array([v for m in a for v in m.shape[-2:]])
+        dev = a[0].device
+        ws = torch.empty(lib.lgd_distill_ws_doubles(hw, n_levels, B, C), dtype=torch.float64, device=dev)
+        stats = torch.empty((n_levels * B * C, 8), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        hip.check(lib.lgd_distill_fwd(hip.ptr_array(a), hip.ptr_array(b), hw, n_levels, B, C, float(coef), hip.ptr(ws),
+                                      hip.ptr(stats), hip.ptr(loss), hip.stream_ptr()), "lgd_distill_fwd")
+        ctx.save_for_backward(stats, *a, *b)
+        ctx.meta = (float(coef), n_levels, B, C, hw)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = hip.load()
+        coef, L, B, C, hw = ctx.meta
+        stats = ctx.saved_tensors[0]
+        a = ctx.saved_tensors[1:1 + L]
+        b = ctx.saved_tensors[1 + L:]
+        g = g.contiguous().to(torch.float32)
+        ga = [torch.empty_like(x) for x in a]
+        hip.check(lib.lgd_distill_bwd(hip.ptr_array(a), hip.ptr_array(b), hw, L, B, C, coef, hip.ptr(stats), hip.ptr(g),
+                                      hip.ptr_array(ga), hip.stream_ptr()), "lgd_distill_bwd")
+        return (None, None, *ga, *([None] * L))
+
+
+def distill_in_mse(stu_maps, tea_maps, coef):
+    """coef * mse(InstanceNorm(tea), InstanceNorm(stu)) over all levels; the teacher side is
+    detached.  [ref: models/base_distillator.py:55-64]"""
+    stu_maps, tea_maps = list(stu_maps), list(tea_maps)
+    return _DistillInMse.apply(float(coef), len(stu_maps), *stu_maps, *tea_maps)
