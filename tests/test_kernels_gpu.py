@@ -169,7 +169,9 @@ def test_pool_of_paint_roundtrip_full_size():
     back = ops.mask_pool(geom, ops.render_paint(geom, vals, skip_last=False))
     r = geom.rects()
     nonempty = (r[..., 1] >= r[..., 0]).unsqueeze(-1)
-    assert torch.equal(back, torch.where(nonempty, vals, torch.zeros_like(vals)))
+    want = torch.where(nonempty, vals, torch.zeros_like(vals))
+    assert torch.equal(back == 0, want == 0)  # empty boxes give exact zeros
+    assert cm.rel_err(back, want) < 1e-6      # mean of n copies of v: only summation rounding
 
 
 # ------------------------------------------------------------------------------------------- distill loss
