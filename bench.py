@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Benchmark of the LGD training step (BASELINE.json metric: images/sec, RetinaNet R-50 + LGD, fwd+bwd).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One step = student forward -> dynamic teacher -> head re-run on teacher features -> distillation loss
+-> backward -> clip -> both SGD optimizers -> both LR schedulers, on a synthetic COCO-shaped batch
+(8 images/GPU of 800x1333 padded to 800x1344, 10 GT boxes each, context box on).
+Weak scaling: the per-GPU batch is fixed, `value` = all images of all ranks / max-over-ranks time.
+
+Extra objects on the JSON line (task statement section 4):
+  roofline     -- dominant hand-written HIP kernel of the step: algorithmic bytes per launch / mean launch time,
+                  measured live with HIP events on the launch stream inside the timed region
+  cpu_baseline -- the CPU oracle (oracle/lgd_oracle.py, kind "port") timed on the host cores, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml"))
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--boxes", type=int, default=10)
+    ap.add_argument("--phase", default="distill", choices=["distill", "nondistill", "frozen"],
+                    help="training phase to time: distill = steady state (distill on, backbone training; 150k of the "
+                         "180k iterations), nondistill = iterations 20k-30k, frozen = first 20k iterations")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-images", type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, n_boxes, ctx):
+    """Oracle LGD path (teacher fwd + adapter + distill loss, fwd+bwd) on the host cores; bounded sample."""
+    from lgd_amd import synth
+    from oracle import lgd_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, H, W = args.cpu_sample_images, args.height, (args.width + 31) // 32 * 32
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.closed_form_params(O.teacher_param_shapes()).items()}
+    pa = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.closed_form_params(O.adapter_param_shapes()).items()}
+    feats = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.synth_features(B, H, W, seed=3).items()}
+    gt = [(torch.from_numpy(b), torch.from_numpy(c)) for b, c in synth.synth_gt(B, args.height, args.width, n_boxes, seed=0)]
+    t0 = time.perf_counter()
+    tea, _, _ = O.teacher_forward(p, feats, gt, (H, W), add_ctx=ctx)
+    loss = O.distill_loss(pa, feats, tea, 1.0, 1) + sum(t.mean() for t in tea.values())
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "oracle LGD path only (dynamic teacher fwd + adapter + distill loss, fwd+bwd; no student "
+                      "backbone/head -- the reference's detectron2 student is not runnable), %d image(s) %dx%d, "
+                      "%d GT boxes, %.1f s" % (B, H, W, n_boxes, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    from lgd_amd import config, hip, ops
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    hip.load()  # fail loudly if the HIP extension is missing
+
+    cfg = config.setup_cfg(args.config, ["MODEL.DEVICE", "cuda:%d" % local_rank])
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    trainer = Trainer(cfg, model, device=dev)
+    d = cfg.MODEL.DISTILLATOR
+    it0 = {"distill": max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS),
+           "nondistill": d.PRE_FREEZE_STUDENT_BACKBONE_ITERS, "frozen": 0}[args.phase]
+    Bg = args.batch_per_gpu
+    data = synthetic_batch(Bg, args.height, args.width, args.boxes, seed=1000 + rank, pin=True)
+    ctx = bool(d.TEACHER.ADD_CONTEXT_BOX)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(data, it0 + i)
+    trainer.fetch_metrics()
+    sync()
+    ops.kernel_timer_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(data, it0 + args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    ktimes = ops.kernel_timer_collect()
+    ops.kernel_timer_enable(False)
+    metrics = trainer.fetch_metrics()  # raises on non-finite losses
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        Hp, Wp = (args.height + 31) // 32 * 32, (args.width + 31) // 32 * 32
+        from lgd_amd import synth
+        P = Bg * 256 * sum(h * w for h, w in synth.pyramid_shapes(Hp, Wp)) * 4  # one fp32 pyramid, bytes
+        # algorithmic bytes per launch
+        alg = {"in_moments_kernel": 2 * P, "in_mse_bwd_kernel": 3 * P, "box_sum_kernel": P, "box_paint_kernel": P,
+               "gn_stats_kernel": P, "gn_apply_kernel": 2 * P, "gn_bwd_stats_kernel": 2 * P, "gn_bwd_apply_kernel": 3 * P}
+        kernels = {}
+        for name, (n, ms) in ktimes.items():
+            kernels[name] = {"launches": n, "avg_us": 1e3 * ms / max(n, 1), "total_ms": ms}
+            if name in alg:
+                kernels[name]["alg_bytes"] = alg[name]
+                kernels[name]["GBps"] = alg[name] / (1e-3 * ms / n) / 1e9
+        dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k]["total_ms"], default=None)
+        roofline = None
+        if dom:
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
+                        "alg_bytes_per_launch": alg[dom], "avg_launch_us": kernels[dom]["avg_us"],
+                        "all_hip_kernels": {k: {"avg_us": round(v["avg_us"], 2), "GBps": round(v.get("GBps", 0.0), 1),
+                                                "launches_per_step": v["launches"] / args.steps} for k, v in kernels.items()}}
+        out = {
+            "metric": "images/sec/node RetinaNet R-50+LGD fwd+bwd",
+            "value": world * Bg * args.steps / dt,
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: RetinaNet R-50 FPN + LGD, %d img/GPU, %dx%d (padded %dx%d), "
+                                   "%d GT boxes/img, ctx box %s, phase=%s (fwd+bwd+clip+2xSGD)"
+                                   % (Bg, args.height, args.width, Hp, Wp, args.boxes, "on" if ctx else "off", args.phase),
+                       "yaml": os.path.relpath(args.config, ROOT), "global_batch": world * Bg, "parallelism": "dp%d" % world},
+            "losses": {k: round(v, 6) for k, v in metrics.items()},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.boxes, ctx)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,14 @@ int lgd_distill_bwd(const float* const* a_host, const float* const* b_host, cons
                     int L, int B, int C, float coef, const float* stats, const float* grad_loss,
                     float* const* grad_a_host, void* stream);
 
+/* ------------------------------------------------------------------ per-kernel timing (bench.py)
+ * When enabled every kernel launch of this library is bracketed by a HIP event pair recorded on
+ * the launch stream.  lgd_timing_collect waits for the recorded events, sums the elapsed time per
+ * kernel name and clears the records: names = NUL-separated kernel names, total_ms/launches per
+ * name; returns the number of names written. */
+int lgd_timing_enable(int on);
+int lgd_timing_collect(char* names, size_t names_len, double* total_ms, int32_t* launches, int max_entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,7 +123,7 @@ int lgd_box_prep(const float* boxes, const int32_t* img_off, int B, int T, int m
     for (int l = 0; l < L; ++l) { a.H[l] = level_hw_host[2 * l]; a.W[l] = level_hw_host[2 * l + 1]; }
     const size_t smem = 3 * (size_t)lgd::geom_maxbp(max_n) * sizeof(int);
     if (smem > 160 * 1024) return LGD_EINVAL;
-    hipLaunchKernelGGL(lgd::box_prep_kernel, dim3(L * B), dim3(256), smem, (hipStream_t)stream, a);
+    LGD_LAUNCH("box_prep_kernel", lgd::box_prep_kernel, dim3(L * B), dim3(256), smem, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 

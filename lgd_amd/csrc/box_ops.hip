@@ -216,7 +216,7 @@ int lgd_box_sum(const float* const* feats_host, const int32_t* level_hw_host, in
     for (int l = 0; l < L; ++l) { if (!feats_host[l]) return LGD_EINVAL; a.in[l] = feats_host[l]; }
     a.pooled = out;
     if (T == 0) return LGD_OK;
-    hipLaunchKernelGGL(lgd::box_sum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    LGD_LAUNCH("box_sum_kernel", lgd::box_sum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 
@@ -228,7 +228,7 @@ int lgd_box_paint(const float* vals, const int32_t* level_hw_host, int L, int B,
     if (nblk < 0 || !outs_host || !vals) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!outs_host[l]) return LGD_EINVAL; a.out[l] = outs_host[l]; }
     a.vals = vals;
-    hipLaunchKernelGGL(lgd::box_paint_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    LGD_LAUNCH("box_paint_kernel", lgd::box_paint_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 

@@ -90,4 +90,19 @@ inline int check_launch() {
     return LGD_OK;
 }
 
+// RAII event pair around one kernel launch (timing.hip); a no-op unless lgd_timing_enable(1).
+class KTimer {
+public:
+    KTimer(const char* name, hipStream_t s);
+    ~KTimer();
+private:
+    const char* name_; hipStream_t s_; hipEvent_t a_, b_;
+};
+
 }  // namespace lgd
+
+#define LGD_LAUNCH(name, kernel, grid, block, smem, stream, ...)                 \
+    do {                                                                          \
+        lgd::KTimer _lgd_t(name, stream);                                         \
+        hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);       \
+    } while (0)

@@ -216,9 +216,9 @@ int lgd_distill_fwd(const float* const* a_host, const float* const* b_host, cons
     if (lgd::fill(a, a_host, b_host, level_hw_host, L, B, C, coef) != LGD_OK || !ws || !stats || !loss) return LGD_EINVAL;
     a.ws = ws; a.stats = stats; a.loss = loss; a.grad_loss = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(lgd::in_moments_kernel, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(lgd::in_finalize_kernel, dim3(a.nfin), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(lgd::in_loss_kernel, dim3(1), dim3(64), 0, s, a);
+    LGD_LAUNCH("in_moments_kernel", lgd::in_moments_kernel, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
+    LGD_LAUNCH("in_finalize_kernel", lgd::in_finalize_kernel, dim3(a.nfin), dim3(256), 0, s, a);
+    LGD_LAUNCH("in_loss_kernel", lgd::in_loss_kernel, dim3(1), dim3(64), 0, s, a);
     return lgd::check_launch();
 }
 
@@ -230,7 +230,7 @@ int lgd_distill_bwd(const float* const* a_host, const float* const* b_host, cons
         return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!grad_a_host[l]) return LGD_EINVAL; a.ga[l] = grad_a_host[l]; }
     a.ws = nullptr; a.stats = const_cast<float*>(stats); a.loss = nullptr; a.grad_loss = grad_loss;
-    hipLaunchKernelGGL(lgd::in_mse_bwd_kernel, dim3((a.nwaves + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    LGD_LAUNCH("in_mse_bwd_kernel", lgd::in_mse_bwd_kernel, dim3((a.nwaves + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 

@@ -1,0 +1,228 @@
+"""Training step of the LGD path: two optimizers, distill-flag schedule, student-backbone freeze,
+RCCL data parallelism  [ref: train.py:148-234 do_train, 279-281 DDP wrap; utils/build.py:492-553].
+
+MI355X-first differences (behaviour-preserving):
+  * no per-iteration host sync: the reference reduces and `.item()`s every loss each step
+    (train.py:196); here losses stay on the device and are fetched once per log period, already
+    averaged over ranks by ONE small all-reduce;
+  * the backbone freeze is applied as `requires_grad=False` for the phase instead of computing,
+    all-reducing and then discarding the gradients (train.py:205-207) -- SGD skips the same
+    parameters (grad None), the backward pass and the gradient buckets shrink;
+  * parameters that can never receive a gradient (global_ctx_proj_1D without a context box) are
+    frozen statically, so DDP runs with a static graph instead of find_unused_parameters=True;
+  * works at world size 1 (the reference dereferences `model.module` unconditionally).
+"""
+import bisect
+import os
+
+import torch
+import torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel
+
+
+def warmup_multistep_factor(it, steps, gamma, warmup_factor, warmup_iters, warmup_method="linear"):
+    """detectron2 WarmupMultiStepLR multiplier at iteration `it` ([d2-memory])."""
+    w = 1.0
+    if it < warmup_iters:
+        if warmup_method == "constant":
+            w = warmup_factor
+        elif warmup_method == "linear":
+            a = it / warmup_iters
+            w = warmup_factor * (1 - a) + a
+        else:
+            raise ValueError("Unknown warmup method: {}".format(warmup_method))
+    return w * gamma ** bisect.bisect_right(list(steps), it)
+
+
+def build_distillator_lr_scheduler(solver, optimizer):
+    """[ref: utils/build.py:531-553]"""
+    name = solver.LR_SCHEDULER_NAME
+    if name == "WarmupMultiStepLR":
+        f = lambda it: warmup_multistep_factor(it, solver.STEPS, solver.GAMMA, solver.WARMUP_FACTOR,  # noqa: E731
+                                               solver.WARMUP_ITERS, solver.WARMUP_METHOD)
+        return torch.optim.lr_scheduler.LambdaLR(optimizer, f)
+    raise ValueError("Unknown LR sheduler: {}".format(name))
+
+
+def _unwrap(model):
+    return model.module if isinstance(model, DistributedDataParallel) else model
+
+
+def _params(modules):
+    seen, out = set(), []
+    for m in modules:
+        for p in m.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out
+
+
+def build_distillator_optimizer(cfg, network):
+    """student+adapter share one optimizer, the teacher has its own; weight decay on every
+    parameter, SGD momentum  [ref: utils/build.py:492-529].  Multi-tensor (`foreach`) updates."""
+    net = _unwrap(network)
+    d = cfg.MODEL.DISTILLATOR
+
+    def make(solver, params):
+        if solver.OPTIMIZER == "SGD":
+            return torch.optim.SGD(params, solver.BASE_LR, momentum=solver.MOMENTUM, weight_decay=solver.WEIGHT_DECAY,
+                                   foreach=True)
+        if solver.OPTIMIZER == "ADAMW":
+            return torch.optim.AdamW(params, solver.BASE_LR, betas=(0.9, 0.999), weight_decay=solver.WEIGHT_DECAY,
+                                     foreach=True)
+        raise NotImplementedError("no optimizer type %s" % solver.OPTIMIZER)
+    # every parameter is registered (also currently-frozen backbone ones: SGD skips grad-less params)
+    stu = [p for p in _all_params([net.student, net.adapter]) if not getattr(p, "_lgd_never_trained", False)]
+    tea = [p for p in _all_params([net.teacher]) if not getattr(p, "_lgd_never_trained", False)]
+    return make(d.STUDENT.SOLVER, stu), make(d.TEACHER.SOLVER, tea)
+
+
+def _all_params(modules):
+    seen, out = set(), []
+    for m in modules:
+        for p in m.parameters():
+            if id(p) not in seen and (p.requires_grad or getattr(p, "_lgd_phase_frozen", False)):
+                seen.add(id(p))
+                out.append(p)
+    return out
+
+
+def freeze_static_unused(model):
+    """Parameters that never get a gradient in this configuration (reference: DDP find_unused_parameters)."""
+    net = _unwrap(model)
+    t = net.teacher
+    unused = []
+    if not t.add_context_box:
+        unused += list(t.global_ctx_proj_1D.parameters())  # dynamic_teacher.py:153-190 never calls it
+    if t.interact_pattern in ("student_fill", "teacher_fill"):
+        unused += list(t.multi_head_attn.parameters())
+    for p in unused:
+        p.requires_grad = False
+        p._lgd_never_trained = True
+    return unused
+
+
+class Trainer:
+    """Owns model (+DDP), optimizers, schedulers and the per-iteration phase logic of do_train."""
+
+    def __init__(self, cfg, model, distributed=None, device=None):
+        self.cfg = cfg
+        self.d = cfg.MODEL.DISTILLATOR
+        self.max_iter = cfg.SOLVER.MAX_ITER
+        self.raw_model = model
+        self.device = device or next(model.parameters()).device
+        self.distributed = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) \
+            if distributed is None else distributed
+        freeze_static_unused(model)
+        self._backbone_frozen = None
+        self.model = model
+        self._set_backbone_frozen(0 < self.d.PRE_FREEZE_STUDENT_BACKBONE_ITERS)
+        self.stu_optimizer, self.tea_optimizer = build_distillator_optimizer(cfg, model)
+        self.stu_scheduler = build_distillator_lr_scheduler(self.d.STUDENT.SOLVER, self.stu_optimizer)
+        self.tea_scheduler = build_distillator_lr_scheduler(self.d.TEACHER.SOLVER, self.tea_optimizer)
+        self.clip = cfg.SOLVER.CLIP_GRADIENTS
+        self.iteration = 0
+        self._log_acc, self._log_n = None, 0
+
+    # ---- phases ----------------------------------------------------------------------------
+    def _set_backbone_frozen(self, frozen):
+        """[ref: train.py:205-207] as a requires_grad phase; the DDP reducer is rebuilt at the (rare) phase changes."""
+        if frozen == self._backbone_frozen:
+            return
+        net = self.raw_model
+        for p in net.student.raw_backbone.parameters():
+            if getattr(p, "_lgd_trainable", None) is None:
+                p._lgd_trainable = p.requires_grad  # FREEZE_AT already froze stem/res2 for good
+            if p._lgd_trainable:
+                p.requires_grad = not frozen
+                p._lgd_phase_frozen = frozen
+                if frozen:
+                    p.grad = None
+        self._backbone_frozen = frozen
+        if self.distributed:
+            dev_ids = [self.device.index] if self.device.type == "cuda" else None
+            self.model = DistributedDataParallel(net, device_ids=dev_ids, broadcast_buffers=False,
+                                                 find_unused_parameters=False, gradient_as_bucket_view=True,
+                                                 bucket_cap_mb=int(os.environ.get("LGD_BUCKET_MB", "64")))
+        else:
+            self.model = net
+
+    def set_phase(self, iteration):
+        """distill flag and backbone freeze for this iteration [ref: train.py:184-189,205-207]."""
+        d = self.d
+        if iteration < d.PRE_NONDISTILL_ITERS or iteration > self.max_iter - d.POST_NONDISTILL_ITERS:
+            self.raw_model.distill_flag = d.DISTILL_OFF
+        else:
+            self.raw_model.distill_flag = d.DISTILL_ON
+        self._set_backbone_frozen(iteration < d.PRE_FREEZE_STUDENT_BACKBONE_ITERS)
+
+    # ---- one iteration ----------------------------------------------------------------------
+    def step(self, data, iteration=None):
+        it = self.iteration if iteration is None else iteration
+        self.set_phase(it)
+        self.model.train()
+        loss_dict = self.model(data)
+        losses = sum(loss_dict.values())
+        self.stu_optimizer.zero_grad(set_to_none=True)
+        self.tea_optimizer.zero_grad(set_to_none=True)
+        losses.backward()  # DDP: bucketed RCCL all-reduce over xGMI overlaps with this
+        if self.clip.ENABLED:
+            self._clip()
+        self.stu_optimizer.step()
+        self.tea_optimizer.step()
+        self.stu_scheduler.step()
+        self.tea_scheduler.step()
+        # device-side running sums; no host sync here
+        vals = torch.stack([v.detach() for v in loss_dict.values()])
+        self._log_keys = list(loss_dict.keys())
+        self._log_acc = vals if self._log_acc is None else self._log_acc + vals
+        self._log_n += 1
+        self.iteration = it + 1
+        return loss_dict
+
+    def _clip(self):
+        """detectron2 default CLIP_TYPE='value', CLIP_VALUE=1.0: element-wise clamp of every gradient."""
+        grads = [p.grad for g in self.stu_optimizer.param_groups + self.tea_optimizer.param_groups
+                 for p in g["params"] if p.grad is not None]
+        if self.clip.CLIP_TYPE == "value":
+            v = float(self.clip.CLIP_VALUE)
+            torch._foreach_clamp_min_(grads, -v)
+            torch._foreach_clamp_max_(grads, v)
+        else:
+            torch.nn.utils.clip_grad_norm_([p for g in self.stu_optimizer.param_groups + self.tea_optimizer.param_groups
+                                            for p in g["params"]], float(self.clip.CLIP_VALUE), float(self.clip.NORM_TYPE))
+
+    def fetch_metrics(self):
+        """Mean of every loss since the last call, averaged over ranks (ONE all-reduce, ONE host copy),
+        plus total_loss / stu_lr / tea_lr  [ref: train.py:196-199, 212-213 scalar names].  Raises if a loss went
+        non-finite (the reference asserts every iteration, train.py:194)."""
+        if self._log_acc is None:
+            return {}
+        v = self._log_acc / self._log_n
+        if self.distributed:
+            dist.all_reduce(v)
+            v = v / dist.get_world_size()
+        vals = v.tolist()
+        self._log_acc, self._log_n = None, 0
+        out = dict(zip(self._log_keys, vals))
+        out["total_loss"] = sum(vals)
+        out["stu_lr"] = self.stu_optimizer.param_groups[0]["lr"]
+        out["tea_lr"] = self.tea_optimizer.param_groups[0]["lr"]
+        if not all(x == x and abs(x) != float("inf") for x in vals):
+            raise FloatingPointError("non-finite loss: %s" % out)
+        return out
+
+    def state_dict(self):
+        """checkpoint payload with the reference's keys [ref: train.py:155-157]."""
+        return {"model": self.raw_model.state_dict(), "stu_optimizer": self.stu_optimizer.state_dict(),
+                "tea_optimizer": self.tea_optimizer.state_dict(), "stu_scheduler": self.stu_scheduler.state_dict(),
+                "tea_scheduler": self.tea_scheduler.state_dict(), "iteration": self.iteration - 1}
+
+    def load_state_dict(self, sd):
+        self.raw_model.load_state_dict(sd["model"])
+        self.stu_optimizer.load_state_dict(sd["stu_optimizer"])
+        self.tea_optimizer.load_state_dict(sd["tea_optimizer"])
+        self.stu_scheduler.load_state_dict(sd["stu_scheduler"])
+        self.tea_scheduler.load_state_dict(sd["tea_scheduler"])
+        self.iteration = sd.get("iteration", -1) + 1

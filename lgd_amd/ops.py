@@ -171,3 +171,90 @@ def distill_in_mse(stu_maps, tea_maps, coef):
     detached.  [ref: models/base_distillator.py:55-64]"""
     stu_maps, tea_maps = list(stu_maps), list(tea_maps)
     return _DistillInMse.apply(float(coef), len(stu_maps), *stu_maps, *tea_maps)
+
+
+# ------------------------------------------------------------------------------------------------
+# Ops below are composed from torch primitives in this revision and are being replaced one by one
+# by HIP kernels (K2 attention, K5 GN(1)+ReLU / bias+ctx+ReLU epilogues, K6 label encoder); their
+# signatures are the kernels' signatures so the modules above do not change.
+# ------------------------------------------------------------------------------------------------
+import math  # noqa: E402
+
+import torch.nn.functional as F  # noqa: E402
+
+
+def _offsets(counts):
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + c)
+    return off
+
+
+def segment_ids(counts, device):
+    """(T,) int64 image index of every box row; built on the host (counts are host-known)."""
+    ids = [b for b, n in enumerate(counts) for _ in range(n)]
+    return torch.tensor(ids, dtype=torch.int64).to(device, non_blocking=True)
+
+
+def segment_max_broadcast(x, counts):
+    """per-image max over the image's rows, broadcast back to those rows: (T,F) -> (T,F).
+    [ref: label_encoder.py:195-213 hier_pool + 262-264 repeat]"""
+    seg = segment_ids(counts, x.device)
+    g = torch.full((len(counts), x.shape[1]), float("-inf"), device=x.device, dtype=x.dtype)
+    g = g.scatter_reduce(0, seg[:, None].expand(-1, x.shape[1]), x, reduce="amax", include_self=True)
+    return g[seg]
+
+
+def gn1(x, relu):
+    """GroupNorm(num_groups=1, affine=False, eps=1e-5) [+ ReLU]  [ref: layers.py:6-7, 22-32]"""
+    y = F.group_norm(x, 1, eps=1e-5)
+    return F.relu(y) if relu else y
+
+
+def bias_ctx_relu(x, ctx):
+    """ReLU(x + ctx[:, :, None, None])  [ref: dynamic_teacher.py:151]"""
+    return F.relu(x + ctx[:, :, None, None])
+
+
+def mha_blockdiag(q_in, kv_in, counts, in_w, in_b, out_w, out_b, heads):
+    """nn.MultiheadAttention(E, heads) forward as called at [ref: dynamic_teacher.py:255-273]:
+    sequence-first, batch 1, boolean mask blocking attention between boxes of different images.
+    q_in (Lq,T,E), kv_in (Lk,T,E) with Lq == Lk or one of them 1 (levels broadcast) -> (max(Lq,Lk),T,E)."""
+    E = q_in.shape[-1]
+    d = E // heads
+    T = q_in.shape[1]
+    q = F.linear(q_in, in_w[:E], in_b[:E]) * (1.0 / math.sqrt(d))
+    k = F.linear(kv_in, in_w[E:2 * E], in_b[E:2 * E])
+    v = F.linear(kv_in, in_w[2 * E:], in_b[2 * E:])
+    seg = segment_ids(counts, q_in.device)
+    blocked = seg[:, None] != seg[None, :]
+    qh = q.view(-1, T, heads, d).transpose(1, 2)
+    kh = k.view(-1, T, heads, d).transpose(1, 2)
+    vh = v.view(-1, T, heads, d).transpose(1, 2)
+    s = torch.matmul(qh, kh.transpose(-1, -2)).masked_fill(blocked, float("-inf"))
+    o = torch.matmul(torch.softmax(s, -1), vh)  # (L,heads,T,d)
+    o = o.transpose(1, 2).reshape(-1, T, E)
+    return F.linear(o, out_w, out_b)
+
+
+# ------------------------------------------------------------------------------------------------ timing
+def kernel_timer_enable(on):
+    """bracket every HIP kernel launch of the library with an event pair on its stream (bench.py)."""
+    hip.check(hip.load().lgd_timing_enable(int(bool(on))), "lgd_timing_enable")
+
+
+def kernel_timer_collect():
+    """{kernel name: (launches, total_ms)} since the last collect (synchronises the recorded events)."""
+    import ctypes
+    lib = hip.load()
+    names = ctypes.create_string_buffer(4096)
+    ms = (ctypes.c_double * 64)()
+    cnt = (ctypes.c_int32 * 64)()
+    n = lib.lgd_timing_collect(names, 4096, ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), 64)
+    out, off = {}, 0
+    raw = names.raw
+    for i in range(n):
+        end = raw.index(b"\0", off)
+        out[raw[off:end].decode()] = (int(cnt[i]), float(ms[i]))
+        off = end + 1
+    return out

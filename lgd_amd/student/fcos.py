@@ -1,0 +1,258 @@
+"""FCOSCT: cvpods-style FCOS student with the reference's surface
+[ref: models/customized_detectors/fcos.py:17-77, thirdparty_heads/fcos.py:68-546].
+cvpods is not available: ShiftGenerator / Shift2BoxTransform / iou_loss / focal loss follow their
+public definitions (parity unpinned); GT assignment, losses and the head
+follow the in-repo reference code cited per function.  Loss path: no host syncs, and the two
+scalar all-reduces of the reference are packed into one 2-element all-reduce per call."""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..registry import CUSTOMIZED_DETECTORS_REGISTRY
+from ..structures import ImageList
+from .retinanet import batched_nms, build_resnet_fpn, sigmoid_focal_sum
+
+INF = float("inf")
+
+
+class Scale(nn.Module):
+    """[ref: thirdparty_heads/scale.py]"""
+
+    def __init__(self, init_value=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor([init_value], dtype=torch.float32))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+class FCOSHead(nn.Module):
+    """towers of conv3x3 + GN(32) + ReLU; per-level Scale; ReLU(.)*stride regression
+    [ref: thirdparty_heads/fcos.py:433-546]"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        f = cfg.MODEL.FCOS
+        C = cfg.MODEL.FPN.OUT_CHANNELS
+        self.fpn_strides = list(f.FPN_STRIDES)
+        self.centerness_on_reg, self.norm_reg_targets = f.CENTERNESS_ON_REG, f.NORM_REG_TARGETS
+        cls, box = [], []
+        for _ in range(f.NUM_CONVS):
+            cls += [nn.Conv2d(C, C, 3, 1, 1), nn.GroupNorm(32, C), nn.ReLU()]
+            box += [nn.Conv2d(C, C, 3, 1, 1), nn.GroupNorm(32, C), nn.ReLU()]
+        self.cls_subnet, self.bbox_subnet = nn.Sequential(*cls), nn.Sequential(*box)
+        self.cls_score = nn.Conv2d(C, f.NUM_CLASSES, 3, 1, 1)
+        self.bbox_pred = nn.Conv2d(C, 4, 3, 1, 1)
+        self.centerness = nn.Conv2d(C, 1, 3, 1, 1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, mean=0, std=0.01)
+                nn.init.constant_(m.bias, 0)
+        nn.init.constant_(self.cls_score.bias, -math.log((1 - f.PRIOR_PROB) / f.PRIOR_PROB))
+        self.scales = nn.ModuleList([Scale(1.0) for _ in self.fpn_strides])
+
+    def forward(self, features):
+        logits, reg, ctr = [], [], []
+        for lvl, x in enumerate(features):
+            c, b = self.cls_subnet(x), self.bbox_subnet(x)
+            logits.append(self.cls_score(c))
+            ctr.append(self.centerness(b if self.centerness_on_reg else c))
+            r = self.scales[lvl](self.bbox_pred(b))
+            reg.append(F.relu(r) * self.fpn_strides[lvl] if self.norm_reg_targets else torch.exp(r))
+        return logits, reg, ctr
+
+
+def _flatten_levels(per_level, K):
+    """list of (N, K, H, W) -> (N, sum HW, K)"""
+    return torch.cat([t.permute(0, 2, 3, 1).reshape(t.shape[0], -1, K) for t in per_level], 1)
+
+
+def giou_ltrb_loss(pred, target):
+    """cvpods iou_loss(box_mode='ltrb', loss_type='giou') per element (no reduction)."""
+    eps = torch.finfo(torch.float32).eps
+    p = torch.cat((-pred[..., :2], pred[..., 2:]), -1)
+    t = torch.cat((-target[..., :2], target[..., 2:]), -1)
+    pa = (p[..., 2] - p[..., 0]).clamp(min=0) * (p[..., 3] - p[..., 1]).clamp(min=0)
+    ta = (t[..., 2] - t[..., 0]).clamp(min=0) * (t[..., 3] - t[..., 1]).clamp(min=0)
+    wi = (torch.min(p[..., 2], t[..., 2]) - torch.max(p[..., 0], t[..., 0])).clamp(min=0)
+    hi = (torch.min(p[..., 3], t[..., 3]) - torch.max(p[..., 1], t[..., 1])).clamp(min=0)
+    inter = wi * hi
+    union = ta + pa - inter
+    iou = inter / union.clamp(min=eps)
+    gw = torch.max(p[..., 2], t[..., 2]) - torch.min(p[..., 0], t[..., 0])
+    gh = torch.max(p[..., 3], t[..., 3]) - torch.min(p[..., 1], t[..., 1])
+    ac = gw * gh
+    return 1 - (iou - (ac - union) / ac.clamp(min=eps))
+
+
+@CUSTOMIZED_DETECTORS_REGISTRY.register()
+class FCOSCT(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        f = cfg.MODEL.FCOS
+        self.num_classes = f.NUM_CLASSES
+        self.in_features = list(f.IN_FEATURES)
+        self.head_in_features = self.in_features
+        self.fpn_strides = list(f.FPN_STRIDES)
+        self.focal_loss_alpha, self.focal_loss_gamma = f.FOCAL_LOSS_ALPHA, f.FOCAL_LOSS_GAMMA
+        self.iou_loss_type = f.IOU_LOSS_TYPE
+        assert self.iou_loss_type == "giou"
+        self.center_sampling_radius = f.CENTER_SAMPLING_RADIUS
+        self.object_sizes_of_interest = [list(map(float, s)) for s in f.OBJECT_SIZES_OF_INTEREST]
+        self.score_threshold, self.topk_candidates = f.SCORE_THRESH_TEST, f.TOPK_CANDIDATES_TEST
+        self.nms_threshold, self.max_detections_per_image = f.NMS_THRESH_TEST, cfg.TEST.DETECTIONS_PER_IMAGE
+        self.shift_offset = cfg.MODEL.SHIFT_GENERATOR.OFFSET
+        self.backbone = build_resnet_fpn(cfg)
+        self.fpn = self.backbone  # [ref: customized_detectors/fcos.py:23-27]
+        self.raw_backbone = self.fpn.bottom_up
+        self.fpn.bottom_up = nn.Sequential()
+        self.head = FCOSHead(cfg)
+        self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), persistent=False)
+        self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), persistent=False)
+        self._shift_cache = {}
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, batched_inputs):
+        imgs = [(x["image"].to(self.device, non_blocking=True).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
+        return ImageList.from_tensors(imgs, self.backbone.size_divisibility)
+
+    def shift_generator(self, features):
+        """cvpods ShiftGenerator(NUM_SHIFTS=1, OFFSET=0.5): level-wise (HW,2) centres (x,y), row-major.
+        The per-image replication of cvpods is dropped: shifts do not depend on the image."""
+        key = tuple(tuple(x.shape[-2:]) for x in features) + (str(features[0].device),)
+        if key not in self._shift_cache:
+            out = []
+            for x, s in zip(features, self.fpn_strides):
+                H, W = x.shape[-2:]
+                sx = torch.arange(0, W * s, s, dtype=torch.float32, device=x.device) + self.shift_offset * s
+                sy = torch.arange(0, H * s, s, dtype=torch.float32, device=x.device) + self.shift_offset * s
+                yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+                out.append(torch.stack((xx.reshape(-1), yy.reshape(-1)), 1))
+            self._shift_cache = {key: out}
+        return self._shift_cache[key]
+
+    def predict(self, features):
+        """[ref: customized_detectors/fcos.py:29-33]"""
+        box_cls, box_delta, box_center = self.head(features)
+        return self.shift_generator(features), box_cls, box_delta, box_center
+
+    @torch.no_grad()
+    def get_ground_truth(self, shifts, targets):
+        """centre sampling + scale ranges + min-area tie break [ref: thirdparty_heads/fcos.py:177-284]."""
+        all_shifts = torch.cat(shifts, 0)  # (R,2)
+        soi = torch.cat([all_shifts.new_tensor(s)[None].expand(len(sh), -1) for sh, s in zip(shifts, self.object_sizes_of_interest)], 0)
+        gt_classes, gt_deltas, gt_ctr = [], [], []
+        for t in targets:
+            if len(t) == 0:
+                gt_classes.append(torch.full((len(all_shifts),), self.num_classes, dtype=torch.int64, device=all_shifts.device))
+                gt_deltas.append(torch.zeros((len(all_shifts), 4), device=all_shifts.device))
+                gt_ctr.append(torch.zeros((len(all_shifts),), device=all_shifts.device))
+                continue
+            gb = t.gt_boxes.tensor  # (M,4)
+            deltas = torch.cat((all_shifts[None] - gb[:, None, :2], gb[:, None, 2:] - all_shifts[None]), -1)  # (M,R,4) ltrb
+            if self.center_sampling_radius > 0:
+                centers = (gb[:, :2] + gb[:, 2:]) / 2
+                inside = []
+                for stride, sh in zip(self.fpn_strides, shifts):
+                    rad = stride * self.center_sampling_radius
+                    cb = torch.cat((torch.max(centers - rad, gb[:, :2]), torch.min(centers + rad, gb[:, 2:])), -1)
+                    cd = torch.cat((sh[None] - cb[:, None, :2], cb[:, None, 2:] - sh[None]), -1)
+                    inside.append(cd.min(-1).values > 0)
+                inside = torch.cat(inside, 1)
+            else:
+                inside = deltas.min(-1).values > 0
+            mx = deltas.max(-1).values
+            cared = (mx >= soi[None, :, 0]) & (mx <= soi[None, :, 1])
+            area = ((gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1]))[:, None].expand(-1, len(all_shifts))
+            area = torch.where(inside & cared, area, torch.full_like(area, INF))
+            min_area, idx = area.min(0)
+            d = torch.cat((all_shifts - gb[idx][:, :2], gb[idx][:, 2:] - all_shifts), -1)
+            cls = t.gt_classes[idx].to(torch.int64)
+            cls = torch.where(min_area == INF, torch.full_like(cls, self.num_classes), cls)
+            lr, tb = d[:, [0, 2]], d[:, [1, 3]]
+            ctr = torch.sqrt((lr.min(-1).values / lr.max(-1).values).clamp(min=0) * (tb.min(-1).values / tb.max(-1).values).clamp(min=0))
+            gt_classes.append(cls)
+            gt_deltas.append(d)
+            gt_ctr.append(ctr)
+        return torch.stack(gt_classes), torch.stack(gt_deltas), torch.stack(gt_ctr)
+
+    def losses(self, gt_classes, gt_shifts_deltas, gt_centerness, pred_class_logits, pred_shift_deltas, pred_centerness):
+        """[ref: thirdparty_heads/fcos.py:107-175] without boolean-index gathers / host syncs."""
+        logits = _flatten_levels(pred_class_logits, self.num_classes)
+        deltas = _flatten_levels(pred_shift_deltas, 4)
+        ctr = _flatten_levels(pred_centerness, 1).squeeze(-1)
+        valid = gt_classes >= 0
+        fg = valid & (gt_classes != self.num_classes)
+        gt_ctr = torch.where(fg, gt_centerness, torch.zeros_like(gt_centerness))
+        counts = torch.stack((fg.sum().to(torch.float32), gt_ctr.sum()))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(counts)  # one packed all-reduce instead of two (fcos.py:141,143)
+            counts = counts / dist.get_world_size()
+        num_fg, num_targets = counts[0].clamp(min=1.0), counts[1].clamp(min=1.0)
+        loss_cls = sigmoid_focal_sum(logits, gt_classes, valid, self.num_classes, self.focal_loss_alpha,
+                                     self.focal_loss_gamma) / num_fg
+        safe_t = torch.where(fg[..., None], gt_shifts_deltas, torch.ones_like(gt_shifts_deltas))
+        safe_p = torch.where(fg[..., None], deltas, torch.ones_like(deltas))
+        loss_box = (torch.where(fg, giou_ltrb_loss(safe_p, safe_t) * gt_ctr, torch.zeros_like(gt_ctr))).sum() / num_targets
+        bce = F.binary_cross_entropy_with_logits(ctr, gt_ctr, reduction="none")
+        loss_ctr = torch.where(fg, bce, torch.zeros_like(bce)).sum() / num_fg
+        return {"loss_cls": loss_cls, "loss_box_reg": loss_box, "loss_centerness": loss_ctr}
+
+    def forward(self, batched_inputs):
+        """[ref: customized_detectors/fcos.py:36-63]"""
+        images = self.preprocess_image(batched_inputs)
+        raw_features = self.raw_backbone(images.tensor)
+        features = self.fpn(raw_features)
+        features = [features[f] for f in self.in_features]
+        shifts, box_cls, box_delta, box_center = self.predict(features)
+        features = dict(zip(self.in_features, features))
+        if self.training:
+            assert "instances" in batched_inputs[0], "Instance annotations are missing in training!"
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+            gt = self.get_ground_truth(shifts, gt_instances)
+            losses = self.losses(*gt, box_cls, box_delta, box_center)
+            return losses, raw_features, features, images, gt
+        results = self.inference(box_cls, box_delta, box_center, shifts, images)
+        return self.get_processed_results(results, batched_inputs, images), raw_features, features, images
+
+    @torch.no_grad()
+    def inference(self, box_cls, box_delta, box_center, shifts, images):
+        """[ref: thirdparty_heads/fcos.py:286-394] score = sqrt(cls * centerness), top-k per level, NMS."""
+        from ..structures import Boxes, Instances
+        results = []
+        for i, size in enumerate(images.image_sizes):
+            bs, ss, cs = [], [], []
+            for cl, dl, ce, sh in zip(box_cls, box_delta, box_center, shifts):
+                K = self.num_classes
+                sc = (cl[i].permute(1, 2, 0).reshape(-1, K).sigmoid() * ce[i].permute(1, 2, 0).reshape(-1, 1).sigmoid()).flatten()
+                k = min(self.topk_candidates, sc.numel())
+                sc, idx = sc.sort(descending=True)
+                sc, idx = sc[:k], idx[:k]
+                keep = sc > self.score_threshold
+                sc, idx = sc[keep], idx[keep]
+                pos, c = idx // K, idx % K
+                d = dl[i].permute(1, 2, 0).reshape(-1, 4)[pos]
+                p = sh[pos]
+                bs.append(torch.cat((p - d[:, :2], p + d[:, 2:]), 1))
+                ss.append(torch.sqrt(sc))
+                cs.append(c)
+            b, s, c = torch.cat(bs), torch.cat(ss), torch.cat(cs)
+            keep = batched_nms(b, s, c, self.nms_threshold)[:self.max_detections_per_image]
+            results.append(Instances(size, pred_boxes=Boxes(b[keep]), scores=s[keep], pred_classes=c[keep]))
+        return results
+
+    def get_processed_results(self, results, batched_inputs, images):
+        from ..structures import Boxes, Instances
+        out = []
+        for r, inp, size in zip(results, batched_inputs, images.image_sizes):
+            h, w = inp.get("height", size[0]), inp.get("width", size[1])
+            sx, sy = w / size[1], h / size[0]
+            b = r.pred_boxes.tensor * torch.tensor([sx, sy, sx, sy], device=r.pred_boxes.tensor.device)
+            out.append({"instances": Instances((h, w), pred_boxes=Boxes(b), scores=r.scores, pred_classes=r.pred_classes)})
+        return out

@@ -1,0 +1,58 @@
+"""FPN with LastLevelP6P7, detectron2 names (`fpn_lateral3`, `fpn_output5`, `top_block.p6`)
+[d2-memory: detectron2/modeling/backbone/fpn.py @ v0.3].  `forward` takes the bottom-up feature
+dict: the reference replaces `fpn.bottom_up` by an identity nn.Sequential() and feeds it the raw
+ResNet features (models/customized_detectors/retinanet.py:29-34,52-53)."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class LastLevelP6P7(nn.Module):
+    def __init__(self, cin, cout, in_feature="res5"):
+        super().__init__()
+        self.num_levels = 2
+        self.in_feature = in_feature
+        self.p6 = nn.Conv2d(cin, cout, 3, 2, 1)
+        self.p7 = nn.Conv2d(cout, cout, 3, 2, 1)
+        for m in (self.p6, self.p7):
+            nn.init.kaiming_uniform_(m.weight, a=1)
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, c5):
+        p6 = self.p6(c5)
+        return [p6, self.p7(F.relu(p6))]
+
+
+class FPN(nn.Module):
+    def __init__(self, bottom_up, in_features, in_channels, out_channels=256, top_block=None):
+        super().__init__()
+        self.bottom_up = bottom_up
+        self.in_features = tuple(in_features)
+        self.stages = []
+        for f, c in zip(in_features, in_channels):
+            idx = int(f[3:]) if f.startswith("res") else int(f[-1])
+            lat = nn.Conv2d(c, out_channels, 1)
+            out = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+            for m in (lat, out):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+            self.add_module("fpn_lateral%d" % idx, lat)
+            self.add_module("fpn_output%d" % idx, out)
+            self.stages.append(idx)
+        self.top_block = top_block
+        self.size_divisibility = 32
+        self.out_features = ["p%d" % i for i in self.stages] + \
+            (["p%d" % (self.stages[-1] + 1 + k) for k in range(top_block.num_levels)] if top_block else [])
+
+    def forward(self, x):
+        feats = self.bottom_up(x)
+        results = []
+        prev = None
+        for f, idx in zip(reversed(self.in_features), reversed(self.stages)):
+            lat = getattr(self, "fpn_lateral%d" % idx)(feats[f])
+            if prev is not None:
+                lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
+            prev = lat
+            results.insert(0, getattr(self, "fpn_output%d" % idx)(prev))
+        if self.top_block is not None:
+            results.extend(self.top_block(feats[self.top_block.in_feature]))
+        return dict(zip(self.out_features, results))

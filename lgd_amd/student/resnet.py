@@ -1,0 +1,118 @@
+"""ResNet-50/101 bottom-up backbone with FrozenBN, detectron2 parameter names
+(`stem.conv1.weight`, `res3.0.conv2.norm.running_var`, `res4.5.shortcut.weight`, ...)
+[d2-memory: detectron2/modeling/backbone/resnet.py @ v0.3; SURVEY.md appendix A]."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """y = x * w * rsqrt(var + eps) + (b - mean * w * rsqrt(var + eps)); all four are buffers."""
+
+    def __init__(self, c, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(c))
+        self.register_buffer("bias", torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c) - eps)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.scale_shift()
+        return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+
+
+class ConvBN(nn.Conv2d):
+    """bias-free conv followed by FrozenBN [+ReLU].  The frozen affine is folded into the conv
+    (scaled weights + bias) so no separate normalisation pass touches the activation."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, groups=1):
+        super().__init__(cin, cout, k, stride, padding, dilation, groups, bias=False)
+        self.norm = FrozenBatchNorm2d(cout)
+
+    def forward(self, x, relu=False):
+        scale, shift = self.norm.scale_shift()
+        y = F.conv2d(x, self.weight * scale.view(-1, 1, 1, 1), shift, self.stride, self.padding, self.dilation, self.groups)
+        return F.relu_(y) if relu else y
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, cout, mid, stride, stride_in_1x1=True, groups=1, dilation=1):
+        super().__init__()
+        self.shortcut = ConvBN(cin, cout, 1, stride) if (cin != cout or stride != 1) else None
+        s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = ConvBN(cin, mid, 1, s1)
+        self.conv2 = ConvBN(mid, mid, 3, s3, padding=dilation, dilation=dilation, groups=groups)
+        self.conv3 = ConvBN(mid, cout, 1)
+
+    def forward(self, x):
+        out = self.conv1(x, relu=True)
+        out = self.conv2(out, relu=True)
+        out = self.conv3(out)
+        sc = self.shortcut(x) if self.shortcut is not None else x
+        return F.relu_(out + sc)
+
+
+class Stem(nn.Module):
+    def __init__(self, cin=3, cout=64):
+        super().__init__()
+        self.conv1 = ConvBN(cin, cout, 7, 2, 3)
+
+    def forward(self, x):
+        return F.max_pool2d(self.conv1(x, relu=True), 3, 2, 1)
+
+
+class ResNet(nn.Module):
+    """returns {"res3","res4","res5"} (strides 8/16/32; 512/1024/2048 channels)."""
+    BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth=50, out_features=("res3", "res4", "res5"), freeze_at=2, stride_in_1x1=True,
+                 num_groups=1, width_per_group=64, res2_out=256, stem_out=64):
+        super().__init__()
+        self.stem = Stem(3, stem_out)
+        self.out_features = tuple(out_features)
+        cin, cout, mid = stem_out, res2_out, num_groups * width_per_group
+        self.stage_names = []
+        for i, n in enumerate(self.BLOCKS[depth]):
+            blocks = []
+            for j in range(n):
+                stride = 2 if (j == 0 and i > 0) else 1
+                blocks.append(Bottleneck(cin, cout, mid, stride, stride_in_1x1, num_groups))
+                cin = cout
+            name = "res%d" % (i + 2)
+            self.add_module(name, nn.Sequential(*blocks))
+            self.stage_names.append(name)
+            cout, mid = cout * 2, mid * 2
+        self.out_channels = {"res2": res2_out, "res3": res2_out * 2, "res4": res2_out * 4, "res5": res2_out * 8}
+        self.freeze_at = freeze_at
+        self.freeze(freeze_at)
+
+    def freeze(self, freeze_at):
+        """FREEZE_AT=k: stem and res2..res(k) get requires_grad=False [d2-memory: ResNet.freeze]."""
+        if freeze_at >= 1:
+            for p in self.stem.parameters():
+                p.requires_grad = False
+        for idx, name in enumerate(self.stage_names, start=2):
+            if freeze_at >= idx:
+                for p in getattr(self, name).parameters():
+                    p.requires_grad = False
+
+    def forward(self, x):
+        outs = {}
+        # frozen prefix: no autograd graph, nothing saved for backward
+        frozen = torch.no_grad() if self.freeze_at >= 1 else torch.enable_grad()
+        with frozen:
+            x = self.stem(x)
+        for idx, name in enumerate(self.stage_names, start=2):
+            if self.freeze_at >= idx:
+                with torch.no_grad():
+                    x = getattr(self, name)(x)
+            else:
+                x = getattr(self, name)(x)
+            if name in self.out_features:
+                outs[name] = x
+        return outs

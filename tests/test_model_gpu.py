@@ -1,0 +1,157 @@
+"""GPU parity of the PRODUCT modules (lgd_amd.DynamicTeacher / BaseDistillator.distill / meta-archs) against
+the reference golden vectors and the CPU oracle.  Bar: 1e-4 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import common as cm
+from lgd_amd import synth
+from oracle import lgd_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+
+
+def _cfg(ctx, interact, fmt, coef=1.0, student="RetinaNetCT", meta="RetinaNet"):
+    from lgd_amd import config
+    return config.setup_cfg(None, [
+        "MODEL.DEVICE", DEV, "MODEL.META_ARCHITECTURE", meta,
+        "MODEL.DISTILLATOR.STUDENT.META_ARCH", student, "MODEL.DISTILLATOR.TEACHER.META_ARCH", "DynamicTeacher",
+        "MODEL.DISTILLATOR.TEACHER.ADD_CONTEXT_BOX", str(ctx), "MODEL.DISTILLATOR.TEACHER.INTERACT_PATTERN", interact,
+        "MODEL.DISTILLATOR.LABEL_ENCODER.BOX_FORMAT", fmt, "MODEL.DISTILLATOR.LAMBDA", str(coef)])
+
+
+def _batched_inputs(gt, H, W):
+    from lgd_amd.structures import Boxes, Instances
+    return [{"image": torch.zeros(3, H, W), "instances": Instances((H, W), gt_boxes=Boxes(b.clone()), gt_classes=c.clone())}
+            for b, c in gt]
+
+
+def _teacher(name):
+    from lgd_amd.dynamic_teacher import DynamicTeacher
+    B, H, W, ctx, interact, fmt, coef, _ = cm.CASES[name]
+    t = DynamicTeacher(_cfg(ctx, interact, fmt, coef))
+    # strict load under the REFERENCE's state_dict names (tests/golden/make_golden.py loads the same dict into the reference)
+    missing, unexpected = t.load_state_dict({k: v for k, v in cm.teacher_params().items()}, strict=True)
+    assert not missing and not unexpected
+    return t.to(DEV).train()
+
+
+@pytest.fixture(scope="module", params=list(cm.CASES))
+def run(request):
+    from lgd_amd.structures import ImageList
+    name = request.param
+    B, H, W, ctx, interact, fmt, coef, _ = cm.CASES[name]
+    teacher = _teacher(name)
+    feats = {k: v.to(DEV).requires_grad_(True) for k, v in cm.case_feats(name).items()}
+    images = ImageList(torch.zeros(B, 3, H, W, device=DEV), [(H, W)] * B)
+    bi = _batched_inputs(cm.case_gt(name), H, W)
+    cap = {}
+    h = teacher.label_encoder_.register_forward_hook(lambda m, i, o: cap.__setitem__("le", o))
+    tea, inst_labels, geom = teacher((bi, images, None, feats))
+    h.remove()
+    return dict(name=name, g=cm.golden(name), teacher=teacher, feats=feats, tea=tea, geom=geom, le=cap["le"], coef=coef,
+                inst_labels=inst_labels)
+
+
+def test_label_encoder_and_geometry(run):
+    g = run["g"]
+    embed, m1, m2, boxes, _, _, counts = run["le"]
+    assert np.array_equal(np.array(counts, np.int32), g["counts"])
+    assert np.array_equal(boxes.cpu().double().numpy(), g["boxlists"])  # clamped boxes: bit-exact
+    assert cm.rel_err(embed, g["label_embed"]) < TOL
+    assert cm.rel_err(m1.reshape(-1)[::cm.SAMPLE_STRIDE], g["stn_desc_sample"]) < TOL
+    rects = run["geom"].rects().cpu().numpy()
+    for i, k in enumerate(O.LEVELS):
+        ref = g["rects_" + k].copy()
+        ref[(ref[:, 0] > ref[:, 1]) | (ref[:, 2] > ref[:, 3])] = [0, -1, 0, -1]
+        assert np.array_equal(rects[i], ref), k
+    lab = torch.cat([l.reshape(-1) for l in run["inst_labels"]]).cpu().numpy().astype(np.int64)
+    assert np.array_equal(lab, g["inst_labels"])
+
+
+def test_teacher_features_match_reference(run):
+    g, tea = run["g"], run["tea"]
+    for k in O.LEVELS:
+        s, _, sq = cm.sample(tea[k])
+        assert cm.rel_err(s, g["tea_s_" + k]) < TOL, k
+        assert abs(sq - float(g["tea_sq_" + k])) / float(g["tea_sq_" + k]) < 2 * TOL, k
+        if k in ("p6", "p7"):
+            assert cm.rel_err(tea[k], g["tea_full_" + k]) < TOL, k
+
+
+def test_distill_loss_and_grads_match_reference(run):
+    g = run["g"]
+    if "total_loss" not in g:
+        pytest.skip("case stored without grads")
+    from lgd_amd.adapters import SequentialConvs
+    from lgd_amd.base_distillator import BaseDistillator
+
+    class D(BaseDistillator):  # distill() only needs coef / adapter / distill_flag
+        def __init__(self, coef):
+            torch.nn.Module.__init__(self)
+            self.coef = coef
+            self.adapter = torch.nn.ModuleDict({"distill": SequentialConvs(None)})
+    d = D(run["coef"])
+    d.adapter["distill"].load_state_dict(cm.adapter_params(), strict=True)
+    d.to(DEV)
+    tea, feats, teacher = run["tea"], run["feats"], run["teacher"]
+    for flag in (0, 1):
+        d.distill_flag = flag
+        loss = d.distill({"stu": feats, "tea": tea}, None, None, None, None)
+        ref = float(g["loss_distill_flag%d" % flag])
+        assert abs(loss.item() - ref) / ref < TOL
+    pr = cm.probes({k: tea[k] for k in O.LEVELS})
+    total = loss + sum((tea[k] * pr[k].to(DEV)).sum() for k in O.LEVELS)
+    assert abs(total.item() - float(g["total_loss"])) < TOL * abs(float(g["total_loss"])) + 1e-6
+    total.backward()
+    for k in O.LEVELS:
+        s, _, sq = cm.sample(feats[k].grad)
+        assert cm.rel_err(s, g["gfeat_s_" + k]) < 5e-4, k
+    named = list(teacher.named_parameters()) + [("adapter." + n, p) for n, p in d.adapter["distill"].named_parameters()]
+    for n, prm in named:
+        if "gnone_" + n in g:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n
+            continue
+        s, _, sq = cm.sample(prm.grad)
+        ref_sq = float(g["gw_sq_" + n])
+        assert abs(sq - ref_sq) <= 5e-3 * ref_sq + 1e-12, n
+        assert np.abs(s[:64] - g["gw_s_" + n]).max() <= 5e-3 * np.abs(g["gw_s_" + n]).max() + 1e-7, n
+
+
+@pytest.mark.parametrize("yaml_name,keys", [
+    ("lgd_retinanet_r50", {"loss_cls", "loss_box_reg", "loss_cls.tea", "loss_box_reg.tea", "loss_distill"}),
+    ("lgd_fcos_r50", {"loss_cls", "loss_box_reg", "loss_centerness", "loss_cls.tea", "loss_box_reg.tea",
+                      "loss_centerness.tea", "loss_distill"}),
+])
+def test_meta_arch_train_step(yaml_name, keys):
+    """one full training iteration (both optimizers) on a small synthetic batch; loss keys as in the reference
+    [ref: distillator.py:66-68,110-112,292-295]."""
+    import os
+    from lgd_amd import config
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", yaml_name + ".yaml"), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    tr = Trainer(cfg, model)
+    data = synthetic_batch(2, 256, 320, 5, seed=1)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    for it in (0, 25000, 40000):  # frozen-backbone phase, non-distill phase, distill phase
+        losses = tr.step(data, it)
+        assert set(losses) == keys
+    m = tr.fetch_metrics()
+    assert all(np.isfinite(v) for v in m.values()), m
+    changed = {n for n, p in model.named_parameters() if not torch.equal(p, before[n])}
+    assert any(n.startswith("teacher.") for n in changed)
+    assert any(n.startswith("adapter.") for n in changed)
+    assert any(n.startswith("student.raw_backbone.res5") for n in changed)
+    assert not any(n.startswith("student.raw_backbone.stem") or n.startswith("student.raw_backbone.res2") for n in changed)
+    # eval branch (incl. teacher upper-bound probe) runs and returns one result per image
+    model.eval()
+    with torch.no_grad():
+        out = model(data, eval_teacher=True)
+    assert len(out) == 2 and "instances" in out[0]
