@@ -145,7 +145,7 @@ def stn_forward(p, prefix, x, k):
 def label_encoder_forward(p, descs, return_all=False):
     """label_encoder.py:216-276 with R=1, noise 0.  descs: list B x (Ni,84) -> (T,256)."""
     counts = [int(d.shape[0]) for d in descs]
-    x = torch.cat(descs, 0)  # (T,84)
+    x = torch.cat(descs, 0).to(p["label_encoder_.conv1.weight"].dtype)  # (T,84)
     k = x.shape[1]
     pre = "label_encoder_."
     m1 = stn_forward(p, pre + "stn_desc.", x, k)
@@ -190,7 +190,6 @@ def box_rects(boxlist, src_hw, dst_hw):
     true-set is one interval; this is what the HIP box-prep kernel emits.
     """
     n = len(boxlist)
-    m = inside_box_mask(boxlist, src_hw, dst_hw).reshape(n, dst_hw[0], dst_hw[1]) > 0
     out = np.zeros((n, 4), np.int32)
     bt = torch.tensor(boxlist, dtype=torch.float32).reshape(-1, 4)
     r_h, r_w = dst_hw[0] / src_hw[0], dst_hw[1] / src_hw[1]
@@ -209,7 +208,6 @@ def box_rects(boxlist, src_hw, dst_hw):
             assert len(xs) == int(xs[-1]) - int(xs[0]) + 1
         if len(ys):
             assert len(ys) == int(ys[-1]) - int(ys[0]) + 1
-    del m
     return out
 
 
@@ -219,8 +217,9 @@ def mask_pool(feat, masks):
     flat = feat.flatten(2)
     out = []
     for b, m in enumerate(masks):
+        m = m.to(feat.dtype)  # fp64 "truth" runs reuse the fp32-exact masks
         pooled = m @ flat[b].T
-        cnt = torch.maximum(m.sum(-1), torch.ones(()))
+        cnt = torch.maximum(m.sum(-1), torch.ones((), dtype=feat.dtype))
         out.append(pooled / cnt[:, None])
     return torch.cat(out, 0)
 
@@ -238,7 +237,7 @@ def mha_blockdiag(p, q_in, kv_in, counts, heads=8):
     v = F.linear(kv_in, w[2 * E:], bias[2 * E:])
     T = q.shape[0]
     img = torch.repeat_interleave(torch.arange(len(counts)), torch.tensor(counts))
-    blocked = img[:, None] != img[None, :]
+    blocked = (img[:, None] != img[None, :]).to(q.device)
     qh = q.view(T, heads, d).transpose(0, 1)
     kh = k.view(T, heads, d).transpose(0, 1)
     vh = v.view(T, heads, d).transpose(0, 1)
@@ -262,7 +261,7 @@ def render(p, attn_out, masks, counts, hw, add_ctx):
         inst = rows[b][:-1] if add_ctx else rows[b]
         m = masks[b][:-1] if add_ctx else masks[b]
         proj = F.linear(inst, p["local_inst_proj_1D.weight"], p["local_inst_proj_1D.bias"])
-        painted.append(proj.T @ m)  # (C,HW): per-pixel SUM over covering boxes
+        painted.append(proj.T @ m.to(proj.dtype))  # (C,HW): per-pixel SUM over covering boxes
     fmap = torch.cat(painted, 0).reshape(B, -1, hw[0], hw[1])
     fmap = F.conv2d(fmap, p["local_inst_proj_2D.weight"], p["local_inst_proj_2D.bias"], padding=1)
     if add_ctx:
@@ -287,7 +286,7 @@ def teacher_forward(p, feats, gt, img_hw, add_ctx=True, interact="stuGuided", de
     """dynamic_teacher.py:209-301.  feats: dict p3..p7 of (B,C,H,W); gt as encode_box_descriptors.
     Returns (teacher feature dict, inst_labels, masks[level][image])."""
     descs, boxlists, inst_labels = encode_box_descriptors(gt, img_hw[0], img_hw[1], add_ctx, box_format)
-    label_embed = label_encoder_forward(p, descs)
+    label_embed = label_encoder_forward(p, [d.to(p["canoni_proj_1D.0.0.weight"].device) for d in descs])
     counts = [len(b) for b in boxlists]
     if detach_app:
         feats = {k: v.detach() for k, v in feats.items()}
@@ -296,7 +295,8 @@ def teacher_forward(p, feats, gt, img_hw, add_ctx=True, interact="stuGuided", de
     proj = {k: F.relu(_gn1(F.conv2d(feats[k], p["student_proj_2D.0.0.weight"], p["student_proj_2D.0.0.bias"],
                                     padding=1))) for k in keys}
     hws = [tuple(feats[k].shape[-2:]) for k in keys]
-    masks = [[inside_box_mask(bl, img_hw, hw) for bl in boxlists] for hw in hws]
+    dev = feats[keys[0]].device  # (the oracle also runs on a GPU for diagnostics; masks are always built on the CPU)
+    masks = [[inside_box_mask(bl, img_hw, hw).to(dev) for bl in boxlists] for hw in hws]
     app = [mask_pool(proj[k], masks[i]) for i, k in enumerate(keys)]
     if interact == "stuGuided":
         att = [mha_blockdiag(p, a, canoni, counts) for a in app]

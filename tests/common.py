@@ -68,3 +68,21 @@ def rel_err(a, b):
 def sample(t):
     f = t.detach().reshape(-1).double().cpu()
     return f[::SAMPLE_STRIDE].float().numpy(), float(f.sum()), float((f * f).sum())
+
+
+def kink_robust_close(a, b, tol=1e-4, max_outlier_frac=5e-4, max_rel=2e-2):
+    """Gradient comparison that tolerates ReLU-kink flips.
+
+    Backward masks are `activation > 0`; forward values that differ in the last ulp between two
+    fp32 platforms (MKL vs MIOpen/rocBLAS summation order) flip the mask of the few activations that
+    sit within an ulp of zero, which changes isolated gradient elements by O(1) while everything else
+    agrees to ~1e-6 (measured on MI355X: oracle-on-GPU vs oracle-on-CPU, identical torch ops, shows
+    1e-3 relative L2 on exactly the levels where a flip happened and 1e-6 elsewhere).  So: all but a
+    tiny fraction of elements must agree to `tol` (relative to the tensor's RMS), and the whole tensor
+    to `max_rel`.  Returns (ok, message)."""
+    a = torch.as_tensor(a).detach().cpu().double().reshape(-1)
+    b = torch.as_tensor(b).detach().cpu().double().reshape(-1)
+    rms = float(b.pow(2).mean().sqrt()) + 1e-30
+    bad = ((a - b).abs() > tol * (b.abs() + rms)).double().mean().item()
+    rel = float((a - b).norm() / (b.norm() + 1e-30))
+    return (bad <= max_outlier_frac and rel <= max_rel), "outlier frac %.2e (max %.0e), rel L2 %.2e (max %.0e)" % (bad, max_outlier_frac, rel, max_rel)

@@ -108,7 +108,8 @@ def test_distill_loss_and_grads_match_reference(run):
     total.backward()
     for k in O.LEVELS:
         s, _, sq = cm.sample(feats[k].grad)
-        assert cm.rel_err(s, g["gfeat_s_" + k]) < 5e-4, k
+        ok, msg = cm.kink_robust_close(s, g["gfeat_s_" + k])
+        assert ok, "%s: %s" % (k, msg)
     named = list(teacher.named_parameters()) + [("adapter." + n, p) for n, p in d.adapter["distill"].named_parameters()]
     for n, prm in named:
         if "gnone_" + n in g:
