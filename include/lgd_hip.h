@@ -107,6 +107,31 @@ int lgd_distill_bwd(const float* const* a_host, const float* const* b_host, cons
                     int L, int B, int C, float coef, const float* stats, const float* grad_loss,
                     float* const* grad_a_host, void* stream);
 
+/* ------------------------------------------------------------------ K5: GroupNorm(1 group, no affine) [+ReLU]
+ * [ref: dynamic_teacher/layers.py:6-7 get_norm, 22-32 get_CONVS; dynamic_teacher.py:57 student_proj_2D,
+ *  67-73 refinement_module]  y = (x - mean_b) * rsqrt(var_b + 1e-5) over each sample's C*H*W elements
+ * (biased variance), optionally followed by ReLU; all pyramid levels in one call.
+ *   ws    : fp64 workspace, lgd_gn1_ws_doubles(...) entries (shared by fwd and bwd)
+ *   stats : fp32 [L*B][2] (mean, rstd), written by fwd, read by bwd
+ *   bstats: fp32 [L*B][2] scratch of the backward (mean(g), mean(g*xhat))
+ * backward: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy * [y > 0] when relu.
+ */
+size_t lgd_gn1_ws_doubles(const int32_t* level_hw_host, int L, int B, int C);
+int lgd_gn1_fwd(const float* const* x_host, const int32_t* level_hw_host, int L, int B, int C, int relu,
+                double* ws, float* stats, float* const* y_host, void* stream);
+int lgd_gn1_bwd(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L,
+                int B, int C, int relu, const float* stats, double* ws, float* bstats,
+                float* const* dx_host, void* stream);
+
+/* ------------------------------------------------------------------ K3b: ReLU(x + ctx[b,c]) epilogue of the rendering
+ * [ref: dynamic_teacher.py:151  F.relu(inst_featmap + ctx_feature[:, :, None, None])]
+ * ctx / dctx: [L][B][C].  backward takes the saved OUTPUT y: dx = dy * [y > 0], dctx = sum_hw dx.
+ */
+int lgd_ctx_relu_fwd(const float* const* x_host, const float* ctx, const int32_t* level_hw_host, int L, int B,
+                     int C, float* const* y_host, void* stream);
+int lgd_ctx_relu_bwd(const float* const* y_host, const float* const* dy_host, const int32_t* level_hw_host,
+                     int L, int B, int C, float* const* dx_host, float* dctx, void* stream);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench.py)
  * When enabled every kernel launch of this library is bracketed by a HIP event pair recorded on
  * the launch stream.  lgd_timing_collect waits for the recorded events, sums the elapsed time per

@@ -215,14 +215,15 @@ class DynamicTeacher(nn.Module):
             last = torch.tensor([o - 1 for o in _offsets(geom.counts)[1:]], dtype=torch.int64).to(attn_out.device,
                                                                                                 non_blocking=True)
             ctx = self.global_ctx_proj_1D(attn_out[:, last])  # (L,B,C)
-            return [ops.bias_ctx_relu(F.conv2d(p, conv.weight, conv.bias, padding=1), ctx[i]) for i, p in enumerate(painted)]
+            return ops.bias_ctx_relu([F.conv2d(p, conv.weight, conv.bias, padding=1) for p in painted], ctx)
         return [F.relu(F.conv2d(p, conv.weight, conv.bias, padding=1)) for p in painted]
 
-    def refine(self, x):
+    def refine(self, xs):
+        """[ref: dynamic_teacher.py:67-73,280-281] on all levels: conv (MIOpen) per level, GN(1)[+ReLU] in one HIP call."""
         m = self.refinement_module
-        x = ops.gn1(F.conv2d(x, m[0].weight, m[0].bias, padding=1), relu=True)
-        x = ops.gn1(F.conv2d(x, m[3].weight, m[3].bias, padding=1), relu=True)
-        return ops.gn1(F.conv2d(x, m[6].weight, m[6].bias, padding=1), relu=False)
+        for idx, relu in ((0, True), (3, True), (6, False)):
+            xs = ops.gn1([F.conv2d(x, m[idx].weight, m[idx].bias, padding=1) for x in xs], relu=relu)
+        return xs
 
     def interactive_remapping(self, label_embed, boxes, counts, feats, img_size_dict):
         """[ref: dynamic_teacher.py:209-283]"""
@@ -231,7 +232,7 @@ class DynamicTeacher(nn.Module):
         keys = list(feats.keys())
         canoni = F.relu(_ln(self.canoni_proj_1D[0][0](label_embed)))
         sp = self.student_proj_2D[0][0]
-        proj = [ops.gn1(F.conv2d(feats[k], sp.weight, sp.bias, padding=1), relu=True) for k in keys]
+        proj = ops.gn1([F.conv2d(feats[k], sp.weight, sp.bias, padding=1) for k in keys], relu=True)
         geom = ops.BoxGeometry(boxes, counts, (img_size_dict["h"], img_size_dict["w"]),
                                [tuple(feats[k].shape[-2:]) for k in keys])
         app = ops.mask_pool(geom, proj)  # (L,T,C) appearance embeddings
@@ -246,8 +247,7 @@ class DynamicTeacher(nn.Module):
         else:  # labelGuided: Q = label embeddings, K = V = appearance
             att = ops.mha_blockdiag(canoni.unsqueeze(0), app, counts, a.in_proj_weight, a.in_proj_bias,
                                     a.out_proj.weight, a.out_proj.bias, self.nr_transformer_heads)
-        raw = self.rendering(att, geom)
-        tea = {k: self.refine(raw[i]) for i, k in enumerate(keys)}
+        tea = dict(zip(keys, self.refine(self.rendering(att, geom))))
         return tea, geom
 
     def forward(self, info_list):

@@ -35,6 +35,11 @@ SIGNATURES = {
     "lgd_distill_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
     "lgd_distill_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
     "lgd_distill_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gn1_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
+    "lgd_gn1_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gn1_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_ctx_relu_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_ctx_relu_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_timing_enable": (c_i, [c_i]),
     "lgd_timing_collect": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_i]),
 }

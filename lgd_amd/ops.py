@@ -205,15 +205,87 @@ def segment_max_broadcast(x, counts):
     return g[seg]
 
 
-def gn1(x, relu):
-    """GroupNorm(num_groups=1, affine=False, eps=1e-5) [+ ReLU]  [ref: layers.py:6-7, 22-32]"""
-    y = F.group_norm(x, 1, eps=1e-5)
-    return F.relu(y) if relu else y
+def _levels_meta(maps):
+    B, C = maps[0].shape[0], maps[0].shape[1]
+    for m in maps:
+        if m.dim() != 4 or m.shape[0] != B or m.shape[1] != C:
+            raise hip.LgdHipError("pyramid levels must share (B, C); got %s" % [tuple(x.shape) for x in maps])
+    return B, C, hip.int_array([v for m in maps for v in m.shape[-2:]])
 
 
-def bias_ctx_relu(x, ctx):
-    """ReLU(x + ctx[:, :, None, None])  [ref: dynamic_teacher.py:151]"""
-    return F.relu(x + ctx[:, :, None, None])
+class _Gn1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, relu, *xs):
+        lib = hip.load()
+        hip.require_gpu(*xs)
+        xs = [hip.dense_f32(x) for x in xs]
+        L = len(xs)
+        B, C, hw = _levels_meta(xs)
+        dev = xs[0].device
+        ws = torch.empty(lib.lgd_gn1_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)
+        stats = torch.empty((L * B, 2), dtype=torch.float32, device=dev)
+        ys = [torch.empty_like(x) for x in xs]
+        hip.check(lib.lgd_gn1_fwd(hip.ptr_array(xs), hw, L, B, C, int(relu), hip.ptr(ws), hip.ptr(stats),
+                                  hip.ptr_array(ys), hip.stream_ptr()), "lgd_gn1_fwd")
+        ctx.save_for_backward(stats, *xs)
+        ctx.meta = (bool(relu), L, B, C, hw)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = hip.load()
+        relu, L, B, C, hw = ctx.meta
+        stats, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dys = [hip.dense_f32(d) for d in dys]
+        dev = xs[0].device
+        ws = torch.empty(lib.lgd_gn1_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)
+        bstats = torch.empty((L * B, 2), dtype=torch.float32, device=dev)
+        dxs = [torch.empty_like(x) for x in xs]
+        hip.check(lib.lgd_gn1_bwd(hip.ptr_array(xs), hip.ptr_array(dys), hw, L, B, C, int(relu), hip.ptr(stats), hip.ptr(ws),
+                                  hip.ptr(bstats), hip.ptr_array(dxs), hip.stream_ptr()), "lgd_gn1_bwd")
+        return (None, *dxs)
+
+
+def gn1(xs, relu):
+    """GroupNorm(num_groups=1, affine=False, eps=1e-5) [+ ReLU] on every pyramid level in one call.
+    xs: list of (B,C,H_l,W_l) -> list.  [ref: layers.py:6-7, 22-32]"""
+    return list(_Gn1.apply(bool(relu), *xs))
+
+
+class _CtxRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cvec, *xs):
+        lib = hip.load()
+        hip.require_gpu(cvec, *xs)
+        xs = [hip.dense_f32(x) for x in xs]
+        L = len(xs)
+        B, C, hw = _levels_meta(xs)
+        cvec = hip.dense_f32(cvec)
+        if tuple(cvec.shape) != (L, B, C):
+            raise hip.LgdHipError("ctx must be (L,B,C)=(%d,%d,%d), got %s" % (L, B, C, tuple(cvec.shape)))
+        ys = [torch.empty_like(x) for x in xs]
+        hip.check(lib.lgd_ctx_relu_fwd(hip.ptr_array(xs), hip.ptr(cvec), hw, L, B, C, hip.ptr_array(ys), hip.stream_ptr()),
+                  "lgd_ctx_relu_fwd")
+        ctx.save_for_backward(*ys)
+        ctx.meta = (L, B, C, hw)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = hip.load()
+        L, B, C, hw = ctx.meta
+        ys = ctx.saved_tensors
+        dys = [hip.dense_f32(d) for d in dys]
+        dxs = [torch.empty_like(y) for y in ys]
+        dctx = torch.empty((L, B, C), dtype=torch.float32, device=ys[0].device)
+        hip.check(lib.lgd_ctx_relu_bwd(hip.ptr_array(ys), hip.ptr_array(dys), hw, L, B, C, hip.ptr_array(dxs), hip.ptr(dctx),
+                                       hip.stream_ptr()), "lgd_ctx_relu_bwd")
+        return (dctx, *dxs)
+
+
+def bias_ctx_relu(xs, ctx):
+    """ReLU(x_l + ctx[l][:, :, None, None]) for every level; ctx (L,B,C).  [ref: dynamic_teacher.py:151]"""
+    return list(_CtxRelu.apply(ctx, *xs))
 
 
 def mha_blockdiag(q_in, kv_in, counts, in_w, in_b, out_w, out_b, heads):

@@ -214,3 +214,64 @@ def test_distill_large_mean_small_variance():
     loss = ops.distill_in_mse([x.to(DEV)], [y.to(DEV)], 1.0)
     ref = O.in_mse([x.double()], [y.double()], 1.0)
     assert abs(loss.item() - ref.item()) / ref.item() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- GN(1) / epilogue
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("shapes", [[(2, 256, 64, 64), (2, 256, 32, 32), (2, 256, 4, 4)], [(3, 8, 25, 41), (3, 8, 13, 21)],
+                                    [(1, 256, 100, 168)]])
+def test_gn1_fwd_bwd(shapes, relu):
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    xs = [torch.from_numpy(synth.det_uniform(s, 300 + i)) * (1.0 + i) + 0.3 * i for i, s in enumerate(shapes)]
+    xg = [x.to(DEV).requires_grad_(True) for x in xs]
+    ys = ops.gn1(xg, relu)
+    xc = [x.clone().requires_grad_(True) for x in xs]
+    yr = [F.relu(F.group_norm(x, 1, eps=1e-5)) if relu else F.group_norm(x, 1, eps=1e-5) for x in xc]
+    lg = lc = 0
+    for i, (a, b) in enumerate(zip(ys, yr)):
+        assert cm.rel_err(a, b) < FTOL
+        if relu:
+            assert torch.equal(a.cpu() > 0, b > 0) or cm.rel_err((a.cpu() > 0).float(), (b > 0).float()) < 1e-3
+        pr = torch.from_numpy(synth.det_uniform(tuple(b.shape), 400 + i))
+        lg = lg + (a * pr.to(DEV)).sum()
+        lc = lc + (b * pr).sum()
+    lg.backward()
+    lc.backward()
+    for a, b in zip(xg, xc):
+        ok, msg = cm.kink_robust_close(a.grad, b.grad, tol=1e-4)
+        assert ok, msg
+
+
+def test_gn1_large_mean():
+    from lgd_amd import ops
+    import torch.nn.functional as F
+    x = torch.from_numpy(synth.det_uniform((2, 16, 32, 32), 9)) * 0.01 + 100.0
+    y = ops.gn1([x.to(DEV)], False)[0]
+    assert cm.rel_err(y, F.group_norm(x.double(), 1, eps=1e-5)) < 2e-3  # fp32 input resolution at |mean|/std = 1e4
+
+
+@pytest.mark.parametrize("shapes", [[(2, 256, 64, 64), (2, 256, 8, 8)], [(3, 8, 25, 41), (3, 8, 7, 11)]])
+def test_bias_ctx_relu_fwd_bwd(shapes):
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    L, B, C = len(shapes), shapes[0][0], shapes[0][1]
+    xs = [torch.from_numpy(synth.det_uniform(s, 500 + i)) for i, s in enumerate(shapes)]
+    ctx = torch.from_numpy(synth.det_uniform((L, B, C), 77)) * 0.5
+    xg = [x.to(DEV).requires_grad_(True) for x in xs]
+    cg = ctx.to(DEV).requires_grad_(True)
+    ys = ops.bias_ctx_relu(xg, cg)
+    xc = [x.clone().requires_grad_(True) for x in xs]
+    cc = ctx.clone().requires_grad_(True)
+    yr = [F.relu(x + cc[i][:, :, None, None]) for i, x in enumerate(xc)]
+    lg = lc = 0
+    for i, (a, b) in enumerate(zip(ys, yr)):
+        assert torch.equal(a.cpu(), b)
+        pr = torch.from_numpy(synth.det_uniform(tuple(b.shape), 600 + i))
+        lg = lg + (a * pr.to(DEV)).sum()
+        lc = lc + (b * pr).sum()
+    lg.backward()
+    lc.backward()
+    for a, b in zip(xg, xc):
+        assert torch.equal(a.grad.cpu(), b.grad)
+    assert cm.rel_err(cg.grad, cc.grad) < FTOL
