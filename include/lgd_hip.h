@@ -132,6 +132,38 @@ int lgd_ctx_relu_fwd(const float* const* x_host, const float* ctx, const int32_t
 int lgd_ctx_relu_bwd(const float* const* y_host, const float* const* dy_host, const int32_t* level_hw_host,
                      int L, int B, int C, float* const* dx_host, float* dctx, void* stream);
 
+/* ------------------------------------------------------------------ K2: block-diagonal multi-head cross-attention
+ * [ref: dynamic_teacher.py:76-78 nn.MultiheadAttention(256, 8); 255-273 attn_mask + per-level calls]
+ *
+ * lgd_gemm_batch: up to 6 small fp32 GEMMs in one launch on the MFMA pipe (v_mfma_f32_16x16x4_f32),
+ *   C[m,n] = alpha * (sum_k A(m,k) * B(n,k) + bias[n]),  A(m,k) = A[m*sa_m + k*sa_k], B(n,k) = B[n*sb_n + k*sb_k],
+ *   C at C[m*sc_m + n*sc_n]; rowsum (optional) [M] = alpha * sum_k A(m,k)  (bias gradients).
+ *   Used for the in/out projections [ref: torch MultiheadAttention in_proj_weight (3E,E) / out_proj] and
+ *   their backward products.  The problem array lives in HOST memory.
+ * lgd_attn_fwd: per (image, head) softmax(q k^T) v over the image's own boxes only (the reference's
+ *   (T,T) boolean mask blocks exactly the cross-image pairs).  q is already scaled by 1/sqrt(E/H).
+ *   q (Lq,T,E), k/v (Lk,T,E), Lq == Lk or one of them 1 (operand shared by all levels);
+ *   out (L,T,E), lse (L,T,H) = log-sum-exp of each score row (kept for the backward), L = max(Lq,Lk).
+ * lgd_attn_bwd: dq (Lq,T,E), dk/dv (Lk,T,E); gradients of a shared operand are summed over levels.
+ */
+typedef struct lgd_gemm_problem {
+    const float* A;
+    const float* B;
+    const float* bias;   /* may be NULL */
+    float* C;
+    float* rowsum;       /* may be NULL */
+    int32_t M, N, K, reserved0;
+    int64_t sa_m, sa_k, sb_n, sb_k, sc_m, sc_n;
+    float alpha;
+    int32_t reserved1;
+} lgd_gemm_problem;
+int lgd_gemm_batch(const lgd_gemm_problem* probs_host, int np, void* stream);
+int lgd_attn_fwd(const float* q, const float* k, const float* v, const int32_t* img_off, int Lq, int Lk, int B,
+                 int T, int E, int H, float* out, float* lse, void* stream);
+int lgd_attn_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse,
+                 const float* dout, const int32_t* img_off, int Lq, int Lk, int B, int T, int E, int H,
+                 float* dq, float* dk, float* dv, void* stream);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench.py)
  * When enabled every kernel launch of this library is bracketed by a HIP event pair recorded on
  * the launch stream.  lgd_timing_collect waits for the recorded events, sums the elapsed time per

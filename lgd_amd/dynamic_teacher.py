@@ -130,8 +130,9 @@ class LabelEncoder(nn.Module):
                 if self.add_context_box:
                     rows.append(ctx_row)
                     n += 1
-            else:  # label_encoder.py:64-66
-                rows.append(torch.tensor([[0.0, 0.0, 1.0, 1.0]], device=device))
+            else:  # label_encoder.py:64-66; the substitute box goes through the format conversion too (72-73)
+                unit = [0.0, 0.0, 0.0, 0.0] if self.box_format == "x1y1wh" else [0.0, 0.0, 1.0, 1.0]
+                rows.append(torch.tensor([unit], device=device))
                 inst_labels.append(torch.zeros(1, device=device))
                 n = 1
             counts.append(n)
@@ -243,10 +244,10 @@ class DynamicTeacher(nn.Module):
             att = canoni.unsqueeze(0).expand(len(keys), -1, -1)
         elif self.interact_pattern == "stuGuided":  # Q = appearance, K = V = label embeddings
             att = ops.mha_blockdiag(app, canoni.unsqueeze(0), counts, a.in_proj_weight, a.in_proj_bias,
-                                    a.out_proj.weight, a.out_proj.bias, self.nr_transformer_heads)
+                                    a.out_proj.weight, a.out_proj.bias, self.nr_transformer_heads, geom.img_off)
         else:  # labelGuided: Q = label embeddings, K = V = appearance
             att = ops.mha_blockdiag(canoni.unsqueeze(0), app, counts, a.in_proj_weight, a.in_proj_bias,
-                                    a.out_proj.weight, a.out_proj.bias, self.nr_transformer_heads)
+                                    a.out_proj.weight, a.out_proj.bias, self.nr_transformer_heads, geom.img_off)
         tea = dict(zip(keys, self.refine(self.rendering(att, geom))))
         return tea, geom
 

@@ -40,9 +40,20 @@ SIGNATURES = {
     "lgd_gn1_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_ctx_relu_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_ctx_relu_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_gemm_batch": (c_i, [c_fp, c_i, c_fp]),
+    "lgd_attn_fwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_attn_bwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_timing_enable": (c_i, [c_i]),
     "lgd_timing_collect": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_i]),
 }
+
+
+class GemmProblem(ctypes.Structure):
+    """mirror of `lgd_gemm_problem` (include/lgd_hip.h)."""
+    _fields_ = [("A", c_fp), ("B", c_fp), ("bias", c_fp), ("C", c_fp), ("rowsum", c_fp),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("sa_m", ctypes.c_int64), ("sa_k", ctypes.c_int64), ("sb_n", ctypes.c_int64), ("sb_k", ctypes.c_int64),
+                ("sc_m", ctypes.c_int64), ("sc_n", ctypes.c_int64), ("alpha", ctypes.c_float), ("reserved1", ctypes.c_int32)]
 
 
 class LgdHipError(RuntimeError):

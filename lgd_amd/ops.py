@@ -178,6 +178,7 @@ def distill_in_mse(stu_maps, tea_maps, coef):
 # by HIP kernels (K2 attention, K5 GN(1)+ReLU / bias+ctx+ReLU epilogues, K6 label encoder); their
 # signatures are the kernels' signatures so the modules above do not change.
 # ------------------------------------------------------------------------------------------------
+import ctypes  # noqa: E402
 import math  # noqa: E402
 
 import torch.nn.functional as F  # noqa: E402
@@ -288,25 +289,97 @@ def bias_ctx_relu(xs, ctx):
     return list(_CtxRelu.apply(ctx, *xs))
 
 
-def mha_blockdiag(q_in, kv_in, counts, in_w, in_b, out_w, out_b, heads):
-    """nn.MultiheadAttention(E, heads) forward as called at [ref: dynamic_teacher.py:255-273]:
-    sequence-first, batch 1, boolean mask blocking attention between boxes of different images.
-    q_in (Lq,T,E), kv_in (Lk,T,E) with Lq == Lk or one of them 1 (levels broadcast) -> (max(Lq,Lk),T,E)."""
-    E = q_in.shape[-1]
-    d = E // heads
-    T = q_in.shape[1]
-    q = F.linear(q_in, in_w[:E], in_b[:E]) * (1.0 / math.sqrt(d))
-    k = F.linear(kv_in, in_w[E:2 * E], in_b[E:2 * E])
-    v = F.linear(kv_in, in_w[2 * E:], in_b[2 * E:])
-    seg = segment_ids(counts, q_in.device)
-    blocked = seg[:, None] != seg[None, :]
-    qh = q.view(-1, T, heads, d).transpose(1, 2)
-    kh = k.view(-1, T, heads, d).transpose(1, 2)
-    vh = v.view(-1, T, heads, d).transpose(1, 2)
-    s = torch.matmul(qh, kh.transpose(-1, -2)).masked_fill(blocked, float("-inf"))
-    o = torch.matmul(torch.softmax(s, -1), vh)  # (L,heads,T,d)
-    o = o.transpose(1, 2).reshape(-1, T, E)
-    return F.linear(o, out_w, out_b)
+def _gemm(A, sa, B, sb, C, sc, M, N, K, bias=None, alpha=1.0, rowsum=None):
+    """one lgd_gemm_problem: C[m,n] = alpha*(sum_k A(m,k)B(n,k) + bias[n]); strides in elements; A/B/C are (tensor, offset)."""
+    def addr(t):
+        ten, off = t
+        return ten.data_ptr() + 4 * off
+    return hip.GemmProblem(addr(A), addr(B), addr(bias) if bias is not None else None, addr(C),
+                           addr(rowsum) if rowsum is not None else None, M, N, K, 0,
+                           sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(alpha), 0)
+
+
+def _gemm_batch(problems):
+    arr = (hip.GemmProblem * len(problems))(*problems)
+    hip.check(hip.load().lgd_gemm_batch(ctypes.cast(arr, ctypes.c_void_p), len(problems), hip.stream_ptr()), "lgd_gemm_batch")
+
+
+class _MhaBlockDiag(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q_in, kv_in, in_w, in_b, out_w, out_b, img_off, heads):
+        lib = hip.load()
+        hip.require_gpu(q_in, kv_in, in_w)
+        q_in, kv_in = hip.dense_f32(q_in), hip.dense_f32(kv_in)
+        in_w, in_b, out_w, out_b = (hip.dense_f32(t) for t in (in_w, in_b, out_w, out_b))
+        Lq, T, E = q_in.shape
+        Lk = kv_in.shape[0]
+        L = max(Lq, Lk)
+        B = img_off.numel() - 1
+        scale = 1.0 / math.sqrt(E // heads)
+        dev = q_in.device
+        Q = torch.empty((Lq, T, E), dtype=torch.float32, device=dev)
+        K = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
+        V = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
+        _gemm_batch([
+            _gemm((q_in, 0), (E, 1), (in_w, 0), (E, 1), (Q, 0), (E, 1), Lq * T, E, E, bias=(in_b, 0), alpha=scale),
+            _gemm((kv_in, 0), (E, 1), (in_w, E * E), (E, 1), (K, 0), (E, 1), Lk * T, E, E, bias=(in_b, E)),
+            _gemm((kv_in, 0), (E, 1), (in_w, 2 * E * E), (E, 1), (V, 0), (E, 1), Lk * T, E, E, bias=(in_b, 2 * E)),
+        ])
+        O = torch.empty((L, T, E), dtype=torch.float32, device=dev)
+        lse = torch.empty((L, T, heads), dtype=torch.float32, device=dev)
+        hip.check(lib.lgd_attn_fwd(hip.ptr(Q), hip.ptr(K), hip.ptr(V), hip.ptr(img_off), Lq, Lk, B, T, E, heads, hip.ptr(O),
+                                   hip.ptr(lse), hip.stream_ptr()), "lgd_attn_fwd")
+        out = torch.empty((L, T, E), dtype=torch.float32, device=dev)
+        _gemm_batch([_gemm((O, 0), (E, 1), (out_w, 0), (E, 1), (out, 0), (E, 1), L * T, E, E, bias=(out_b, 0))])
+        ctx.save_for_backward(q_in, kv_in, in_w, out_w, Q, K, V, O, lse, img_off)
+        ctx.meta = (Lq, Lk, L, B, T, E, heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = hip.load()
+        q_in, kv_in, in_w, out_w, Q, K, V, O, lse, img_off = ctx.saved_tensors
+        Lq, Lk, L, B, T, E, heads, scale = ctx.meta
+        dout = hip.dense_f32(dout)
+        dev = dout.device
+        dO = torch.empty((L, T, E), dtype=torch.float32, device=dev)
+        d_out_w = torch.empty((E, E), dtype=torch.float32, device=dev)
+        d_out_b = torch.empty((E,), dtype=torch.float32, device=dev)
+        _gemm_batch([
+            _gemm((dout, 0), (E, 1), (out_w, 0), (1, E), (dO, 0), (E, 1), L * T, E, E),                       # dO = dY Wo
+            _gemm((dout, 0), (1, E), (O, 0), (1, E), (d_out_w, 0), (E, 1), E, E, L * T, rowsum=(d_out_b, 0)),  # dWo = dY^T O
+        ])
+        dQ = torch.empty((Lq, T, E), dtype=torch.float32, device=dev)
+        dK = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
+        dV = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
+        hip.check(lib.lgd_attn_bwd(hip.ptr(Q), hip.ptr(K), hip.ptr(V), hip.ptr(O), hip.ptr(lse), hip.ptr(dO), hip.ptr(img_off),
+                                   Lq, Lk, B, T, E, heads, hip.ptr(dQ), hip.ptr(dK), hip.ptr(dV), hip.stream_ptr()),
+                  "lgd_attn_bwd")
+        d_q_in = torch.empty((Lq, T, E), dtype=torch.float32, device=dev)
+        d_k_in = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
+        d_v_in = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
+        d_in_w = torch.empty((3 * E, E), dtype=torch.float32, device=dev)
+        d_in_b = torch.empty((3 * E,), dtype=torch.float32, device=dev)
+        Mq, Mk = Lq * T, Lk * T
+        _gemm_batch([
+            _gemm((dQ, 0), (E, 1), (in_w, 0), (1, E), (d_q_in, 0), (E, 1), Mq, E, E, alpha=scale),
+            _gemm((dK, 0), (E, 1), (in_w, E * E), (1, E), (d_k_in, 0), (E, 1), Mk, E, E),
+            _gemm((dV, 0), (E, 1), (in_w, 2 * E * E), (1, E), (d_v_in, 0), (E, 1), Mk, E, E),
+            _gemm((dQ, 0), (1, E), (q_in, 0), (1, E), (d_in_w, 0), (E, 1), E, E, Mq, alpha=scale, rowsum=(d_in_b, 0)),
+            _gemm((dK, 0), (1, E), (kv_in, 0), (1, E), (d_in_w, E * E), (E, 1), E, E, Mk, rowsum=(d_in_b, E)),
+            _gemm((dV, 0), (1, E), (kv_in, 0), (1, E), (d_in_w, 2 * E * E), (E, 1), E, E, Mk, rowsum=(d_in_b, 2 * E)),
+        ])
+        return d_q_in, d_k_in + d_v_in, d_in_w, d_in_b, d_out_w, d_out_b, None, None
+
+
+def mha_blockdiag(q_in, kv_in, counts, in_w, in_b, out_w, out_b, heads, img_off=None):
+    """nn.MultiheadAttention(E, heads) forward as called at [ref: dynamic_teacher.py:255-273]: sequence-first,
+    batch 1, boolean mask blocking attention between boxes of different images -- computed per image block.
+    q_in (Lq,T,E), kv_in (Lk,T,E) with Lq == Lk or one of them 1 (operand shared by all levels) -> (max(Lq,Lk),T,E).
+    In/out projections: fp32 MFMA GEMM kernel; softmax(QK^T)V: one wave per (image, head)."""
+    if img_off is None:
+        img_off = torch.tensor(_offsets(counts), dtype=torch.int32).to(q_in.device, non_blocking=True)
+    return _MhaBlockDiag.apply(q_in, kv_in, in_w, in_b, out_w, out_b, img_off, int(heads))
 
 
 # ------------------------------------------------------------------------------------------------ timing

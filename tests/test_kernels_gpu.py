@@ -275,3 +275,64 @@ def test_bias_ctx_relu_fwd_bwd(shapes):
     for a, b in zip(xg, xc):
         assert torch.equal(a.grad.cpu(), b.grad)
     assert cm.rel_err(cg.grad, cc.grad) < FTOL
+
+
+# ------------------------------------------------------------------------------------------- MHA
+def _mha_params(E=256):
+    sh = {"multi_head_attn.in_proj_weight": (3 * E, E), "multi_head_attn.in_proj_bias": (3 * E,),
+          "multi_head_attn.out_proj.weight": (E, E), "multi_head_attn.out_proj.bias": (E,)}
+    return {k: torch.from_numpy(v) for k, v in synth.closed_form_params(sh, gain=2.0).items()}
+
+
+@pytest.mark.parametrize("counts,Lq,Lk", [([11, 11], 5, 1), ([5, 1, 9], 1, 5), ([3, 70, 2], 3, 1), ([130], 2, 2), ([1], 1, 1)])
+def test_mha_blockdiag_fwd_bwd(counts, Lq, Lk):
+    """vs the oracle's restatement of nn.MultiheadAttention (pinned to the reference's real module by the
+    golden attn_* vectors); includes > 64 boxes per image (tiling) and both shared-operand directions."""
+    from lgd_amd import ops
+    T, E = sum(counts), 256
+    p = _mha_params(E)
+    q = torch.from_numpy(synth.det_uniform((Lq, T, E), 41)) * 2
+    kv = torch.from_numpy(synth.det_uniform((Lk, T, E), 42)) * 2
+    L = max(Lq, Lk)
+    pg = {k: v.to(DEV).requires_grad_(True) for k, v in p.items()}
+    qg, kvg = q.to(DEV).requires_grad_(True), kv.to(DEV).requires_grad_(True)
+    out = ops.mha_blockdiag(qg, kvg, counts, pg["multi_head_attn.in_proj_weight"], pg["multi_head_attn.in_proj_bias"],
+                            pg["multi_head_attn.out_proj.weight"], pg["multi_head_attn.out_proj.bias"], 8)
+    pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    qc, kvc = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    ref = torch.stack([O.mha_blockdiag(pc, qc[0 if Lq == 1 else l], kvc[0 if Lk == 1 else l], counts) for l in range(L)], 0)
+    assert cm.rel_err(out, ref) < FTOL
+    probe = torch.from_numpy(synth.det_uniform(tuple(ref.shape), 43))
+    (out * probe.to(DEV)).sum().backward()
+    (ref * probe).sum().backward()
+    assert cm.rel_err(qg.grad, qc.grad) < FTOL
+    assert cm.rel_err(kvg.grad, kvc.grad) < FTOL
+    for k in p:
+        assert cm.rel_err(pg[k].grad, pc[k].grad) < FTOL, k
+
+
+def test_gemm_batch_strided():
+    """the MFMA GEMM list with ragged sizes and all operand layouts (A=I-style check with asymmetric B included)."""
+    import ctypes
+    from lgd_amd import hip, ops
+    M, N, K = 37, 70, 45
+    A = torch.from_numpy(synth.det_uniform((M, K), 1)).to(DEV)
+    Bm = torch.from_numpy(synth.det_uniform((N, K), 2)).to(DEV)
+    bias = torch.from_numpy(synth.det_uniform((N,), 3)).to(DEV)
+    C1 = torch.zeros(M, N, device=DEV)
+    C2 = torch.zeros(N, M, device=DEV)  # transposed output via strides
+    At = A.t().contiguous()              # (K,M): A(m,k) = At[k*M + m]
+    rs = torch.zeros(M, device=DEV)
+    eye = torch.eye(16, device=DEV)
+    asym = torch.arange(16 * 16, device=DEV, dtype=torch.float32).reshape(16, 16)
+    C3 = torch.zeros(16, 16, device=DEV)
+    ops._gemm_batch([
+        ops._gemm((A, 0), (K, 1), (Bm, 0), (K, 1), (C1, 0), (N, 1), M, N, K, bias=(bias, 0), alpha=0.5, rowsum=(rs, 0)),
+        ops._gemm((At, 0), (1, M), (Bm, 0), (K, 1), (C2, 0), (1, M), M, N, K),
+        ops._gemm((eye, 0), (16, 1), (asym, 0), (1, 16), (C3, 0), (16, 1), 16, 16, 16),  # C = I @ asym
+    ])
+    ref = (A.double() @ Bm.double().t())
+    assert cm.rel_err(C1, 0.5 * (ref + bias.double())) < 1e-6
+    assert cm.rel_err(C2, ref.t()) < 1e-6
+    assert cm.rel_err(rs, 0.5 * A.double().sum(1)) < 1e-6
+    assert torch.equal(C3, asym)
