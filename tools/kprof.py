@@ -21,8 +21,13 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     a, b = sets[2 * (it % NSET)], sets[2 * (it % NSET) + 1]
     ops._box_sum(geom, a, True, False)
     ops._box_paint(geom, vals, False, True)
-    fr = [f.requires_grad_(True) for f in a]
+    fr = [f.detach().requires_grad_(True) for f in a]
     loss = ops.distill_in_mse(fr, b, 1.0)
     torch.autograd.grad(loss, fr)
+    ys = ops.gn1(fr, True)
+    torch.autograd.grad(sum(y.sum() for y in ys), fr)
+    cvec = torch.randn(len(level_hw), B, C, device="cuda", requires_grad=True)
+    zs = ops.bias_ctx_relu(fr, cvec)
+    torch.autograd.grad(sum(z.sum() for z in zs), fr)
 torch.cuda.synchronize()
 print("done")
