@@ -22,7 +22,8 @@ struct BoxArgs {
     const float* in[LGD_MAX_LEVELS];   // box_sum: feature maps
     float* out[LGD_MAX_LEVELS];        // box_paint: painted maps
     int H[LGD_MAX_LEVELS], W[LGD_MAX_LEVELS];
-    int blk0[LGD_MAX_LEVELS + 1];      // first block of each level
+    int blk0[LGD_MAX_LEVELS + 1];      // first block of each dispatch slot
+    int lev[LGD_MAX_LEVELS];           // level handled by slot i (largest planes first)
     const float* vals;                 // box_paint: [L][T][C]
     float* pooled;                     // box_sum:   [L][T][C]
     const int32_t* img_off;
@@ -32,25 +33,35 @@ struct BoxArgs {
 
 struct Plane { int l, b, c, H, W, t0, n, nbp; const int32_t* rects; const int32_t* bands; };
 
-__device__ __forceinline__ Plane locate(const BoxArgs& a) {
+// ppb = planes per workgroup: 4 (one wave per plane, box_paint) or 1 (four waves share a plane, box_sum)
+__device__ __forceinline__ Plane locate(const BoxArgs& a, int ppb) {
     Plane p;
-    int l = 0;
+    int slot = 0;
     #pragma unroll
-    for (int i = 1; i < LGD_MAX_LEVELS; ++i) l += (i < a.L && (int)blockIdx.x >= a.blk0[i]) ? 1 : 0;
-    const int wave = threadIdx.x >> 6;
-    const int plane = ((int)blockIdx.x - a.blk0[l]) * 4 + wave;  // 4 waves = 4 consecutive channels
+    for (int i = 1; i < LGD_MAX_LEVELS; ++i) slot += (i < a.L && (int)blockIdx.x >= a.blk0[i]) ? 1 : 0;
+    const int l = a.lev[slot];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the plane bookkeeping on the scalar unit
+    const int plane = ppb == 4 ? ((int)blockIdx.x - a.blk0[slot]) * 4 + wave : (int)blockIdx.x - a.blk0[slot];
     p.l = l; p.b = plane / a.C; p.c = plane % a.C;
     p.H = a.H[l]; p.W = a.W[l];
-    p.t0 = a.img_off[p.b];
-    p.n = a.img_off[p.b + 1] - p.t0;
+    p.t0 = __builtin_amdgcn_readfirstlane(a.img_off[p.b]);
+    p.n = __builtin_amdgcn_readfirstlane(a.img_off[p.b + 1]) - p.t0;
     p.rects = a.geom + geom_rects_off() + ((size_t)l * a.T + p.t0) * 4;
-    p.nbp = a.geom[geom_nbp_off(a.L, a.T) + (size_t)l * a.B + p.b];
+    p.nbp = __builtin_amdgcn_readfirstlane(a.geom[geom_nbp_off(a.L, a.T) + (size_t)l * a.B + p.b]);
     p.bands = a.geom + geom_bands_off(a.L, a.B, a.T) + ((size_t)l * a.B + p.b) * geom_maxbp(a.max_n);
     return p;
 }
 
 struct LaneBox { int x0, x1, y0, y1; };  // lane-resident rectangle of box (pass*64 + lane); empty: x1 < x0
 
+__device__ __forceinline__ LaneBox load_lane_box_at(const Plane& p, int n, int skip_last) {
+    LaneBox r{0, -1, 0, -1};
+    if (n < p.n && !(skip_last && n == p.n - 1)) {
+        const int4 q = reinterpret_cast<const int4*>(p.rects)[n];
+        r.x0 = q.x; r.x1 = q.y; r.y0 = q.z; r.y1 = q.w;
+    }
+    return r;
+}
 __device__ __forceinline__ LaneBox load_lane_box(const Plane& p, int pass, int lane, int skip_last) {
     const int n = pass * 64 + lane;
     LaneBox r{0, -1, 0, -1};
@@ -62,70 +73,124 @@ __device__ __forceinline__ LaneBox load_lane_box(const Plane& p, int pass, int l
 }
 
 // ------------------------------------------------------------------------------------------- box_sum
+// One wave per plane.  Rows stream through a two-deep register pipeline of FIXED 4-row groups that ignores band
+// boundaries: every group is exactly 4 loads, so the compiler can keep one group in flight with a counted
+// s_waitcnt while the other is reduced (62 VGPRs -> 8 waves/SIMD: the whole grid is co-resident).  (The first
+// version loaded band by band and exposed one HBM latency per band: ~20 x 2.5 us per p3 wave, 3.3 TB/s.
+// Variable-length groups force s_waitcnt vmcnt(0) and serialise the pipeline again: 1.9 TB/s measured.)
+// Band bookkeeping happens at consume time with wave-uniform control flow; the band table and the rectangles
+// live in registers (lane k <- bands[k], lane n <- box n; v_readlane), so the loop touches memory only for rows.
+// Band flush: every active box adds one masked partial per lane into that lane's private LDS slot
+// sacc[box][lane] (conflict-free); the 64 -> 1 reductions happen once per (plane, box) at the end.
 template <int VW>
-__device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p) {
+__device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, float* sacc /* [nb][64] of this wave */, int nb) {
+    constexpr int G = 4;
     const int lane = threadIdx.x & 63;
     const float* __restrict__ src = a.in[p.l] + ((size_t)p.b * a.C + p.c) * p.H * p.W;
-    const int npass = (p.n + 63) >> 6;
+    const int npass = (p.n + nb - 1) / nb;   // nb = boxes per pass (LDS budget), <= 64
+    const int bandreg = lane < p.nbp ? p.bands[lane] : p.H;  // nbp <= 64 is the fast path
+    auto band = [&](int k) {  // wave-uniform by construction: say so, or every band test becomes an exec-masked vector loop
+        return __builtin_amdgcn_readfirstlane(p.nbp <= 64 ? __builtin_amdgcn_readlane(bandreg, k) : p.bands[k]);
+    };
     for (int pass = 0; pass < npass; ++pass) {
-        const LaneBox bx = load_lane_box(p, pass, lane, a.skip_last);
-        float acc = 0.f;
-        for (int xc = 0; xc < p.W; xc += 64 * VW) {
+        LaneBox bx{0, -1, 0, -1};
+        if (lane < nb) bx = load_lane_box_at(p, pass * nb + lane, a.skip_last);
+        for (int n = 0; n < nb; ++n) sacc[n * 64 + lane] = 0.f;
+        // rows below ylo / above yhi are covered by no box of this pass: never fetched
+        int ylo = p.H, yhi = -1;
+        {
+            unsigned long long live = __ballot(bx.x1 >= bx.x0);
+            while (live) {
+                const int n = __builtin_ctzll(live);
+                live &= live - 1;
+                ylo = min(ylo, __builtin_amdgcn_readlane(bx.y0, n));
+                yhi = max(yhi, __builtin_amdgcn_readlane(bx.y1, n));
+            }
+        }
+        for (int xc = 0; yhi >= ylo && xc < p.W; xc += 64 * VW) {
             const int xl = xc + lane * VW;
             const bool on = xl < p.W;  // VW | W, so a lane's vector is wholly inside or outside the row
-            const float* col = src + xl;
-            for (int k = 0; k + 1 < p.nbp; ++k) {
-                const int ya = p.bands[k], yb = p.bands[k + 1];
-                unsigned long long act = __ballot(bx.x1 >= bx.x0 && bx.y0 <= ya && ya <= bx.y1 &&
-                                                  bx.x1 >= xc && bx.x0 < xc + 64 * VW);
-                if (!act) continue;  // wave-uniform: rows no box of this pass covers are never fetched
-                float cs[VW];
-                #pragma unroll
-                for (int j = 0; j < VW; ++j) cs[j] = 0.f;
-                if (on) {
-                    int y = ya;
-                    for (; y + 4 <= yb; y += 4) {
-                        const Vec<VW> v0 = vload<VW>(col + (size_t)(y + 0) * p.W);
-                        const Vec<VW> v1 = vload<VW>(col + (size_t)(y + 1) * p.W);
-                        const Vec<VW> v2 = vload<VW>(col + (size_t)(y + 2) * p.W);
-                        const Vec<VW> v3 = vload<VW>(col + (size_t)(y + 3) * p.W);
-                        #pragma unroll
-                        for (int j = 0; j < VW; ++j) cs[j] += (v0.v[j] + v1.v[j]) + (v2.v[j] + v3.v[j]);
-                    }
-                    for (; y < yb; ++y) {
-                        const Vec<VW> v0 = vload<VW>(col + (size_t)y * p.W);
-                        #pragma unroll
-                        for (int j = 0; j < VW; ++j) cs[j] += v0.v[j];
-                    }
-                }
-                while (act) {
-                    const int n = __builtin_ctzll(act);
-                    act &= act - 1;
+            const float* col = src + (on ? xl : 0);
+            auto band_act = [&](int ya) {
+                return __ballot(bx.x1 >= bx.x0 && bx.y0 <= ya && ya <= bx.y1 && bx.x1 >= xc && bx.x0 < xc + 64 * VW);
+            };
+            int k = 0;
+            while (band(k + 1) <= ylo) ++k;      // band containing ylo
+            int yb = band(k + 1);
+            unsigned long long act = band_act(band(k));
+            float cs[VW];
+            #pragma unroll
+            for (int j = 0; j < VW; ++j) cs[j] = 0.f;
+            auto flush = [&]() {
+                unsigned long long m = act;
+                while (m) {
+                    const int n = __builtin_ctzll(m);
+                    m &= m - 1;
                     const int bx0 = __builtin_amdgcn_readlane(bx.x0, n), bx1 = __builtin_amdgcn_readlane(bx.x1, n);
                     float part = 0.f;
                     #pragma unroll
                     for (int j = 0; j < VW; ++j) part += (xl + j >= bx0 && xl + j <= bx1) ? cs[j] : 0.f;
-                    const float tot = wave_sum(part);
-                    if (lane == n) acc += tot;
+                    sacc[n * 64 + lane] += part;
                 }
+                #pragma unroll
+                for (int j = 0; j < VW; ++j) cs[j] = 0.f;
+            };
+            auto issue = [&](Vec<VW>* v, int y0) {  // always G loads (rows clamped into the plane)
+                #pragma unroll
+                for (int u = 0; u < G; ++u) v[u] = vload<VW>(col + (size_t)min(y0 + u, p.H - 1) * p.W);
+            };
+            auto consume = [&](const Vec<VW>* v, int y0) {
+                #pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int y = y0 + u;
+                    if (y <= yhi) {
+                        while (y == yb) {  // wave-uniform: close the band, open the next
+                            flush();
+                            ++k;
+                            yb = band(k + 1);
+                            act = band_act(y);
+                        }
+                        if (act && on) {
+                            #pragma unroll
+                            for (int j = 0; j < VW; ++j) cs[j] += v[u].v[j];
+                        }
+                    }
+                }
+            };
+            Vec<VW> va[G], vb[G];
+            issue(va, ylo);
+            for (int y0 = ylo; y0 <= yhi; y0 += 2 * G) {
+                issue(vb, y0 + G);
+                consume(va, y0);
+                issue(va, y0 + 2 * G);
+                consume(vb, y0 + G);
             }
+            flush();
         }
-        const int n = pass * 64 + lane;
-        if (n < p.n) {
+        // one 64 -> 1 reduction per box of the pass; lane n keeps box n's total
+        float mine = 0.f;
+        const int nlive = min(nb, p.n - pass * nb);
+        for (int n = 0; n < nlive; ++n) {
+            const float tot = wave_sum(sacc[n * 64 + lane]);
+            if (lane == n) mine = tot;
+        }
+        if (lane < nlive) {
             if (a.normalize) {
                 const float cnt = (bx.x1 >= bx.x0) ? (float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)) : 0.f;
-                acc = acc / fmaxf(cnt, 1.f);  // [ref: dynamic_teacher.py:97-100]
+                mine = mine / fmaxf(cnt, 1.f);  // [ref: dynamic_teacher.py:97-100]
             }
-            a.pooled[((size_t)p.l * a.T + p.t0 + n) * a.C + p.c] = acc;
+            a.pooled[((size_t)p.l * a.T + p.t0 + pass * nb + lane) * a.C + p.c] = mine;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void box_sum_kernel(BoxArgs a) {
-    const Plane p = locate(a);
-    if ((p.W & 3) == 0) box_sum_plane<4>(a, p);
-    else if ((p.W & 1) == 0) box_sum_plane<2>(a, p);
-    else box_sum_plane<1>(a, p);
+__global__ __launch_bounds__(256) void box_sum_kernel(BoxArgs a, int nb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][nb][64]
+    const Plane p = locate(a, 4);
+    float* sacc = smem + (size_t)(threadIdx.x >> 6) * nb * 64;
+    if ((p.W & 3) == 0) box_sum_plane<4>(a, p, sacc, nb);
+    else if ((p.W & 1) == 0) box_sum_plane<2>(a, p, sacc, nb);
+    else box_sum_plane<1>(a, p, sacc, nb);
 }
 
 // ------------------------------------------------------------------------------------------- box_paint
@@ -154,7 +219,7 @@ __device__ __forceinline__ void box_paint_plane(const BoxArgs& a, const Plane& p
         const bool on = xl < p.W;
         float* col = dst + xl;
         for (int k = 0; k + 1 < p.nbp; ++k) {
-            const int ya = p.bands[k], yb = p.bands[k + 1];
+            const int ya = __builtin_amdgcn_readfirstlane(p.bands[k]), yb = __builtin_amdgcn_readfirstlane(p.bands[k + 1]);
             Vec<VW> pv;
             #pragma unroll
             for (int j = 0; j < VW; ++j) pv.v[j] = 0.f;
@@ -180,14 +245,14 @@ __device__ __forceinline__ void box_paint_plane(const BoxArgs& a, const Plane& p
 }
 
 __global__ __launch_bounds__(256) void box_paint_kernel(BoxArgs a) {
-    const Plane p = locate(a);
+    const Plane p = locate(a, 4);
     if ((p.W & 3) == 0) box_paint_plane<4>(a, p);
     else if ((p.W & 1) == 0) box_paint_plane<2>(a, p);
     else box_paint_plane<1>(a, p);
 }
 
 static int fill_args(BoxArgs& a, const int32_t* level_hw_host, int L, int B, int C, int T, int max_n,
-                     const int32_t* img_off, const int32_t* geom, int normalize, int skip_last) {
+                     const int32_t* img_off, const int32_t* geom, int normalize, int skip_last, int ppb) {
     if (!level_hw_host || !img_off || !geom || L < 1 || L > LGD_MAX_LEVELS || B < 1 || C < 4 || (C & 3) || T < 0)
         return LGD_EINVAL;
     a.L = L; a.B = B; a.C = C; a.T = T; a.max_n = max_n; a.normalize = normalize; a.skip_last = skip_last;
@@ -197,8 +262,18 @@ static int fill_args(BoxArgs& a, const int32_t* level_hw_host, int L, int B, int
         a.in[l] = nullptr; a.out[l] = nullptr;
         a.H[l] = l < L ? level_hw_host[2 * l] : 0;
         a.W[l] = l < L ? level_hw_host[2 * l + 1] : 0;
-        a.blk0[l] = blk;
-        if (l < L) blk += B * C / 4;
+        a.lev[l] = 0;
+    }
+    // dispatch slots by DESCENDING plane size (stable): the long p3 waves must start first (small-first measured 15 % slower)
+    int order[LGD_MAX_LEVELS];
+    for (int i = 0; i < L; ++i) order[i] = i;
+    for (int i = 1; i < L; ++i)
+        for (int j = i; j > 0 && a.H[order[j]] * a.W[order[j]] > a.H[order[j - 1]] * a.W[order[j - 1]]; --j) {
+            const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+        }
+    for (int i = 0; i < LGD_MAX_LEVELS; ++i) {
+        a.blk0[i] = blk;
+        if (i < L) { a.lev[i] = order[i]; blk += B * C / ppb; }
     }
     a.blk0[LGD_MAX_LEVELS] = blk;
     return blk;
@@ -211,12 +286,14 @@ extern "C" {
 int lgd_box_sum(const float* const* feats_host, const int32_t* level_hw_host, int L, int B, int C, int T, int max_n,
                 const int32_t* img_off, const int32_t* geom, float* out, int normalize, int skip_last, void* stream) {
     lgd::BoxArgs a;
-    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last);
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last, 4);
     if (nblk < 0 || !feats_host || !out) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!feats_host[l]) return LGD_EINVAL; a.in[l] = feats_host[l]; }
     a.pooled = out;
     if (T == 0) return LGD_OK;
-    LGD_LAUNCH("box_sum_kernel", lgd::box_sum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    const int nb = max_n < 1 ? 1 : (max_n > 64 ? 64 : max_n);  // boxes per pass: 256 B of LDS per wave and box
+    LGD_LAUNCH("box_sum_kernel", lgd::box_sum_kernel, dim3(nblk), dim3(256), (size_t)4 * nb * 64 * sizeof(float),
+               (hipStream_t)stream, a, nb);
     return lgd::check_launch();
 }
 
@@ -224,7 +301,7 @@ int lgd_box_paint(const float* vals, const int32_t* level_hw_host, int L, int B,
                   const int32_t* img_off, const int32_t* geom, float* const* outs_host, int normalize, int skip_last,
                   void* stream) {
     lgd::BoxArgs a;
-    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last);
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last, 4);
     if (nblk < 0 || !outs_host || !vals) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!outs_host[l]) return LGD_EINVAL; a.out[l] = outs_host[l]; }
     a.vals = vals;

@@ -49,7 +49,7 @@ __device__ __forceinline__ Where locate_wave(const DistArgs& a, int w) {
 }
 
 __global__ __launch_bounds__(256) void in_moments_kernel(DistArgs a) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (w >= a.nwaves) return;
     const int lane = threadIdx.x & 63;
     const Where q = locate_wave(a, w);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void in_moments_kernel(DistArgs a) {
             #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ee = e + u * 256;
-                if (ee < e1) { va[u] = *reinterpret_cast<const float4*>(pa + ee); vb[u] = *reinterpret_cast<const float4*>(pb + ee); }
+                if (ee < e1) { va[u] = ldg_stream4(pa + ee); vb[u] = ldg_stream4(pb + ee); }
                 else { va[u] = make_float4(0, 0, 0, 0); vb[u] = make_float4(0, 0, 0, 0); }
             }
             #pragma unroll
@@ -80,9 +80,21 @@ __global__ __launch_bounds__(256) void in_moments_kernel(DistArgs a) {
             }
         }
     } else {
-        for (int e = e0 + lane; e < e1; e += 64) {
-            const double x = pa[e], y = pb[e];
-            sa += x; saa = fma(x, x, saa); sb += y; sbb = fma(y, y, sbb); sab = fma(x, y, sab);
+        // planes whose size is not a multiple of 4 floats (p5..p7 at most sizes): 8 independent loads per tensor in
+        // flight per lane -- a dependent one-load-per-iteration loop here was the tail of the whole launch
+        for (int e = e0 + lane; e < e1; e += 64 * 8) {
+            float xa[8], xb[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ee = e + u * 64;
+                xa[u] = ee < e1 ? ldg_stream(pa + ee) : 0.f;
+                xb[u] = ee < e1 ? ldg_stream(pb + ee) : 0.f;
+            }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double x = xa[u], y = xb[u];
+                sa += x; saa = fma(x, x, saa); sb += y; sbb = fma(y, y, sbb); sab = fma(x, y, sab);
+            }
         }
     }
     sa = wave_sum(sa); saa = wave_sum(saa); sb = wave_sum(sb); sbb = wave_sum(sbb); sab = wave_sum(sab);
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(64) void in_loss_kernel(DistArgs a) {
 
 // d loss / d a  for one chunk:  g * 2*coef/Ntot * ra * (a^*(1-q) - b^)
 __global__ __launch_bounds__(256) void in_mse_bwd_kernel(DistArgs a) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (w >= a.nwaves) return;
     const int lane = threadIdx.x & 63;
     const Where q = locate_wave(a, w);
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(256) void in_mse_bwd_kernel(DistArgs a) {
             #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ee = e + u * 256;
-                if (ee < e1) { va[u] = *reinterpret_cast<const float4*>(pa + ee); vb[u] = *reinterpret_cast<const float4*>(pb + ee); }
+                if (ee < e1) { va[u] = ldg_stream4(pa + ee); vb[u] = ldg_stream4(pb + ee); }
             }
             #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -168,7 +180,19 @@ __global__ __launch_bounds__(256) void in_mse_bwd_kernel(DistArgs a) {
             }
         }
     } else {
-        for (int e = e0 + lane; e < e1; e += 64) pg[e] = g * ((pa[e] - ma) * ka - (pb[e] - mb) * rb);
+        for (int e = e0 + lane; e < e1; e += 64 * 8) {
+            float xa[8], xb[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ee = e + u * 64;
+                if (ee < e1) { xa[u] = ldg_stream(pa + ee); xb[u] = ldg_stream(pb + ee); }
+            }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ee = e + u * 64;
+                if (ee < e1) pg[ee] = g * ((xa[u] - ma) * ka - (xb[u] - mb) * rb);
+            }
+        }
     }
 }
 

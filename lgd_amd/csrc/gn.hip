@@ -43,7 +43,7 @@ __device__ __forceinline__ float gn_norm(float x, float mu, float r) { return __
 
 template <int MODE>  // 0: fwd stats (x, x^2)   1: bwd stats (g, g*xhat)
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (w >= a.nwaves) return;
     const int lane = threadIdx.x & 63;
     const GnWhere q = gn_locate(a, w);
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
         for (int u = 0; u < 4; ++u) {
             const int ee = e + u * 256;
             if (ee < e1) {
-                vx[u] = *reinterpret_cast<const float4*>(px + ee);
-                if (MODE == 1) vd[u] = *reinterpret_cast<const float4*>(pd + ee);
+                vx[u] = ldg_stream4(px + ee);
+                if (MODE == 1) vd[u] = ldg_stream4(pd + ee);
             } else { vx[u] = make_float4(0, 0, 0, 0); vd[u] = make_float4(0, 0, 0, 0); }
         }
         #pragma unroll
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GnArgs a) {
 
 template <int MODE>  // 0: y = relu?((x-mu)*r)   1: dx = r*(g - m1 - xhat*m2)
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (w >= a.nwaves) return;
     const int lane = threadIdx.x & 63;
     const GnWhere q = gn_locate(a, w);
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
         for (int u = 0; u < 4; ++u) {
             const int ee = e + u * 256;
             if (ee < e1) {
-                vx[u] = *reinterpret_cast<const float4*>(px + ee);
-                if (MODE == 1) vd[u] = *reinterpret_cast<const float4*>(pd + ee);
+                vx[u] = ldg_stream4(px + ee);
+                if (MODE == 1) vd[u] = ldg_stream4(pd + ee);
             }
         }
         #pragma unroll
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void ctx_relu_kernel(CtxArgs a) {
     int l = 0;
     #pragma unroll
     for (int i = 1; i < LGD_MAX_LEVELS; ++i) l += (i < a.L && (int)blockIdx.x >= a.blk0[i]) ? 1 : 0;
-    const int plane = ((int)blockIdx.x - a.blk0[l]) * 4 + (threadIdx.x >> 6);
+    const int plane = ((int)blockIdx.x - a.blk0[l]) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int HW = a.HW[l];
     const float* __restrict__ px = a.x[l] + (size_t)plane * HW;
@@ -184,22 +184,43 @@ __global__ __launch_bounds__(256) void ctx_relu_kernel(CtxArgs a) {
     const float c = MODE == 0 ? a.ctx[(size_t)l * a.BC + plane] : 0.f;
     float acc = 0.f;
     if ((HW & 3) == 0) {
-        for (int e = lane * 4; e < HW; e += 256) {
-            const float4 v = *reinterpret_cast<const float4*>(px + e);
-            float4 o;
-            if (MODE == 0) {
-                o = make_float4(fmaxf(v.x + c, 0.f), fmaxf(v.y + c, 0.f), fmaxf(v.z + c, 0.f), fmaxf(v.w + c, 0.f));
-            } else {
-                const float4 d = *reinterpret_cast<const float4*>(pd + e);
-                o = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
-                acc += (o.x + o.y) + (o.z + o.w);
+        for (int e = lane * 4; e < HW; e += 256 * 4) {  // 4 independent 16-byte loads per tensor in flight
+            float4 v[4], d[4];
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e + u * 256;
+                if (ee < HW) { v[u] = ldg_stream4(px + ee); if (MODE == 1) d[u] = ldg_stream4(pd + ee); }
             }
-            *reinterpret_cast<float4*>(po + e) = o;
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e + u * 256;
+                if (ee >= HW) continue;
+                float4 o;
+                if (MODE == 0) {
+                    o = make_float4(fmaxf(v[u].x + c, 0.f), fmaxf(v[u].y + c, 0.f), fmaxf(v[u].z + c, 0.f), fmaxf(v[u].w + c, 0.f));
+                } else {
+                    o = make_float4(v[u].x > 0.f ? d[u].x : 0.f, v[u].y > 0.f ? d[u].y : 0.f, v[u].z > 0.f ? d[u].z : 0.f,
+                                    v[u].w > 0.f ? d[u].w : 0.f);
+                    acc += (o.x + o.y) + (o.z + o.w);
+                }
+                *reinterpret_cast<float4*>(po + ee) = o;
+            }
         }
     } else {
-        for (int e = lane; e < HW; e += 64) {
-            if (MODE == 0) { po[e] = fmaxf(px[e] + c, 0.f); }
-            else { const float o = px[e] > 0.f ? pd[e] : 0.f; po[e] = o; acc += o; }
+        for (int e = lane; e < HW; e += 64 * 8) {
+            float v[8], d[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ee = e + u * 64;
+                if (ee < HW) { v[u] = ldg_stream(px + ee); if (MODE == 1) d[u] = ldg_stream(pd + ee); }
+            }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ee = e + u * 64;
+                if (ee >= HW) continue;
+                if (MODE == 0) { po[ee] = fmaxf(v[u] + c, 0.f); }
+                else { const float o = v[u] > 0.f ? d[u] : 0.f; po[ee] = o; acc += o; }
+            }
         }
     }
     if (MODE == 1) {

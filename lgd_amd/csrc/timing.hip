@@ -18,11 +18,11 @@ static std::vector<Rec> g_recs;
 KTimer::KTimer(const char* name, hipStream_t s) : name_(name), s_(s), a_(nullptr), b_(nullptr) {
     if (!g_on) return;
     if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) { a_ = b_ = nullptr; return; }
-    hipEventRecord(a_, s_);
+    (void)hipEventRecord(a_, s_);
 }
 KTimer::~KTimer() {
     if (!a_) return;
-    hipEventRecord(b_, s_);
+    (void)hipEventRecord(b_, s_);
     std::lock_guard<std::mutex> lk(g_mu);
     g_recs.push_back({name_, a_, b_});
 }
@@ -45,15 +45,15 @@ int lgd_timing_collect(char* names, size_t names_len, double* total_ms, int32_t*
     }
     std::map<std::string, std::pair<double, int>> acc;
     for (auto& r : recs) {
-        hipEventSynchronize(r.b);
+        (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             auto& e = acc[r.name];
             e.first += ms;
             e.second += 1;
         }
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     int n = 0;
     size_t off = 0;
