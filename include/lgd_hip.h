@@ -144,7 +144,8 @@ int lgd_ctx_relu_bwd(const float* const* y_host, const float* const* dy_host, co
  *   (T,T) boolean mask blocks exactly the cross-image pairs).  q is already scaled by 1/sqrt(E/H).
  *   q (Lq,T,E), k/v (Lk,T,E), Lq == Lk or one of them 1 (operand shared by all levels);
  *   out (L,T,E), lse (L,T,H) = log-sum-exp of each score row (kept for the backward), L = max(Lq,Lk).
- * lgd_attn_bwd: dq (Lq,T,E), dk/dv (Lk,T,E); gradients of a shared operand are summed over levels.
+ * lgd_attn_bwd: dq, dk, dv are PER-LEVEL partials, each (L,T,E); for an operand shared by all levels (Lq or
+ *   Lk == 1) the caller sums its partials over the level axis.
  */
 typedef struct lgd_gemm_problem {
     const float* A;

@@ -6,10 +6,10 @@
 //   * lgd_gemm_batch : fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32 fma chains) for the dense in/out
 //     projections of ALL levels in one launch (a list of strided GEMM problems; also serves the
 //     backward's dX / dW / dbias products);
-//   * mha core       : one wave64 per (image, head); lanes own query rows (forward, dQ) or key rows
+//   * mha core       : one wave64 per (level, image, head); lanes own query rows (forward, dQ) or key rows
 //     (dK, dV), the partner rows are broadcast from LDS, softmax is an online max/sum per lane --
-//     only the image's own n x n block is ever touched (no (T,T) mask), levels are looped inside so a
-//     broadcast operand's gradient is accumulated in registers (deterministic, no atomics).
+//     only the image's own n x n block is ever touched (no (T,T) mask); the backward emits per-level
+//     partial gradients, a shared operand's gradient is their fixed-order sum (no atomics).
 // Sizes are tiny (T ~ 10^2 tokens): these kernels are latency-bound, not roofline-bound; MFMA is used
 // because the projections are GEMM-shaped, not because it pays.
 #include "common.h"
@@ -29,41 +29,112 @@ struct GemmArgs { GemmProb p[kMaxProb]; int np, ntiles; };
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// C[m,n] = alpha * (sum_k A(m,k) * B(n,k) + bias[n]);  rowsum[m] = sum_k A(m,k) (optional, n-tile 0 only)
-// One wave per 16(m) x 64(n) tile: 4 accumulators of v_mfma_f32_16x16x4_f32 (A: lane l holds
-// A[i=l&15][k=l>>4]; B: B[k=l>>4][j=l&15]; C/D: col=l&15, row=(l>>4)*4+reg).
+constexpr int kBM = 64, kBN = 64, kBK = 64;   // block tile; 4 waves, wave w owns rows [16w, 16w+16) x all 64 columns
+constexpr int kLd = kBM + 1;                   // LDS row stride (floats): +1 breaks the 4-way write conflict
+
+// C[m,n] = alpha * (sum_k A(m,k) * B(n,k) + bias[n]);  rowsum[m] = alpha * sum_k A(m,k) (optional, n-tile 0 only)
+// Each operand must be contiguous along m (n) or along k.  Per k-chunk of 64 every thread fetches four 16-byte
+// vectors of A and four of B along the operand's contiguous axis (coalesced), the chunk is transposed into LDS as
+// [k][m] / [k][n], and each wave issues 64 v_mfma_f32_16x16x4_f32 (A: lane l holds A[i=l&15][k=l>>4];
+// B: B[k=l>>4][j=l&15]; C/D: col=l&15, row=(l>>4)*4+reg).  The next chunk's global loads are in flight while
+// the current one is multiplied (register-staged double buffering).
+__device__ __forceinline__ float4 gemm_fetch(const float* base, long long s_row, long long s_k, int row0, int nrows, int k0, int K, int tid,
+                                             int& r, int& kk) {
+    // returns 4 consecutive elements along the contiguous axis; (r, kk) = tile coordinates of element 0
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s_k == 1) {            // k-contiguous: 4 threads per row
+        r = tid >> 2; kk = (tid & 3) * 4;
+        if (row0 + r < nrows) {
+            const float* p = base + (long long)(row0 + r) * s_row + (k0 + kk);
+            if (k0 + kk + 3 < K && ((reinterpret_cast<size_t>(p) & 15) == 0)) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (k0 + kk + 0 < K) v.x = p[0];
+                if (k0 + kk + 1 < K) v.y = p[1];
+                if (k0 + kk + 2 < K) v.z = p[2];
+                if (k0 + kk + 3 < K) v.w = p[3];
+            }
+        }
+    } else {                   // row-contiguous: 16 threads per k
+        kk = tid >> 4; r = (tid & 15) * 4;
+        if (k0 + kk < K) {
+            const float* p = base + (long long)(k0 + kk) * s_k + (row0 + r);
+            if (row0 + r + 3 < nrows && ((reinterpret_cast<size_t>(p) & 15) == 0)) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (row0 + r + 0 < nrows) v.x = p[0];
+                if (row0 + r + 1 < nrows) v.y = p[1];
+                if (row0 + r + 2 < nrows) v.z = p[2];
+                if (row0 + r + 3 < nrows) v.w = p[3];
+            }
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ void gemm_stage(float* lds, const float4& v, bool k_contig, int r, int kk) {
+    if (k_contig) { lds[(kk + 0) * kLd + r] = v.x; lds[(kk + 1) * kLd + r] = v.y; lds[(kk + 2) * kLd + r] = v.z; lds[(kk + 3) * kLd + r] = v.w; }
+    else { lds[kk * kLd + r + 0] = v.x; lds[kk * kLd + r + 1] = v.y; lds[kk * kLd + r + 2] = v.z; lds[kk * kLd + r + 3] = v.w; }
+}
+
 __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmArgs a) {
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= a.ntiles) return;
-    const int lane = threadIdx.x & 63;
+    __shared__ float sA[2][kBK * kLd];
+    __shared__ float sB[2][kBK * kLd];
+    const int tile = blockIdx.x;
     int pi = 0;
     #pragma unroll
     for (int i = 1; i < kMaxProb; ++i) pi += (i < a.np && tile >= a.p[i].tile0) ? 1 : 0;
     const GemmProb& p = a.p[pi];
     const int t = tile - p.tile0;
-    const int m0 = (t / p.tiles_n) * 16, n0 = (t % p.tiles_n) * 64;
+    const int m0 = (t / p.tiles_n) * kBM, n0 = (t % p.tiles_n) * kBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    const bool mok = m0 + r < p.M;
-    const float* pa = p.A + (long long)(m0 + r) * p.sa_m;
-    const float* pb[4];
-    bool nok[4];
-    #pragma unroll
-    for (int j = 0; j < 4; ++j) { nok[j] = n0 + 16 * j + r < p.N; pb[j] = p.B + (long long)(n0 + 16 * j + r) * p.sb_n; }
+    const bool a_kc = p.sa_k == 1, b_kc = p.sb_k == 1;
+    const long long sa_row = a_kc ? p.sa_m : 1, sa_kk = a_kc ? 1 : p.sa_k;
+    const long long sb_row = b_kc ? p.sb_n : 1, sb_kk = b_kc ? 1 : p.sb_k;
     f32x4 acc[4];
     #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = {0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
-    #pragma unroll 4
-    for (int k0 = 0; k0 < p.K; k0 += 4) {
-        const int k = k0 + kq;
-        const bool kok = k < p.K;
-        const float av = (mok && kok) ? pa[(long long)k * p.sa_k] : 0.f;
-        asum += av;
-        #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float bv = (nok[j] && kok) ? pb[j][(long long)k * p.sb_k] : 0.f;
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+    constexpr int NS = kBK / 16;  // 16-deep sub-chunks per thread: NS 16-byte loads per operand in flight
+    int ra, ka, rb, kb;
+    float4 va[NS], vb[NS];
+    #pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        va[u] = gemm_fetch(p.A, sa_row, sa_kk, m0, p.M, 16 * u, p.K, tid, ra, ka);
+        vb[u] = gemm_fetch(p.B, sb_row, sb_kk, n0, p.N, 16 * u, p.K, tid, rb, kb);
+    }
+    #pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        gemm_stage(sA[0] + 16 * u * kLd, va[u], a_kc, ra, ka);
+        gemm_stage(sB[0] + 16 * u * kLd, vb[u], b_kc, rb, kb);
+    }
+    __syncthreads();
+    const int nchunk = (p.K + kBK - 1) / kBK;
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunk) {  // next chunk's global loads fly while this chunk is multiplied
+            #pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                va[u] = gemm_fetch(p.A, sa_row, sa_kk, m0, p.M, (c + 1) * kBK + 16 * u, p.K, tid, ra, ka);
+                vb[u] = gemm_fetch(p.B, sb_row, sb_kk, n0, p.N, (c + 1) * kBK + 16 * u, p.K, tid, rb, kb);
+            }
         }
+        #pragma unroll
+        for (int ks = 0; ks < kBK; ks += 4) {
+            const float av = sA[cur][(ks + kq) * kLd + wave * 16 + r];
+            asum += av;
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bv = sB[cur][(ks + kq) * kLd + j * 16 + r];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunk) {
+            #pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                gemm_stage(sA[cur ^ 1] + 16 * u * kLd, va[u], a_kc, ra, ka);
+                gemm_stage(sB[cur ^ 1] + 16 * u * kLd, vb[u], b_kc, rb, kb);
+            }
+        }
+        __syncthreads();
     }
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -72,14 +143,15 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmArgs a) {
         const float bias = p.bias ? p.bias[n] : 0.f;
         #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int m = m0 + kq * 4 + q;
+            const int m = m0 + wave * 16 + kq * 4 + q;
             if (m < p.M) p.C[(long long)m * p.sc_m + (long long)n * p.sc_n] = p.alpha * (acc[j][q] + bias);
         }
     }
-    if (p.rowsum && n0 == 0) {  // lanes r, r+16, r+32, r+48 hold the four k-quarters of row m0+r
+    if (p.rowsum && n0 == 0) {  // lanes r, r+16, r+32, r+48 hold the four k-quarters of row m0+16*wave+r
         asum += __shfl_xor(asum, 16);
         asum += __shfl_xor(asum, 32);
-        if (kq == 0 && mok) p.rowsum[m0 + r] = p.alpha * asum;
+        const int m = m0 + wave * 16 + r;
+        if (kq == 0 && m < p.M) p.rowsum[m] = p.alpha * asum;
     }
 }
 
@@ -94,7 +166,7 @@ struct AttnArgs {
     const float* dO;                                  // bwd
     float* dQ; float* dK; float* dV;                  // bwd: (Lq,T,E), (Lk,T,E), (Lk,T,E)
     const int32_t* img_off;
-    int Lq, Lk, L, T, E, H;
+    int Lq, Lk, L, T, E, H, B;
 };
 
 __device__ __forceinline__ void load_row(float* dst, const float* src) {
@@ -109,182 +181,165 @@ __device__ __forceinline__ void store_row(float* dst, const float* src) {
     for (int c = 0; c < kD; c += 4) *reinterpret_cast<float4*>(dst + c) = make_float4(src[c], src[c + 1], src[c + 2], src[c + 3]);
 }
 __device__ __forceinline__ float dot_lds(const float* reg, const float* lds_row) {
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains
     #pragma unroll
     for (int c = 0; c < kD; c += 4) {
         const float4 v = *reinterpret_cast<const float4*>(lds_row + c);  // same address in every lane: LDS broadcast
-        s = fmaf(reg[c], v.x, s); s = fmaf(reg[c + 1], v.y, s); s = fmaf(reg[c + 2], v.z, s); s = fmaf(reg[c + 3], v.w, s);
+        s0 = fmaf(reg[c], v.x, s0); s1 = fmaf(reg[c + 1], v.y, s1); s2 = fmaf(reg[c + 2], v.z, s2); s3 = fmaf(reg[c + 3], v.w, s3);
     }
-    return s;
+    return (s0 + s1) + (s2 + s3);
 }
 
-// forward: lanes = queries; K/V tiles broadcast from LDS; online softmax per lane
+// forward: one wave per (level, image, head); lanes = queries; K/V tiles broadcast from LDS; online softmax per lane
 __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float sK[kTile * kRow];
     __shared__ __attribute__((aligned(16))) float sV[kTile * kRow];
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, lane = threadIdx.x;
+    const int h = blockIdx.x % a.H, b = (blockIdx.x / a.H) % a.B, l = blockIdx.x / (a.H * a.B), lane = threadIdx.x;
     const int t0 = a.img_off[b], n = a.img_off[b + 1] - t0;
     const size_t lvl = (size_t)a.T * a.E;
-    for (int l = 0; l < a.L; ++l) {
-        const float* Q = a.Q + (a.Lq == 1 ? 0 : l) * lvl + (size_t)t0 * a.E + h * kD;
-        const float* K = a.K + (a.Lk == 1 ? 0 : l) * lvl + (size_t)t0 * a.E + h * kD;
-        const float* V = a.V + (a.Lk == 1 ? 0 : l) * lvl + (size_t)t0 * a.E + h * kD;
-        for (int q0 = 0; q0 < n; q0 += kTile) {
-            const int i = q0 + lane;
-            const bool qok = i < n;
-            float q[kD], o[kD];
-            if (qok) load_row(q, Q + (size_t)i * a.E);
-            #pragma unroll
-            for (int c = 0; c < kD; ++c) { o[c] = 0.f; if (!qok) q[c] = 0.f; }
-            float m = -INFINITY, s = 0.f;
-            for (int k0 = 0; k0 < n; k0 += kTile) {
-                const int nk = min(kTile, n - k0);
-                __syncthreads();
-                if (lane < nk) {
-                    float tmp[kD];
-                    load_row(tmp, K + (size_t)(k0 + lane) * a.E); store_row(sK + lane * kRow, tmp);
-                    load_row(tmp, V + (size_t)(k0 + lane) * a.E); store_row(sV + lane * kRow, tmp);
-                }
-                __syncthreads();
-                for (int j = 0; j < nk; ++j) {
-                    const float sc = dot_lds(q, sK + j * kRow);
-                    const float mn = fmaxf(m, sc);
-                    const float corr = expf(m - mn), pj = expf(sc - mn);
-                    s = s * corr + pj;
-                    #pragma unroll
-                    for (int c = 0; c < kD; c += 4) {
-                        const float4 v = *reinterpret_cast<const float4*>(sV + j * kRow + c);
-                        o[c] = fmaf(pj, v.x, o[c] * corr); o[c + 1] = fmaf(pj, v.y, o[c + 1] * corr);
-                        o[c + 2] = fmaf(pj, v.z, o[c + 2] * corr); o[c + 3] = fmaf(pj, v.w, o[c + 3] * corr);
-                    }
-                    m = mn;
-                }
+    const float* Q = a.Q + (a.Lq == 1 ? 0 : l) * lvl + (size_t)t0 * a.E + h * kD;
+    const float* K = a.K + (a.Lk == 1 ? 0 : l) * lvl + (size_t)t0 * a.E + h * kD;
+    const float* V = a.V + (a.Lk == 1 ? 0 : l) * lvl + (size_t)t0 * a.E + h * kD;
+    for (int q0 = 0; q0 < n; q0 += kTile) {
+        const int i = q0 + lane;
+        const bool qok = i < n;
+        float q[kD], o[kD];
+        if (qok) load_row(q, Q + (size_t)i * a.E);
+        #pragma unroll
+        for (int c = 0; c < kD; ++c) { o[c] = 0.f; if (!qok) q[c] = 0.f; }
+        float m = -INFINITY, s = 0.f;
+        for (int k0 = 0; k0 < n; k0 += kTile) {
+            const int nk = min(kTile, n - k0);
+            __syncthreads();
+            if (lane < nk) {
+                float tmp[kD];
+                load_row(tmp, K + (size_t)(k0 + lane) * a.E); store_row(sK + lane * kRow, tmp);
+                load_row(tmp, V + (size_t)(k0 + lane) * a.E); store_row(sV + lane * kRow, tmp);
             }
-            if (qok) {
-                const float inv = 1.f / s;
+            __syncthreads();
+            for (int j = 0; j < nk; ++j) {
+                const float sc = dot_lds(q, sK + j * kRow);
+                const float mn = fmaxf(m, sc);
+                const float corr = expf(m - mn), pj = expf(sc - mn);
+                s = s * corr + pj;
                 #pragma unroll
-                for (int c = 0; c < kD; ++c) o[c] *= inv;
-                store_row(a.O + l * lvl + (size_t)(t0 + i) * a.E + h * kD, o);
-                a.lse[((size_t)l * a.T + t0 + i) * a.H + h] = m + logf(s);
+                for (int c = 0; c < kD; c += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(sV + j * kRow + c);
+                    o[c] = fmaf(pj, v.x, o[c] * corr); o[c + 1] = fmaf(pj, v.y, o[c + 1] * corr);
+                    o[c + 2] = fmaf(pj, v.z, o[c + 2] * corr); o[c + 3] = fmaf(pj, v.w, o[c + 3] * corr);
+                }
+                m = mn;
             }
+        }
+        if (qok) {
+            const float inv = 1.f / s;
+            #pragma unroll
+            for (int c = 0; c < kD; ++c) o[c] *= inv;
+            store_row(a.O + l * lvl + (size_t)(t0 + i) * a.E + h * kD, o);
+            a.lse[((size_t)l * a.T + t0 + i) * a.H + h] = m + logf(s);
         }
     }
 }
 
-// backward: phase A lanes = queries (dQ), phase B lanes = keys (dK, dV); p_ij = exp(s_ij - lse_i)
+// backward: one wave per (level, image, head); phase A lanes = queries (dQ), phase B lanes = keys (dK, dV);
+// p_ij = exp(s_ij - lse_i).  Outputs are PER-LEVEL partials (L,T,E): the caller sums over levels for an operand
+// that was shared by all levels (deterministic, no atomics).
 __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float sA[kTile * kRow];   // phase A: K rows | phase B: Q rows
     __shared__ __attribute__((aligned(16))) float sB[kTile * kRow];   // phase A: V rows | phase B: dO rows
     __shared__ float sLse[kTile], sDelta[kTile];
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, lane = threadIdx.x;
+    const int h = blockIdx.x % a.H, b = (blockIdx.x / a.H) % a.B, l = blockIdx.x / (a.H * a.B), lane = threadIdx.x;
     const int t0 = a.img_off[b], n = a.img_off[b + 1] - t0;
     const size_t lvl = (size_t)a.T * a.E;
     const size_t base = (size_t)t0 * a.E + h * kD;
+    const int lq = a.Lq == 1 ? 0 : l, lk = a.Lk == 1 ? 0 : l;
 
-    // ---- phase A: dQ_i = sum_j dS_ij K_j ; summed over levels when the query operand is shared (Lq == 1)
+    // ---- phase A: dQ_i = sum_j dS_ij K_j
     for (int q0 = 0; q0 < n; q0 += kTile) {
         const int i = q0 + lane;
         const bool qok = i < n;
-        float dq[kD];
+        float dq[kD], q[kD], go[kD];
+        float lse = 0.f, delta = 0.f;
         #pragma unroll
         for (int c = 0; c < kD; ++c) dq[c] = 0.f;
-        for (int l = 0; l < a.L; ++l) {
-            const int lq = a.Lq == 1 ? 0 : l, lk = a.Lk == 1 ? 0 : l;
-            float q[kD], go[kD];
-            float lse = 0.f, delta = 0.f;
-            if (qok) {
-                load_row(q, a.Q + lq * lvl + base + (size_t)i * a.E);
-                load_row(go, a.dO + l * lvl + base + (size_t)i * a.E);
-                float o[kD];
-                load_row(o, a.O + l * lvl + base + (size_t)i * a.E);
-                #pragma unroll
-                for (int c = 0; c < kD; ++c) delta = fmaf(go[c], o[c], delta);
-                lse = a.lse[((size_t)l * a.T + t0 + i) * a.H + h];
-            } else {
-                #pragma unroll
-                for (int c = 0; c < kD; ++c) { q[c] = 0.f; go[c] = 0.f; }
+        if (qok) {
+            load_row(q, a.Q + lq * lvl + base + (size_t)i * a.E);
+            load_row(go, a.dO + l * lvl + base + (size_t)i * a.E);
+            float o[kD];
+            load_row(o, a.O + l * lvl + base + (size_t)i * a.E);
+            #pragma unroll
+            for (int c = 0; c < kD; ++c) delta = fmaf(go[c], o[c], delta);
+            lse = a.lse[((size_t)l * a.T + t0 + i) * a.H + h];
+        } else {
+            #pragma unroll
+            for (int c = 0; c < kD; ++c) { q[c] = 0.f; go[c] = 0.f; }
+        }
+        for (int k0 = 0; k0 < n; k0 += kTile) {
+            const int nk = min(kTile, n - k0);
+            __syncthreads();
+            if (lane < nk) {
+                float tmp[kD];
+                load_row(tmp, a.K + lk * lvl + base + (size_t)(k0 + lane) * a.E); store_row(sA + lane * kRow, tmp);
+                load_row(tmp, a.V + lk * lvl + base + (size_t)(k0 + lane) * a.E); store_row(sB + lane * kRow, tmp);
             }
-            for (int k0 = 0; k0 < n; k0 += kTile) {
-                const int nk = min(kTile, n - k0);
-                __syncthreads();
-                if (lane < nk) {
-                    float tmp[kD];
-                    load_row(tmp, a.K + lk * lvl + base + (size_t)(k0 + lane) * a.E); store_row(sA + lane * kRow, tmp);
-                    load_row(tmp, a.V + lk * lvl + base + (size_t)(k0 + lane) * a.E); store_row(sB + lane * kRow, tmp);
-                }
-                __syncthreads();
-                for (int j = 0; j < nk; ++j) {
-                    const float p = qok ? expf(dot_lds(q, sA + j * kRow) - lse) : 0.f;
-                    const float ds = p * (dot_lds(go, sB + j * kRow) - delta);
-                    #pragma unroll
-                    for (int c = 0; c < kD; c += 4) {
-                        const float4 kv = *reinterpret_cast<const float4*>(sA + j * kRow + c);
-                        dq[c] = fmaf(ds, kv.x, dq[c]); dq[c + 1] = fmaf(ds, kv.y, dq[c + 1]);
-                        dq[c + 2] = fmaf(ds, kv.z, dq[c + 2]); dq[c + 3] = fmaf(ds, kv.w, dq[c + 3]);
-                    }
-                }
-            }
-            if (a.Lq != 1) {
-                if (qok) store_row(a.dQ + l * lvl + base + (size_t)i * a.E, dq);
+            __syncthreads();
+            for (int j = 0; j < nk; ++j) {
+                const float p = qok ? expf(dot_lds(q, sA + j * kRow) - lse) : 0.f;
+                const float ds = p * (dot_lds(go, sB + j * kRow) - delta);
                 #pragma unroll
-                for (int c = 0; c < kD; ++c) dq[c] = 0.f;
+                for (int c = 0; c < kD; c += 4) {
+                    const float4 kv = *reinterpret_cast<const float4*>(sA + j * kRow + c);
+                    dq[c] = fmaf(ds, kv.x, dq[c]); dq[c + 1] = fmaf(ds, kv.y, dq[c + 1]);
+                    dq[c + 2] = fmaf(ds, kv.z, dq[c + 2]); dq[c + 3] = fmaf(ds, kv.w, dq[c + 3]);
+                }
             }
         }
-        if (a.Lq == 1 && qok) store_row(a.dQ + base + (size_t)i * a.E, dq);
+        if (qok) store_row(a.dQ + l * lvl + base + (size_t)i * a.E, dq);
     }
 
-    // ---- phase B: dK_j = sum_i dS_ij Q_i, dV_j = sum_i p_ij dO_i ; summed over levels when Lk == 1
+    // ---- phase B: dK_j = sum_i dS_ij Q_i, dV_j = sum_i p_ij dO_i
     for (int k0 = 0; k0 < n; k0 += kTile) {
         const int j = k0 + lane;
         const bool kok = j < n;
-        float dk[kD], dv[kD];
+        float dk[kD], dv[kD], kr[kD], vr[kD];
         #pragma unroll
         for (int c = 0; c < kD; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
-        for (int l = 0; l < a.L; ++l) {
-            const int lq = a.Lq == 1 ? 0 : l, lk = a.Lk == 1 ? 0 : l;
-            float kr[kD], vr[kD];
-            if (kok) { load_row(kr, a.K + lk * lvl + base + (size_t)j * a.E); load_row(vr, a.V + lk * lvl + base + (size_t)j * a.E); }
-            else {
+        if (kok) { load_row(kr, a.K + lk * lvl + base + (size_t)j * a.E); load_row(vr, a.V + lk * lvl + base + (size_t)j * a.E); }
+        else {
+            #pragma unroll
+            for (int c = 0; c < kD; ++c) { kr[c] = 0.f; vr[c] = 0.f; }
+        }
+        for (int q0 = 0; q0 < n; q0 += kTile) {
+            const int nq = min(kTile, n - q0);
+            __syncthreads();
+            if (lane < nq) {
+                float tq[kD], tg[kD], to[kD];
+                load_row(tq, a.Q + lq * lvl + base + (size_t)(q0 + lane) * a.E);
+                load_row(tg, a.dO + l * lvl + base + (size_t)(q0 + lane) * a.E);
+                load_row(to, a.O + l * lvl + base + (size_t)(q0 + lane) * a.E);
+                float delta = 0.f;
                 #pragma unroll
-                for (int c = 0; c < kD; ++c) { kr[c] = 0.f; vr[c] = 0.f; }
+                for (int c = 0; c < kD; ++c) delta = fmaf(tg[c], to[c], delta);
+                store_row(sA + lane * kRow, tq); store_row(sB + lane * kRow, tg);
+                sDelta[lane] = delta;
+                sLse[lane] = a.lse[((size_t)l * a.T + t0 + q0 + lane) * a.H + h];
             }
-            for (int q0 = 0; q0 < n; q0 += kTile) {
-                const int nq = min(kTile, n - q0);
-                __syncthreads();
-                if (lane < nq) {
-                    float tq[kD], tg[kD], to[kD];
-                    load_row(tq, a.Q + lq * lvl + base + (size_t)(q0 + lane) * a.E);
-                    load_row(tg, a.dO + l * lvl + base + (size_t)(q0 + lane) * a.E);
-                    load_row(to, a.O + l * lvl + base + (size_t)(q0 + lane) * a.E);
-                    float delta = 0.f;
-                    #pragma unroll
-                    for (int c = 0; c < kD; ++c) delta = fmaf(tg[c], to[c], delta);
-                    store_row(sA + lane * kRow, tq); store_row(sB + lane * kRow, tg);
-                    sDelta[lane] = delta;
-                    sLse[lane] = a.lse[((size_t)l * a.T + t0 + q0 + lane) * a.H + h];
-                }
-                __syncthreads();
-                for (int i = 0; i < nq; ++i) {
-                    const float p = kok ? expf(dot_lds(kr, sA + i * kRow) - sLse[i]) : 0.f;
-                    const float ds = p * (dot_lds(vr, sB + i * kRow) - sDelta[i]);
-                    #pragma unroll
-                    for (int c = 0; c < kD; c += 4) {
-                        const float4 qv = *reinterpret_cast<const float4*>(sA + i * kRow + c);
-                        const float4 gv = *reinterpret_cast<const float4*>(sB + i * kRow + c);
-                        dk[c] = fmaf(ds, qv.x, dk[c]); dk[c + 1] = fmaf(ds, qv.y, dk[c + 1]);
-                        dk[c + 2] = fmaf(ds, qv.z, dk[c + 2]); dk[c + 3] = fmaf(ds, qv.w, dk[c + 3]);
-                        dv[c] = fmaf(p, gv.x, dv[c]); dv[c + 1] = fmaf(p, gv.y, dv[c + 1]);
-                        dv[c + 2] = fmaf(p, gv.z, dv[c + 2]); dv[c + 3] = fmaf(p, gv.w, dv[c + 3]);
-                    }
-                }
-            }
-            if (a.Lk != 1) {
-                if (kok) { store_row(a.dK + l * lvl + base + (size_t)j * a.E, dk); store_row(a.dV + l * lvl + base + (size_t)j * a.E, dv); }
+            __syncthreads();
+            for (int i = 0; i < nq; ++i) {
+                const float p = kok ? expf(dot_lds(kr, sA + i * kRow) - sLse[i]) : 0.f;
+                const float ds = p * (dot_lds(vr, sB + i * kRow) - sDelta[i]);
                 #pragma unroll
-                for (int c = 0; c < kD; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+                for (int c = 0; c < kD; c += 4) {
+                    const float4 qv = *reinterpret_cast<const float4*>(sA + i * kRow + c);
+                    const float4 gv = *reinterpret_cast<const float4*>(sB + i * kRow + c);
+                    dk[c] = fmaf(ds, qv.x, dk[c]); dk[c + 1] = fmaf(ds, qv.y, dk[c + 1]);
+                    dk[c + 2] = fmaf(ds, qv.z, dk[c + 2]); dk[c + 3] = fmaf(ds, qv.w, dk[c + 3]);
+                    dv[c] = fmaf(p, gv.x, dv[c]); dv[c + 1] = fmaf(p, gv.y, dv[c + 1]);
+                    dv[c + 2] = fmaf(p, gv.z, dv[c + 2]); dv[c + 3] = fmaf(p, gv.w, dv[c + 3]);
+                }
             }
         }
-        if (a.Lk == 1 && kok) { store_row(a.dK + base + (size_t)j * a.E, dk); store_row(a.dV + base + (size_t)j * a.E, dv); }
+        if (kok) { store_row(a.dK + l * lvl + base + (size_t)j * a.E, dk); store_row(a.dV + l * lvl + base + (size_t)j * a.E, dv); }
     }
 }
 
@@ -306,13 +361,14 @@ int lgd_gemm_batch(const lgd_gemm_problem* probs_host, int np, void* stream) {
         p.M = s.M; p.N = s.N; p.K = s.K;
         p.sa_m = s.sa_m; p.sa_k = s.sa_k; p.sb_n = s.sb_n; p.sb_k = s.sb_k; p.sc_m = s.sc_m; p.sc_n = s.sc_n;
         p.alpha = s.alpha;
-        p.tile0 = tile; p.tiles_n = (s.N + 63) / 64;
-        tile += ((s.M + 15) / 16) * p.tiles_n;
+        if (!((s.sa_m == 1 || s.sa_k == 1) && (s.sb_n == 1 || s.sb_k == 1))) return LGD_EINVAL;  // one contiguous axis each
+        p.tile0 = tile; p.tiles_n = (s.N + lgd::kBN - 1) / lgd::kBN;
+        tile += ((s.M + lgd::kBM - 1) / lgd::kBM) * p.tiles_n;
     }
     for (int i = np; i < lgd::kMaxProb; ++i) { a.p[i] = a.p[0]; a.p[i].tile0 = 0x7fffffff; }
     a.ntiles = tile;
     if (tile == 0) return LGD_OK;
-    LGD_LAUNCH("gemm_batch_kernel", lgd::gemm_batch_kernel, dim3((tile + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    LGD_LAUNCH("gemm_batch_kernel", lgd::gemm_batch_kernel, dim3(tile), dim3(256), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 
@@ -322,7 +378,7 @@ static int attn_fill(lgd::AttnArgs& a, const float* q, const float* k, const flo
         !(Lq == Lk || Lq == 1 || Lk == 1))
         return LGD_EINVAL;
     a.Q = q; a.K = k; a.V = v; a.img_off = img_off;
-    a.Lq = Lq; a.Lk = Lk; a.L = Lq > Lk ? Lq : Lk; a.T = T; a.E = E; a.H = H;
+    a.Lq = Lq; a.Lk = Lk; a.L = Lq > Lk ? Lq : Lk; a.T = T; a.E = E; a.H = H; a.B = B;
     a.O = nullptr; a.lse = nullptr; a.dO = nullptr; a.dQ = a.dK = a.dV = nullptr;
     return LGD_OK;
 }
@@ -332,7 +388,7 @@ int lgd_attn_fwd(const float* q, const float* k, const float* v, const int32_t* 
     lgd::AttnArgs a;
     if (attn_fill(a, q, k, v, img_off, Lq, Lk, B, T, E, H) != LGD_OK || !out || !lse) return LGD_EINVAL;
     a.O = out; a.lse = lse;
-    LGD_LAUNCH("attn_fwd_kernel", lgd::attn_fwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, a);
+    LGD_LAUNCH("attn_fwd_kernel", lgd::attn_fwd_kernel, dim3(B * H * a.L), dim3(64), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 
@@ -343,7 +399,7 @@ int lgd_attn_bwd(const float* q, const float* k, const float* v, const float* ou
     if (attn_fill(a, q, k, v, img_off, Lq, Lk, B, T, E, H) != LGD_OK || !out || !lse || !dout || !dq || !dk || !dv)
         return LGD_EINVAL;
     a.O = const_cast<float*>(out); a.lse = const_cast<float*>(lse); a.dO = dout; a.dQ = dq; a.dK = dk; a.dV = dv;
-    LGD_LAUNCH("attn_bwd_kernel", lgd::attn_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, a);
+    LGD_LAUNCH("attn_bwd_kernel", lgd::attn_bwd_kernel, dim3(B * H * a.L), dim3(64), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 

@@ -349,12 +349,16 @@ class _MhaBlockDiag(torch.autograd.Function):
             _gemm((dout, 0), (E, 1), (out_w, 0), (1, E), (dO, 0), (E, 1), L * T, E, E),                       # dO = dY Wo
             _gemm((dout, 0), (1, E), (O, 0), (1, E), (d_out_w, 0), (E, 1), E, E, L * T, rowsum=(d_out_b, 0)),  # dWo = dY^T O
         ])
-        dQ = torch.empty((Lq, T, E), dtype=torch.float32, device=dev)
-        dK = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
-        dV = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
+        dQ = torch.empty((L, T, E), dtype=torch.float32, device=dev)   # per-level partials
+        dK = torch.empty((L, T, E), dtype=torch.float32, device=dev)
+        dV = torch.empty((L, T, E), dtype=torch.float32, device=dev)
         hip.check(lib.lgd_attn_bwd(hip.ptr(Q), hip.ptr(K), hip.ptr(V), hip.ptr(O), hip.ptr(lse), hip.ptr(dO), hip.ptr(img_off),
                                    Lq, Lk, B, T, E, heads, hip.ptr(dQ), hip.ptr(dK), hip.ptr(dV), hip.stream_ptr()),
                   "lgd_attn_bwd")
+        if Lq == 1 and L > 1:
+            dQ = dQ.sum(0, keepdim=True)
+        if Lk == 1 and L > 1:
+            dK, dV = dK.sum(0, keepdim=True), dV.sum(0, keepdim=True)
         d_q_in = torch.empty((Lq, T, E), dtype=torch.float32, device=dev)
         d_k_in = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
         d_v_in = torch.empty((Lk, T, E), dtype=torch.float32, device=dev)
