@@ -139,14 +139,19 @@ def main():
         P = Bg * 256 * sum(h * w for h, w in synth.pyramid_shapes(Hp, Wp)) * 4  # one fp32 pyramid, bytes
         # algorithmic bytes per launch
         alg = {"in_moments_kernel": 2 * P, "in_mse_bwd_kernel": 3 * P, "box_sum_kernel": P, "box_paint_kernel": P,
-               "gn_stats_kernel": P, "gn_apply_kernel": 2 * P, "gn_bwd_stats_kernel": 2 * P, "gn_bwd_apply_kernel": 3 * P}
+               "gn_stats_kernel": P, "gn_apply_kernel": 2 * P, "gn_bwd_stats_kernel": 2 * P, "gn_bwd_apply_kernel": 3 * P,
+               "ctx_relu_kernel": 2 * P, "ctx_relu_bwd_kernel": 3 * P}
+        # focal loss: logits (N, 9*80, H, W) read once (fwd) / read + written (bwd); int32 label planes (N, 9, H, W) on top
+        Pf = Bg * sum(h * w for h, w in synth.pyramid_shapes(Hp, Wp)) * 9 * 4
+        alg.update({"focal_fwd_kernel": 80 * Pf + Pf, "focal_bwd_kernel": 2 * 80 * Pf + Pf})
         kernels = {}
         for name, (n, ms) in ktimes.items():
             kernels[name] = {"launches": n, "avg_us": 1e3 * ms / max(n, 1), "total_ms": ms}
             if name in alg:
                 kernels[name]["alg_bytes"] = alg[name]
                 kernels[name]["GBps"] = alg[name] / (1e-3 * ms / n) / 1e9
-        dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k]["total_ms"], default=None)
+        hbm_bound = [k for k in kernels if k in alg and not k.startswith("focal")]  # focal is exp/log bound, reported but not the roofline line
+        dom = max(hbm_bound, key=lambda k: kernels[k]["total_ms"], default=None)
         roofline = None
         if dom:
             traffic = None

@@ -165,6 +165,20 @@ int lgd_attn_bwd(const float* q, const float* k, const float* v, const float* ou
                  const float* dout, const int32_t* img_off, int Lq, int Lk, int B, int T, int E, int H,
                  float* dq, float* dk, float* dv, void* stream);
 
+/* ------------------------------------------------------------------ sigmoid focal loss on raw NCHW head outputs (section 8f-1)
+ * [ref: distillator.py:107-112 / 288-295 -> student.losses -> fvcore sigmoid_focal_loss_jit(alpha, gamma, "sum");
+ *  thirdparty_heads/fcos.py:146-152]  logits_l: (N, A*K, H_l, W_l) fp32 NCHW as the head's conv emits them;
+ * labels_l: (N, A, H_l, W_l) int32, class index in [0,K), K = background, < 0 = ignored anchor.
+ * loss = sum over non-ignored anchors and classes; backward writes grad_loss[0] * dloss/dlogits in NCHW.
+ */
+size_t lgd_focal_ws_doubles(const int32_t* level_hw_host, int L, int N, int A, int K);
+int lgd_focal_loss_fwd(const float* const* logits_host, const int32_t* const* labels_host,
+                       const int32_t* level_hw_host, int L, int N, int A, int K, float alpha, float gamma,
+                       double* ws, float* loss, void* stream);
+int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* labels_host,
+                       const int32_t* level_hw_host, int L, int N, int A, int K, float alpha, float gamma,
+                       const float* grad_loss, float* const* grad_logits_host, void* stream);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench.py)
  * When enabled every kernel launch of this library is bracketed by a HIP event pair recorded on
  * the launch stream.  lgd_timing_collect waits for the recorded events, sums the elapsed time per

@@ -1,0 +1,215 @@
+// Sigmoid focal loss over the detection head's raw NCHW outputs (the student head is
+// re-run on the teacher features, so this loss runs twice per iteration over 8 x 201,600 anchors x 80 classes).
+//   [ref: distillator.py:107-112 -> student.losses(...) -> detectron2 RetinaNet.losses -> fvcore
+//    sigmoid_focal_loss_jit(alpha, gamma, reduction="sum"); same loss in thirdparty_heads/fcos.py:146-152]
+// The library path permutes the (N, A*K, H, W) logits to (N, HWA, K) (a 516 MB copy, and its backward), builds a
+// one-hot target of the same size and runs ~15 elementwise kernels over it.  Here the loss is evaluated in place
+// on the NCHW tensor: element (n, a*K + k, y, x) is anchor (y, x, a) / class k, its target is
+// [label(n, a, y, x) == k] from a small int32 label plane, ignored anchors (label < 0) contribute nothing.
+//   forward : sum over valid anchors and classes (fp64 partials, fixed-order reduction)      -- reads logits once
+//   backward: dlogits in the same NCHW layout, scaled by the upstream gradient (device scalar) -- read + write
+#include "common.h"
+
+namespace lgd {
+
+constexpr int kFocalChunk = 4096;
+
+struct FocalArgs {
+    const float* x[LGD_MAX_LEVELS];
+    const int32_t* lab[LGD_MAX_LEVELS];   // (N, A, H, W) int32; K = background, < 0 = ignore
+    float* gx[LGD_MAX_LEVELS];
+    int HW[LGD_MAX_LEVELS], cpp[LGD_MAX_LEVELS], wave0[LGD_MAX_LEVELS + 1];
+    int L, N, A, K, nwaves, nfin;
+    float alpha, gamma;
+    double* ws;        // [nwaves] partial sums | [nfin] block sums
+    float* loss;
+    const float* gscale;
+};
+
+// One exp, one log and one reciprocal per element: e = exp(-|x|), p = sigmoid(x), softplus(+-x) share log1p(e).
+// v_exp_f32 / v_log_f32 / v_rcp_f32 (~1 ulp) -- the loss is compared at 1e-5 relative.
+struct FocalTerms { float p, sp_pos, sp_neg; };  // sigmoid(x), softplus(x), softplus(-x)
+__device__ __forceinline__ FocalTerms focal_terms(float x) {
+    const float e = __expf(-fabsf(x));
+    const float inv = __frcp_rn(1.f + e);
+    const float l1p = e < 1e-4f ? e * (1.f - 0.5f * e) : __logf(1.f + e);
+    FocalTerms t;
+    t.p = x >= 0.f ? inv : e * inv;
+    t.sp_pos = fmaxf(x, 0.f) + l1p;
+    t.sp_neg = fmaxf(-x, 0.f) + l1p;
+    return t;
+}
+// fvcore: ce = BCEWithLogits(x, t); p_t = p*t + (1-p)*(1-t); loss = alpha_t * ce * (1 - p_t)^gamma
+__device__ __forceinline__ float focal_elem(float x, bool t, float alpha, float gamma) {
+    const FocalTerms f = focal_terms(x);
+    const float ce = t ? f.sp_neg : f.sp_pos;
+    const float q = t ? 1.f - f.p : f.p;  // 1 - p_t
+    const float mod = gamma == 2.f ? q * q : powf(q, gamma);
+    const float at = alpha >= 0.f ? (t ? alpha : 1.f - alpha) : 1.f;
+    return at * ce * mod;
+}
+// d/dx of the above:  t=1: alpha (1-p)^g [g p log p - (1-p)] ; t=0: (1-alpha) p^g [p - g (1-p) log(1-p)]
+__device__ __forceinline__ float focal_grad(float x, bool t, float alpha, float gamma) {
+    const FocalTerms f = focal_terms(x);
+    const float at = alpha >= 0.f ? (t ? alpha : 1.f - alpha) : 1.f;
+    if (t) {
+        const float q = 1.f - f.p, mod = gamma == 2.f ? q * q : powf(q, gamma);
+        return at * mod * (gamma * f.p * (-f.sp_neg) - q);
+    }
+    const float mod = gamma == 2.f ? f.p * f.p : powf(f.p, gamma);
+    return at * mod * (f.p + gamma * (1.f - f.p) * f.sp_pos);
+}
+
+template <int MODE>  // 0 forward, 1 backward
+__global__ __launch_bounds__(256) void focal_kernel(FocalArgs a) {
+    const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= a.nwaves) return;
+    const int lane = threadIdx.x & 63;
+    int l = 0;
+    #pragma unroll
+    for (int i = 1; i < LGD_MAX_LEVELS; ++i) l += (i < a.L && w >= a.wave0[i]) ? 1 : 0;
+    const int local = w - a.wave0[l];
+    const int cpp = a.cpp[l], HW = a.HW[l];
+    const int plane = local / cpp, chunk = local % cpp;   // plane = (n * A + an) * K + k
+    const int k = plane % a.K, na = plane / a.K;
+    const float* __restrict__ px = a.x[l] + (size_t)plane * HW;
+    const int32_t* __restrict__ pl = a.lab[l] + (size_t)na * HW;
+    float* __restrict__ pg = MODE == 1 ? a.gx[l] + (size_t)plane * HW : nullptr;
+    const float gs = MODE == 1 ? a.gscale[0] : 0.f;
+    const int e0 = chunk * kFocalChunk, e1 = min(HW, e0 + kFocalChunk);
+    double acc = 0.0;
+    if ((HW & 3) == 0) {
+        for (int e = e0 + lane * 4; e < e1; e += 1024) {
+            float4 v[4];
+            int4 t[4];
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e + u * 256;
+                if (ee < e1) { v[u] = ldg_stream4(px + ee); t[u] = *reinterpret_cast<const int4*>(pl + ee); }
+            }
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e + u * 256;
+                if (ee >= e1) continue;
+                const float xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                const int ls[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+                float o[4], part = 0.f;
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (MODE == 0) part += ls[j] >= 0 ? focal_elem(xs[j], ls[j] == k, a.alpha, a.gamma) : 0.f;
+                    else o[j] = ls[j] >= 0 ? gs * focal_grad(xs[j], ls[j] == k, a.alpha, a.gamma) : 0.f;
+                }
+                if (MODE == 0) acc += (double)part;
+                else *reinterpret_cast<float4*>(pg + ee) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    } else {
+        for (int e = e0 + lane; e < e1; e += 64 * 8) {
+            float xs[8];
+            int ls[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ee = e + u * 64;
+                if (ee < e1) { xs[u] = ldg_stream(px + ee); ls[u] = pl[ee]; }
+            }
+            float part = 0.f;
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ee = e + u * 64;
+                if (ee >= e1) continue;
+                if (MODE == 0) part += ls[u] >= 0 ? focal_elem(xs[u], ls[u] == k, a.alpha, a.gamma) : 0.f;
+                else pg[ee] = ls[u] >= 0 ? gs * focal_grad(xs[u], ls[u] == k, a.alpha, a.gamma) : 0.f;
+            }
+            acc += (double)part;
+        }
+    }
+    if (MODE == 0) {
+        acc = wave_sum(acc);
+        if (lane == 0) a.ws[w] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void focal_reduce_kernel(FocalArgs a, int stage) {
+    __shared__ double red[4];
+    // stage 0: nwaves partials -> nfin block sums ; stage 1: nfin block sums -> loss
+    const double* src = stage == 0 ? a.ws : a.ws + a.nwaves;
+    const int n = stage == 0 ? a.nwaves : a.nfin;
+    double s = 0.0;
+    if (stage == 0) {
+        const int i0 = blockIdx.x * 4096;
+        for (int i = i0 + threadIdx.x; i < min(n, i0 + 4096); i += 256) s += src[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) s += src[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        if (stage == 0) a.ws[a.nwaves + blockIdx.x] = tot;
+        else a.loss[0] = (float)tot;
+    }
+}
+
+static int focal_fill(FocalArgs& a, const float* const* x_host, const int32_t* const* lab_host, const int32_t* level_hw_host,
+                      int L, int N, int A, int K, float alpha, float gamma) {
+    if (!x_host || !lab_host || !level_hw_host || L < 1 || L > LGD_MAX_LEVELS || N < 1 || A < 1 || K < 1) return LGD_EINVAL;
+    a.L = L; a.N = N; a.A = A; a.K = K; a.alpha = alpha; a.gamma = gamma;
+    int w = 0;
+    for (int l = 0; l < LGD_MAX_LEVELS; ++l) {
+        a.x[l] = nullptr; a.lab[l] = nullptr; a.gx[l] = nullptr;
+        a.wave0[l] = w;
+        if (l < L) {
+            if (!x_host[l] || !lab_host[l]) return LGD_EINVAL;
+            a.x[l] = x_host[l]; a.lab[l] = lab_host[l];
+            a.HW[l] = level_hw_host[2 * l] * level_hw_host[2 * l + 1];
+            a.cpp[l] = (a.HW[l] + kFocalChunk - 1) / kFocalChunk;
+            w += N * A * K * a.cpp[l];
+        } else { a.HW[l] = 0; a.cpp[l] = 1; }
+    }
+    a.wave0[LGD_MAX_LEVELS] = w;
+    a.nwaves = w;
+    a.nfin = (w + 4095) / 4096;
+    return LGD_OK;
+}
+
+}  // namespace lgd
+
+extern "C" {
+
+size_t lgd_focal_ws_doubles(const int32_t* level_hw_host, int L, int N, int A, int K) {
+    size_t w = 0;
+    for (int l = 0; l < L; ++l) {
+        const int hw = level_hw_host[2 * l] * level_hw_host[2 * l + 1];
+        w += (size_t)N * A * K * ((hw + lgd::kFocalChunk - 1) / lgd::kFocalChunk);
+    }
+    return w + (w + 4095) / 4096;
+}
+
+int lgd_focal_loss_fwd(const float* const* logits_host, const int32_t* const* labels_host, const int32_t* level_hw_host, int L,
+                       int N, int A, int K, float alpha, float gamma, double* ws, float* loss, void* stream) {
+    lgd::FocalArgs a;
+    if (lgd::focal_fill(a, logits_host, labels_host, level_hw_host, L, N, A, K, alpha, gamma) != LGD_OK || !ws || !loss)
+        return LGD_EINVAL;
+    a.ws = ws; a.loss = loss; a.gscale = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    LGD_LAUNCH("focal_fwd_kernel", lgd::focal_kernel<0>, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
+    LGD_LAUNCH("focal_reduce_kernel", lgd::focal_reduce_kernel, dim3(a.nfin), dim3(256), 0, s, a, 0);
+    LGD_LAUNCH("focal_reduce_kernel", lgd::focal_reduce_kernel, dim3(1), dim3(256), 0, s, a, 1);
+    return lgd::check_launch();
+}
+
+int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* labels_host, const int32_t* level_hw_host, int L,
+                       int N, int A, int K, float alpha, float gamma, const float* grad_loss, float* const* grad_logits_host,
+                       void* stream) {
+    lgd::FocalArgs a;
+    if (lgd::focal_fill(a, logits_host, labels_host, level_hw_host, L, N, A, K, alpha, gamma) != LGD_OK || !grad_loss ||
+        !grad_logits_host)
+        return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) { if (!grad_logits_host[l]) return LGD_EINVAL; a.gx[l] = grad_logits_host[l]; }
+    a.ws = nullptr; a.loss = nullptr; a.gscale = grad_loss;
+    LGD_LAUNCH("focal_bwd_kernel", lgd::focal_kernel<1>, dim3((a.nwaves + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    return lgd::check_launch();
+}
+
+}  // extern "C"

@@ -386,6 +386,60 @@ def mha_blockdiag(q_in, kv_in, counts, in_w, in_b, out_w, out_b, heads, img_off=
     return _MhaBlockDiag.apply(q_in, kv_in, in_w, in_b, out_w, out_b, img_off, int(heads))
 
 
+# ------------------------------------------------------------------------------------------------ focal loss
+class _FocalSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, K, alpha, gamma, n_levels, *tensors):
+        lib = hip.load()
+        logits = [hip.dense_f32(t) for t in tensors[:n_levels]]
+        labels = list(tensors[n_levels:])
+        hip.require_gpu(*logits, *labels)
+        N = logits[0].shape[0]
+        for x, y in zip(logits, labels):
+            if x.shape[0] != N or x.shape[1] != A * K or y.dtype != torch.int32 or tuple(y.shape) != (N, A) + tuple(x.shape[-2:]) \
+                    or not y.is_contiguous():
+                raise hip.LgdHipError("focal loss: logits (N,A*K,H,W) / int32 labels (N,A,H,W) expected, got %s / %s %s"
+                                      % (tuple(x.shape), tuple(y.shape), y.dtype))
+        hw = hip.int_array([v for m in logits for v in m.shape[-2:]])
+        dev = logits[0].device
+        ws = torch.empty(lib.lgd_focal_ws_doubles(hw, n_levels, N, A, K), dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        hip.check(lib.lgd_focal_loss_fwd(hip.ptr_array(logits), hip.ptr_array(labels), hw, n_levels, N, A, K, float(alpha),
+                                         float(gamma), hip.ptr(ws), hip.ptr(loss), hip.stream_ptr()), "lgd_focal_loss_fwd")
+        ctx.save_for_backward(*logits, *labels)
+        ctx.meta = (A, K, float(alpha), float(gamma), n_levels, N, hw)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = hip.load()
+        A, K, alpha, gamma, L, N, hw = ctx.meta
+        logits, labels = ctx.saved_tensors[:L], ctx.saved_tensors[L:]
+        g = g.contiguous().to(torch.float32)
+        grads = [torch.empty_like(x) for x in logits]
+        hip.check(lib.lgd_focal_loss_bwd(hip.ptr_array(logits), hip.ptr_array(labels), hw, L, N, A, K, alpha, gamma, hip.ptr(g),
+                                         hip.ptr_array(grads), hip.stream_ptr()), "lgd_focal_loss_bwd")
+        return (None, None, None, None, None, *grads, *([None] * L))
+
+
+def focal_loss_sum(raw_logits, label_planes, A, K, alpha, gamma):
+    """sum of fvcore's sigmoid focal loss over non-ignored anchors and classes, evaluated in place on the head's raw
+    (N, A*K, H, W) outputs; label_planes: per level (N, A, H, W) int32 (K = background, < 0 = ignore)."""
+    raw_logits, label_planes = list(raw_logits), list(label_planes)
+    return _FocalSum.apply(int(A), int(K), float(alpha), float(gamma), len(raw_logits), *raw_logits, *label_planes)
+
+
+def label_planes(labels, level_hw, A):
+    """(N, R) integer anchor labels ordered (level, y, x, a) -> per level (N, A, H, W) int32 planes."""
+    out, off = [], 0
+    N = labels.shape[0]
+    for h, w in level_hw:
+        n = h * w * A
+        out.append(labels[:, off:off + n].view(N, h, w, A).permute(0, 3, 1, 2).to(torch.int32).contiguous())
+        off += n
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ timing
 def kernel_timer_enable(on):
     """bracket every HIP kernel launch of the library with an event pair on its stream (bench.py)."""

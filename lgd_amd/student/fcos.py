@@ -184,7 +184,7 @@ class FCOSCT(nn.Module):
 
     def losses(self, gt_classes, gt_shifts_deltas, gt_centerness, pred_class_logits, pred_shift_deltas, pred_centerness):
         """[ref: thirdparty_heads/fcos.py:107-175] without boolean-index gathers / host syncs."""
-        logits = _flatten_levels(pred_class_logits, self.num_classes)
+        logits = None if pred_class_logits[0].is_cuda else _flatten_levels(pred_class_logits, self.num_classes)
         deltas = _flatten_levels(pred_shift_deltas, 4)
         ctr = _flatten_levels(pred_centerness, 1).squeeze(-1)
         valid = gt_classes >= 0
@@ -195,8 +195,14 @@ class FCOSCT(nn.Module):
             dist.all_reduce(counts)  # one packed all-reduce instead of two (fcos.py:141,143)
             counts = counts / dist.get_world_size()
         num_fg, num_targets = counts[0].clamp(min=1.0), counts[1].clamp(min=1.0)
-        loss_cls = sigmoid_focal_sum(logits, gt_classes, valid, self.num_classes, self.focal_loss_alpha,
-                                     self.focal_loss_gamma) / num_fg
+        if pred_class_logits[0].is_cuda:  # fused HIP kernel on the raw (N, K, H, W) outputs
+            from .. import ops
+            hw = [tuple(x.shape[-2:]) for x in pred_class_logits]
+            loss_cls = ops.focal_loss_sum(pred_class_logits, ops.label_planes(gt_classes, hw, 1), 1, self.num_classes,
+                                          self.focal_loss_alpha, self.focal_loss_gamma) / num_fg
+        else:
+            loss_cls = sigmoid_focal_sum(logits, gt_classes, valid, self.num_classes, self.focal_loss_alpha,
+                                         self.focal_loss_gamma) / num_fg
         safe_t = torch.where(fg[..., None], gt_shifts_deltas, torch.ones_like(gt_shifts_deltas))
         safe_p = torch.where(fg[..., None], deltas, torch.ones_like(deltas))
         loss_box = (torch.where(fg, giou_ltrb_loss(safe_p, safe_t) * gt_ctr, torch.zeros_like(gt_ctr))).sum() / num_targets

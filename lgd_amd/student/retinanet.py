@@ -125,6 +125,31 @@ def sigmoid_focal_sum(logits, labels, valid, num_classes, alpha, gamma):
     return (loss * valid[..., None].to(loss.dtype)).sum()
 
 
+class HeadOutputs(list):
+    """What `predict()` hands to `losses()` / `inference()`: behaves as the reference's list of per-level
+    (N, HWA, K) tensors (materialised lazily, on first element access) and keeps the head's raw (N, A*K, H, W)
+    outputs in `.raw`, which the fused HIP loss kernels read in place (no 516 MB permute copy per pass)."""
+
+    def __init__(self, raw, K):
+        super().__init__([None] * len(raw))
+        self.raw, self.K = list(raw), K
+
+    def _get(self, i):
+        v = list.__getitem__(self, i)
+        if v is None:
+            v = permute_to_N_HWA_K(self.raw[i], self.K)
+            list.__setitem__(self, i, v)
+        return v
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._get(j) for j in range(*i.indices(len(self)))]
+        return self._get(i if i >= 0 else len(self) + i)
+
+    def __iter__(self):
+        return (self._get(i) for i in range(len(self)))
+
+
 def batched_nms(boxes, scores, idxs, thresh):
     """plain greedy class-aware NMS (inference only, not on the training hot path)."""
     if boxes.numel() == 0:
@@ -200,9 +225,7 @@ class RetinaNetCT(nn.Module):
         """[ref: retinanet.py:36-43]"""
         anchors = self.anchor_generator(features)
         logits, deltas = self.head(features)
-        logits = [permute_to_N_HWA_K(x, self.num_classes) for x in logits]
-        deltas = [permute_to_N_HWA_K(x, 4) for x in deltas]
-        return anchors, logits, deltas
+        return anchors, HeadOutputs(logits, self.num_classes), HeadOutputs(deltas, 4)
 
     @torch.no_grad()
     def label_anchors(self, anchors, gt_instances):
@@ -242,9 +265,20 @@ class RetinaNetCT(nn.Module):
         num_pos = pos.sum().to(torch.float32)
         self.loss_normalizer = (self.loss_normalizer_momentum * self.loss_normalizer
                                 + (1 - self.loss_normalizer_momentum) * num_pos.clamp(min=1.0)).detach()
-        logits = torch.cat(pred_logits, 1)
-        deltas = torch.cat(pred_anchor_deltas, 1)
-        loss_cls = sigmoid_focal_sum(logits, labels, valid, self.num_classes, self.focal_loss_alpha, self.focal_loss_gamma)
+        deltas = torch.cat(list(pred_anchor_deltas), 1)
+        raw = getattr(pred_logits, "raw", None)
+        if raw is not None and raw[0].is_cuda:  # fused HIP kernel on the head's NCHW output (no permute copy, no one-hot)
+            from .. import ops
+            key = (id(gt_labels[0]), len(gt_labels))
+            if getattr(self, "_label_plane_key", None) != key:  # student and teacher passes share the same labels
+                hw = [tuple(x.shape[-2:]) for x in raw]
+                self._label_planes = ops.label_planes(labels, hw, raw[0].shape[1] // self.num_classes)
+                self._label_plane_key = key
+            loss_cls = ops.focal_loss_sum(raw, self._label_planes, raw[0].shape[1] // self.num_classes, self.num_classes,
+                                          self.focal_loss_alpha, self.focal_loss_gamma)
+        else:
+            loss_cls = sigmoid_focal_sum(torch.cat(list(pred_logits), 1), labels, valid, self.num_classes,
+                                         self.focal_loss_alpha, self.focal_loss_gamma)
         diff = (deltas - torch.where(pos[..., None], gt_deltas, deltas.detach())).abs()
         if self.smooth_l1_beta >= 1e-5:
             b = self.smooth_l1_beta

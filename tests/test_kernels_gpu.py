@@ -340,3 +340,27 @@ def test_gemm_batch_strided():
     assert cm.rel_err(C2, ref.t()) < 1e-6
     assert cm.rel_err(rs, 0.5 * A.double().sum(1)) < 1e-6
     assert torch.equal(C3, asym)
+
+
+# ------------------------------------------------------------------------------------------- focal loss
+@pytest.mark.parametrize("N,A,K,level_hw,gamma", [(2, 9, 80, [(16, 20), (8, 10), (3, 5)], 2.0), (3, 1, 80, [(25, 42), (7, 11)], 2.0),
+                                                  (1, 3, 7, [(9, 13)], 1.5)])
+def test_focal_loss_sum_fwd_bwd(N, A, K, level_hw, gamma):
+    """vs the torch restatement of fvcore's sigmoid_focal_loss (lgd_amd.student.retinanet.sigmoid_focal_sum)
+    evaluated on the permuted (N, HWA, K) layout with explicit one-hot semantics."""
+    from lgd_amd import ops
+    from lgd_amd.student.retinanet import permute_to_N_HWA_K, sigmoid_focal_sum
+    rng = np.random.default_rng(3)
+    R = sum(h * w * A for h, w in level_hw)
+    labels = torch.from_numpy(rng.integers(-1, K + 1, size=(N, R)))  # -1 ignore, K background
+    raw = [torch.from_numpy(synth.det_uniform((N, A * K, h, w), 700 + i)) * 6 for i, (h, w) in enumerate(level_hw)]
+    rg = [x.to(DEV).requires_grad_(True) for x in raw]
+    planes = ops.label_planes(labels.to(DEV), level_hw, A)
+    loss = ops.focal_loss_sum(rg, planes, A, K, 0.25, gamma)
+    rc = [x.clone().requires_grad_(True) for x in raw]
+    ref = sigmoid_focal_sum(torch.cat([permute_to_N_HWA_K(x, K) for x in rc], 1), labels, labels >= 0, K, 0.25, gamma)
+    assert abs(loss.item() - ref.item()) / ref.item() < 1e-5
+    (loss * 0.37).backward()
+    (ref * 0.37).backward()
+    for a, b in zip(rg, rc):
+        assert cm.rel_err(a.grad, b.grad) < FTOL
