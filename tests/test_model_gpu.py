@@ -159,3 +159,26 @@ def test_meta_arch_train_step(yaml_name, keys):
     with torch.no_grad():
         out = model(data, eval_teacher=True)
     assert len(out) == 2 and "instances" in out[0]
+
+
+def test_train_cli_checkpoint_resume(tmp_path):
+    """train.py with the reference's CLI surface: trains a few synthetic iterations, writes metrics.json with the
+    reference's scalar names and a checkpoint with the reference's keys, resumes from it, runs --eval-only."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "train.py"), "--config-file", os.path.join(root, "configs", "lgd_retinanet_r50.yaml"),
+            "--num-gpus", "1", "--image-size", "256", "320"]
+    opts = ["OUTPUT_DIR", str(tmp_path), "SOLVER.IMS_PER_BATCH", "2", "SOLVER.CHECKPOINT_PERIOD", "3",
+            "MODEL.DISTILLATOR.PRE_NONDISTILL_ITERS", "2", "MODEL.DISTILLATOR.PRE_FREEZE_STUDENT_BACKBONE_ITERS", "1"]
+    subprocess.check_call(base + ["--max-iter", "4"] + opts)
+    ck = torch.load(os.path.join(str(tmp_path), "model_final.pth"), map_location="cpu")
+    assert set(ck) == {"model", "stu_optimizer", "tea_optimizer", "stu_scheduler", "tea_scheduler", "iteration"} and ck["iteration"] == 3
+    m = [json.loads(l) for l in open(os.path.join(str(tmp_path), "metrics.json"))]
+    assert {"total_loss", "stu_lr", "tea_lr", "loss_distill", "loss_cls.tea"} <= set(m[-1])
+    subprocess.check_call(base + ["--max-iter", "6", "--resume"] + opts)
+    m2 = [json.loads(l) for l in open(os.path.join(str(tmp_path), "metrics.json"))]
+    assert m2[-1]["iteration"] == 5 and len(m2) == len(m) + 1
+    subprocess.check_call(base + ["--eval-only", "--resume"] + opts)

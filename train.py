@@ -1,0 +1,108 @@
+#!/usr/bin/env python
+"""Training entry with the reference's command line
+    python train.py --config-file CFG --num-gpus N [--resume] [--eval-only] [KEY VALUE ...]
+[ref: train.py:237-310; README.md:97-126].  N > 1: launch one process per GPU with
+    python -m torch.distributed.run --nproc-per-node N train.py --config-file CFG --num-gpus N ...
+(RCCL over xGMI; the reference's detectron2 `launch` + tcp rendezvous is replaced by the env rendezvous).
+Data: synthetic COCO-shaped batches (lgd_amd/data.py) -- real-image IO/evaluation are out of scope.
+Checkpoints carry the reference's keys {model, stu_optimizer, tea_optimizer, stu_scheduler, tea_scheduler,
+iteration} [ref: train.py:155-167]; metrics go to OUTPUT_DIR/metrics.json every 20 iterations with the
+reference's scalar names [ref: train.py:199,212-213,229-233]."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config-file", default=os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml"))
+    ap.add_argument("--num-gpus", type=int, default=1)
+    ap.add_argument("--resume", action="store_true")
+    ap.add_argument("--eval-only", action="store_true")
+    ap.add_argument("--max-iter", type=int, default=None, help="stop early (synthetic runs)")
+    ap.add_argument("--image-size", type=int, nargs=2, default=(800, 1333))
+    ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
+    return ap.parse_args()
+
+
+def latest_checkpoint(out_dir):
+    f = os.path.join(out_dir, "last_checkpoint")
+    if os.path.exists(f):
+        return os.path.join(out_dir, open(f).read().strip())
+    return None
+
+
+def save_checkpoint(trainer, out_dir, name):
+    os.makedirs(out_dir, exist_ok=True)
+    torch.save(trainer.state_dict(), os.path.join(out_dir, name))
+    with open(os.path.join(out_dir, "last_checkpoint"), "w") as f:
+        f.write(name)
+
+
+def main():
+    args = parse()
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if args.num_gpus > 1 and world != args.num_gpus:
+        raise SystemExit("use: python -m torch.distributed.run --nproc-per-node %d train.py --num-gpus %d ..." % (args.num_gpus, args.num_gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from lgd_amd import config
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    cfg = config.setup_cfg(args.config_file, ["MODEL.DEVICE", "cuda:%d" % local_rank] + [o for o in args.opts if o != "--"])
+    torch.manual_seed(0 if cfg.SEED < 0 else cfg.SEED)
+    model = build_model(cfg)
+    model.distill_flag = cfg.MODEL.DISTILLATOR.DISTILL_OFF  # train.py:266
+    per_gpu = max(1, cfg.SOLVER.IMS_PER_BATCH // world)
+    h, w = args.image_size
+    if args.eval_only:
+        ck = latest_checkpoint(cfg.OUTPUT_DIR) if args.resume else (cfg.MODEL.WEIGHTS if os.path.exists(cfg.MODEL.WEIGHTS) else None)
+        if ck:
+            model.load_state_dict(torch.load(ck, map_location=dev)["model"])
+        model.eval()
+        with torch.no_grad():
+            for probe in ([True, False] if cfg.MODEL.DISTILLATOR.EVAL_TEACHER else [False]):  # train.py:268-276
+                out = model(synthetic_batch(per_gpu, h, w, 10, seed=7), eval_teacher=probe)
+                if rank == 0:
+                    print("eval_teacher=%s: %d images, %d detections" % (probe, len(out), sum(len(o["instances"]) for o in out)))
+        return
+    trainer = Trainer(cfg, model, device=dev)
+    start = 0
+    if args.resume and latest_checkpoint(cfg.OUTPUT_DIR):
+        trainer.load_state_dict(torch.load(latest_checkpoint(cfg.OUTPUT_DIR), map_location=dev))
+        start = trainer.iteration
+    max_iter = cfg.SOLVER.MAX_ITER if args.max_iter is None else min(cfg.SOLVER.MAX_ITER, args.max_iter)
+    metrics_f = open(os.path.join(cfg.OUTPUT_DIR, "metrics.json"), "a") if rank == 0 and (os.makedirs(cfg.OUTPUT_DIR, exist_ok=True) or True) else None
+    t0 = time.perf_counter()
+    for it in range(start, max_iter):
+        data = synthetic_batch(per_gpu, h, w, 10, seed=it * world + rank)
+        trainer.step(data, it)
+        if (it + 1) % 20 == 0 or it == max_iter - 1:  # train.py:229-233
+            m = trainer.fetch_metrics()  # one all-reduce + one host copy per log period; raises on non-finite loss
+            if rank == 0:
+                m.update(iteration=it, time=(time.perf_counter() - t0) / (it + 1 - start))
+                metrics_f.write(json.dumps(m) + "\n")
+                metrics_f.flush()
+                print("iter %d  total_loss %.4f  %s  stu_lr %.6f  %.3f s/iter" % (
+                    it, m["total_loss"], "  ".join("%s %.4f" % (k, v) for k, v in m.items() if k.startswith("loss")), m["stu_lr"], m["time"]))
+        if rank == 0 and ((it + 1) % cfg.SOLVER.CHECKPOINT_PERIOD == 0 or it == max_iter - 1):  # train.py:165-167,234
+            save_checkpoint(trainer, cfg.OUTPUT_DIR, "model_%07d.pth" % it if it != max_iter - 1 else "model_final.pth")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
