@@ -19,21 +19,25 @@ struct PrepArgs {
     int H[LGD_MAX_LEVELS], W[LGD_MAX_LEVELS];
 };
 
-// [lo, hi] = the integer coordinates p in [0, n) with |c - p| / s <= 0.5 evaluated in fp32
-// exactly as torch does (abs, IEEE divide, compare).  The true-set is an interval because every
-// operation is monotone in |c - p|; an empty set returns hi < lo.
-__device__ __forceinline__ void axis_interval(float a, float b, float ratio, int n, int& lo, int& hi) {
+// [lo, hi] = the integer coordinates p in [0, n) with |c - p| / s <= 0.5 evaluated in fp32 exactly as torch does
+// (abs, IEEE divide, compare).  The true-set is an interval because every operation is monotone in |c - p|; an
+// empty set returns hi < lo.  One WAVE evaluates one box axis: lane j tests coordinates j, j+64, ... and the
+// interval ends come from the ballots (no serial loop over the pixels).
+__device__ __forceinline__ void axis_interval(float a, float b, float ratio, int n, int lane, int& lo, int& hi) {
     const float a1 = __fmul_rn(a, ratio);       // box_tensor[:, [0,2]] * r_w  (utils.py:69)
     const float b1 = __fmul_rn(b, ratio);
     const float c = __fmul_rn(__fadd_rn(a1, b1), 0.5f);  // (x1 + x2) * 0.5     (utils.py:73)
     const float s = __fsub_rn(b1, a1);                   // x2 - x1             (utils.py:77)
     lo = n;
     hi = -1;
-    for (int p = 0; p < n; ++p) {
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        const int p = p0 + lane;
         const float d = __fdiv_rn(fabsf(__fsub_rn(c, (float)p)), s);  // utils.py:87
-        if (d <= 0.5f) {  // false for NaN (0/0) and +inf (x/0): zero-extent boxes are empty
-            lo = min(lo, p);
-            hi = max(hi, p);
+        // false for NaN (0/0) and +inf (x/0): zero-extent boxes are empty
+        const unsigned long long m = __ballot(p < n && d <= 0.5f);
+        if (m) {
+            lo = min(lo, p0 + (int)__builtin_ctzll(m));
+            hi = max(hi, p0 + 63 - (int)__builtin_clzll(m));
         }
     }
 }
@@ -52,16 +56,19 @@ __global__ __launch_bounds__(256) void box_prep_kernel(PrepArgs a) {
     const float r_h = (float)((double)H / (double)a.img_h);
     int32_t* rects = a.geom + geom_rects_off() + ((size_t)l * a.T + t0) * 4;
 
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = wave; i < n; i += 4) {  // one wave per box
         const float4 bx = reinterpret_cast<const float4*>(a.boxes)[t0 + i];
         int x0, x1, y0, y1;
-        axis_interval(bx.x, bx.z, r_w, W, x0, x1);
-        axis_interval(bx.y, bx.w, r_h, H, y0, y1);
+        axis_interval(bx.x, bx.z, r_w, W, lane, x0, x1);
+        axis_interval(bx.y, bx.w, r_h, H, lane, y0, y1);
         if (x1 < x0 || y1 < y0) { x0 = 0; x1 = -1; y0 = 0; y1 = -1; }
-        reinterpret_cast<int4*>(rects)[i] = make_int4(x0, x1, y0, y1);
-        // row breakpoints: a band starts where a box starts and right after it ends
-        keys[2 * i] = (y1 >= y0) ? y0 : 0;
-        keys[2 * i + 1] = (y1 >= y0) ? y1 + 1 : H;
+        if (lane == 0) {
+            reinterpret_cast<int4*>(rects)[i] = make_int4(x0, x1, y0, y1);
+            // row breakpoints: a band starts where a box starts and right after it ends
+            keys[2 * i] = (y1 >= y0) ? y0 : 0;
+            keys[2 * i + 1] = (y1 >= y0) ? y1 + 1 : H;
+        }
     }
     if (threadIdx.x == 0) { keys[2 * n] = 0; keys[2 * n + 1] = H; }
     __syncthreads();

@@ -57,6 +57,35 @@ class Bottleneck(nn.Module):
         return F.relu_(out + sc)
 
 
+class DeformBottleneck(Bottleneck):
+    """Bottleneck whose 3x3 conv is a (modulated) deformable conv driven by a zero-initialised offset conv
+    (`conv2_offset`: 18 offsets [+ 9 masks, sigmoid]) [d2-memory: DeformBottleneckBlock]."""
+
+    def __init__(self, cin, cout, mid, stride, stride_in_1x1=True, groups=1, dilation=1, modulated=True):
+        super().__init__(cin, cout, mid, stride, stride_in_1x1, groups, dilation)
+        self.modulated = modulated
+        self.conv2_offset = nn.Conv2d(mid, 27 if modulated else 18, 3, self.conv2.stride, dilation, dilation)
+        nn.init.constant_(self.conv2_offset.weight, 0)
+        nn.init.constant_(self.conv2_offset.bias, 0)
+
+    def forward(self, x):
+        from .deform import modulated_deform_conv2d
+        out = self.conv1(x, relu=True)
+        om = self.conv2_offset(out)
+        if self.modulated:
+            o1, o2, m = torch.chunk(om, 3, dim=1)
+            offset, mask = torch.cat((o1, o2), 1), m.sigmoid()
+        else:
+            offset, mask = om, torch.ones_like(om[:, :9])
+        c2 = self.conv2
+        scale, shift = c2.norm.scale_shift()
+        out = modulated_deform_conv2d(out, offset, mask, c2.weight * scale.view(-1, 1, 1, 1), shift, c2.stride[0],
+                                      c2.padding[0], c2.dilation[0])
+        out = self.conv3(F.relu_(out))
+        sc = self.shortcut(x) if self.shortcut is not None else x
+        return F.relu_(out + sc)
+
+
 class Stem(nn.Module):
     def __init__(self, cin=3, cout=64):
         super().__init__()
@@ -71,7 +100,8 @@ class ResNet(nn.Module):
     BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
     def __init__(self, depth=50, out_features=("res3", "res4", "res5"), freeze_at=2, stride_in_1x1=True,
-                 num_groups=1, width_per_group=64, res2_out=256, stem_out=64):
+                 num_groups=1, width_per_group=64, res2_out=256, stem_out=64, deform_on_per_stage=(False,) * 4,
+                 deform_modulated=False):
         super().__init__()
         self.stem = Stem(3, stem_out)
         self.out_features = tuple(out_features)
@@ -81,7 +111,10 @@ class ResNet(nn.Module):
             blocks = []
             for j in range(n):
                 stride = 2 if (j == 0 and i > 0) else 1
-                blocks.append(Bottleneck(cin, cout, mid, stride, stride_in_1x1, num_groups))
+                if deform_on_per_stage[i]:
+                    blocks.append(DeformBottleneck(cin, cout, mid, stride, stride_in_1x1, num_groups, modulated=deform_modulated))
+                else:
+                    blocks.append(Bottleneck(cin, cout, mid, stride, stride_in_1x1, num_groups))
                 cin = cout
             name = "res%d" % (i + 2)
             self.add_module(name, nn.Sequential(*blocks))

@@ -171,11 +171,9 @@ def batched_nms(boxes, scores, idxs, thresh):
 
 def build_resnet_fpn(cfg, top_in="res5"):
     r = cfg.MODEL.RESNETS
-    if any(r.DEFORM_ON_PER_STAGE):
-        raise NotImplementedError("DEFORM_ON_PER_STAGE (DCNv2, BASELINE config 5) needs a modulated deformable "
-                                  "convolution op; scheduled in SURVEY.md section 8f-4")
     bottom_up = ResNet(r.DEPTH, r.OUT_FEATURES, cfg.MODEL.BACKBONE.FREEZE_AT, r.STRIDE_IN_1X1, r.NUM_GROUPS,
-                       r.WIDTH_PER_GROUP, r.RES2_OUT_CHANNELS, r.STEM_OUT_CHANNELS)
+                       r.WIDTH_PER_GROUP, r.RES2_OUT_CHANNELS, r.STEM_OUT_CHANNELS, tuple(r.DEFORM_ON_PER_STAGE),
+                       r.DEFORM_MODULATED)
     feats = cfg.MODEL.FPN.IN_FEATURES
     cout = cfg.MODEL.FPN.OUT_CHANNELS
     top_c = bottom_up.out_channels[top_in] if top_in.startswith("res") else cout

@@ -154,3 +154,43 @@ def test_retinanet_anchor_labels_and_losses_cpu():
     ce = torch.nn.functional.binary_cross_entropy_with_logits(logits, t, reduction="none")
     ref = ((0.25 * t + 0.75 * (1 - t)) * ce * (1 - (p * t + (1 - p) * (1 - t))) ** 2)[valid].sum()
     assert abs(float(got - ref)) < 1e-5
+
+
+def test_modulated_deform_conv_matches_definition():
+    """DCNv2 (BASELINE config 5): zero offsets + unit mask == plain conv; random offsets == direct bilinear sampling."""
+    import torch.nn.functional as F
+    from lgd_amd.student.deform import modulated_deform_conv2d
+    torch.manual_seed(0)
+    x, w, b = torch.randn(2, 5, 9, 11), torch.randn(7, 5, 3, 3), torch.randn(7)
+    for stride in (1, 2):
+        Ho, Wo = (9 + 2 - 3) // stride + 1, (11 + 2 - 3) // stride + 1
+        y = modulated_deform_conv2d(x, torch.zeros(2, 18, Ho, Wo), torch.ones(2, 9, Ho, Wo), w, b, stride, 1, 1)
+        assert float((y - F.conv2d(x, w, b, stride, 1)).abs().max()) < 1e-4
+    off, m = torch.randn(2, 18, 9, 11) * 1.5, torch.rand(2, 9, 9, 11)
+    y = modulated_deform_conv2d(x, off, m, w, b)
+
+    def bil(img, py, px):
+        H, W = img.shape[-2:]
+        y0, x0 = int(torch.floor(py)), int(torch.floor(px))
+        r = torch.zeros(img.shape[0])
+        for yy, wy in ((y0, 1 - (py - y0)), (y0 + 1, py - y0)):
+            for xx, wx in ((x0, 1 - (px - x0)), (x0 + 1, px - x0)):
+                if 0 <= yy < H and 0 <= xx < W:
+                    r = r + img[:, yy, xx] * wy * wx
+        return r
+    for n, yy, xx in ((0, 0, 0), (1, 4, 5), (0, 8, 10), (1, 3, 0)):
+        acc = b.clone()
+        for k in range(9):
+            ky, kx = divmod(k, 3)
+            acc = acc + (w[:, :, ky, kx] @ bil(x[n], yy - 1 + ky + off[n, 2 * k, yy, xx], xx - 1 + kx + off[n, 2 * k + 1, yy, xx])) * m[n, k, yy, xx]
+        assert float((y[n, :, yy, xx] - acc).abs().max()) < 1e-4
+
+
+def test_dcnv2_config_builds():
+    from lgd_amd.distillator import build_model
+    cfg = config.setup_cfg(os.path.join(ROOT, "configs", "lgd_retinanet_r101_dcnv2.yaml"), ["MODEL.DEVICE", "cpu"])
+    m = build_model(cfg)
+    keys = m.state_dict().keys()
+    assert "student.raw_backbone.res3.0.conv2_offset.weight" in keys and "student.raw_backbone.res5.2.conv2_offset.bias" in keys
+    assert "student.raw_backbone.res2.0.conv2_offset.weight" not in keys
+    assert m.state_dict()["student.raw_backbone.res4.22.conv2_offset.weight"].shape == (27, 256, 3, 3)

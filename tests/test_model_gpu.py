@@ -128,6 +128,7 @@ def test_distill_loss_and_grads_match_reference(run):
     ("lgd_retinanet_r50", {"loss_cls", "loss_box_reg", "loss_cls.tea", "loss_box_reg.tea", "loss_distill"}),
     ("lgd_fcos_r50", {"loss_cls", "loss_box_reg", "loss_centerness", "loss_cls.tea", "loss_box_reg.tea",
                       "loss_centerness.tea", "loss_distill"}),
+    ("lgd_retinanet_r101_dcnv2", {"loss_cls", "loss_box_reg", "loss_cls.tea", "loss_box_reg.tea", "loss_distill"}),
 ])
 def test_meta_arch_train_step(yaml_name, keys):
     """one full training iteration (both optimizers) on a small synthetic batch; loss keys as in the reference
