@@ -165,6 +165,29 @@ int lgd_attn_bwd(const float* q, const float* k, const float* v, const float* ou
                  const float* dout, const int32_t* img_off, int Lq, int Lk, int B, int T, int E, int H,
                  float* dq, float* dk, float* dv, void* stream);
 
+/* ------------------------------------------------------------------ K6: label-encoder glue
+ * lgd_box_descriptors [ref: label_encoder.py:12-115 box_descriptor_encode, utils.py:16-51]: per-box 4+K descriptor
+ *   (clamped xyxy / image size, one-hot class, scaled to [-1,1]) and the clamped boxes ("boxlists"), on the device:
+ *   boxes_in (T0,4) instance boxes as annotated (x1y1x2y2, or x1y1wh when wh_format), classes (T0,) int32,
+ *   in_off/out_off (B+1) int32 row offsets of the instances / of the output rows (instances [+1 context row],
+ *   or ONE substitute row [0,0,1,1] for an image without ground truth).  desc (T,4+K), boxes_out (T,4).
+ * lgd_rowln_*   : LayerNorm over the last axis, no affine, eps 1e-5 [+ReLU]  [ref: label_encoder.py:157-160,243-270;
+ *   spatial_transformer.py:23-40; layers.py:9-19]; stats (T,2) = mean, rstd.
+ * lgd_rowvecmat_*: out[t,:] = x[t,:] @ M[t,:,:]  (T-Net transforms)  [ref: label_encoder.py:241,248]; k <= 128.
+ * lgd_segmax_*  : per-image max over the image's rows, broadcast back to them  [ref: label_encoder.py:195-213,262-264];
+ *   arg (B,F) int32 = arg-max row, consumed by the backward.
+ */
+int lgd_box_descriptors(const float* boxes_in, const int32_t* classes, const int32_t* in_off, const int32_t* out_off,
+                        int B, int T, int num_classes, int img_h, int img_w, int add_ctx, int wh_format,
+                        float* desc, float* boxes_out, void* stream);
+int lgd_rowln_fwd(const float* x, int T, int F, int relu, float* y, float* stats, void* stream);
+int lgd_rowln_bwd(const float* x, const float* dy, const float* stats, int T, int F, int relu, float* dx, void* stream);
+int lgd_rowvecmat_fwd(const float* x, const float* M, int T, int k, float* out, void* stream);
+int lgd_rowvecmat_bwd(const float* x, const float* M, const float* dout, int T, int k, float* dx, float* dM,
+                      void* stream);
+int lgd_segmax_fwd(const float* x, const int32_t* off, int B, int F, float* out, int32_t* arg, void* stream);
+int lgd_segmax_bwd(const float* dout, const int32_t* off, const int32_t* arg, int B, int F, float* dx, void* stream);
+
 /* ------------------------------------------------------------------ sigmoid focal loss on raw NCHW head outputs (section 8f-1)
  * [ref: distillator.py:107-112 / 288-295 -> student.losses -> fvcore sigmoid_focal_loss_jit(alpha, gamma, "sum");
  *  thirdparty_heads/fcos.py:146-152]  logits_l: (N, A*K, H_l, W_l) fp32 NCHW as the head's conv emits them;

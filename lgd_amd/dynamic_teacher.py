@@ -48,13 +48,10 @@ def get_CONVS(nr_layers, channels, has_norm, has_relu=True, nr_groups=1, affine_
     return nn.Sequential(*[unit() for _ in range(nr_layers)])
 
 
-def _pointwise(conv, x):
-    """nn.Conv1d(k_in, k_out, 1) applied to length-1 sequences == a row-wise linear map."""
-    return F.linear(x, conv.weight.squeeze(-1), conv.bias)
-
-
-def _ln(x):
-    return F.layer_norm(x, (x.shape[-1],), eps=1e-5)
+def _lin_ln_relu(layer, x, relu=True):
+    """Linear / pointwise Conv1d (length-1 sequences == row-wise linear map) -> LayerNorm(no affine) -> ReLU:
+    fp32 MFMA GEMM kernel + one fused row-LN(+ReLU) kernel."""
+    return ops.row_ln(ops.linear(x, layer.weight, layer.bias), relu)
 
 
 # ----------------------------------------------------------------------------------------- STN
@@ -72,12 +69,12 @@ class STN(nn.Module):
         self.k = k
 
     def forward(self, x):
-        h = F.relu(_ln(_pointwise(self.conv1, x)))
-        h = F.relu(_ln(_pointwise(self.conv2, h)))
-        h = F.relu(_ln(_pointwise(self.conv3, h)))
-        h = F.relu(_ln(self.fc1(h)))
-        h = F.relu(_ln(self.fc2(h)))
-        return self.fc3(h).view(-1, self.k, self.k)
+        h = _lin_ln_relu(self.conv1, x)
+        h = _lin_ln_relu(self.conv2, h)
+        h = _lin_ln_relu(self.conv3, h)  # the max over the length-1 axis (spatial_transformer.py:34) is a no-op
+        h = _lin_ln_relu(self.fc1, h)
+        h = _lin_ln_relu(self.fc2, h)
+        return ops.linear(h, self.fc3.weight, self.fc3.bias).view(-1, self.k, self.k)
 
 
 # ----------------------------------------------------------------------------------------- label encoder
@@ -106,68 +103,48 @@ class LabelEncoder(nn.Module):
 
     @torch.no_grad()
     def encode_descriptors(self, targets, img_h, img_w, device):
-        """[ref: label_encoder.py:12-115] without the per-image host round trips.
-        Returns descriptors (T,84) in [-1,1], clamped boxes (T,4) (device), counts (host list),
+        """[ref: label_encoder.py:12-115] without the per-image host round trips: the annotations are concatenated,
+        moved to the device once, and ONE kernel emits descriptors + clamped boxes for the whole mini-batch.
+        Returns descriptors (T,84) in [-1,1], clamped boxes (T,4), counts (host list), img_off (B+1 int32, device),
         inst_labels (list of per-image class tensors)."""
         K = self.nr_fg_classes
-        rows, counts, inst_rows, labels, inst_labels = [], [], [], [], []
-        ctx_row = torch.tensor([[0.0, 0.0, float(img_w), float(img_h)]], device=device)
-        t = 0
+        in_counts, out_counts, boxes, classes, inst_labels = [], [], [], [], []
         for inst in targets:
             n = len(inst)
+            in_counts.append(n)
+            out_counts.append(n + 1 if (n > 0 and self.add_context_box) else max(n, 1))
             if n > 0:
-                bb = inst.gt_boxes.tensor.reshape(n, 4).to(device=device, dtype=torch.float32, non_blocking=True)
                 cls = inst.gt_classes.reshape(n)
                 if not cls.is_cuda:  # validate where it is free (label_encoder.py:98)
                     assert bool(((cls >= 0) & (cls <= K - 1)).all()), "gt_classes outside [0, %d]" % (K - 1)
-                cls = cls.to(device=device, non_blocking=True)
-                if self.box_format == "x1y1wh":  # utils.py:26-38
-                    bb = torch.stack([bb[:, 0], bb[:, 1], bb[:, 0] + bb[:, 2] - 1.0, bb[:, 1] + bb[:, 3] - 1.0], 1)
-                rows.append(bb)
-                inst_rows.extend(range(t, t + n))
-                labels.append(cls.to(torch.int64))
+                boxes.append(inst.gt_boxes.tensor.reshape(n, 4).to(torch.float32))
+                classes.append(cls)
                 inst_labels.append(cls)
-                if self.add_context_box:
-                    rows.append(ctx_row)
-                    n += 1
-            else:  # label_encoder.py:64-66; the substitute box goes through the format conversion too (72-73)
-                unit = [0.0, 0.0, 0.0, 0.0] if self.box_format == "x1y1wh" else [0.0, 0.0, 1.0, 1.0]
-                rows.append(torch.tensor([unit], device=device))
-                inst_labels.append(torch.zeros(1, device=device))
-                n = 1
-            counts.append(n)
-            t += n
-        bb = torch.cat(rows, 0)
-        # clamp to the PADDED batch tensor size (utils.py:40-51, label_encoder.py:167)
-        boxes = torch.stack([bb[:, 0].clamp(0, img_w - 1), bb[:, 1].clamp(0, img_h - 1),
-                             bb[:, 2].clamp(0, img_w - 1), bb[:, 3].clamp(0, img_h - 1)], 1)
-        d = torch.zeros((t, 4 + K), device=device)
-        d[:, 0] = boxes[:, 0] / img_w
-        d[:, 2] = boxes[:, 2] / img_w
-        d[:, 1] = boxes[:, 1] / img_h
-        d[:, 3] = boxes[:, 3] / img_h
-        if inst_rows:
-            ridx = torch.tensor(inst_rows, dtype=torch.int64).to(device, non_blocking=True)
-            d[ridx, 4 + torch.cat(labels)] = 1.0
-        d = 2.0 * d + (-1.0)  # range_scaling [0,1] -> [-1,1] (utils.py:16-24)
-        return d, boxes, counts, inst_labels
+            else:
+                inst_labels.append(torch.zeros(1))  # label_encoder.py:66,114
+        if boxes:
+            bb = torch.cat(boxes, 0).to(device, non_blocking=True)
+            cc = torch.cat(classes, 0).to(device, non_blocking=True)
+        else:
+            bb, cc = torch.zeros((0, 4), device=device), torch.zeros((0,), dtype=torch.int64, device=device)
+        desc, clamped, img_off = ops.box_descriptors(bb, cc, in_counts, out_counts, img_h, img_w, K, self.add_context_box,
+                                                     self.box_format == "x1y1wh")
+        return desc, clamped, out_counts, img_off, inst_labels
 
     def forward(self, x0):
         batched_inputs, images, _, fpn = x0
         device = fpn["p3"].device if isinstance(fpn, dict) else fpn[0].device
         _, _, h, w = images.tensor.shape
         targets = [x["instances"] for x in batched_inputs]
-        desc, boxes, counts, inst_labels = self.encode_descriptors(targets, h, w, device)
-        x = desc
+        x, boxes, counts, img_off, inst_labels = self.encode_descriptors(targets, h, w, device)
         m1 = self.stn_desc(x)
-        x1 = torch.bmm(x.unsqueeze(1), m1).squeeze(1)
-        hfeat = F.relu(_ln(_pointwise(self.conv1, x1)))
+        x1 = ops.row_vecmat(x, m1)                       # (x^T M)^T, label_encoder.py:241
+        hfeat = _lin_ln_relu(self.conv1, x1)
         m2 = self.stn_feat(hfeat)
-        xf = torch.bmm(hfeat.unsqueeze(1), m2).squeeze(1)
-        h2 = F.relu(_ln(_pointwise(self.conv2, xf)))
-        h3 = F.relu(_ln(_pointwise(self.conv3, h2)))
-        g = ops.segment_max_broadcast(h3, counts)  # per-image max, broadcast back to the image's rows
-        out = F.relu(_ln(_pointwise(self.conv4, torch.cat([xf, g], 1))))
+        xf = ops.row_vecmat(hfeat, m2)                   # label_encoder.py:248
+        h3 = _lin_ln_relu(self.conv3, _lin_ln_relu(self.conv2, xf))
+        g = ops.segment_max_broadcast(h3, img_off)       # per-image max, broadcast back to the image's rows
+        out = _lin_ln_relu(self.conv4, torch.cat([xf, g], 1))
         return out, m1, m2, boxes, {"h": h, "w": w}, inst_labels, counts
 
 
@@ -209,13 +186,13 @@ class DynamicTeacher(nn.Module):
     def rendering(self, attn_out, geom):
         """attn_out (L,T,C) -> list of L maps.  [ref: dynamic_teacher.py:106-190]
         The context row of every image is projected too (one GEMM for all rows) but never painted."""
-        proj = self.local_inst_proj_1D(attn_out)
+        proj = ops.linear(attn_out, self.local_inst_proj_1D.weight, self.local_inst_proj_1D.bias)
         painted = ops.render_paint(geom, proj, skip_last=self.add_context_box)
         conv = self.local_inst_proj_2D
         if self.add_context_box:
             last = torch.tensor([o - 1 for o in _offsets(geom.counts)[1:]], dtype=torch.int64).to(attn_out.device,
                                                                                                 non_blocking=True)
-            ctx = self.global_ctx_proj_1D(attn_out[:, last])  # (L,B,C)
+            ctx = ops.linear(attn_out[:, last], self.global_ctx_proj_1D.weight, self.global_ctx_proj_1D.bias)  # (L,B,C)
             return ops.bias_ctx_relu([F.conv2d(p, conv.weight, conv.bias, padding=1) for p in painted], ctx)
         return [F.relu(F.conv2d(p, conv.weight, conv.bias, padding=1)) for p in painted]
 
@@ -231,7 +208,7 @@ class DynamicTeacher(nn.Module):
         if self.detach_appearance_embed:
             feats = {k: v.detach() for k, v in feats.items()}
         keys = list(feats.keys())
-        canoni = F.relu(_ln(self.canoni_proj_1D[0][0](label_embed)))
+        canoni = _lin_ln_relu(self.canoni_proj_1D[0][0], label_embed)
         sp = self.student_proj_2D[0][0]
         proj = ops.gn1([F.conv2d(feats[k], sp.weight, sp.bias, padding=1) for k in keys], relu=True)
         geom = ops.BoxGeometry(boxes, counts, (img_size_dict["h"], img_size_dict["w"]),

@@ -43,6 +43,13 @@ SIGNATURES = {
     "lgd_gemm_batch": (c_i, [c_fp, c_i, c_fp]),
     "lgd_attn_fwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_attn_bwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_box_descriptors": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_rowln_fwd": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_rowln_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_rowvecmat_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
+    "lgd_rowvecmat_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_segmax_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_segmax_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_focal_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i, c_i]),
     "lgd_focal_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
     "lgd_focal_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),

@@ -197,15 +197,6 @@ def segment_ids(counts, device):
     return torch.tensor(ids, dtype=torch.int64).to(device, non_blocking=True)
 
 
-def segment_max_broadcast(x, counts):
-    """per-image max over the image's rows, broadcast back to those rows: (T,F) -> (T,F).
-    [ref: label_encoder.py:195-213 hier_pool + 262-264 repeat]"""
-    seg = segment_ids(counts, x.device)
-    g = torch.full((len(counts), x.shape[1]), float("-inf"), device=x.device, dtype=x.dtype)
-    g = g.scatter_reduce(0, seg[:, None].expand(-1, x.shape[1]), x, reduce="amax", include_self=True)
-    return g[seg]
-
-
 def _levels_meta(maps):
     B, C = maps[0].shape[0], maps[0].shape[1]
     for m in maps:
@@ -384,6 +375,152 @@ def mha_blockdiag(q_in, kv_in, counts, in_w, in_b, out_w, out_b, heads, img_off=
     if img_off is None:
         img_off = torch.tensor(_offsets(counts), dtype=torch.int32).to(q_in.device, non_blocking=True)
     return _MhaBlockDiag.apply(q_in, kv_in, in_w, in_b, out_w, out_b, img_off, int(heads))
+
+
+# ------------------------------------------------------------------------------------------------ K6: label-encoder ops
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b on the fp32 MFMA GEMM kernel; backward = one launch with dX, dW (+ db as a row sum)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        hip.require_gpu(x, w)
+        x, w = hip.dense_f32(x), hip.dense_f32(w)
+        b = hip.dense_f32(b) if b is not None else None
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _gemm_batch([_gemm((x, 0), (K, 1), (w, 0), (K, 1), (y, 0), (N, 1), M, N, K, bias=(b, 0) if b is not None else None)])
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = hip.dense_f32(dy)
+        M, K = x.shape
+        N = w.shape[0]
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty((N,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        _gemm_batch([
+            _gemm((dy, 0), (N, 1), (w, 0), (1, K), (dx, 0), (K, 1), M, K, N),
+            _gemm((dy, 0), (1, N), (x, 0), (1, K), (dw, 0), (K, 1), N, K, M, rowsum=(db, 0) if db is not None else None),
+        ])
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """F.linear for (..., K) inputs; weights may be Conv1d-shaped (N, K, 1)."""
+    w2 = w.reshape(w.shape[0], -1)
+    lead = x.shape[:-1]
+    return _Linear.apply(x.reshape(-1, x.shape[-1]), w2, b).reshape(*lead, w2.shape[0])
+
+
+class _RowLn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, relu):
+        lib = hip.load()
+        hip.require_gpu(x)
+        x = hip.dense_f32(x)
+        T, F_ = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((T, 2), dtype=torch.float32, device=x.device)
+        hip.check(lib.lgd_rowln_fwd(hip.ptr(x), T, F_, int(relu), hip.ptr(y), hip.ptr(stats), hip.stream_ptr()), "lgd_rowln_fwd")
+        ctx.save_for_backward(x, stats)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = hip.load()
+        x, stats = ctx.saved_tensors
+        dy = hip.dense_f32(dy)
+        dx = torch.empty_like(x)
+        hip.check(lib.lgd_rowln_bwd(hip.ptr(x), hip.ptr(dy), hip.ptr(stats), x.shape[0], x.shape[1], int(ctx.relu), hip.ptr(dx),
+                                    hip.stream_ptr()), "lgd_rowln_bwd")
+        return dx, None
+
+
+def row_ln(x, relu):
+    """LayerNorm over the last axis (no affine, eps 1e-5) [+ ReLU] of a (T, F) tensor."""
+    return _RowLn.apply(x, bool(relu))
+
+
+class _RowVecMat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, M):
+        lib = hip.load()
+        hip.require_gpu(x, M)
+        x, M = hip.dense_f32(x), hip.dense_f32(M)
+        T, k = x.shape
+        out = torch.empty_like(x)
+        hip.check(lib.lgd_rowvecmat_fwd(hip.ptr(x), hip.ptr(M), T, k, hip.ptr(out), hip.stream_ptr()), "lgd_rowvecmat_fwd")
+        ctx.save_for_backward(x, M)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = hip.load()
+        x, M = ctx.saved_tensors
+        dout = hip.dense_f32(dout)
+        dx, dM = torch.empty_like(x), torch.empty_like(M)
+        hip.check(lib.lgd_rowvecmat_bwd(hip.ptr(x), hip.ptr(M), hip.ptr(dout), x.shape[0], x.shape[1], hip.ptr(dx), hip.ptr(dM),
+                                        hip.stream_ptr()), "lgd_rowvecmat_bwd")
+        return dx, dM
+
+
+def row_vecmat(x, M):
+    """out[t] = x[t] @ M[t]; x (T,k), M (T,k,k)  [ref: label_encoder.py:241,248]"""
+    return _RowVecMat.apply(x, M)
+
+
+class _SegMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, off):
+        lib = hip.load()
+        hip.require_gpu(x, off)
+        x = hip.dense_f32(x)
+        B, F_ = off.numel() - 1, x.shape[1]
+        out = torch.empty_like(x)
+        arg = torch.empty((B, F_), dtype=torch.int32, device=x.device)
+        hip.check(lib.lgd_segmax_fwd(hip.ptr(x), hip.ptr(off), B, F_, hip.ptr(out), hip.ptr(arg), hip.stream_ptr()), "lgd_segmax_fwd")
+        ctx.save_for_backward(off, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = hip.load()
+        off, arg = ctx.saved_tensors
+        dout = hip.dense_f32(dout)
+        dx = torch.empty_like(dout)
+        hip.check(lib.lgd_segmax_bwd(hip.ptr(dout), hip.ptr(off), hip.ptr(arg), arg.shape[0], arg.shape[1], hip.ptr(dx),
+                                     hip.stream_ptr()), "lgd_segmax_bwd")
+        return dx, None
+
+
+def segment_max_broadcast(x, img_off):
+    """per-image max over the image's rows, broadcast back to those rows: (T,F) -> (T,F); img_off (B+1) int32 device.
+    [ref: label_encoder.py:195-213 hier_pool + 262-264 repeat]"""
+    return _SegMax.apply(x, img_off)
+
+
+def box_descriptors(boxes_in, classes, in_counts, out_counts, img_h, img_w, num_classes, add_ctx, wh_format):
+    """[ref: label_encoder.py:12-115] on the device, one launch: returns (desc (T,4+K), clamped boxes (T,4), out_off (B+1) int32).
+    boxes_in (T0,4) / classes (T0,) are the concatenated annotations (device); counts are host lists."""
+    lib = hip.load()
+    hip.require_gpu(boxes_in)
+    dev = boxes_in.device
+    B, T = len(out_counts), int(sum(out_counts))
+    offs = torch.tensor([_offsets(in_counts), _offsets(out_counts)], dtype=torch.int32).to(dev, non_blocking=True)
+    boxes_in = hip.dense_f32(boxes_in.reshape(-1, 4)) if boxes_in.numel() else torch.zeros((1, 4), device=dev)
+    classes = classes.to(torch.int32).contiguous() if classes.numel() else torch.zeros((1,), dtype=torch.int32, device=dev)
+    desc = torch.empty((T, 4 + num_classes), dtype=torch.float32, device=dev)
+    boxes = torch.empty((T, 4), dtype=torch.float32, device=dev)
+    hip.check(lib.lgd_box_descriptors(hip.ptr(boxes_in), hip.ptr(classes), hip.ptr(offs[0]), hip.ptr(offs[1]), B, T, num_classes,
+                                      int(img_h), int(img_w), int(add_ctx), int(wh_format), hip.ptr(desc), hip.ptr(boxes),
+                                      hip.stream_ptr()), "lgd_box_descriptors")
+    return desc, boxes, offs[1]
 
 
 # ------------------------------------------------------------------------------------------------ focal loss

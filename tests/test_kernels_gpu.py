@@ -364,3 +364,91 @@ def test_focal_loss_sum_fwd_bwd(N, A, K, level_hw, gamma):
     (ref * 0.37).backward()
     for a, b in zip(rg, rc):
         assert cm.rel_err(a.grad, b.grad) < FTOL
+
+
+# ------------------------------------------------------------------------------------------- K6 label-encoder ops
+@pytest.mark.parametrize("name", list(cm.CASES) + ["c2_masks_800x1344"])
+def test_box_descriptors_bit_exact(name):
+    """descriptors + clamped boxes from ONE kernel == the reference's box_descriptor_encode (golden), bit for bit:
+    ctx on/off, x1y1wh, an empty-GT image, out-of-bounds boxes."""
+    from lgd_amd import ops
+    g = cm.golden(name)
+    if name in cm.CASES:
+        _, H, W, ctx, _, fmt, _, _ = cm.CASES[name]
+    else:
+        H, W, ctx, fmt = 800, 1344, True, "x1y1x2y2"
+    gt = cm.case_gt(name)
+    in_counts = [int(b.shape[0]) for b, _ in gt]
+    out_counts = [n + 1 if (n > 0 and ctx) else max(n, 1) for n in in_counts]
+    bb = torch.cat([b for b, _ in gt]).to(DEV)
+    cc = torch.cat([c for _, c in gt]).to(DEV)
+    desc, boxes, off = ops.box_descriptors(bb, cc, in_counts, out_counts, H, W, 80, ctx, fmt == "x1y1wh")
+    assert np.array_equal(boxes.cpu().double().numpy(), g["boxlists"])
+    if "descs" in g:
+        assert np.array_equal(desc.cpu().numpy(), g["descs"])
+    assert off.cpu().tolist() == np.concatenate([[0], np.cumsum(out_counts)]).tolist()
+
+
+@pytest.mark.parametrize("M,K,N", [(88, 84, 64), (22, 1088, 256), (7, 256, 7056), (160, 256, 256)])
+def test_linear_fwd_bwd(M, K, N):
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    x = torch.from_numpy(synth.det_uniform((M, K), 1)); w = torch.from_numpy(synth.det_uniform((N, K, 1), 2)) * 0.1
+    b = torch.from_numpy(synth.det_uniform((N,), 3))
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xg, wg, bg)
+    xc, wc, bc = (t.clone().requires_grad_(True) for t in (x, w, b))
+    r = F.linear(xc, wc.squeeze(-1), bc)
+    assert cm.rel_err(y, r) < FTOL
+    pr = torch.from_numpy(synth.det_uniform((M, N), 4))
+    (y * pr.to(DEV)).sum().backward(); (r * pr).sum().backward()
+    for a, c in ((xg, xc), (wg, wc), (bg, bc)):
+        assert cm.rel_err(a.grad, c.grad) < FTOL
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("T,F_", [(88, 64), (22, 1024), (5, 1088), (1, 256)])
+def test_row_ln_fwd_bwd(T, F_, relu):
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    x = torch.from_numpy(synth.det_uniform((T, F_), 5)) * 3 + 0.7
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.row_ln(xg, relu)
+    xc = x.clone().requires_grad_(True)
+    r = F.layer_norm(xc, (F_,), eps=1e-5)
+    r = F.relu(r) if relu else r
+    assert cm.rel_err(y, r) < FTOL
+    pr = torch.from_numpy(synth.det_uniform((T, F_), 6))
+    (y * pr.to(DEV)).sum().backward(); (r * pr).sum().backward()
+    ok, msg = cm.kink_robust_close(xg.grad, xc.grad, tol=1e-4)
+    assert ok, msg
+
+
+@pytest.mark.parametrize("T,k", [(88, 84), (12, 64), (3, 5)])
+def test_row_vecmat_fwd_bwd(T, k):
+    from lgd_amd import ops
+    x = torch.from_numpy(synth.det_uniform((T, k), 7)); M = torch.from_numpy(synth.det_uniform((T, k, k), 8))
+    xg, Mg = x.to(DEV).requires_grad_(True), M.to(DEV).requires_grad_(True)
+    y = ops.row_vecmat(xg, Mg)
+    xc, Mc = x.clone().requires_grad_(True), M.clone().requires_grad_(True)
+    r = torch.bmm(xc.unsqueeze(1), Mc).squeeze(1)
+    assert cm.rel_err(y, r) < FTOL
+    pr = torch.from_numpy(synth.det_uniform((T, k), 9))
+    (y * pr.to(DEV)).sum().backward(); (r * pr).sum().backward()
+    assert cm.rel_err(xg.grad, xc.grad) < FTOL and cm.rel_err(Mg.grad, Mc.grad) < FTOL
+
+
+def test_segment_max_fwd_bwd():
+    from lgd_amd import ops
+    counts = [11, 1, 70, 2]
+    T, F_ = sum(counts), 1024
+    x = torch.from_numpy(synth.det_uniform((T, F_), 10))
+    off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device=DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.segment_max_broadcast(xg, off)
+    xc = x.clone().requires_grad_(True)
+    r = torch.cat([t.max(0, keepdim=True)[0].expand(n, -1) for t, n in zip(xc.split(counts), counts)])
+    assert torch.equal(y.cpu(), r)
+    pr = torch.from_numpy(synth.det_uniform((T, F_), 11))
+    (y * pr.to(DEV)).sum().backward(); (r * pr).sum().backward()
+    assert cm.rel_err(xg.grad, xc.grad) < 1e-6
