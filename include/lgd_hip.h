@@ -135,7 +135,7 @@ int lgd_ctx_relu_bwd(const float* const* y_host, const float* const* dy_host, co
 /* ------------------------------------------------------------------ K2: block-diagonal multi-head cross-attention
  * [ref: dynamic_teacher.py:76-78 nn.MultiheadAttention(256, 8); 255-273 attn_mask + per-level calls]
  *
- * lgd_gemm_batch: up to 6 small fp32 GEMMs in one launch on the MFMA pipe (v_mfma_f32_16x16x4_f32),
+ * lgd_gemm_batch: up to 16 small fp32 GEMMs in one launch on the MFMA pipe (v_mfma_f32_16x16x4_f32),
  *   C[m,n] = alpha * (sum_k A(m,k) * B(n,k) + bias[n]),  A(m,k) = A[m*sa_m + k*sa_k], B(n,k) = B[n*sb_n + k*sb_k],
  *   C at C[m*sc_m + n*sc_n]; rowsum (optional) [M] = alpha * sum_k A(m,k)  (bias gradients).
  *   Used for the in/out projections [ref: torch MultiheadAttention in_proj_weight (3E,E) / out_proj] and

@@ -17,7 +17,7 @@
 namespace lgd {
 
 // ------------------------------------------------------------------------------------------- GEMM list
-constexpr int kMaxProb = 6;
+constexpr int kMaxProb = 16;
 struct GemmProb {
     const float* A; const float* B; const float* bias; float* C; float* rowsum;
     int M, N, K;

@@ -400,13 +400,22 @@ class _Linear(torch.autograd.Function):
         dy = hip.dense_f32(dy)
         M, K = x.shape
         N = w.shape[0]
-        dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         db = torch.empty((N,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        _gemm_batch([
-            _gemm((dy, 0), (N, 1), (w, 0), (1, K), (dx, 0), (K, 1), M, K, N),
-            _gemm((dy, 0), (1, N), (x, 0), (1, K), (dw, 0), (K, 1), N, K, M, rowsum=(db, 0) if db is not None else None),
-        ])
+        probs = [_gemm((dy, 0), (1, N), (x, 0), (1, K), (dw, 0), (K, 1), N, K, M, rowsum=(db, 0) if db is not None else None)]
+        # dX = dY W reduces over N; a wide layer on few rows (T-Net fc3: N = 7056, M ~ 10^2) would be ONE long serial
+        # MFMA chain per tile, so the reduction is cut into <= 14 slices (separate problems of the same launch) whose
+        # partial products are summed in a fixed order.
+        S = min(14, max(1, N // 512)) if (N > 1024 and ((M + 63) // 64) * ((K + 63) // 64) < 64) else 1
+        step = (N + S - 1) // S
+        step = (step + 3) // 4 * 4  # keep 16-byte alignment of the slices
+        S = (N + step - 1) // step
+        dxp = torch.empty((S, M, K), dtype=torch.float32, device=x.device)
+        for i in range(S):
+            n0, n1 = i * step, min(N, (i + 1) * step)
+            probs.append(_gemm((dy, n0), (N, 1), (w, n0 * K), (1, K), (dxp, i * M * K), (K, 1), M, K, n1 - n0))
+        _gemm_batch(probs)
+        dx = dxp[0] if S == 1 else dxp.sum(0)
         return dx, dw, db
 
 
