@@ -98,8 +98,8 @@ def synth_gt(B, img_h, img_w, n_per_img=10, seed=5, table=False):
 
 
 def synth_images(B, h, w, seed=3):
-    """uint8-valued float32 images (B,3,h,w), BGR order as detectron2 feeds them."""
-    return np.floor(det_uniform((B, 3, h, w), seed, 0.0, 256.0)).astype(np.float32)
+    """uint8 images (B,3,h,w), BGR order, as detectron2's DatasetMapper hands them to the model."""
+    return np.floor(det_uniform((B, 3, h, w), seed, 0.0, 256.0)).astype(np.uint8)
 
 
 def closed_form_params(shapes, gain=1.0):
