@@ -452,3 +452,27 @@ def test_segment_max_fwd_bwd():
     pr = torch.from_numpy(synth.det_uniform((T, F_), 11))
     (y * pr.to(DEV)).sum().backward(); (r * pr).sum().backward()
     assert cm.rel_err(xg.grad, xc.grad) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------- determinism
+def test_kernels_are_bit_reproducible():
+    """fixed-order reductions, no atomics: two launches on the same inputs give identical bits (fwd and bwd)."""
+    from lgd_amd import ops
+    B, H, W, C = 2, 256, 320, 256
+    level_hw = synth.pyramid_shapes(H, W)
+    boxlists, feats = _random_case(B, H, W, [11, 70], level_hw, C, seed=5, ctx=True)
+    geom = _geom(boxlists, (H, W), level_hw)
+    fg = [f.to(DEV) for f in feats]
+    tg = [torch.from_numpy(synth.det_uniform(tuple(f.shape), 800 + i)).to(DEV) for i, f in enumerate(feats)]
+    vals = torch.from_numpy(synth.det_uniform((len(level_hw), 81, C), 3)).to(DEV)
+
+    def run():
+        a = [f.clone().requires_grad_(True) for f in fg]
+        pooled = ops.mask_pool(geom, ops.gn1(a, True))
+        painted = ops.render_paint(geom, vals + pooled, True)
+        loss = ops.distill_in_mse(painted, tg, 1.0) + pooled.sum() * 1e-3
+        g = torch.autograd.grad(loss, a)
+        return [loss.detach(), pooled.detach()] + [x.detach() for x in painted] + list(g)
+    r1, r2 = run(), run()
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)

@@ -155,6 +155,11 @@ def test_meta_arch_train_step(yaml_name, keys):
     assert any(n.startswith("adapter.") for n in changed)
     assert any(n.startswith("student.raw_backbone.res5") for n in changed)
     assert not any(n.startswith("student.raw_backbone.stem") or n.startswith("student.raw_backbone.res2") for n in changed)
+    # multi-scale batch (INPUT.MIN_SIZE_TRAIN sampling): images of different sizes are padded to one tensor, the
+    # teacher works in the padded frame [ref: label_encoder.py:167]
+    ragged = synthetic_batch(1, 224, 288, 4, seed=3) + synthetic_batch(1, 256, 320, 6, seed=4)
+    losses = tr.step(ragged, 40001)
+    assert set(losses) == keys and all(np.isfinite(v) for v in tr.fetch_metrics().values())
     # eval branch (incl. teacher upper-bound probe) runs and returns one result per image
     model.eval()
     with torch.no_grad():
