@@ -87,6 +87,21 @@ int lgd_box_paint(const float* vals /* [L][T][C] */, const int32_t* level_hw_hos
                   int max_n, const int32_t* img_off, const int32_t* geom, float* const* outs_host,
                   int normalize, int skip_last, void* stream);
 
+/* ------------------------------------------------------------------ K5+K1 fused: pool(relu(GroupNorm1(x)))
+ * The appearance encoder pools `student_proj_2D(feat)` = conv3x3 -> GN(1) -> ReLU  [ref: dynamic_teacher.py:57,235,
+ * 249-253] and nothing else reads that map, so the normalised map is never written: after lgd_gn1 statistics
+ * (gn_stats [L*B][2] mean, rstd -- e.g. from lgd_gn1_fwd's stats pass), lgd_gn_pool_fwd streams the CONV OUTPUT x
+ * once, applies (x-mean)*rstd and ReLU in registers and accumulates the box means: out [L][T][C].
+ * lgd_gn_pool_bwd: dx for the conv output from dpool [L][T][C]; the painted gradient is composed per row band on
+ * the fly (never materialised); ws = 2*L*B*C doubles, bstats = [L*B][2] scratch.
+ * HBM traffic: fwd P (+P for the statistics), bwd 2P read + P write  (unfused: 4P / 6P).
+ */
+int lgd_gn_pool_fwd(const float* const* x_host, const float* gn_stats, const int32_t* level_hw_host, int L, int B,
+                    int C, int T, int max_n, const int32_t* img_off, const int32_t* geom, float* out, void* stream);
+int lgd_gn_pool_bwd(const float* const* x_host, const float* gn_stats, const float* dpool,
+                    const int32_t* level_hw_host, int L, int B, int C, int T, int max_n, const int32_t* img_off,
+                    const int32_t* geom, double* ws, float* bstats, float* const* dx_host, void* stream);
+
 /* ------------------------------------------------------------------ K4: InstanceNorm x2 + MSE
  * [ref: models/base_distillator.py:59-64  norm_stu / norm_tea (InstanceNorm2d(256, affine=False),
  *  eps 1e-5, biased variance), flatten+cat over levels, coef * F.mse_loss]
@@ -119,6 +134,9 @@ int lgd_distill_bwd(const float* const* a_host, const float* const* b_host, cons
 size_t lgd_gn1_ws_doubles(const int32_t* level_hw_host, int L, int B, int C);
 int lgd_gn1_fwd(const float* const* x_host, const int32_t* level_hw_host, int L, int B, int C, int relu,
                 double* ws, float* stats, float* const* y_host, void* stream);
+/* statistics pass of lgd_gn1_fwd alone (mean, rstd per (level, sample)); used by the fused lgd_gn_pool_* path */
+int lgd_gn1_stats(const float* const* x_host, const int32_t* level_hw_host, int L, int B, int C, double* ws,
+                  float* stats, void* stream);
 int lgd_gn1_bwd(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L,
                 int B, int C, int relu, const float* stats, double* ws, float* bstats,
                 float* const* dx_host, void* stream);

@@ -29,6 +29,11 @@ struct BoxArgs {
     const int32_t* img_off;
     const int32_t* geom;
     int L, B, C, T, max_n, normalize, skip_last;
+    // fused GroupNorm(1)+ReLU on the fly (gn_pool): y = relu((x - mean_b) * rstd_b) is what gets pooled
+    const float* gn_stats;             // [L*B][2] mean, rstd (nullptr: plain box_sum)
+    const float* gn_bstats;            // [L*B][2] m1, m2 (backward apply)
+    const float* gx[LGD_MAX_LEVELS];   // backward: conv output x
+    double* ws;                        // backward stats: [L][B*C][2] per-plane partial sums
 };
 
 struct Plane { int l, b, c, H, W, t0, n, nbp; const int32_t* rects; const int32_t* bands; };
@@ -92,6 +97,8 @@ __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, 
     auto band = [&](int k) {  // wave-uniform by construction: say so, or every band test becomes an exec-masked vector loop
         return __builtin_amdgcn_readfirstlane(p.nbp <= 64 ? __builtin_amdgcn_readlane(bandreg, k) : p.bands[k]);
     };
+    const bool gn = a.gn_stats != nullptr;
+    const float gmu = gn ? a.gn_stats[2 * (p.l * a.B + p.b)] : 0.f, grs = gn ? a.gn_stats[2 * (p.l * a.B + p.b) + 1] : 1.f;
     for (int pass = 0; pass < npass; ++pass) {
         LaneBox bx{0, -1, 0, -1};
         if (lane < nb) bx = load_lane_box_at(p, pass * nb + lane, a.skip_last);
@@ -152,7 +159,8 @@ __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, 
                         }
                         if (act && on) {
                             #pragma unroll
-                            for (int j = 0; j < VW; ++j) cs[j] += v[u].v[j];
+                            for (int j = 0; j < VW; ++j)
+                                cs[j] += gn ? fmaxf(__fmul_rn(__fsub_rn(v[u].v[j], gmu), grs), 0.f) : v[u].v[j];
                         }
                     }
                 }
@@ -251,12 +259,123 @@ __global__ __launch_bounds__(256) void box_paint_kernel(BoxArgs a) {
     else box_paint_plane<1>(a, p);
 }
 
+// ------------------------------------------------------------------------------------------- gn_pool backward
+// d/dx of  pool(relu(GN1(x))):  dy = paint(dpool / count) restricted to y > 0, then the GroupNorm(1) backward
+// dx = rstd * (g - m1 - xhat * m2), m1 = mean(g), m2 = mean(g * xhat) over the sample.  dy is never materialised:
+// every band's row pattern pv is composed from the active boxes (as in box_paint) and applied while x streams by.
+//   MODE 0: per-plane partial sums of g and g*xhat (fp64) -> ws        (reads x once)
+//   MODE 1: dx                                                         (reads x once, writes dx)
+template <int VW, int MODE>
+__device__ __forceinline__ void gn_pool_bwd_plane(const BoxArgs& a, const Plane& p) {
+    const int lane = threadIdx.x & 63;
+    const size_t base = ((size_t)p.b * a.C + p.c) * p.H * p.W;
+    const float* __restrict__ src = a.gx[p.l] + base;
+    float* __restrict__ dst = MODE == 1 ? a.out[p.l] + base : nullptr;
+    const float* __restrict__ vals = a.vals + ((size_t)p.l * a.T + p.t0) * a.C + p.c;
+    const int seg = p.l * a.B + p.b;
+    const float mu = a.gn_stats[2 * seg], rs = a.gn_stats[2 * seg + 1];
+    float m1 = 0.f, m2 = 0.f;
+    if (MODE == 1) { m1 = a.gn_bstats[2 * seg]; m2 = a.gn_bstats[2 * seg + 1]; }
+    const int npass = (p.n + 63) >> 6;
+    auto lane_val = [&](const LaneBox& bx, int pass) -> float {
+        float v = 0.f;
+        if (bx.x1 >= bx.x0) v = vals[(size_t)(pass * 64 + lane) * a.C] / fmaxf((float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)), 1.f);
+        return v;
+    };
+    const LaneBox bx0 = load_lane_box(p, 0, lane, 0);
+    const float val0 = lane_val(bx0, 0);
+    double s1 = 0.0, s2 = 0.0;
+    for (int xc = 0; xc < p.W; xc += 64 * VW) {
+        const int xl = xc + lane * VW;
+        const bool on = xl < p.W;
+        const float* col = src + (on ? xl : 0);
+        for (int k = 0; k + 1 < p.nbp; ++k) {
+            const int ya = __builtin_amdgcn_readfirstlane(p.bands[k]), yb = __builtin_amdgcn_readfirstlane(p.bands[k + 1]);
+            float pv[VW];
+            #pragma unroll
+            for (int j = 0; j < VW; ++j) pv[j] = 0.f;
+            bool any = false;
+            for (int pass = 0; pass < npass; ++pass) {
+                LaneBox bx = bx0;
+                float val = val0;
+                if (pass > 0) { bx = load_lane_box(p, pass, lane, 0); val = lane_val(bx, pass); }
+                unsigned long long act = __ballot(bx.x1 >= bx.x0 && bx.y0 <= ya && ya <= bx.y1);
+                any |= act != 0ull;
+                while (act) {
+                    const int n = __builtin_ctzll(act);
+                    act &= act - 1;
+                    const int q0 = __builtin_amdgcn_readlane(bx.x0, n), q1 = __builtin_amdgcn_readlane(bx.x1, n);
+                    const float v = readlane_f32(val, n);
+                    #pragma unroll
+                    for (int j = 0; j < VW; ++j) pv[j] += (xl + j >= q0 && xl + j <= q1) ? v : 0.f;
+                }
+            }
+            if (MODE == 0 && !any) continue;  // uncovered rows contribute g = 0 to both sums: not even read
+            if (!on) continue;
+            for (int y0 = ya; y0 < yb; y0 += 4) {
+                Vec<VW> v[4];
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = vload<VW>(col + (size_t)min(y0 + u, yb - 1) * p.W);
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (y0 + u >= yb) continue;
+                    Vec<VW> o;
+                    float t1 = 0.f, t2 = 0.f;
+                    #pragma unroll
+                    for (int j = 0; j < VW; ++j) {
+                        const float xh = __fmul_rn(__fsub_rn(v[u].v[j], mu), rs);
+                        const float g = xh > 0.f ? pv[j] : 0.f;
+                        if (MODE == 0) { t1 += g; t2 = fmaf(g, xh, t2); }
+                        else o.v[j] = rs * (g - m1 - xh * m2);
+                    }
+                    if (MODE == 0) { s1 += (double)t1; s2 += (double)t2; }
+                    else vstore<VW>(dst + xl + (size_t)(y0 + u) * p.W, o);
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) {
+            double* o = a.ws + 2 * (((size_t)p.l * a.B + p.b) * a.C + p.c);
+            o[0] = s1; o[1] = s2;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_pool_bwd_kernel(BoxArgs a) {
+    const Plane p = locate(a, 4);
+    if ((p.W & 3) == 0) gn_pool_bwd_plane<4, MODE>(a, p);
+    else if ((p.W & 1) == 0) gn_pool_bwd_plane<2, MODE>(a, p);
+    else gn_pool_bwd_plane<1, MODE>(a, p);
+}
+
+// per (level, image): fold the C per-plane partials -> m1 = mean(g), m2 = mean(g*xhat)
+__global__ __launch_bounds__(256) void gn_pool_bwd_finalize_kernel(BoxArgs a, float* bstats) {
+    __shared__ double red[8];
+    const int seg = blockIdx.x, l = seg / a.B;
+    const double* p = a.ws + 2 * (size_t)seg * a.C;
+    double s1 = 0, s2 = 0;
+    for (int c = threadIdx.x; c < a.C; c += 256) { s1 += p[2 * c]; s2 += p[2 * c + 1]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = s1; red[2 * (threadIdx.x >> 6) + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = (double)a.C * a.H[l] * a.W[l];
+        bstats[2 * seg] = (float)(((red[0] + red[2]) + (red[4] + red[6])) / n);
+        bstats[2 * seg + 1] = (float)(((red[1] + red[3]) + (red[5] + red[7])) / n);
+    }
+}
+
 static int fill_args(BoxArgs& a, const int32_t* level_hw_host, int L, int B, int C, int T, int max_n,
                      const int32_t* img_off, const int32_t* geom, int normalize, int skip_last, int ppb) {
     if (!level_hw_host || !img_off || !geom || L < 1 || L > LGD_MAX_LEVELS || B < 1 || C < 4 || (C & 3) || T < 0)
         return LGD_EINVAL;
     a.L = L; a.B = B; a.C = C; a.T = T; a.max_n = max_n; a.normalize = normalize; a.skip_last = skip_last;
     a.img_off = img_off; a.geom = geom; a.vals = nullptr; a.pooled = nullptr;
+    a.gn_stats = nullptr; a.gn_bstats = nullptr; a.ws = nullptr;
+    for (int l = 0; l < LGD_MAX_LEVELS; ++l) a.gx[l] = nullptr;
     int blk = 0;
     for (int l = 0; l < LGD_MAX_LEVELS; ++l) {
         a.in[l] = nullptr; a.out[l] = nullptr;
@@ -294,6 +413,38 @@ int lgd_box_sum(const float* const* feats_host, const int32_t* level_hw_host, in
     const int nb = max_n < 1 ? 1 : (max_n > 64 ? 64 : max_n);  // boxes per pass: 256 B of LDS per wave and box
     LGD_LAUNCH("box_sum_kernel", lgd::box_sum_kernel, dim3(nblk), dim3(256), (size_t)4 * nb * 64 * sizeof(float),
                (hipStream_t)stream, a, nb);
+    return lgd::check_launch();
+}
+
+int lgd_gn_pool_fwd(const float* const* x_host, const float* gn_stats, const int32_t* level_hw_host, int L, int B, int C, int T,
+                    int max_n, const int32_t* img_off, const int32_t* geom, float* out, void* stream) {
+    lgd::BoxArgs a;
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, 1, 0, 4);
+    if (nblk < 0 || !x_host || !gn_stats || !out) return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) { if (!x_host[l]) return LGD_EINVAL; a.in[l] = x_host[l]; }
+    a.pooled = out; a.gn_stats = gn_stats;
+    if (T == 0) return LGD_OK;
+    const int nb = max_n < 1 ? 1 : (max_n > 64 ? 64 : max_n);
+    LGD_LAUNCH("gn_pool_kernel", lgd::box_sum_kernel, dim3(nblk), dim3(256), (size_t)4 * nb * 64 * sizeof(float),
+               (hipStream_t)stream, a, nb);
+    return lgd::check_launch();
+}
+
+int lgd_gn_pool_bwd(const float* const* x_host, const float* gn_stats, const float* dpool, const int32_t* level_hw_host, int L,
+                    int B, int C, int T, int max_n, const int32_t* img_off, const int32_t* geom, double* ws, float* bstats,
+                    float* const* dx_host, void* stream) {
+    lgd::BoxArgs a;
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, 1, 0, 4);
+    if (nblk < 0 || !x_host || !gn_stats || !dpool || !ws || !bstats || !dx_host) return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) {
+        if (!x_host[l] || !dx_host[l]) return LGD_EINVAL;
+        a.gx[l] = x_host[l]; a.out[l] = dx_host[l];
+    }
+    a.vals = dpool; a.gn_stats = gn_stats; a.gn_bstats = bstats; a.ws = ws;
+    hipStream_t s = (hipStream_t)stream;
+    LGD_LAUNCH("gn_pool_bwd_stats_kernel", lgd::gn_pool_bwd_kernel<0>, dim3(nblk), dim3(256), 0, s, a);
+    LGD_LAUNCH("gn_pool_bwd_finalize_kernel", lgd::gn_pool_bwd_finalize_kernel, dim3(L * B), dim3(256), 0, s, a, bstats);
+    LGD_LAUNCH("gn_pool_bwd_apply_kernel", lgd::gn_pool_bwd_kernel<1>, dim3(nblk), dim3(256), 0, s, a);
     return lgd::check_launch();
 }
 

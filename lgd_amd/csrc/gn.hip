@@ -276,6 +276,17 @@ int lgd_gn1_fwd(const float* const* x_host, const int32_t* level_hw_host, int L,
     return lgd::check_launch();
 }
 
+int lgd_gn1_stats(const float* const* x_host, const int32_t* level_hw_host, int L, int B, int C, double* ws, float* stats,
+                  void* stream) {
+    lgd::GnArgs a;
+    if (lgd::gn_fill(a, x_host, level_hw_host, L, B, C, 0) != LGD_OK || !ws || !stats) return LGD_EINVAL;
+    a.ws = ws; a.stats = stats; a.bstats = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    LGD_LAUNCH("gn_stats_kernel", lgd::gn_stats_kernel<0>, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
+    LGD_LAUNCH("gn_finalize_kernel", lgd::gn_finalize_kernel<0>, dim3(L * B), dim3(256), 0, s, a);
+    return lgd::check_launch();
+}
+
 int lgd_gn1_bwd(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L, int B, int C,
                 int relu, const float* stats, double* ws, float* bstats, float* const* dx_host, void* stream) {
     lgd::GnArgs a;

@@ -210,10 +210,11 @@ class DynamicTeacher(nn.Module):
         keys = list(feats.keys())
         canoni = _lin_ln_relu(self.canoni_proj_1D[0][0], label_embed)
         sp = self.student_proj_2D[0][0]
-        proj = ops.gn1([F.conv2d(feats[k], sp.weight, sp.bias, padding=1) for k in keys], relu=True)
         geom = ops.BoxGeometry(boxes, counts, (img_size_dict["h"], img_size_dict["w"]),
                                [tuple(feats[k].shape[-2:]) for k in keys])
-        app = ops.mask_pool(geom, proj)  # (L,T,C) appearance embeddings
+        # student_proj_2D = conv3x3 -> GN(1) -> ReLU, consumed only by the mask pooling: GN+ReLU are applied inside
+        # the pooling kernel, the normalised maps are never written (and never re-read by a separate pooling pass)
+        app = ops.gn_relu_mask_pool(geom, [F.conv2d(feats[k], sp.weight, sp.bias, padding=1) for k in keys])  # (L,T,C)
         a = self.multi_head_attn
         if self.interact_pattern == "student_fill":
             att = app

@@ -244,6 +244,49 @@ def gn1(xs, relu):
     return list(_Gn1.apply(bool(relu), *xs))
 
 
+class _GnReluPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geom, *xs):
+        lib = hip.load()
+        hip.require_gpu(*xs)
+        xs = [hip.dense_f32(x) for x in xs]
+        geom._check(xs)
+        L = len(xs)
+        B, C, hw = _levels_meta(xs)
+        dev = xs[0].device
+        ws = torch.empty(lib.lgd_gn1_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)
+        stats = torch.empty((L * B, 2), dtype=torch.float32, device=dev)
+        hip.check(lib.lgd_gn1_stats(hip.ptr_array(xs), hw, L, B, C, hip.ptr(ws), hip.ptr(stats), hip.stream_ptr()), "lgd_gn1_stats")
+        out = torch.empty((L, geom.T, C), dtype=torch.float32, device=dev)
+        hip.check(lib.lgd_gn_pool_fwd(hip.ptr_array(xs), hip.ptr(stats), hw, L, B, C, geom.T, geom.max_n, hip.ptr(geom.img_off),
+                                      hip.ptr(geom.geom), hip.ptr(out), hip.stream_ptr()), "lgd_gn_pool_fwd")
+        ctx.save_for_backward(stats, *xs)
+        ctx.geom, ctx.meta = geom, (L, B, C, hw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dpool):
+        lib = hip.load()
+        L, B, C, hw = ctx.meta
+        geom = ctx.geom
+        stats, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dpool = hip.dense_f32(dpool)
+        dev = xs[0].device
+        ws = torch.empty(2 * L * B * C, dtype=torch.float64, device=dev)
+        bstats = torch.empty((L * B, 2), dtype=torch.float32, device=dev)
+        dxs = [torch.empty_like(x) for x in xs]
+        hip.check(lib.lgd_gn_pool_bwd(hip.ptr_array(xs), hip.ptr(stats), hip.ptr(dpool), hw, L, B, C, geom.T, geom.max_n,
+                                      hip.ptr(geom.img_off), hip.ptr(geom.geom), hip.ptr(ws), hip.ptr(bstats), hip.ptr_array(dxs),
+                                      hip.stream_ptr()), "lgd_gn_pool_bwd")
+        return (None, *dxs)
+
+
+def gn_relu_mask_pool(geom, xs):
+    """mask_pool(geom, gn1(xs, relu=True)) without ever writing the normalised maps: appearance embeddings (L,T,C)
+    straight from the conv outputs.  [ref: dynamic_teacher.py:57,235 student_proj_2D + 249-253 aggregate_per_level]"""
+    return _GnReluPool.apply(geom, *xs)
+
+
 class _CtxRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cvec, *xs):

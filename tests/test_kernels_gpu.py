@@ -476,3 +476,26 @@ def test_kernels_are_bit_reproducible():
     r1, r2 = run(), run()
     for x, y in zip(r1, r2):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("cfg", CASES_BOX[:4])
+def test_gn_relu_mask_pool_fused_fwd_bwd(cfg):
+    """the fused kernel == mask_pool(gn1(x, relu)) of the oracle, forward and backward."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    B, H, W, counts, level_hw, C, ctx = cfg
+    boxlists, feats = _random_case(B, H, W, counts, level_hw, C, seed=4, ctx=ctx)
+    feats = [f * (1.5 + i) + 0.2 * i for i, f in enumerate(feats)]
+    geom = _geom(boxlists, (H, W), level_hw)
+    fg = [f.to(DEV).requires_grad_(True) for f in feats]
+    out = ops.gn_relu_mask_pool(geom, fg)
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    ref = torch.stack([O.mask_pool(F.relu(F.group_norm(fc[i], 1, eps=1e-5)), [O.inside_box_mask(bl, (H, W), hw) for bl in boxlists])
+                       for i, hw in enumerate(level_hw)], 0)
+    assert cm.rel_err(out, ref) < FTOL
+    probe = torch.from_numpy(synth.det_uniform(tuple(ref.shape), 78))
+    (out * probe.to(DEV)).sum().backward()
+    (ref * probe).sum().backward()
+    for a, b in zip(fg, fc):
+        ok, msg = cm.kink_robust_close(a.grad, b.grad, tol=1e-4)
+        assert ok, msg

@@ -44,6 +44,8 @@ def one(it):
     torch.autograd.grad(loss, fr)
     ys = ops.gn1(fr, True)
     torch.autograd.grad(sum(v.sum() for v in ys), fr)
+    pl = ops.gn_relu_mask_pool(geom, fr)
+    torch.autograd.grad(pl.sum(), fr)
     zs = ops.bias_ctx_relu(fr, cvec)
     torch.autograd.grad(sum(v.sum() for v in zs), fr)
     o = ops.mha_blockdiag(q, kv, counts, mh.in_proj_weight, mh.in_proj_bias, mh.out_proj.weight, mh.out_proj.bias, 8, geom.img_off)
@@ -60,7 +62,8 @@ torch.cuda.synchronize()
 t = ops.kernel_timer_collect()
 ops.kernel_timer_enable(False)
 alg = {"in_moments_kernel": 2 * P, "in_mse_bwd_kernel": 3 * P, "box_sum_kernel": P, "box_paint_kernel": P, "gn_stats_kernel": P,
-       "gn_apply_kernel": 2 * P, "gn_bwd_stats_kernel": 2 * P, "gn_bwd_apply_kernel": 3 * P, "ctx_relu_kernel": 2 * P, "ctx_relu_bwd_kernel": 3 * P}
+       "gn_apply_kernel": 2 * P, "gn_bwd_stats_kernel": 2 * P, "gn_bwd_apply_kernel": 3 * P, "ctx_relu_kernel": 2 * P, "ctx_relu_bwd_kernel": 3 * P,
+       "gn_pool_kernel": P, "gn_pool_bwd_stats_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
 res = {}
 for k, (n, ms) in sorted(t.items(), key=lambda kv: -kv[1][1]):
     us = 1e3 * ms / n

@@ -26,6 +26,8 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     torch.autograd.grad(loss, fr)
     ys = ops.gn1(fr, True)
     torch.autograd.grad(sum(y.sum() for y in ys), fr)
+    pl = ops.gn_relu_mask_pool(geom, fr)
+    torch.autograd.grad(pl.sum(), fr)
     cvec = torch.randn(len(level_hw), B, C, device="cuda", requires_grad=True)
     zs = ops.bias_ctx_relu(fr, cvec)
     torch.autograd.grad(sum(z.sum() for z in zs), fr)
