@@ -60,7 +60,7 @@ int lgd_box_prep(const float* boxes, const int32_t* img_off, int B, int T, int m
                  int img_h, int img_w, const int32_t* level_hw_host /* L x (H,W) */, int L,
                  int32_t* geom, void* stream);
 /* Offsets (in int32 units) of the sub-tables inside `geom`, for tests/debugging:
- * rects [L][T][4], nbp [L][B], bands [L][B][2*max_n+2]. */
+ * rects [L][B][max_n][4] (padded per image), nbp [L][B], bands [L][B][2*max_n+2]. */
 size_t lgd_geom_rects_off(int L, int B, int T, int max_n);
 size_t lgd_geom_nbp_off(int L, int B, int T, int max_n);
 size_t lgd_geom_bands_off(int L, int B, int T, int max_n);

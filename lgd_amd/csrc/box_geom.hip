@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void box_prep_kernel(PrepArgs a) {
     // Python computes dst/src in double, the tensor multiply then uses it as an fp32 scalar (utils.py:66-70).
     const float r_w = (float)((double)W / (double)a.img_w);
     const float r_h = (float)((double)H / (double)a.img_h);
-    int32_t* rects = a.geom + geom_rects_off() + ((size_t)l * a.T + t0) * 4;
+    int32_t* rects = a.geom + geom_rects_off() + ((size_t)l * a.B + b) * a.max_n * 4;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = wave; i < n; i += 4) {  // one wave per box
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void box_prep_kernel(PrepArgs a) {
         sorted[rank] = v;
     }
     __syncthreads();
-    int32_t* bands = a.geom + geom_bands_off(a.L, a.B, a.T) + ((size_t)l * a.B + b) * maxbp;
+    int32_t* bands = a.geom + geom_bands_off(a.L, a.B, a.max_n) + ((size_t)l * a.B + b) * maxbp;
     int cnt = 0;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         const int v = sorted[i];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void box_prep_kernel(PrepArgs a) {
     }
     if (threadIdx.x == 0) {
         for (int i = 0; i < m; ++i) cnt += sorted[i] >= 0 ? 1 : 0;  // distinct values occupy sorted[0..cnt)
-        a.geom[geom_nbp_off(a.L, a.T) + (size_t)l * a.B + b] = cnt;
+        a.geom[geom_nbp_off(a.L, a.B, a.max_n) + (size_t)l * a.B + b] = cnt;
     }
 }
 
@@ -114,10 +114,10 @@ const char* lgd_last_error(void) {
 }
 
 size_t lgd_geom_rects_off(int, int, int, int) { return lgd::geom_rects_off(); }
-size_t lgd_geom_nbp_off(int L, int, int T, int) { return lgd::geom_nbp_off(L, T); }
-size_t lgd_geom_bands_off(int L, int B, int T, int) { return lgd::geom_bands_off(L, B, T); }
-size_t lgd_geom_ints(int L, int B, int T, int max_n) {
-    return lgd::geom_bands_off(L, B, T) + (size_t)L * B * lgd::geom_maxbp(max_n);
+size_t lgd_geom_nbp_off(int L, int B, int, int max_n) { return lgd::geom_nbp_off(L, B, max_n); }
+size_t lgd_geom_bands_off(int L, int B, int, int max_n) { return lgd::geom_bands_off(L, B, max_n); }
+size_t lgd_geom_ints(int L, int B, int, int max_n) {
+    return lgd::geom_bands_off(L, B, max_n) + (size_t)L * B * lgd::geom_maxbp(max_n);
 }
 
 int lgd_box_prep(const float* boxes, const int32_t* img_off, int B, int T, int max_n, int img_h, int img_w,

@@ -51,9 +51,9 @@ __device__ __forceinline__ Plane locate(const BoxArgs& a, int ppb) {
     p.H = a.H[l]; p.W = a.W[l];
     p.t0 = __builtin_amdgcn_readfirstlane(a.img_off[p.b]);
     p.n = __builtin_amdgcn_readfirstlane(a.img_off[p.b + 1]) - p.t0;
-    p.rects = a.geom + geom_rects_off() + ((size_t)l * a.T + p.t0) * 4;
-    p.nbp = __builtin_amdgcn_readfirstlane(a.geom[geom_nbp_off(a.L, a.T) + (size_t)l * a.B + p.b]);
-    p.bands = a.geom + geom_bands_off(a.L, a.B, a.T) + ((size_t)l * a.B + p.b) * geom_maxbp(a.max_n);
+    p.rects = a.geom + geom_rects_off() + ((size_t)l * a.B + p.b) * a.max_n * 4;
+    p.nbp = __builtin_amdgcn_readfirstlane(a.geom[geom_nbp_off(a.L, a.B, a.max_n) + (size_t)l * a.B + p.b]);
+    p.bands = a.geom + geom_bands_off(a.L, a.B, a.max_n) + ((size_t)l * a.B + p.b) * geom_maxbp(a.max_n);
     return p;
 }
 
@@ -87,6 +87,11 @@ __device__ __forceinline__ LaneBox load_lane_box(const Plane& p, int pass, int l
 // live in registers (lane k <- bands[k], lane n <- box n; v_readlane), so the loop touches memory only for rows.
 // Band flush: every active box adds one masked partial per lane into that lane's private LDS slot
 // sacc[box][lane] (conflict-free); the 64 -> 1 reductions happen once per (plane, box) at the end.
+// Measured alternatives that were SLOWER on MI355X (kept out): 4 waves per plane by row interleave or row quarters
+// (80-110 us: per-wave fixed costs x4), small levels dispatched first (56 us), an LDS-tiled variant with full-width
+// 1 KB loads and per-box rectangle sums out of LDS (101 us: 4x the load instructions on the small levels, same
+// VALU/SALU count).  SQ counters of this version: 18.5 M VALU + 14.3 M SALU instructions for 0.5 M loads per launch,
+// 28 % of wave cycles issuing, 26 % waiting on memory -- it is issue/latency-bound, not HBM-bound.
 template <int VW>
 __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, float* sacc /* [nb][64] of this wave */, int nb) {
     constexpr int G = 4;

@@ -85,11 +85,13 @@ __device__ __forceinline__ void vstore(float* p, const Vec<VW>& r) {
     else { *p = r.v[0]; }
 }
 
-// ---- geometry workspace layout (int32 units): rects [L][T][4] | nbp [L][B] | bands [L][B][maxbp]
+// ---- geometry workspace layout (int32 units): rects [L][B][max_n][4] | nbp [L][B] | bands [L][B][maxbp]
+// (rectangles are padded per image so that a wave's start-up loads -- counts, band table, its box -- depend only on
+//  (level, image) and issue together: one memory latency instead of a chain of three)
 __host__ __device__ inline int geom_maxbp(int max_n) { return 2 * max_n + 2; }
 __host__ __device__ inline size_t geom_rects_off() { return 0; }
-__host__ __device__ inline size_t geom_nbp_off(int L, int T) { return (size_t)L * T * 4; }
-__host__ __device__ inline size_t geom_bands_off(int L, int B, int T) { return geom_nbp_off(L, T) + (size_t)L * B; }
+__host__ __device__ inline size_t geom_nbp_off(int L, int B, int max_n) { return (size_t)L * B * max_n * 4; }
+__host__ __device__ inline size_t geom_bands_off(int L, int B, int max_n) { return geom_nbp_off(L, B, max_n) + (size_t)L * B; }
 
 // Thread-local record of the last launch failure (see lgd_last_error()).
 void set_last_error(hipError_t e);

@@ -47,7 +47,9 @@ class BoxGeometry:
         """(L, T, 4) int32 [x0, x1, y0, y1] inclusive (empty: x1 < x0)."""
         lib = hip.load()
         o = lib.lgd_geom_rects_off(self.L, self.B, self.T, self.max_n)
-        return self.geom[o:o + self.L * self.T * 4].view(self.L, self.T, 4)
+        padded = self.geom[o:o + self.L * self.B * self.max_n * 4].view(self.L, self.B * self.max_n, 4)
+        rows = [b * self.max_n + j for b, n in enumerate(self.counts) for j in range(n)]
+        return padded[:, torch.tensor(rows, dtype=torch.int64, device=padded.device)]
 
     def bands(self):
         """list[L][B] of python lists of row breakpoints."""

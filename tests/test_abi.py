@@ -45,7 +45,7 @@ def test_version_and_arch(lib):
 
 def test_size_helpers_no_gpu_needed(lib):
     L, B, T, mx = 5, 2, 22, 11
-    assert lib.lgd_geom_ints(L, B, T, mx) == L * T * 4 + L * B + L * B * (2 * mx + 2)
+    assert lib.lgd_geom_ints(L, B, T, mx) == L * B * mx * 4 + L * B + L * B * (2 * mx + 2)
     from lgd_amd import hip
     hw = hip.int_array([64, 64, 32, 32])
     # chunks of 4096 elements: 1 chunk per plane at both levels; 5 doubles per chunk + block terms
