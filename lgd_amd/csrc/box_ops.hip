@@ -14,6 +14,7 @@
 //   * lane n of the wave holds box n's rectangle/accumulator (64 boxes per pass), band activity is a
 //     single v_cmp ballot, box parameters travel by v_readlane, sums by DPP -- no LDS, no atomics,
 //     fixed reduction order (bit-reproducible run to run).
+#include <cstdlib>
 #include "common.h"
 
 namespace lgd {
@@ -46,7 +47,8 @@ __device__ __forceinline__ Plane locate(const BoxArgs& a, int ppb) {
     for (int i = 1; i < LGD_MAX_LEVELS; ++i) slot += (i < a.L && (int)blockIdx.x >= a.blk0[i]) ? 1 : 0;
     const int l = a.lev[slot];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the plane bookkeeping on the scalar unit
-    const int plane = ppb == 4 ? ((int)blockIdx.x - a.blk0[slot]) * 4 + wave : (int)blockIdx.x - a.blk0[slot];
+    // ppb planes per workgroup: each wave owns ppb/4 consecutive channel planes (ppb == 1: all four waves share one)
+    const int plane = ppb >= 4 ? ((int)blockIdx.x - a.blk0[slot]) * ppb + wave * (ppb / 4) : (int)blockIdx.x - a.blk0[slot];
     p.l = l; p.b = plane / a.C; p.c = plane % a.C;
     p.H = a.H[l]; p.W = a.W[l];
     p.t0 = __builtin_amdgcn_readfirstlane(a.img_off[p.b]);
@@ -92,11 +94,14 @@ __device__ __forceinline__ LaneBox load_lane_box(const Plane& p, int pass, int l
 // 1 KB loads and per-box rectangle sums out of LDS (101 us: 4x the load instructions on the small levels, same
 // VALU/SALU count).  SQ counters of this version: 18.5 M VALU + 14.3 M SALU instructions for 0.5 M loads per launch,
 // 28 % of wave cycles issuing, 26 % waiting on memory -- it is issue/latency-bound, not HBM-bound.
-template <int VW>
-__device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, float* sacc /* [nb][64] of this wave */, int nb) {
+// NP = channel planes per wave: planes c, c+1 of one image share every piece of bookkeeping (band walk, activity
+// ballots, box column tests, v_readlane traffic), which is what bounds this kernel -- not bytes.
+template <int VW, int NP>
+__device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, float* sacc /* [NP][nb][64] of this wave */, int nb) {
     constexpr int G = 4;
     const int lane = threadIdx.x & 63;
-    const float* __restrict__ src = a.in[p.l] + ((size_t)p.b * a.C + p.c) * p.H * p.W;
+    const size_t psz = (size_t)p.H * p.W;
+    const float* __restrict__ src = a.in[p.l] + ((size_t)p.b * a.C + p.c) * psz;
     const int npass = (p.n + nb - 1) / nb;   // nb = boxes per pass (LDS budget), <= 64
     const int bandreg = lane < p.nbp ? p.bands[lane] : p.H;  // nbp <= 64 is the fast path
     auto band = [&](int k) {  // wave-uniform by construction: say so, or every band test becomes an exec-masked vector loop
@@ -107,7 +112,7 @@ __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, 
     for (int pass = 0; pass < npass; ++pass) {
         LaneBox bx{0, -1, 0, -1};
         if (lane < nb) bx = load_lane_box_at(p, pass * nb + lane, a.skip_last);
-        for (int n = 0; n < nb; ++n) sacc[n * 64 + lane] = 0.f;
+        for (int n = 0; n < NP * nb; ++n) sacc[n * 64 + lane] = 0.f;
         // rows below ylo / above yhi are covered by no box of this pass: never fetched
         int ylo = p.H, yhi = -1;
         {
@@ -130,28 +135,43 @@ __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, 
             while (band(k + 1) <= ylo) ++k;      // band containing ylo
             int yb = band(k + 1);
             unsigned long long act = band_act(band(k));
-            float cs[VW];
+            float cs[NP][VW];
             #pragma unroll
-            for (int j = 0; j < VW; ++j) cs[j] = 0.f;
+            for (int q = 0; q < NP; ++q)
+                #pragma unroll
+                for (int j = 0; j < VW; ++j) cs[q][j] = 0.f;
             auto flush = [&]() {
                 unsigned long long m = act;
                 while (m) {
                     const int n = __builtin_ctzll(m);
                     m &= m - 1;
                     const int bx0 = __builtin_amdgcn_readlane(bx.x0, n), bx1 = __builtin_amdgcn_readlane(bx.x1, n);
-                    float part = 0.f;
+                    float part[NP];
                     #pragma unroll
-                    for (int j = 0; j < VW; ++j) part += (xl + j >= bx0 && xl + j <= bx1) ? cs[j] : 0.f;
-                    sacc[n * 64 + lane] += part;
+                    for (int q = 0; q < NP; ++q) part[q] = 0.f;
+                    #pragma unroll
+                    for (int j = 0; j < VW; ++j) {
+                        const bool in = xl + j >= bx0 && xl + j <= bx1;
+                        #pragma unroll
+                        for (int q = 0; q < NP; ++q) part[q] += in ? cs[q][j] : 0.f;
+                    }
+                    #pragma unroll
+                    for (int q = 0; q < NP; ++q) sacc[(q * nb + n) * 64 + lane] += part[q];
                 }
                 #pragma unroll
-                for (int j = 0; j < VW; ++j) cs[j] = 0.f;
+                for (int q = 0; q < NP; ++q)
+                    #pragma unroll
+                    for (int j = 0; j < VW; ++j) cs[q][j] = 0.f;
             };
-            auto issue = [&](Vec<VW>* v, int y0) {  // always G loads (rows clamped into the plane)
+            auto issue = [&](Vec<VW> (*v)[G], int y0) {  // always NP*G loads (rows clamped into the plane)
                 #pragma unroll
-                for (int u = 0; u < G; ++u) v[u] = vload<VW>(col + (size_t)min(y0 + u, p.H - 1) * p.W);
+                for (int u = 0; u < G; ++u) {
+                    const float* rp = col + (size_t)min(y0 + u, p.H - 1) * p.W;
+                    #pragma unroll
+                    for (int q = 0; q < NP; ++q) v[q][u] = vload<VW>(rp + q * psz);
+                }
             };
-            auto consume = [&](const Vec<VW>* v, int y0) {
+            auto consume = [&](Vec<VW> (*v)[G], int y0) {
                 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const int y = y0 + u;
@@ -164,13 +184,15 @@ __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, 
                         }
                         if (act && on) {
                             #pragma unroll
-                            for (int j = 0; j < VW; ++j)
-                                cs[j] += gn ? fmaxf(__fmul_rn(__fsub_rn(v[u].v[j], gmu), grs), 0.f) : v[u].v[j];
+                            for (int q = 0; q < NP; ++q)
+                                #pragma unroll
+                                for (int j = 0; j < VW; ++j)
+                                    cs[q][j] += gn ? fmaxf(__fmul_rn(__fsub_rn(v[q][u].v[j], gmu), grs), 0.f) : v[q][u].v[j];
                         }
                     }
                 }
             };
-            Vec<VW> va[G], vb[G];
+            Vec<VW> va[NP][G], vb[NP][G];
             issue(va, ylo);
             for (int y0 = ylo; y0 <= yhi; y0 += 2 * G) {
                 issue(vb, y0 + G);
@@ -180,30 +202,53 @@ __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, 
             }
             flush();
         }
-        // one 64 -> 1 reduction per box of the pass; lane n keeps box n's total
-        float mine = 0.f;
+        // one 64 -> 1 reduction per (plane, box) of the pass; lane n keeps box n's totals
+        float mine[NP];
+        #pragma unroll
+        for (int q = 0; q < NP; ++q) mine[q] = 0.f;
         const int nlive = min(nb, p.n - pass * nb);
         for (int n = 0; n < nlive; ++n) {
-            const float tot = wave_sum(sacc[n * 64 + lane]);
-            if (lane == n) mine = tot;
+            #pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const float tot = wave_sum(sacc[(q * nb + n) * 64 + lane]);
+                if (lane == n) mine[q] = tot;
+            }
         }
         if (lane < nlive) {
-            if (a.normalize) {
-                const float cnt = (bx.x1 >= bx.x0) ? (float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)) : 0.f;
-                mine = mine / fmaxf(cnt, 1.f);  // [ref: dynamic_teacher.py:97-100]
+            const float cnt = (bx.x1 >= bx.x0) ? (float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)) : 0.f;
+            #pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                float o = mine[q];
+                if (a.normalize) o = o / fmaxf(cnt, 1.f);  // [ref: dynamic_teacher.py:97-100]
+                a.pooled[((size_t)p.l * a.T + p.t0 + pass * nb + lane) * a.C + p.c + q] = o;
             }
-            a.pooled[((size_t)p.l * a.T + p.t0 + pass * nb + lane) * a.C + p.c] = mine;
         }
     }
 }
 
+template <int NP>  // channel planes per wave
 __global__ __launch_bounds__(256) void box_sum_kernel(BoxArgs a, int nb) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][nb][64]
-    const Plane p = locate(a, 4);
-    float* sacc = smem + (size_t)(threadIdx.x >> 6) * nb * 64;
-    if ((p.W & 3) == 0) box_sum_plane<4>(a, p, sacc, nb);
-    else if ((p.W & 1) == 0) box_sum_plane<2>(a, p, sacc, nb);
-    else box_sum_plane<1>(a, p, sacc, nb);
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][NP][nb][64]
+    const Plane p = locate(a, 4 * NP);
+    float* sacc = smem + (size_t)(threadIdx.x >> 6) * NP * nb * 64;
+    if ((p.W & 3) == 0) box_sum_plane<4, NP>(a, p, sacc, nb);
+    else if ((p.W & 1) == 0) box_sum_plane<2, NP>(a, p, sacc, nb);
+    else box_sum_plane<1, NP>(a, p, sacc, nb);
+}
+
+// planes per wave: as many as the channel count allows (the shared bookkeeping is the cost centre)
+static int sum_planes(int C) {
+    const char* e = getenv("LGD_SUM_NP");
+    const int want = e ? atoi(e) : 2;
+    if (want >= 4 && C % 16 == 0) return 4;
+    if (want >= 2 && C % 8 == 0) return 2;
+    return 1;
+}
+static void launch_box_sum(const char* name, const BoxArgs& a, int np, int nblk, int nb, hipStream_t s) {
+    const size_t smem = (size_t)4 * np * nb * 64 * sizeof(float);
+    if (np == 4) LGD_LAUNCH(name, box_sum_kernel<4>, dim3(nblk), dim3(256), smem, s, a, nb);
+    else if (np == 2) LGD_LAUNCH(name, box_sum_kernel<2>, dim3(nblk), dim3(256), smem, s, a, nb);
+    else LGD_LAUNCH(name, box_sum_kernel<1>, dim3(nblk), dim3(256), smem, s, a, nb);
 }
 
 // ------------------------------------------------------------------------------------------- box_paint
@@ -410,28 +455,28 @@ extern "C" {
 int lgd_box_sum(const float* const* feats_host, const int32_t* level_hw_host, int L, int B, int C, int T, int max_n,
                 const int32_t* img_off, const int32_t* geom, float* out, int normalize, int skip_last, void* stream) {
     lgd::BoxArgs a;
-    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last, 4);
+    const int np = lgd::sum_planes(C);
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last, 4 * np);
     if (nblk < 0 || !feats_host || !out) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!feats_host[l]) return LGD_EINVAL; a.in[l] = feats_host[l]; }
     a.pooled = out;
     if (T == 0) return LGD_OK;
     const int nb = max_n < 1 ? 1 : (max_n > 64 ? 64 : max_n);  // boxes per pass: 256 B of LDS per wave and box
-    LGD_LAUNCH("box_sum_kernel", lgd::box_sum_kernel, dim3(nblk), dim3(256), (size_t)4 * nb * 64 * sizeof(float),
-               (hipStream_t)stream, a, nb);
+    lgd::launch_box_sum("box_sum_kernel", a, np, nblk, nb, (hipStream_t)stream);
     return lgd::check_launch();
 }
 
 int lgd_gn_pool_fwd(const float* const* x_host, const float* gn_stats, const int32_t* level_hw_host, int L, int B, int C, int T,
                     int max_n, const int32_t* img_off, const int32_t* geom, float* out, void* stream) {
     lgd::BoxArgs a;
-    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, 1, 0, 4);
+    const int np = lgd::sum_planes(C);
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, 1, 0, 4 * np);
     if (nblk < 0 || !x_host || !gn_stats || !out) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!x_host[l]) return LGD_EINVAL; a.in[l] = x_host[l]; }
     a.pooled = out; a.gn_stats = gn_stats;
     if (T == 0) return LGD_OK;
     const int nb = max_n < 1 ? 1 : (max_n > 64 ? 64 : max_n);
-    LGD_LAUNCH("gn_pool_kernel", lgd::box_sum_kernel, dim3(nblk), dim3(256), (size_t)4 * nb * 64 * sizeof(float),
-               (hipStream_t)stream, a, nb);
+    lgd::launch_box_sum("gn_pool_kernel", a, np, nblk, nb, (hipStream_t)stream);
     return lgd::check_launch();
 }
 
