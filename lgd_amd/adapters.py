@@ -3,6 +3,7 @@
 import torch
 from torch import nn
 
+from . import ops
 from .registry import ADAPTERS_REGISTRY
 
 
@@ -14,13 +15,18 @@ class SequentialConvs(nn.Module):
         super().__init__()
         layers = []
         for i in range(3):
-            layers.append(nn.Conv2d(256, 256, 3, 1, 1))
+            layers.append(ops.Conv3x3(256, 256))
             if i < 2:
                 layers.append(nn.ReLU())
         self.adapter = nn.Sequential(*layers)
 
     def forward(self, x):
         return self.adapter(x)
+
+    def levels(self, xs):
+        """the adapter on a list of pyramid levels: each conv is one pass over the concatenated levels, ReLU fused."""
+        a = self.adapter
+        return a[4].levels(a[2].levels(a[0].levels(xs, relu=True), relu=True))
 
 
 def build_adapter(cfg):

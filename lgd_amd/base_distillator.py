@@ -47,7 +47,7 @@ class BaseDistillator(nn.Module):
         if self.distill_flag == 0:
             stu = [f.detach() for f in stu]
         adapter = self.adapter["distill"]
-        stu = [adapter(f) for f in stu]
+        stu = adapter.levels(stu) if hasattr(adapter, "levels") else [adapter(f) for f in stu]
         return ops.distill_in_mse(stu, tea, self.coef)
 
     @abstractmethod

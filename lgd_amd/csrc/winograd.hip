@@ -1,0 +1,377 @@
+// Winograd F(2x2, 3x3) data transforms for the 3x3 / stride 1 / pad 1 convolutions of the LGD path
+//   [ref: dynamic_teacher.py:57,61,67-73 (student_proj_2D, local_inst_proj_2D, refinement_module),
+//    models/adapters/sequential_convs.py:10-12, and the student head re-run on the teacher features,
+//    distillator.py:107-109 -> retinanet.py:36-43].
+// 87 % of the training step was fp32 3x3 convolutions on the library's kernels (100-116 TFLOP/s effective).  The
+// minimal-filtering form needs 2.25x fewer multiplies, and its 16 independent (C_out x C_in) x (C_in x tiles) products
+// are plain library GEMMs (hipBLASLt via torch.bmm, 100-140 TFLOP/s fp32 MFMA).  What is left is pure HBM streaming,
+// which is what these kernels do:
+//   wino_in   : x_l (N,C,H_l,W_l)        -> V [16][C][T]       V = B^T d B   per 4x4 input window (stride 2, halo 1)
+//   wino_out  : M [16][C][T], bias       -> y_l (N,C,H_l,W_l)  Y = A^T m A   per tile (2x2 outputs) [+bias] [ReLU]
+//   wino_out_t: dy_l                     -> dM [16][C][T]      dM = A dy A^T (adjoint of wino_out, weight gradient)
+//   wino_in_dual: dy_l -> V(flip) and dM in one pass over dy (the two operands of the backward pass)
+// Every module on the path applies ONE filter to all pyramid levels, and a Winograd tile does not care which level it
+// came from: the tiles of all L levels are concatenated along T (level l starts at an even offset), so one conv over
+// the pyramid is one transform launch + one batched GEMM + one transform launch, and p6/p7 (1.6 % of the pixels, but a
+// third of the launches on the per-level library path) ride along for free.  Tile index is the fastest axis everywhere:
+// all global accesses are coalesced along x and nothing is transposed (GEMM orientation U[16][Co][Ci] @ V[16][Ci][T]).
+// The input gradient is the same pipeline on dy with the 180-degree rotated, (Co,Ci)-transposed filter; the rotation
+// is a permutation of the 16 frequencies (flip = 1), so the host reuses U.
+#include "common.h"
+
+namespace lgd {
+
+struct WinoArgs {
+    const float* maps_in[LGD_MAX_LEVELS];   // per-level NCHW inputs (wino_in / wino_out_t)
+    float* maps_out[LGD_MAX_LEVELS];        // per-level NCHW outputs (wino_out)
+    const float* mask_ref[LGD_MAX_LEVELS];  // optional: forward outputs y_l; the incoming gradient is zeroed where y <= 0
+    const float* buf_in;                    // [16][C][T]
+    float* buf_out;                         // [16][C][T]
+    float* buf_out2;                        // [16][C][T] (dual)
+    const float* bias;
+    long long tile_off[LGD_MAX_LEVELS];     // first tile of the level (even)
+    long long T;                            // total tiles incl. per-level padding to an even count
+    unsigned blk_off[LGD_MAX_LEVELS + 1];   // first workgroup of the level
+    int H[LGD_MAX_LEVELS], W[LGD_MAX_LEVELS], TH[LGD_MAX_LEVELS], TW[LGD_MAX_LEVELS], pair[LGD_MAX_LEVELS];
+    int L, N, C, flip, relu;
+};
+
+__device__ __forceinline__ int wino_level(const WinoArgs& a) {
+    int l = 0;
+    #pragma unroll
+    for (int i = 1; i < LGD_MAX_LEVELS; ++i)
+        if (i < a.L && blockIdx.x >= a.blk_off[i]) l = i;
+    return __builtin_amdgcn_readfirstlane(l);
+}
+
+// G g G^T of the rotated filter is the frequency permutation 0<->3 (rows 1,2 of G are symmetric under the flip)
+__device__ __forceinline__ int freq(int i, int j, int flip) {
+    const int pi = (i == 0 || i == 3) ? 3 - i : i, pj = (j == 0 || j == 3) ? 3 - j : j;
+    return flip ? 4 * pi + pj : 4 * i + j;
+}
+
+// B^T d B with B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+__device__ __forceinline__ void bt4(const float* d, float* o) {
+    o[0] = d[0] - d[2]; o[1] = d[1] + d[2]; o[2] = d[2] - d[1]; o[3] = d[1] - d[3];
+}
+
+template <int PAIR>
+__device__ __forceinline__ void store_freq(float* q, const float (&v)[PAIR]) {
+    if constexpr (PAIR == 2) *reinterpret_cast<float2*>(q) = make_float2(v[0], v[1]);
+    else *q = v[0];
+}
+
+// One thread transforms PAIR horizontally adjacent tiles.  PAIR = 2 needs W % 4 == 0: the 6 input columns 4p-1 .. 4p+4
+// of a row are one aligned float4 + 2 scalars, and the two tile indices are even/odd neighbours -> float2 stores.
+// DUAL also emits dM = A g A^T of the window's 2x2 centre block (rows/cols 1,2 of the window are exactly the tile's
+// outputs), so the backward pass reads dy once for both the input-gradient and the weight-gradient operand.
+// MASK: the gradient is multiplied by (y > 0) of the forward output (ReLU fused into the producing conv).
+template <int PAIR, bool DUAL, bool MASK>
+__device__ __forceinline__ void wino_in_body(const WinoArgs& a, int l) {
+    const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
+    const int TWP = (TW + PAIR - 1) / PAIR;
+    const long long units = (long long)a.N * TH * TWP;
+    const long long u = (long long)(blockIdx.x - a.blk_off[l]) * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    const size_t plane = (size_t)a.C * a.T;
+    if (u >= units) {
+        // an odd tile count is padded by one all-zero tile so that every level starts on an even tile
+        if (PAIR == 1 && u == units && (units & 1)) {
+            const size_t t = (size_t)a.tile_off[l] + units;
+            for (int f = 0; f < 16; ++f) {
+                a.buf_out[(size_t)f * plane + (size_t)c * a.T + t] = 0.f;
+                if (DUAL) a.buf_out2[(size_t)f * plane + (size_t)c * a.T + t] = 0.f;
+            }
+        }
+        return;
+    }
+    const int txp = (int)(u % TWP), ty = (int)((u / TWP) % TH), n = (int)(u / ((long long)TWP * TH));
+    const int tx = txp * PAIR;
+    const size_t img = ((size_t)n * a.C + c) * H * W;
+    const float* p = a.maps_in[l] + img;
+    const float* pm = MASK ? a.mask_ref[l] + img : nullptr;
+    const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    constexpr int NC = 2 * PAIR + 2;
+    float d[4][NC];
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = y0 + i;
+        const bool yok = y >= 0 && y < H;
+        const size_t ro = (size_t)(yok ? y : 0) * W;
+        const float* row = p + ro;
+        if constexpr (PAIR == 2) {
+            float4 m = yok ? *reinterpret_cast<const float4*>(row + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float e0 = (yok && x0 >= 0) ? row[x0] : 0.f;
+            float e5 = (yok && x0 + 5 < W) ? row[x0 + 5] : 0.f;
+            if constexpr (MASK) {
+                const float* mr = pm + ro;
+                const float4 k = yok ? *reinterpret_cast<const float4*>(mr + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+                m.x = k.x > 0.f ? m.x : 0.f; m.y = k.y > 0.f ? m.y : 0.f; m.z = k.z > 0.f ? m.z : 0.f; m.w = k.w > 0.f ? m.w : 0.f;
+                if (yok && x0 >= 0) e0 = mr[x0] > 0.f ? e0 : 0.f;
+                if (yok && x0 + 5 < W) e5 = mr[x0 + 5] > 0.f ? e5 : 0.f;
+            }
+            d[i][0] = e0; d[i][1] = m.x; d[i][2] = m.y; d[i][3] = m.z; d[i][4] = m.w; d[i][5] = e5;
+        } else {
+            #pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int x = x0 + j;
+                const bool ok = yok && x >= 0 && x < W;
+                float e = ok ? row[x] : 0.f;
+                if constexpr (MASK) { if (ok) e = pm[ro + x] > 0.f ? e : 0.f; }
+                d[i][j] = e;
+            }
+        }
+    }
+    const size_t t = (size_t)a.tile_off[l] + ((size_t)n * TH + ty) * TW + tx;
+    float* o = a.buf_out + (size_t)c * a.T + t;
+    float v[4][4][PAIR];
+    #pragma unroll
+    for (int q = 0; q < PAIR; ++q) {
+        float r[4][4];
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {  // columns: B^T d
+            const float col[4] = {d[0][2 * q + j], d[1][2 * q + j], d[2][2 * q + j], d[3][2 * q + j]};
+            float w[4];
+            bt4(col, w);
+            r[0][j] = w[0]; r[1][j] = w[1]; r[2][j] = w[2]; r[3][j] = w[3];
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) {  // rows: (B^T d) B
+            float w[4];
+            bt4(r[i], w);
+            v[i][0][q] = w[0]; v[i][1][q] = w[1]; v[i][2][q] = w[2]; v[i][3][q] = w[3];
+        }
+    }
+    #pragma unroll
+    for (int i = 0; i < 4; ++i)
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) store_freq<PAIR>(o + (size_t)freq(i, j, a.flip) * plane, v[i][j]);
+    if constexpr (DUAL) {
+        float* o2 = a.buf_out2 + (size_t)c * a.T + t;
+        float w[4][4][PAIR];
+        #pragma unroll
+        for (int q = 0; q < PAIR; ++q) {
+            // A = [[1,0],[1,1],[1,-1],[0,-1]] on g = window rows/cols 1,2 (outside the map these are the zero halo)
+            const float g00 = d[1][2 * q + 1], g01 = d[1][2 * q + 2], g10 = d[2][2 * q + 1], g11 = d[2][2 * q + 2];
+            const float r[4][2] = {{g00, g01}, {g00 + g10, g01 + g11}, {g00 - g10, g01 - g11}, {-g10, -g11}};
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[i][0][q] = r[i][0]; w[i][1][q] = r[i][0] + r[i][1]; w[i][2][q] = r[i][0] - r[i][1]; w[i][3][q] = -r[i][1];
+            }
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; ++i)
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) store_freq<PAIR>(o2 + (size_t)(4 * i + j) * plane, w[i][j]);
+    }
+}
+
+template <bool DUAL, bool MASK>
+__global__ __launch_bounds__(256) void wino_in_kernel(WinoArgs a) {
+    const int l = wino_level(a);
+    if (a.pair[l]) wino_in_body<2, DUAL, MASK>(a, l);
+    else wino_in_body<1, DUAL, MASK>(a, l);
+}
+
+// Y = A^T m A with A^T = [[1,1,1,0],[0,1,-1,-1]]; PAIR = 2: float2 loads of two neighbouring tiles, float4 row stores
+template <int PAIR>
+__device__ __forceinline__ void wino_out_body(const WinoArgs& a, int l) {
+    const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
+    const int TWP = (TW + PAIR - 1) / PAIR;
+    const long long u = (long long)(blockIdx.x - a.blk_off[l]) * 256 + threadIdx.x;
+    if (u >= (long long)a.N * TH * TWP) return;
+    const int c = blockIdx.y;
+    const int txp = (int)(u % TWP), ty = (int)((u / TWP) % TH), n = (int)(u / ((long long)TWP * TH));
+    const int tx = txp * PAIR;
+    const size_t plane = (size_t)a.C * a.T;
+    const float* m = a.buf_in + (size_t)c * a.T + (size_t)a.tile_off[l] + ((size_t)n * TH + ty) * TW + tx;
+    float q[4][4][PAIR];
+    #pragma unroll
+    for (int i = 0; i < 4; ++i)
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* s = m + (size_t)freq(i, j, a.flip) * plane;
+            if constexpr (PAIR == 2) { const float2 t2 = *reinterpret_cast<const float2*>(s); q[i][j][0] = t2.x; q[i][j][1] = t2.y; }
+            else q[i][j][0] = *s;
+        }
+    const float b = a.bias ? a.bias[c] : 0.f;
+    float y[2][2 * PAIR];
+    #pragma unroll
+    for (int k = 0; k < PAIR; ++k) {
+        float r[2][4];
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[0][j] = q[0][j][k] + q[1][j][k] + q[2][j][k];
+            r[1][j] = q[1][j][k] - q[2][j][k] - q[3][j][k];
+        }
+        #pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            y[i][2 * k] = r[i][0] + r[i][1] + r[i][2] + b;
+            y[i][2 * k + 1] = r[i][1] - r[i][2] - r[i][3] + b;
+        }
+    }
+    if (a.relu) {
+        #pragma unroll
+        for (int i = 0; i < 2; ++i)
+            #pragma unroll
+            for (int j = 0; j < 2 * PAIR; ++j) y[i][j] = fmaxf(y[i][j], 0.f);
+    }
+    float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
+    const int oy = 2 * ty, ox = 2 * tx;
+    #pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (oy + i >= H) continue;
+        float* row = p + (size_t)(oy + i) * W + ox;
+        if constexpr (PAIR == 2) {
+            *reinterpret_cast<float4*>(row) = make_float4(y[i][0], y[i][1], y[i][2], y[i][3]);
+        } else {
+            if (ox + 1 < W && ((W & 1) == 0)) *reinterpret_cast<float2*>(row) = make_float2(y[i][0], y[i][1]);
+            else { row[0] = y[i][0]; if (ox + 1 < W) row[1] = y[i][1]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino_out_kernel(WinoArgs a) {
+    const int l = wino_level(a);
+    if (a.pair[l]) wino_out_body<2>(a, l);
+    else wino_out_body<1>(a, l);
+}
+
+// dM = A dy A^T alone (weight gradient of a conv whose input needs no gradient): the DUAL half of wino_in without V.
+__global__ __launch_bounds__(256) void wino_out_t_kernel(WinoArgs a) {
+    const int l = wino_level(a);
+    const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
+    const long long units = (long long)a.N * TH * TW;
+    const long long u = (long long)(blockIdx.x - a.blk_off[l]) * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    const size_t plane = (size_t)a.C * a.T;
+    float* o = a.buf_out + (size_t)c * a.T + (size_t)a.tile_off[l] + u;
+    if (u >= units) {
+        if (u == units && (units & 1))
+            for (int f = 0; f < 16; ++f) o[(size_t)f * plane] = 0.f;
+        return;
+    }
+    const int tx = (int)(u % TW), ty = (int)((u / TW) % TH), n = (int)(u / ((long long)TW * TH));
+    const size_t img = ((size_t)n * a.C + c) * H * W;
+    const float* p = a.maps_in[l] + img;
+    const float* pm = a.mask_ref[l] ? a.mask_ref[l] + img : nullptr;
+    const int oy = 2 * ty, ox = 2 * tx;
+    float g[2][2];
+    #pragma unroll
+    for (int i = 0; i < 2; ++i)
+        #pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = oy + i < H && ox + j < W;
+            const size_t at = (size_t)(oy + i) * W + ox + j;
+            float e = ok ? p[at] : 0.f;
+            if (ok && pm) e = pm[at] > 0.f ? e : 0.f;
+            g[i][j] = e;
+        }
+    float r[4][2];
+    #pragma unroll
+    for (int j = 0; j < 2; ++j) { r[0][j] = g[0][j]; r[1][j] = g[0][j] + g[1][j]; r[2][j] = g[0][j] - g[1][j]; r[3][j] = -g[1][j]; }
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v[4] = {r[i][0], r[i][0] + r[i][1], r[i][0] - r[i][1], -r[i][1]};
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) o[(size_t)(4 * i + j) * plane] = v[j];
+    }
+}
+
+static long long level_tiles(int N, int H, int W) {
+    const long long t = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    return t + (t & 1);
+}
+
+// fills the per-level tables; mode 0: pair units where W % 4 == 0 (wino_in / wino_out), 1: one tile per thread
+static int wino_fill(WinoArgs& a, const int32_t* level_hw, int L, int N, int C, int flip, int mode, unsigned* blocks) {
+    if (!level_hw || L < 1 || L > LGD_MAX_LEVELS || N < 1 || C < 1 || C > 65535) return LGD_EINVAL;
+    a.L = L; a.N = N; a.C = C; a.flip = flip ? 1 : 0; a.relu = 0;
+    a.bias = nullptr; a.buf_in = nullptr; a.buf_out = a.buf_out2 = nullptr;
+    long long off = 0;
+    unsigned blk = 0;
+    for (int l = 0; l < LGD_MAX_LEVELS; ++l) {
+        a.maps_in[l] = nullptr; a.maps_out[l] = nullptr; a.mask_ref[l] = nullptr;
+        a.H[l] = a.W[l] = a.TH[l] = a.TW[l] = a.pair[l] = 0; a.tile_off[l] = 0; a.blk_off[l] = 0;
+    }
+    for (int l = 0; l < L; ++l) {
+        const int H = level_hw[2 * l], W = level_hw[2 * l + 1];
+        if (H < 1 || W < 1) return LGD_EINVAL;
+        a.H[l] = H; a.W[l] = W; a.TH[l] = (H + 1) / 2; a.TW[l] = (W + 1) / 2;
+        a.pair[l] = (mode == 0 && W % 4 == 0) ? 1 : 0;
+        a.tile_off[l] = off;
+        a.blk_off[l] = blk;
+        const long long units = (long long)N * a.TH[l] * (a.pair[l] ? a.TW[l] / 2 : a.TW[l]);
+        blk += (unsigned)((units + 1 + 255) / 256);  // +1: the thread that writes the zero pad tile
+        off += level_tiles(N, H, W);
+    }
+    a.blk_off[L] = blk;
+    a.T = off;
+    *blocks = blk;
+    return LGD_OK;
+}
+
+}  // namespace lgd
+
+extern "C" {
+
+size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N) {
+    if (!level_hw_host || L < 1 || N < 1) return 0;
+    long long t = 0;
+    for (int l = 0; l < L; ++l) t += lgd::level_tiles(N, level_hw_host[2 * l], level_hw_host[2 * l + 1]);
+    return (size_t)t;
+}
+
+int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, const int32_t* level_hw_host, int L, int N,
+                int C, int flip, float* V, float* dM, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!x_host || !V || lgd::wino_fill(a, level_hw_host, L, N, C, flip, 0, &blocks) != LGD_OK) return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) {
+        if (!x_host[l] || (relu_ref_host && !relu_ref_host[l])) return LGD_EINVAL;
+        a.maps_in[l] = x_host[l];
+        if (relu_ref_host) a.mask_ref[l] = relu_ref_host[l];
+    }
+    a.buf_out = V; a.buf_out2 = dM;
+    const dim3 grid(blocks, C), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dM) {
+        if (relu_ref_host) { LGD_LAUNCH("wino_in_dual_kernel", (lgd::wino_in_kernel<true, true>), grid, block, 0, st, a); }
+        else { LGD_LAUNCH("wino_in_dual_kernel", (lgd::wino_in_kernel<true, false>), grid, block, 0, st, a); }
+    } else {
+        if (relu_ref_host) { LGD_LAUNCH("wino_in_kernel", (lgd::wino_in_kernel<false, true>), grid, block, 0, st, a); }
+        else { LGD_LAUNCH("wino_in_kernel", (lgd::wino_in_kernel<false, false>), grid, block, 0, st, a); }
+    }
+    return lgd::check_launch();
+}
+
+int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host, int L, int N, int C, int flip, int relu,
+                 float* const* y_host, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!M || !y_host || lgd::wino_fill(a, level_hw_host, L, N, C, flip, 0, &blocks) != LGD_OK) return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) {
+        if (!y_host[l]) return LGD_EINVAL;
+        a.maps_out[l] = y_host[l];
+    }
+    a.buf_in = M; a.bias = bias; a.relu = relu ? 1 : 0;
+    LGD_LAUNCH("wino_out_kernel", lgd::wino_out_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a);
+    return lgd::check_launch();
+}
+
+int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const int32_t* level_hw_host, int L,
+                   int N, int C, float* dM, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!dy_host || !dM || lgd::wino_fill(a, level_hw_host, L, N, C, 0, 1, &blocks) != LGD_OK) return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) {
+        if (!dy_host[l] || (relu_ref_host && !relu_ref_host[l])) return LGD_EINVAL;
+        a.maps_in[l] = dy_host[l];
+        if (relu_ref_host) a.mask_ref[l] = relu_ref_host[l];
+    }
+    a.buf_out = dM;
+    LGD_LAUNCH("wino_out_t_kernel", lgd::wino_out_t_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a);
+    return lgd::check_launch();
+}
+
+}  // extern "C"

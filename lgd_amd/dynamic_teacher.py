@@ -39,7 +39,7 @@ def get_MLP(nr_layers, channels, has_norm, has_relu=True, affine_flag=False):
 
 def get_CONVS(nr_layers, channels, has_norm, has_relu=True, nr_groups=1, affine_flag=False):
     def unit():
-        mods = [nn.Conv2d(channels, channels, 3, 1, 1)]
+        mods = [ops.Conv3x3(channels, channels)]
         if has_norm:
             mods.append(get_norm(channels, nr_groups, affine_flag))
         if has_relu:
@@ -172,13 +172,13 @@ class DynamicTeacher(nn.Module):
                                            add_context_box=self.add_context_box, parse_mask=self.use_seg_map)
         self.canoni_proj_1D = get_MLP(1, C, has_norm=True, has_relu=True, affine_flag=False)
         self.student_proj_2D = get_CONVS(1, C, has_norm=True, has_relu=True, nr_groups=1, affine_flag=False)
-        self.local_inst_proj_2D = nn.Conv2d(C, C, 3, 1, 1)
+        self.local_inst_proj_2D = ops.Conv3x3(C, C)
         self.global_ctx_proj_1D = nn.Linear(C, C)
         self.local_inst_proj_1D = nn.Linear(C, C)
         self.refinement_module = nn.Sequential(
-            nn.Conv2d(C, C, 3, 1, 1), get_norm(C, 1, False), nn.ReLU(),
-            nn.Conv2d(C, C, 3, 1, 1), get_norm(C, 1, False), nn.ReLU(),
-            nn.Conv2d(C, C, 3, 1, 1), get_norm(C, 1, False))
+            ops.Conv3x3(C, C), get_norm(C, 1, False), nn.ReLU(),
+            ops.Conv3x3(C, C), get_norm(C, 1, False), nn.ReLU(),
+            ops.Conv3x3(C, C), get_norm(C, 1, False))
         self.nr_transformer_heads = d.TEACHER.NR_TRANSFORMER_HEADS
         self.multi_head_attn = nn.MultiheadAttention(C, self.nr_transformer_heads)
 
@@ -193,14 +193,14 @@ class DynamicTeacher(nn.Module):
             last = torch.tensor([o - 1 for o in _offsets(geom.counts)[1:]], dtype=torch.int64).to(attn_out.device,
                                                                                                 non_blocking=True)
             ctx = ops.linear(attn_out[:, last], self.global_ctx_proj_1D.weight, self.global_ctx_proj_1D.bias)  # (L,B,C)
-            return ops.bias_ctx_relu([F.conv2d(p, conv.weight, conv.bias, padding=1) for p in painted], ctx)
-        return [F.relu(F.conv2d(p, conv.weight, conv.bias, padding=1)) for p in painted]
+            return ops.bias_ctx_relu(conv.levels(painted), ctx)
+        return conv.levels(painted, relu=True)
 
     def refine(self, xs):
-        """[ref: dynamic_teacher.py:67-73,280-281] on all levels: conv (MIOpen) per level, GN(1)[+ReLU] in one HIP call."""
+        """[ref: dynamic_teacher.py:67-73,280-281] on all levels: one Winograd conv over all levels, GN(1)[+ReLU] in one HIP call."""
         m = self.refinement_module
         for idx, relu in ((0, True), (3, True), (6, False)):
-            xs = ops.gn1([F.conv2d(x, m[idx].weight, m[idx].bias, padding=1) for x in xs], relu=relu)
+            xs = ops.gn1(m[idx].levels(xs), relu=relu)
         return xs
 
     def interactive_remapping(self, label_embed, boxes, counts, feats, img_size_dict):
@@ -214,7 +214,7 @@ class DynamicTeacher(nn.Module):
                                [tuple(feats[k].shape[-2:]) for k in keys])
         # student_proj_2D = conv3x3 -> GN(1) -> ReLU, consumed only by the mask pooling: GN+ReLU are applied inside
         # the pooling kernel, the normalised maps are never written (and never re-read by a separate pooling pass)
-        app = ops.gn_relu_mask_pool(geom, [F.conv2d(feats[k], sp.weight, sp.bias, padding=1) for k in keys])  # (L,T,C)
+        app = ops.gn_relu_mask_pool(geom, sp.levels([feats[k] for k in keys]))  # (L,T,C)
         a = self.multi_head_attn
         if self.interact_pattern == "student_fill":
             att = app

@@ -3,6 +3,8 @@ device memory and the stream).  Shapes follow include/lgd_hip.h:
   pyramids  : list of L tensors (B, C, H_l, W_l) fp32 NCHW
   box tables: (L, T, C) fp32, boxes concatenated image-major, context box last per image
 """
+import os
+
 import torch
 
 from . import hip
@@ -629,6 +631,126 @@ def label_planes(labels, level_hw, A):
         out.append(labels[:, off:off + n].view(N, h, w, A).permute(0, 3, 1, 2).to(torch.int32).contiguous())
         off += n
     return out
+
+
+# ------------------------------------------------------------------------------------------------ K8: 3x3 convolutions
+_WINO_GG = {}
+
+
+def _wino_gg(device):
+    """(16, 9) Kronecker form of U = G g G^T for F(2x2, 3x3): U[4a+b] = sum_ij G[a,i] G[b,j] g[i,j]."""
+    key = str(device)
+    if key not in _WINO_GG:
+        G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32)
+        _WINO_GG[key] = torch.kron(G, G).contiguous().to(device)
+    return _WINO_GG[key]
+
+
+class _Conv3x3(torch.autograd.Function):
+    """nn.Conv2d(Ci, Co, 3, stride 1, padding 1) [+ ReLU] with one filter over L maps (the pyramid levels) in the
+    minimal-filtering form F(2x2, 3x3): HIP data transforms (lgd_wino_in / lgd_wino_out / lgd_wino_out_t) around 16
+    per-frequency channel GEMMs (hipBLASLt fp32 MFMA through torch.bmm) over the concatenated tiles of all levels.
+    Forward, input gradient and weight gradient all run at 4/9 of the direct multiplies; backward reads dy once."""
+
+    @staticmethod
+    def forward(ctx, w, b, relu, *xs):
+        hip.require_gpu(w, *xs)
+        lib = hip.load()
+        w = hip.dense_f32(w)
+        xs = [hip.dense_f32(x) for x in xs]
+        b = hip.dense_f32(b) if b is not None else None
+        L, N, Ci = len(xs), xs[0].shape[0], xs[0].shape[1]
+        Co = w.shape[0]
+        dev = w.device
+        hw = hip.int_array([d for x in xs for d in x.shape[2:]])
+        T = lib.lgd_wino_tiles(hw, L, N)
+        U = torch.mm(_wino_gg(dev), w.view(Co * Ci, 9).t()).view(16, Co, Ci)
+        V = torch.empty((16, Ci, T), dtype=torch.float32, device=dev)
+        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, hw, L, N, Ci, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
+        M = torch.bmm(U, V)
+        ys = [torch.empty((N, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
+        hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(b) if b is not None else None, hw, L, N, Co, 0, int(relu),
+                                   hip.ptr_array(ys), hip.stream_ptr()), "lgd_wino_out")
+        need_w = ctx.needs_input_grad[0]
+        ctx.save_for_backward(U, V if need_w else None, *(ys if relu else []))
+        ctx.meta = (L, N, Ci, Co, hw, T, bool(relu), b is not None, [tuple(x.shape[2:]) for x in xs])
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        U, V, *yref = ctx.saved_tensors
+        L, N, Ci, Co, hw, T, relu, has_bias, shapes = ctx.meta
+        lib = hip.load()
+        dev = U.device
+        dys = [hip.dense_f32(g) for g in dys]
+        need_w, need_x = ctx.needs_input_grad[0], any(ctx.needs_input_grad[3:])
+        ref = hip.ptr_array(yref) if relu else None
+        dw = db = None
+        dxs = [None] * L
+        Vd = dM = None
+        if need_x:
+            Vd = torch.empty((16, Co, T), dtype=torch.float32, device=dev)
+            dM = torch.empty_like(Vd) if need_w else None
+            hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, hw, L, N, Co, 1, hip.ptr(Vd), hip.ptr(dM) if need_w else None,
+                                      hip.stream_ptr()), "lgd_wino_in")
+            Md = torch.bmm(U.transpose(1, 2), Vd)
+            del Vd
+            dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
+            hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, 1, 0, hip.ptr_array(dxs), hip.stream_ptr()), "lgd_wino_out")
+            del Md
+        elif need_w:
+            dM = torch.empty((16, Co, T), dtype=torch.float32, device=dev)
+            hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, hw, L, N, Co, hip.ptr(dM), hip.stream_ptr()), "lgd_wino_out_t")
+        if need_w:
+            dU = torch.bmm(dM, V.transpose(1, 2))
+            dw = torch.mm(_wino_gg(dev).t(), dU.view(16, Co * Ci)).t().reshape(Co, Ci, 3, 3)
+            if has_bias and ctx.needs_input_grad[1]:
+                # sum of a tile's 2x2 gradients = its (0,0) frequency of A g A^T ... only without padding rows; use the
+                # masked gradients directly: frequency (1,1) holds g00+g01+g10+g11
+                db = dM[5].sum(1)
+        elif has_bias and ctx.needs_input_grad[1]:
+            db = sum((g * (y > 0) if relu else g).sum((0, 2, 3)) for g, y in zip(dys, yref if relu else dys))
+        return (dw, db, None, *dxs)
+
+
+_WINO_MIN_TILES = int(os.environ.get("LGD_WINO_MIN_TILES", "2000"))
+_WINO_MIN_CH = int(os.environ.get("LGD_WINO_MIN_CH", "192"))  # narrower inputs (res2/res3): the library's direct kernels win
+_WINO_ON = os.environ.get("LGD_WINO", "1") != "0"
+
+
+def _wino_ok(xs, w):
+    x = xs[0]
+    tiles = sum(x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) for x in xs)
+    return (_WINO_ON and x.is_cuda and x.dtype == torch.float32 and tiles >= _WINO_MIN_TILES and x.shape[1] >= _WINO_MIN_CH
+            and (len(xs) > 1 or w.shape[0] >= _WINO_MIN_CH))
+
+
+def conv3x3_levels(xs, w, b=None, relu=False):
+    """one 3x3 / stride 1 / padding 1 filter [+ ReLU] over a list of maps (the FPN levels): a single Winograd pass over
+    the concatenated tiles.  Tiny problems stay on the library's direct kernels."""
+    xs = list(xs)
+    if _wino_ok(xs, w):
+        return list(_Conv3x3.apply(w, b, bool(relu), *xs))
+    ys = [F.conv2d(x, w, b, 1, 1) for x in xs]
+    return [F.relu_(y) for y in ys] if relu else ys
+
+
+def conv3x3(x, w, b=None, relu=False):
+    """single-map form of conv3x3_levels."""
+    return conv3x3_levels([x], w, b, relu)[0]
+
+
+class Conv3x3(torch.nn.Conv2d):
+    """nn.Conv2d(cin, cout, 3, 1, 1) with the same parameters / state_dict keys; `levels` applies it to a pyramid."""
+
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, 3, 1, 1)
+
+    def forward(self, x):
+        return conv3x3(x, self.weight, self.bias)
+
+    def levels(self, xs, relu=False):
+        return conv3x3_levels(xs, self.weight, self.bias, relu)
 
 
 # ------------------------------------------------------------------------------------------------ timing

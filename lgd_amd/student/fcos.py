@@ -11,6 +11,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..registry import CUSTOMIZED_DETECTORS_REGISTRY
 from ..structures import ImageList
 from .retinanet import batched_nms, build_resnet_fpn, sigmoid_focal_sum
@@ -41,12 +42,12 @@ class FCOSHead(nn.Module):
         self.centerness_on_reg, self.norm_reg_targets = f.CENTERNESS_ON_REG, f.NORM_REG_TARGETS
         cls, box = [], []
         for _ in range(f.NUM_CONVS):
-            cls += [nn.Conv2d(C, C, 3, 1, 1), nn.GroupNorm(32, C), nn.ReLU()]
-            box += [nn.Conv2d(C, C, 3, 1, 1), nn.GroupNorm(32, C), nn.ReLU()]
+            cls += [ops.Conv3x3(C, C), nn.GroupNorm(32, C), nn.ReLU()]
+            box += [ops.Conv3x3(C, C), nn.GroupNorm(32, C), nn.ReLU()]
         self.cls_subnet, self.bbox_subnet = nn.Sequential(*cls), nn.Sequential(*box)
-        self.cls_score = nn.Conv2d(C, f.NUM_CLASSES, 3, 1, 1)
-        self.bbox_pred = nn.Conv2d(C, 4, 3, 1, 1)
-        self.centerness = nn.Conv2d(C, 1, 3, 1, 1)
+        self.cls_score = ops.Conv3x3(C, f.NUM_CLASSES)
+        self.bbox_pred = ops.Conv3x3(C, 4)
+        self.centerness = ops.Conv3x3(C, 1)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.normal_(m.weight, mean=0, std=0.01)
@@ -55,12 +56,16 @@ class FCOSHead(nn.Module):
         self.scales = nn.ModuleList([Scale(1.0) for _ in self.fpn_strides])
 
     def forward(self, features):
-        logits, reg, ctr = [], [], []
-        for lvl, x in enumerate(features):
-            c, b = self.cls_subnet(x), self.bbox_subnet(x)
-            logits.append(self.cls_score(c))
-            ctr.append(self.centerness(b if self.centerness_on_reg else c))
-            r = self.scales[lvl](self.bbox_pred(b))
+        # the towers share their filters across levels: every conv is ONE pass over the concatenated pyramid
+        c = b = list(features)
+        for i in range(0, len(self.cls_subnet), 3):
+            c = [self.cls_subnet[i + 2](self.cls_subnet[i + 1](t)) for t in self.cls_subnet[i].levels(c)]
+            b = [self.bbox_subnet[i + 2](self.bbox_subnet[i + 1](t)) for t in self.bbox_subnet[i].levels(b)]
+        logits = self.cls_score.levels(c)
+        ctr = self.centerness.levels(b if self.centerness_on_reg else c)
+        reg = []
+        for lvl, r in enumerate(self.bbox_pred.levels(b)):
+            r = self.scales[lvl](r)
             reg.append(F.relu(r) * self.fpn_strides[lvl] if self.norm_reg_targets else torch.exp(r))
         return logits, reg, ctr
 

@@ -5,6 +5,8 @@ ResNet features (models/customized_detectors/retinanet.py:29-34,52-53)."""
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
 
 class LastLevelP6P7(nn.Module):
     def __init__(self, cin, cout, in_feature="res5"):
@@ -31,7 +33,7 @@ class FPN(nn.Module):
         for f, c in zip(in_features, in_channels):
             idx = int(f[3:]) if f.startswith("res") else int(f[-1])
             lat = nn.Conv2d(c, out_channels, 1)
-            out = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+            out = ops.Conv3x3(out_channels, out_channels)
             for m in (lat, out):
                 nn.init.kaiming_uniform_(m.weight, a=1)
                 nn.init.constant_(m.bias, 0)

@@ -5,6 +5,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
 
 class FrozenBatchNorm2d(nn.Module):
     """y = x * w * rsqrt(var + eps) + (b - mean * w * rsqrt(var + eps)); all four are buffers."""
@@ -33,10 +35,14 @@ class ConvBN(nn.Conv2d):
     def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, groups=1):
         super().__init__(cin, cout, k, stride, padding, dilation, groups, bias=False)
         self.norm = FrozenBatchNorm2d(cout)
+        self._plain3x3 = (k == 3 and stride == 1 and padding == 1 and dilation == 1 and groups == 1)
 
     def forward(self, x, relu=False):
         scale, shift = self.norm.scale_shift()
-        y = F.conv2d(x, self.weight * scale.view(-1, 1, 1, 1), shift, self.stride, self.padding, self.dilation, self.groups)
+        w = self.weight * scale.view(-1, 1, 1, 1)
+        if self._plain3x3:  # res4 / res5 conv2: Winograd transforms + GEMMs (ReLU fused); narrower stages: direct kernels
+            return ops.conv3x3(x, w, shift, relu=relu)
+        y = F.conv2d(x, w, shift, self.stride, self.padding, self.dilation, self.groups)
         return F.relu_(y) if relu else y
 
 

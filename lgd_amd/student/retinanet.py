@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..registry import CUSTOMIZED_DETECTORS_REGISTRY
 from ..structures import ImageList
 from .fpn import FPN, LastLevelP6P7
@@ -27,12 +28,12 @@ class RetinaNetHead(nn.Module):
         super().__init__()
         cls, box = [], []
         for _ in range(num_convs):
-            cls += [nn.Conv2d(cin, cin, 3, 1, 1), nn.ReLU()]
-            box += [nn.Conv2d(cin, cin, 3, 1, 1), nn.ReLU()]
+            cls += [ops.Conv3x3(cin, cin), nn.ReLU()]
+            box += [ops.Conv3x3(cin, cin), nn.ReLU()]
         self.cls_subnet = nn.Sequential(*cls)
         self.bbox_subnet = nn.Sequential(*box)
-        self.cls_score = nn.Conv2d(cin, num_anchors * num_classes, 3, 1, 1)
-        self.bbox_pred = nn.Conv2d(cin, num_anchors * 4, 3, 1, 1)
+        self.cls_score = ops.Conv3x3(cin, num_anchors * num_classes)
+        self.bbox_pred = ops.Conv3x3(cin, num_anchors * 4)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.normal_(m.weight, mean=0, std=0.01)
@@ -40,11 +41,12 @@ class RetinaNetHead(nn.Module):
         nn.init.constant_(self.cls_score.bias, -math.log((1 - prior_prob) / prior_prob))
 
     def forward(self, features):
-        logits, deltas = [], []
-        for f in features:
-            logits.append(self.cls_score(self.cls_subnet(f)))
-            deltas.append(self.bbox_pred(self.bbox_subnet(f)))
-        return logits, deltas
+        # the towers share their filters across levels: every conv is ONE pass over the concatenated pyramid, ReLU fused
+        c = b = list(features)
+        for i in range(0, len(self.cls_subnet), 2):
+            c = self.cls_subnet[i].levels(c, relu=True)
+            b = self.bbox_subnet[i].levels(b, relu=True)
+        return self.cls_score.levels(c), self.bbox_pred.levels(b)
 
 
 class AnchorGenerator(nn.Module):

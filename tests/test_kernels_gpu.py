@@ -499,3 +499,75 @@ def test_gn_relu_mask_pool_fused_fwd_bwd(cfg):
     for a, b in zip(fg, fc):
         ok, msg = cm.kink_robust_close(a.grad, b.grad, tol=1e-4)
         assert ok, msg
+
+
+# ------------------------------------------------------------------------------------------- K8: 3x3 convolutions
+@pytest.mark.parametrize("N,Ci,Co,hws,bias,relu", [
+    (2, 64, 64, [(16, 24)], True, False),                       # W % 4 == 0: paired tiles
+    (1, 64, 72, [(13, 21)], True, True),                        # odd H and W: clipped tiles, odd tile count -> zero pad tile
+    (3, 68, 64, [(7, 10)], False, False),
+    (2, 128, 256, [(25, 42)], True, True),
+    (1, 64, 64, [(1, 1)], True, False), (1, 64, 64, [(2, 3)], False, True),   # maps smaller than one tile
+    (2, 64, 96, [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)], True, True),   # a pyramid: one filter over 5 levels
+    (1, 64, 36, [(13, 21), (7, 11), (4, 6)], True, False),                    # odd levels + narrow output (bbox_pred)
+    (2, 64, 1, [(8, 12), (4, 6)], True, False),                               # single output channel (centerness)
+])
+def test_conv3x3_winograd_fwd_bwd(N, Ci, Co, hws, bias, relu):
+    """F(2x2,3x3) transforms + GEMMs against the direct convolution in fp64 (what the oracle runs: F.conv2d [+ReLU]):
+    values, input / weight / bias gradients (summed over the levels sharing the filter)."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    xs = [torch.from_numpy(synth.det_uniform((N, Ci, h, w), 901 + i, -2.0, 2.0)) for i, (h, w) in enumerate(hws)]
+    w = torch.from_numpy(synth.det_uniform((Co, Ci, 3, 3), 902, -0.1, 0.1))
+    b = torch.from_numpy(synth.det_uniform((Co,), 903, -0.5, 0.5)) if bias else None
+    gys = [torch.from_numpy(synth.det_uniform((N, Co, h, w_), 950 + i, -1.0, 1.0)) for i, (h, w_) in enumerate(hws)]
+    xr = [x.double().requires_grad_(True) for x in xs]
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = [F.conv2d(x, wr, br, 1, 1) for x in xr]
+    if relu:
+        yr = [F.relu(y) for y in yr]
+    torch.autograd.backward(yr, [g.double() for g in gys])
+    xg = [x.to(DEV).requires_grad_(True) for x in xs]
+    wg = w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if bias else None
+    ys = ops._Conv3x3.apply(wg, bg, relu, *xg)
+    torch.autograd.backward(ys, [g.to(DEV) for g in gys])
+    scale = lambda t: float(t.detach().abs().max()) + 1e-30
+    for y, r in zip(ys, yr):
+        assert float((y.detach().cpu().double() - r.detach()).abs().max()) <= FTOL * scale(r)
+        if relu:  # the ReLU masks agree except where the pre-activation is within rounding of 0
+            assert float(((y.detach().cpu() > 0) != (r.detach() > 0)).double().mean()) < 1e-4
+    gscale = max(scale(x.grad) for x in xr)
+    for x, r in zip(xg, xr):
+        assert float((x.grad.cpu().double() - r.grad).abs().max()) <= FTOL * gscale
+    assert float((wg.grad.cpu().double() - wr.grad).abs().max()) <= FTOL * scale(wr.grad)
+    if bias:
+        assert float((bg.grad.cpu().double() - br.grad).abs().max()) <= FTOL * scale(br.grad)
+
+
+def test_conv3x3_dispatch_and_partial_grads():
+    """conv3x3 picks the Winograd path for large maps, the library's direct kernels for small ones; both agree;
+    input-only and weight-only gradients (frozen filter / detached input)."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    x = torch.from_numpy(synth.det_uniform((4, 192, 48, 64), 911, -1.0, 1.0)).to(DEV).requires_grad_(True)
+    w = torch.from_numpy(synth.det_uniform((192, 192, 3, 3), 912, -0.05, 0.05)).to(DEV)
+    b = torch.from_numpy(synth.det_uniform((192,), 913, -0.5, 0.5)).to(DEV)
+    y = ops.conv3x3(x, w, b, relu=True)
+    assert type(y.grad_fn).__name__.startswith("_Conv3x3")
+    yr = F.relu(F.conv2d(x.detach().double(), w.double(), b.double(), 1, 1))
+    assert float((y.detach().double() - yr).abs().max()) <= FTOL * float(yr.abs().max())
+    y.square().sum().backward()
+    xr = x.detach().double().requires_grad_(True)
+    F.relu(F.conv2d(xr, w.double(), b.double(), 1, 1)).square().sum().backward()
+    assert float((x.grad.double() - xr.grad).abs().max()) <= FTOL * float(xr.grad.abs().max())
+    small = ops.conv3x3(x[:, :, :8, :8], w, b)
+    assert not type(small.grad_fn).__name__.startswith("_Conv3x3")
+    # weight + bias gradient only (detached input, e.g. the first conv after a frozen stage)
+    wv, bv = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ops.conv3x3(x.detach(), wv, bv, relu=True).square().sum().backward()
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    F.relu(F.conv2d(x.detach().double(), wr, br, 1, 1)).square().sum().backward()
+    assert float((wv.grad.double() - wr.grad).abs().max()) <= FTOL * float(wr.grad.abs().max())
+    assert float((bv.grad.double() - br.grad).abs().max()) <= FTOL * float(br.grad.abs().max())
