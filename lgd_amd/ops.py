@@ -713,6 +713,23 @@ class _Conv3x3(torch.autograd.Function):
         return (dw, db, None, *dxs)
 
 
+def enable_tuned_gemms(path=None):
+    """Library GEMM solution selection for the Winograd channel products: lgd_amd/tuning/tunableop_gfx950.csv holds the
+    fastest rocBLAS / hipBLASLt solution per GEMM shape of the BASELINE configs, measured on an MI355X with torch's
+    TunableOp (regenerate: PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_FILENAME=... python bench.py).  Lookup only --
+    nothing is tuned at run time; shapes not in the table (or a table from another ROCm build) use the default."""
+    if os.environ.get("LGD_TUNED_GEMM", "1") == "0" or "PYTORCH_TUNABLEOP_ENABLED" in os.environ or not torch.cuda.is_available():
+        return False
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
+    if not os.path.exists(path):
+        return False
+    import torch.cuda.tunable as tunable
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    return bool(tunable.read_file(path))
+
+
+_TUNED_GEMM = enable_tuned_gemms()
 _WINO_MIN_TILES = int(os.environ.get("LGD_WINO_MIN_TILES", "2000"))
 _WINO_MIN_CH = int(os.environ.get("LGD_WINO_MIN_CH", "192"))  # narrower inputs (res2/res3): the library's direct kernels win
 _WINO_ON = os.environ.get("LGD_WINO", "1") != "0"
