@@ -136,6 +136,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ktimes = ops.kernel_timer_collect()
+    kbytes = ops.kernel_alg_bytes()  # shape-varying kernels (Winograd transforms): bytes summed over the timed launches
     ops.kernel_timer_enable(False)
     metrics = trainer.fetch_metrics()  # raises on non-finite losses
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -155,6 +156,7 @@ def main():
         # focal loss: logits (N, 9*80, H, W) read once (fwd) / read + written (bwd); int32 label planes (N, 9, H, W) on top
         Pf = Bg * sum(h * w for h, w in synth.pyramid_shapes(Hp, Wp)) * 9 * 4
         alg.update({"focal_fwd_kernel": 80 * Pf + Pf, "focal_bwd_kernel": 2 * 80 * Pf + Pf})
+        alg.update({k: v / max(ktimes[k][0], 1) for k, v in kbytes.items() if k in ktimes})  # mean bytes per launch
         kernels = {}
         for name, (n, ms) in ktimes.items():
             kernels[name] = {"launches": n, "avg_us": 1e3 * ms / max(n, 1), "total_ms": ms}

@@ -667,6 +667,9 @@ class _Conv3x3(torch.autograd.Function):
         U = torch.mm(_wino_gg(dev), w.view(Co * Ci, 9).t()).view(16, Co, Ci)
         V = torch.empty((16, Ci, T), dtype=torch.float32, device=dev)
         hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, hw, L, N, Ci, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
+        px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
+        _count_bytes("wino_in_kernel", px * Ci + 64 * Ci * T)
+        _count_bytes("wino_out_kernel", px * Co + 64 * Co * T)
         M = torch.bmm(U, V)
         ys = [torch.empty((N, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
         hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(b) if b is not None else None, hw, L, N, Co, 0, int(relu),
@@ -674,6 +677,7 @@ class _Conv3x3(torch.autograd.Function):
         need_w = ctx.needs_input_grad[0]
         ctx.save_for_backward(U, V if need_w else None, *(ys if relu else []))
         ctx.meta = (L, N, Ci, Co, hw, T, bool(relu), b is not None, [tuple(x.shape[2:]) for x in xs])
+        ctx.px = px
         return tuple(ys)
 
     @staticmethod
@@ -688,7 +692,10 @@ class _Conv3x3(torch.autograd.Function):
         dw = db = None
         dxs = [None] * L
         Vd = dM = None
+        pdy = ctx.px * Co * (2 if relu else 1)  # dy (+ the forward output as the ReLU mask)
         if need_x:
+            _count_bytes("wino_in_dual_kernel" if need_w else "wino_in_kernel", pdy + 64 * Co * T * (2 if need_w else 1))
+            _count_bytes("wino_out_kernel", ctx.px * Ci + 64 * Ci * T)
             Vd = torch.empty((16, Co, T), dtype=torch.float32, device=dev)
             dM = torch.empty_like(Vd) if need_w else None
             hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, hw, L, N, Co, 1, hip.ptr(Vd), hip.ptr(dM) if need_w else None,
@@ -699,6 +706,7 @@ class _Conv3x3(torch.autograd.Function):
             hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, 1, 0, hip.ptr_array(dxs), hip.stream_ptr()), "lgd_wino_out")
             del Md
         elif need_w:
+            _count_bytes("wino_out_t_kernel", pdy + 64 * Co * T)
             dM = torch.empty((16, Co, T), dtype=torch.float32, device=dev)
             hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, hw, L, N, Co, hip.ptr(dM), hip.stream_ptr()), "lgd_wino_out_t")
         if need_w:
@@ -771,9 +779,29 @@ class Conv3x3(torch.nn.Conv2d):
 
 
 # ------------------------------------------------------------------------------------------------ timing
+_TIMER_ON = False
+_ALG_BYTES = {}
+
+
+def _count_bytes(name, nbytes):
+    """algorithmic HBM bytes of kernels whose launches differ in shape (the Winograd transforms), summed while the
+    timer runs so that bench.py can price total bytes / total time."""
+    if _TIMER_ON:
+        _ALG_BYTES[name] = _ALG_BYTES.get(name, 0) + int(nbytes)
+
+
 def kernel_timer_enable(on):
     """bracket every HIP kernel launch of the library with an event pair on its stream (bench.py)."""
+    global _TIMER_ON
     hip.check(hip.load().lgd_timing_enable(int(bool(on))), "lgd_timing_enable")
+    _TIMER_ON = bool(on)
+    if on:
+        _ALG_BYTES.clear()
+
+
+def kernel_alg_bytes():
+    """{kernel name: algorithmic bytes summed over the launches since kernel_timer_enable(True)} (shape-varying kernels)."""
+    return dict(_ALG_BYTES)
 
 
 def kernel_timer_collect():
