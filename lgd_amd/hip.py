@@ -56,10 +56,10 @@ SIGNATURES = {
     "lgd_focal_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i, c_i]),
     "lgd_focal_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
     "lgd_focal_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
-    "lgd_wino_tiles": (c_sz, [c_fp, c_i, c_i]),
-    "lgd_wino_in": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
-    "lgd_wino_out": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
-    "lgd_wino_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_wino_tiles": (c_sz, [c_fp, c_i, c_i, c_i]),
+    "lgd_wino_in": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_wino_out": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_wino_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_timing_enable": (c_i, [c_i]),
     "lgd_timing_collect": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_i]),
 }

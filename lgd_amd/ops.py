@@ -635,25 +635,29 @@ def label_planes(labels, level_hw, A):
 
 # ------------------------------------------------------------------------------------------------ K8: 3x3 convolutions
 _WINO_GG = {}
+_WINO_G = {2: [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+           4: [[1 / 4, 0.0, 0.0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+               [1 / 24, -1 / 12, 1 / 6], [0.0, 0.0, 1.0]]}
 
 
-def _wino_gg(device):
-    """(16, 9) Kronecker form of U = G g G^T for F(2x2, 3x3): U[4a+b] = sum_ij G[a,i] G[b,j] g[i,j]."""
-    key = str(device)
+def _wino_gg(device, tile):
+    """(F, 9) Kronecker form of U = G g G^T: U[a*n+b] = sum_ij G[a,i] G[b,j] g[i,j]; F = 16 (tile 2) or 36 (tile 4)."""
+    key = (str(device), tile)
     if key not in _WINO_GG:
-        G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32)
-        _WINO_GG[key] = torch.kron(G, G).contiguous().to(device)
+        G = torch.tensor(_WINO_G[tile], dtype=torch.float64)
+        _WINO_GG[key] = torch.kron(G, G).to(torch.float32).contiguous().to(device)
     return _WINO_GG[key]
 
 
 class _Conv3x3(torch.autograd.Function):
     """nn.Conv2d(Ci, Co, 3, stride 1, padding 1) [+ ReLU] with one filter over L maps (the pyramid levels) in the
-    minimal-filtering form F(2x2, 3x3): HIP data transforms (lgd_wino_in / lgd_wino_out / lgd_wino_out_t) around 16
-    per-frequency channel GEMMs (hipBLASLt fp32 MFMA through torch.bmm) over the concatenated tiles of all levels.
-    Forward, input gradient and weight gradient all run at 4/9 of the direct multiplies; backward reads dy once."""
+    minimal-filtering form F(tile x tile, 3x3), tile = 4 (default) or 2: HIP data transforms (lgd_wino_in / lgd_wino_out /
+    lgd_wino_out_t) around per-frequency channel GEMMs (hipBLASLt / rocBLAS fp32 MFMA through torch.bmm) over the
+    concatenated tiles of all levels.  Forward, input gradient and weight gradient all run at 1/4 (tile 4) or 4/9
+    (tile 2) of the direct multiplies; backward reads dy once."""
 
     @staticmethod
-    def forward(ctx, w, b, relu, *xs):
+    def forward(ctx, w, b, relu, tile, *xs):
         hip.require_gpu(w, *xs)
         lib = hip.load()
         w = hip.dense_f32(w)
@@ -662,63 +666,72 @@ class _Conv3x3(torch.autograd.Function):
         L, N, Ci = len(xs), xs[0].shape[0], xs[0].shape[1]
         Co = w.shape[0]
         dev = w.device
+        nf = (tile + 2) ** 2
         hw = hip.int_array([d for x in xs for d in x.shape[2:]])
-        T = lib.lgd_wino_tiles(hw, L, N)
-        U = torch.mm(_wino_gg(dev), w.view(Co * Ci, 9).t()).view(16, Co, Ci)
-        V = torch.empty((16, Ci, T), dtype=torch.float32, device=dev)
-        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, hw, L, N, Ci, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
+        T = lib.lgd_wino_tiles(hw, L, N, tile)
+        U = torch.mm(_wino_gg(dev, tile), w.view(Co * Ci, 9).t()).view(nf, Co, Ci)
+        V = torch.empty((nf, Ci, T), dtype=torch.float32, device=dev)
+        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
-        _count_bytes("wino_in_kernel", px * Ci + 64 * Ci * T)
-        _count_bytes("wino_out_kernel", px * Co + 64 * Co * T)
+        fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
+        _count_bytes("wino_in_kernel", (px + fb) * Ci)
+        _count_bytes("wino_out_kernel", (px + fb) * Co)
         M = torch.bmm(U, V)
         ys = [torch.empty((N, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
-        hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(b) if b is not None else None, hw, L, N, Co, 0, int(relu),
+        hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(b) if b is not None else None, hw, L, N, Co, tile, 0, int(relu),
                                    hip.ptr_array(ys), hip.stream_ptr()), "lgd_wino_out")
         need_w = ctx.needs_input_grad[0]
-        ctx.save_for_backward(U, V if need_w else None, *(ys if relu else []))
-        ctx.meta = (L, N, Ci, Co, hw, T, bool(relu), b is not None, [tuple(x.shape[2:]) for x in xs])
-        ctx.px = px
+        # tile 2 reuses U for the input gradient (the filter rotation is a frequency permutation); tile 4 keeps w
+        ctx.save_for_backward(U if tile == 2 else w, V if need_w else None, *(ys if relu else []))
+        ctx.meta = (L, N, Ci, Co, hw, T, bool(relu), b is not None, [tuple(x.shape[2:]) for x in xs], tile, px, fb)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
-        U, V, *yref = ctx.saved_tensors
-        L, N, Ci, Co, hw, T, relu, has_bias, shapes = ctx.meta
+        Uw, V, *yref = ctx.saved_tensors
+        L, N, Ci, Co, hw, T, relu, has_bias, shapes, tile, px, fb = ctx.meta
         lib = hip.load()
-        dev = U.device
+        dev = Uw.device
+        nf = (tile + 2) ** 2
         dys = [hip.dense_f32(g) for g in dys]
-        need_w, need_x = ctx.needs_input_grad[0], any(ctx.needs_input_grad[3:])
+        need_w, need_x = ctx.needs_input_grad[0], any(ctx.needs_input_grad[4:])
         ref = hip.ptr_array(yref) if relu else None
         dw = db = None
         dxs = [None] * L
-        Vd = dM = None
-        pdy = ctx.px * Co * (2 if relu else 1)  # dy (+ the forward output as the ReLU mask)
+        dM = None
+        pdy = px * Co * (2 if relu else 1)  # dy (+ the forward output as the ReLU mask)
         if need_x:
-            _count_bytes("wino_in_dual_kernel" if need_w else "wino_in_kernel", pdy + 64 * Co * T * (2 if need_w else 1))
-            _count_bytes("wino_out_kernel", ctx.px * Ci + 64 * Ci * T)
-            Vd = torch.empty((16, Co, T), dtype=torch.float32, device=dev)
+            _count_bytes("wino_in_dual_kernel" if need_w else "wino_in_kernel", pdy + fb * Co * (2 if need_w else 1))
+            _count_bytes("wino_out_kernel", (px + fb) * Ci)
+            if tile == 2:
+                Ut, flip = Uw.transpose(1, 2), 1
+            else:  # transform of the rotated, (Co,Ci)-transposed filter
+                wr = Uw.flip(2, 3).transpose(0, 1).reshape(Ci * Co, 9)
+                Ut, flip = torch.mm(_wino_gg(dev, tile), wr.t()).view(nf, Ci, Co), 0
+            Vd = torch.empty((nf, Co, T), dtype=torch.float32, device=dev)
             dM = torch.empty_like(Vd) if need_w else None
-            hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, hw, L, N, Co, 1, hip.ptr(Vd), hip.ptr(dM) if need_w else None,
-                                      hip.stream_ptr()), "lgd_wino_in")
-            Md = torch.bmm(U.transpose(1, 2), Vd)
+            hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, hw, L, N, Co, tile, flip, hip.ptr(Vd),
+                                      hip.ptr(dM) if need_w else None, hip.stream_ptr()), "lgd_wino_in")
+            Md = torch.bmm(Ut, Vd)
             del Vd
             dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-            hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, 1, 0, hip.ptr_array(dxs), hip.stream_ptr()), "lgd_wino_out")
+            hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, flip, 0, hip.ptr_array(dxs), hip.stream_ptr()),
+                      "lgd_wino_out")
             del Md
         elif need_w:
-            _count_bytes("wino_out_t_kernel", pdy + 64 * Co * T)
-            dM = torch.empty((16, Co, T), dtype=torch.float32, device=dev)
-            hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, hw, L, N, Co, hip.ptr(dM), hip.stream_ptr()), "lgd_wino_out_t")
+            _count_bytes("wino_out_t_kernel", pdy + fb * Co)
+            dM = torch.empty((nf, Co, T), dtype=torch.float32, device=dev)
+            hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
+                      "lgd_wino_out_t")
         if need_w:
             dU = torch.bmm(dM, V.transpose(1, 2))
-            dw = torch.mm(_wino_gg(dev).t(), dU.view(16, Co * Ci)).t().reshape(Co, Ci, 3, 3)
+            dw = torch.mm(_wino_gg(dev, tile).t(), dU.view(nf, Co * Ci)).t().reshape(Co, Ci, 3, 3)
             if has_bias and ctx.needs_input_grad[1]:
-                # sum of a tile's 2x2 gradients = its (0,0) frequency of A g A^T ... only without padding rows; use the
-                # masked gradients directly: frequency (1,1) holds g00+g01+g10+g11
-                db = dM[5].sum(1)
+                # A's row of the interpolation point 1 is all ones: that frequency of dM = A g A^T is the tile's gradient sum
+                db = dM[tile + 3].sum(1)
         elif has_bias and ctx.needs_input_grad[1]:
             db = sum((g * (y > 0) if relu else g).sum((0, 2, 3)) for g, y in zip(dys, yref if relu else dys))
-        return (dw, db, None, *dxs)
+        return (dw, db, None, None, *dxs)
 
 
 def enable_tuned_gemms(path=None):
@@ -738,6 +751,7 @@ def enable_tuned_gemms(path=None):
 
 
 _TUNED_GEMM = enable_tuned_gemms()
+_WINO_TILE = int(os.environ.get("LGD_WINO_TILE", "4"))  # output tile of the minimal-filtering form: 4 -> F(4x4,3x3), 2 -> F(2x2,3x3)
 _WINO_MIN_TILES = int(os.environ.get("LGD_WINO_MIN_TILES", "2000"))
 _WINO_MIN_CH = int(os.environ.get("LGD_WINO_MIN_CH", "192"))  # narrower inputs (res2/res3): the library's direct kernels win
 _WINO_ON = os.environ.get("LGD_WINO", "1") != "0"
@@ -755,7 +769,7 @@ def conv3x3_levels(xs, w, b=None, relu=False):
     the concatenated tiles.  Tiny problems stay on the library's direct kernels."""
     xs = list(xs)
     if _wino_ok(xs, w):
-        return list(_Conv3x3.apply(w, b, bool(relu), *xs))
+        return list(_Conv3x3.apply(w, b, bool(relu), _WINO_TILE, *xs))
     ys = [F.conv2d(x, w, b, 1, 1) for x in xs]
     return [F.relu_(y) for y in ys] if relu else ys
 

@@ -502,6 +502,7 @@ def test_gn_relu_mask_pool_fused_fwd_bwd(cfg):
 
 
 # ------------------------------------------------------------------------------------------- K8: 3x3 convolutions
+@pytest.mark.parametrize("tile", [2, 4])
 @pytest.mark.parametrize("N,Ci,Co,hws,bias,relu", [
     (2, 64, 64, [(16, 24)], True, False),                       # W % 4 == 0: paired tiles
     (1, 64, 72, [(13, 21)], True, True),                        # odd H and W: clipped tiles, odd tile count -> zero pad tile
@@ -512,9 +513,11 @@ def test_gn_relu_mask_pool_fused_fwd_bwd(cfg):
     (1, 64, 36, [(13, 21), (7, 11), (4, 6)], True, False),                    # odd levels + narrow output (bbox_pred)
     (2, 64, 1, [(8, 12), (4, 6)], True, False),                               # single output channel (centerness)
 ])
-def test_conv3x3_winograd_fwd_bwd(N, Ci, Co, hws, bias, relu):
-    """F(2x2,3x3) transforms + GEMMs against the direct convolution in fp64 (what the oracle runs: F.conv2d [+ReLU]):
-    values, input / weight / bias gradients (summed over the levels sharing the filter)."""
+def test_conv3x3_winograd_fwd_bwd(N, Ci, Co, hws, bias, relu, tile):
+    """F(2x2,3x3) / F(4x4,3x3) transforms + GEMMs against the direct convolution in fp64 (what the oracle runs:
+    F.conv2d [+ReLU]): values, input / weight / bias gradients (summed over the levels sharing the filter).
+    fp32 rounding of the minimal-filtering forms: <= 2e-5 (tile 2) / 5e-5 (tile 4) of the output scale."""
+    tol = FTOL if tile == 2 else 5e-5
     import torch.nn.functional as F
     from lgd_amd import ops
     xs = [torch.from_numpy(synth.det_uniform((N, Ci, h, w), 901 + i, -2.0, 2.0)) for i, (h, w) in enumerate(hws)]
@@ -531,19 +534,19 @@ def test_conv3x3_winograd_fwd_bwd(N, Ci, Co, hws, bias, relu):
     xg = [x.to(DEV).requires_grad_(True) for x in xs]
     wg = w.to(DEV).requires_grad_(True)
     bg = b.to(DEV).requires_grad_(True) if bias else None
-    ys = ops._Conv3x3.apply(wg, bg, relu, *xg)
+    ys = ops._Conv3x3.apply(wg, bg, relu, tile, *xg)
     torch.autograd.backward(ys, [g.to(DEV) for g in gys])
     scale = lambda t: float(t.detach().abs().max()) + 1e-30
     for y, r in zip(ys, yr):
-        assert float((y.detach().cpu().double() - r.detach()).abs().max()) <= FTOL * scale(r)
+        assert float((y.detach().cpu().double() - r.detach()).abs().max()) <= tol * scale(r)
         if relu:  # the ReLU masks agree except where the pre-activation is within rounding of 0
             assert float(((y.detach().cpu() > 0) != (r.detach() > 0)).double().mean()) < 1e-4
     gscale = max(scale(x.grad) for x in xr)
     for x, r in zip(xg, xr):
-        assert float((x.grad.cpu().double() - r.grad).abs().max()) <= FTOL * gscale
-    assert float((wg.grad.cpu().double() - wr.grad).abs().max()) <= FTOL * scale(wr.grad)
+        assert float((x.grad.cpu().double() - r.grad).abs().max()) <= tol * gscale
+    assert float((wg.grad.cpu().double() - wr.grad).abs().max()) <= tol * scale(wr.grad)
     if bias:
-        assert float((bg.grad.cpu().double() - br.grad).abs().max()) <= FTOL * scale(br.grad)
+        assert float((bg.grad.cpu().double() - br.grad).abs().max()) <= tol * scale(br.grad)
 
 
 def test_conv3x3_dispatch_and_partial_grads():
@@ -557,11 +560,11 @@ def test_conv3x3_dispatch_and_partial_grads():
     y = ops.conv3x3(x, w, b, relu=True)
     assert type(y.grad_fn).__name__.startswith("_Conv3x3")
     yr = F.relu(F.conv2d(x.detach().double(), w.double(), b.double(), 1, 1))
-    assert float((y.detach().double() - yr).abs().max()) <= FTOL * float(yr.abs().max())
+    assert float((y.detach().double() - yr).abs().max()) <= 5e-5 * float(yr.abs().max())
     y.square().sum().backward()
     xr = x.detach().double().requires_grad_(True)
     F.relu(F.conv2d(xr, w.double(), b.double(), 1, 1)).square().sum().backward()
-    assert float((x.grad.double() - xr.grad).abs().max()) <= FTOL * float(xr.grad.abs().max())
+    assert float((x.grad.double() - xr.grad).abs().max()) <= 5e-5 * float(xr.grad.abs().max())
     small = ops.conv3x3(x[:, :, :8, :8], w, b)
     assert not type(small.grad_fn).__name__.startswith("_Conv3x3")
     # weight + bias gradient only (detached input, e.g. the first conv after a frozen stage)
@@ -569,5 +572,5 @@ def test_conv3x3_dispatch_and_partial_grads():
     ops.conv3x3(x.detach(), wv, bv, relu=True).square().sum().backward()
     wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
     F.relu(F.conv2d(x.detach().double(), wr, br, 1, 1)).square().sum().backward()
-    assert float((wv.grad.double() - wr.grad).abs().max()) <= FTOL * float(wr.grad.abs().max())
-    assert float((bv.grad.double() - br.grad).abs().max()) <= FTOL * float(br.grad.abs().max())
+    assert float((wv.grad.double() - wr.grad).abs().max()) <= 5e-5 * float(wr.grad.abs().max())
+    assert float((bv.grad.double() - br.grad).abs().max()) <= 5e-5 * float(br.grad.abs().max())

@@ -25,7 +25,7 @@ for tag, N, Ci, Co, H, W in (("p3", 8, 256, 256, 100, 168), ("p4", 8, 256, 256, 
     w = (torch.randn(Co, Ci, 3, 3, device="cuda") * 0.02).requires_grad_(True)
     b = torch.zeros(Co, device="cuda", requires_grad=True)
     gy = torch.randn(N, Co, H, W, device="cuda")
-    for name, f in (("miopen", lambda: F.conv2d(x, w, b, 1, 1)), ("wino", lambda: ops._Conv3x3.apply(w, b, False, x)[0])):
+    for name, f in (("miopen", lambda: F.conv2d(x, w, b, 1, 1)), ("wino", lambda: ops._Conv3x3.apply(w, b, False, ops._WINO_TILE, x)[0])):
         with torch.no_grad():
             tf = t(f)
 
@@ -39,7 +39,7 @@ ops.kernel_timer_enable(True)
 x = torch.randn(8, 256, 100, 168, device="cuda", requires_grad=True)
 w = (torch.randn(256, 256, 3, 3, device="cuda") * 0.02).requires_grad_(True)
 for _ in range(5):
-    ops._Conv3x3.apply(w, None, False, x)[0].backward(torch.ones(8, 256, 100, 168, device="cuda"))
+    ops._Conv3x3.apply(w, None, False, ops._WINO_TILE, x)[0].backward(torch.ones(8, 256, 100, 168, device="cuda"))
 for k, (n, ms) in sorted(ops.kernel_timer_collect().items()):
     print("%-20s %3d launches  %.1f us avg" % (k, n, ms / n * 1e3))
 
@@ -50,7 +50,7 @@ for Co in (256, 720, 36):
     w = (torch.randn(Co, 256, 3, 3, device="cuda") * 0.02).requires_grad_(True)
     b = torch.zeros(Co, device="cuda", requires_grad=True)
     gys = [torch.randn(8, Co, h, w_, device="cuda") for h, w_ in hws]
-    for name, f in (("miopen", lambda: [F.relu(F.conv2d(x, w, b, 1, 1)) for x in xs]), ("wino", lambda: ops._Conv3x3.apply(w, b, True, *xs))):
+    for name, f in (("miopen", lambda: [F.relu(F.conv2d(x, w, b, 1, 1)) for x in xs]), ("wino", lambda: ops._Conv3x3.apply(w, b, True, ops._WINO_TILE, *xs))):
         def fb():
             torch.autograd.backward(f(), gys)
             w.grad = b.grad = None

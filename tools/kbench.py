@@ -50,7 +50,7 @@ def one(it):
     torch.autograd.grad(pl.sum(), fr)
     zs = ops.bias_ctx_relu(fr, cvec)
     torch.autograd.grad(sum(v.sum() for v in zs), fr)
-    cy = ops._Conv3x3.apply(wconv, bconv, True, *fr)  # one 256->256 filter + ReLU over the pyramid: wino_in / wino_out / dual
+    cy = ops._Conv3x3.apply(wconv, bconv, True, ops._WINO_TILE, *fr)  # one 256->256 filter + ReLU over the pyramid: wino_in / wino_out / dual
     torch.autograd.grad(sum(v.sum() for v in cy), [wconv] + fr)
     o = ops.mha_blockdiag(q, kv, counts, mh.in_proj_weight, mh.in_proj_bias, mh.out_proj.weight, mh.out_proj.bias, 8, geom.img_off)
     torch.autograd.grad(o.sum(), [q, kv])
@@ -68,8 +68,9 @@ ops.kernel_timer_enable(False)
 alg = {"in_moments_kernel": 2 * P, "in_mse_bwd_kernel": 3 * P, "box_sum_kernel": P, "box_paint_kernel": P, "gn_stats_kernel": P,
        "gn_apply_kernel": 2 * P, "gn_bwd_stats_kernel": 2 * P, "gn_bwd_apply_kernel": 3 * P, "ctx_relu_kernel": 2 * P, "ctx_relu_bwd_kernel": 3 * P,
        "gn_pool_kernel": P, "gn_pool_bwd_stats_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
-Tt = sum(B * ((h + 1) // 2) * ((w + 1) // 2) for h, w in level_hw)
-alg.update({"wino_in_kernel": P + 64 * C * Tt, "wino_out_kernel": 2 * (P + 64 * C * Tt) / 2, "wino_in_dual_kernel": 2 * P + 2 * 64 * C * Tt})
+tl = ops._WINO_TILE
+FB = 4 * (tl + 2) ** 2 * C * sum(B * ((h + tl - 1) // tl) * ((w + tl - 1) // tl) for h, w in level_hw)  # one frequency buffer
+alg.update({"wino_in_kernel": P + FB, "wino_out_kernel": P + FB, "wino_in_dual_kernel": 2 * P + 2 * FB})
 res = {}
 for k, (n, ms) in sorted(t.items(), key=lambda kv: -kv[1][1]):
     us = 1e3 * ms / n
