@@ -252,6 +252,16 @@ int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host
 int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const int32_t* level_hw_host, int L,
                    int N, int C, int tile, float* dM, void* stream);
 
+/* ------------------------------------------------------------------ conv epilogues of the student (FrozenBN folded)
+ * [ref: the detectron2 BottleneckBlock of the reference's student: conv -> FrozenBN (a per-channel
+ *  affine, folded into the conv weights + bias) [-> += shortcut] -> relu]
+ * lgd_bias_act_fwd : out = x + bias[c] (+ residual) [then ReLU]; x, residual, out: (N, C, HW) fp32; bias / residual may be NULL
+ * lgd_relu_mask_bwd: dx = dy where the saved forward output y > 0, else 0 (total elements)
+ */
+int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, int N, int C, int HW, int relu, float* out,
+                     void* stream);
+int lgd_relu_mask_bwd(const float* y, const float* dy, long long total, float* dx, void* stream);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench.py)
  * When enabled every kernel launch of this library is bracketed by a HIP event pair recorded on
  * the launch stream.  lgd_timing_collect waits for the recorded events, sums the elapsed time per

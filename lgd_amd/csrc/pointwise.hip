@@ -1,0 +1,81 @@
+// Epilogues of the student's library convolutions [ref: the detectron2 BottleneckBlock the reference builds its student
+// from: out = conv3(...) (FrozenBN folded to a per-channel bias); out += shortcut; relu].
+// torch runs bias add, residual add and ReLU as three passes (7 map transfers); here one kernel reads the conv output
+// [+ the residual] and writes relu(x + bias[c] + r) once (2-3 transfers), and one kernel applies the ReLU mask of the
+// saved output to the incoming gradient.  Pure HBM streaming: thread per float4, plane index from the flat offset.
+#include "common.h"
+
+namespace lgd {
+
+struct BiasActArgs {
+    const float* x;      // (N, C, HW) conv output (no bias)
+    const float* bias;   // [C] or null
+    const float* res;    // (N, C, HW) residual or null
+    float* out;
+    long long total;     // N*C*HW
+    int C, HW, relu;
+};
+
+template <int VW>
+__global__ __launch_bounds__(256) void bias_act_kernel(BiasActArgs a) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * VW;
+    if (i >= a.total) return;
+    const int c = (int)((i / a.HW) % a.C);  // VW divides HW: the VW elements share a plane
+    const float b = a.bias ? a.bias[c] : 0.f;
+    Vec<VW> v = vload<VW>(a.x + i);
+    if (a.res) {
+        const Vec<VW> r = vload<VW>(a.res + i);
+        #pragma unroll
+        for (int k = 0; k < VW; ++k) v.v[k] += r.v[k];
+    }
+    #pragma unroll
+    for (int k = 0; k < VW; ++k) {
+        v.v[k] += b;
+        if (a.relu) v.v[k] = fmaxf(v.v[k], 0.f);
+    }
+    vstore<VW>(a.out + i, v);
+}
+
+template <int VW>
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                        float* __restrict__ dx, long long total) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * VW;
+    if (i >= total) return;
+    const Vec<VW> o = vload<VW>(y + i), g = vload<VW>(dy + i);
+    Vec<VW> r;
+    #pragma unroll
+    for (int k = 0; k < VW; ++k) r.v[k] = o.v[k] > 0.f ? g.v[k] : 0.f;
+    vstore<VW>(dx + i, r);
+}
+
+}  // namespace lgd
+
+extern "C" {
+
+int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, int N, int C, int HW, int relu, float* out,
+                     void* stream) {
+    if (!x || !out || N < 1 || C < 1 || HW < 1) return LGD_EINVAL;
+    lgd::BiasActArgs a{x, bias, residual, out, (long long)N * C * HW, C, HW, relu ? 1 : 0};
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)(residual ? residual : x)) & 15) == 0;
+    if (HW % 4 == 0 && al) {
+        LGD_LAUNCH("bias_act_kernel", lgd::bias_act_kernel<4>, dim3((unsigned)((a.total / 4 + 255) / 256)), dim3(256), 0, st, a);
+    } else {
+        LGD_LAUNCH("bias_act_kernel", lgd::bias_act_kernel<1>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
+    }
+    return lgd::check_launch();
+}
+
+int lgd_relu_mask_bwd(const float* y, const float* dy, long long total, float* dx, void* stream) {
+    if (!y || !dy || !dx || total < 1) return LGD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = (((uintptr_t)y | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+    if (total % 4 == 0 && al) {
+        LGD_LAUNCH("relu_mask_kernel", lgd::relu_mask_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, y, dy, dx, total);
+    } else {
+        LGD_LAUNCH("relu_mask_kernel", lgd::relu_mask_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, dy, dx, total);
+    }
+    return lgd::check_launch();
+}
+
+}  // extern "C"

@@ -753,7 +753,7 @@ def enable_tuned_gemms(path=None):
 _TUNED_GEMM = enable_tuned_gemms()
 _WINO_TILE = int(os.environ.get("LGD_WINO_TILE", "4"))  # output tile of the minimal-filtering form: 4 -> F(4x4,3x3), 2 -> F(2x2,3x3)
 _WINO_MIN_TILES = int(os.environ.get("LGD_WINO_MIN_TILES", "2000"))
-_WINO_MIN_CH = int(os.environ.get("LGD_WINO_MIN_CH", "192"))  # narrower inputs (res2/res3): the library's direct kernels win
+_WINO_MIN_CH = int(os.environ.get("LGD_WINO_MIN_CH", "64"))
 _WINO_ON = os.environ.get("LGD_WINO", "1") != "0"
 
 
@@ -793,6 +793,84 @@ class Conv3x3(torch.nn.Conv2d):
 
 
 # ------------------------------------------------------------------------------------------------ timing
+# ------------------------------------------------------------------------------------------------ student conv epilogues
+class _BiasAct(torch.autograd.Function):
+    """relu(x + bias[c] (+ residual)) in one pass; backward = the ReLU mask of the saved output on the incoming gradient
+    (shared by x and the residual), bias gradient only if the bias is a parameter (FrozenBN shifts are buffers)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, relu):
+        hip.require_gpu(x)
+        x = hip.dense_f32(x)
+        bias = hip.dense_f32(bias) if bias is not None else None
+        residual = hip.dense_f32(residual) if residual is not None else None
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        out = torch.empty_like(x)
+        hip.check(hip.load().lgd_bias_act_fwd(hip.ptr(x), hip.ptr(bias) if bias is not None else None,
+                                              hip.ptr(residual) if residual is not None else None, N, C, HW, int(relu),
+                                              hip.ptr(out), hip.stream_ptr()), "lgd_bias_act_fwd")
+        ctx.relu = bool(relu)
+        if relu:
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = hip.dense_f32(dy)
+        if ctx.relu:
+            (out,) = ctx.saved_tensors
+            dz = torch.empty_like(dy)
+            hip.check(hip.load().lgd_relu_mask_bwd(hip.ptr(out), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
+                      "lgd_relu_mask_bwd")
+        else:
+            dz = dy
+        db = dz.sum((0, 2, 3)) if ctx.needs_input_grad[1] else None
+        return dz, db, (dz if ctx.needs_input_grad[2] else None), None
+
+
+def bias_act(x, bias=None, residual=None, relu=True):
+    """relu(x + bias.view(1,-1,1,1) + residual) for NCHW fp32 maps on the GPU (plain torch ops elsewhere)."""
+    if x.is_cuda and x.dtype == torch.float32:
+        return _BiasAct.apply(x, bias, residual, bool(relu))
+    y = x if bias is None else x + bias.view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+class _Conv1x1(torch.autograd.Function):
+    """pointwise (1x1, stride 1) convolution without bias: forward and input gradient on the library's GEMM path, the
+    weight gradient as per-image NT GEMMs on the NCHW maps, dW = sum_n dy[n] (Co x HW) @ x[n]^T (HW x Ci) -- the library's
+    implicit-GEMM weight-gradient kernels transpose both operands to NHWC first."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = None
+        dy = dy.contiguous()
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            N, Ci = x.shape[0], x.shape[1]
+            Co = w.shape[0]
+            dw = torch.bmm(dy.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2)).sum(0).view(Co, Ci, 1, 1)
+        return dx, dw
+
+
+def conv1x1(x, w):
+    """bias-free pointwise convolution (see _Conv1x1); stride 1 only."""
+    if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and torch.is_grad_enabled() and w.requires_grad:
+        return _Conv1x1.apply(x, w)
+    return F.conv2d(x, w)
+
+
 _TIMER_ON = False
 _ALG_BYTES = {}
 

@@ -36,13 +36,24 @@ class ConvBN(nn.Conv2d):
         super().__init__(cin, cout, k, stride, padding, dilation, groups, bias=False)
         self.norm = FrozenBatchNorm2d(cout)
         self._plain3x3 = (k == 3 and stride == 1 and padding == 1 and dilation == 1 and groups == 1)
+        self._pointwise = (k == 1 and stride == 1 and padding == 0 and groups == 1)
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, residual=None):
+        """conv -> FrozenBN [-> += residual] [-> ReLU]: the affine is folded into the filter; bias, residual and ReLU are ONE
+        pass over the conv output (ops.bias_act) instead of three."""
         scale, shift = self.norm.scale_shift()
         w = self.weight * scale.view(-1, 1, 1, 1)
-        if self._plain3x3:  # res4 / res5 conv2: Winograd transforms + GEMMs (ReLU fused); narrower stages: direct kernels
+        if self._plain3x3 and residual is None:  # 3x3 / stride 1: Winograd transforms + GEMMs (bias + ReLU fused in the output transform)
             return ops.conv3x3(x, w, shift, relu=relu)
+        if x.is_cuda:
+            if self._pointwise:
+                y = ops.conv1x1(x, w)
+            else:
+                y = F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
+            return ops.bias_act(y, shift, residual, relu)
         y = F.conv2d(x, w, shift, self.stride, self.padding, self.dilation, self.groups)
+        if residual is not None:
+            y = y + residual
         return F.relu_(y) if relu else y
 
 
@@ -58,9 +69,8 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         out = self.conv1(x, relu=True)
         out = self.conv2(out, relu=True)
-        out = self.conv3(out)
         sc = self.shortcut(x) if self.shortcut is not None else x
-        return F.relu_(out + sc)
+        return self.conv3(out, relu=True, residual=sc)
 
 
 class DeformBottleneck(Bottleneck):
@@ -87,9 +97,8 @@ class DeformBottleneck(Bottleneck):
         scale, shift = c2.norm.scale_shift()
         out = modulated_deform_conv2d(out, offset, mask, c2.weight * scale.view(-1, 1, 1, 1), shift, c2.stride[0],
                                       c2.padding[0], c2.dilation[0])
-        out = self.conv3(F.relu_(out))
         sc = self.shortcut(x) if self.shortcut is not None else x
-        return F.relu_(out + sc)
+        return self.conv3(F.relu_(out), relu=True, residual=sc)
 
 
 class Stem(nn.Module):

@@ -574,3 +574,51 @@ def test_conv3x3_dispatch_and_partial_grads():
     F.relu(F.conv2d(x.detach().double(), wr, br, 1, 1)).square().sum().backward()
     assert float((wv.grad.double() - wr.grad).abs().max()) <= 5e-5 * float(wr.grad.abs().max())
     assert float((bv.grad.double() - br.grad).abs().max()) <= 5e-5 * float(br.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------- student conv epilogues
+@pytest.mark.parametrize("N,C,H,W,res,relu,bias_grad", [(2, 8, 6, 8, True, True, False), (1, 5, 3, 5, False, True, True),
+                                                        (3, 16, 7, 4, True, False, True), (2, 4, 5, 5, False, False, False)])
+def test_bias_act_fwd_bwd(N, C, H, W, res, relu, bias_grad):
+    """relu(x + bias[c] + residual) in one pass == the three torch ops (bit-exact: same fp32 additions in the same order)."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    x = torch.from_numpy(synth.det_uniform((N, C, H, W), 921, -1.0, 1.0)).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(synth.det_uniform((C,), 922, -0.5, 0.5)).to(DEV).requires_grad_(bias_grad)
+    r = torch.from_numpy(synth.det_uniform((N, C, H, W), 923, -1.0, 1.0)).to(DEV).requires_grad_(True) if res else None
+    gy = torch.from_numpy(synth.det_uniform((N, C, H, W), 924, -1.0, 1.0)).to(DEV)
+    y = ops.bias_act(x, b, r, relu)
+    y.backward(gy)
+    got = [x.grad.clone(), r.grad.clone() if res else None, b.grad.clone() if bias_grad else None]
+    x.grad = None
+    if res:
+        r.grad = None
+    if bias_grad:
+        b.grad = None
+    ref = x + r if res else x  # kernel order: (x + residual) + bias
+    ref = ref + b.view(1, -1, 1, 1)
+    ref = F.relu(ref) if relu else ref
+    ref.backward(gy)
+    assert torch.equal(y.detach(), ref.detach())
+    assert torch.equal(got[0], x.grad)
+    if res:
+        assert torch.equal(got[1], r.grad)
+    if bias_grad:
+        assert float((got[2] - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max())
+
+
+def test_conv1x1_weight_grad_by_gemm():
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    x = torch.from_numpy(synth.det_uniform((3, 24, 9, 14), 931, -1.0, 1.0)).to(DEV).requires_grad_(True)
+    w = torch.from_numpy(synth.det_uniform((40, 24, 1, 1), 932, -0.3, 0.3)).to(DEV).requires_grad_(True)
+    gy = torch.from_numpy(synth.det_uniform((3, 40, 9, 14), 933, -1.0, 1.0)).to(DEV)
+    y = ops.conv1x1(x, w)
+    assert type(y.grad_fn).__name__.startswith("_Conv1x1")
+    y.backward(gy)
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr)
+    yr.backward(gy.double())
+    assert float((y.detach().double() - yr.detach()).abs().max()) <= FTOL * float(yr.detach().abs().max())
+    assert float((x.grad.double() - xr.grad).abs().max()) <= FTOL * float(xr.grad.abs().max())
+    assert float((w.grad.double() - wr.grad).abs().max()) <= FTOL * float(wr.grad.abs().max())
