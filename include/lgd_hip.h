@@ -228,7 +228,8 @@ int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* la
  * sum_l even(N * ceil(H_l/2) * ceil(W_l/2)) (a level with an odd tile count is followed by one all-zero pad tile).
  * The 16 per-frequency channel products M[f] = U[f] (C' x C) @ V[f] (C x T) between the transforms are plain library
  * GEMMs issued by the host (hipBLASLt); U = G g G^T is built by the host from the nn.Conv2d weight.
- * V, M, dM are [16][C][T] fp32 (tile = 2), tile index fastest.  x_host / y_host / dy_host: host arrays of L device pointers
+ * V, M, dM are [C][nf][T] fp32 (nf = 16 frequencies for tile = 2), tile index fastest: the GEMM of frequency f sees a
+ * (C x T) matrix with leading dimension nf*T and batch stride T.  x_host / y_host / dy_host: host arrays of L device pointers
  * to (N, C, H_l, W_l) maps.
  *   lgd_wino_in   : V  = B^T d B  of the 4x4 input window of every tile (stride 2, zero halo 1); if dM != NULL also
  *                   dM = A g A^T of the window's 2x2 centre (the two backward operands in one pass over dy)
@@ -240,8 +241,8 @@ int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* la
  * tile = 2: F(2x2,3x3) as described (16 frequencies, windows 4x4 at stride 2); the rotation is the frequency
  *   permutation (0<->3 on both axes), applied by the transforms when flip = 1, so the host reuses U and only
  *   transposes it: dx = out(U[f]^T @ in(dy, flip=1), flip=1).
- * tile = 4: F(4x4,3x3): 36 frequencies (buffers [36][C][T]), windows 6x6 at stride 4, 4x4 outputs per tile,
- *   T = sum_l N * ceil(H_l/4) * ceil(W_l/4) (no pad tiles); flip must be 0 -- the host transforms the rotated filter.
+ * tile = 4: F(4x4,3x3): 36 frequencies (buffers [C][36][T]), windows 6x6 at stride 4, 4x4 outputs per tile,
+ *   T = sum_l (N * ceil(H_l/4) * ceil(W_l/4) rounded up to a multiple of 4 with zero tiles); flip must be 0 -- the host transforms the rotated filter.
  *   0.56x the GEMM work and ~0.65x the transform traffic of tile = 2; fp32 rounding ~1e-5 of the output scale per
  *   convolution instead of ~6e-7. */
 size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N, int tile);

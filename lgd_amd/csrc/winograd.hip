@@ -6,15 +6,18 @@
 // minimal-filtering form needs 2.25x fewer multiplies, and its 16 independent (C_out x C_in) x (C_in x tiles) products
 // are plain library GEMMs (hipBLASLt via torch.bmm, 100-140 TFLOP/s fp32 MFMA).  What is left is pure HBM streaming,
 // which is what these kernels do:
-//   wino_in   : x_l (N,C,H_l,W_l)        -> V [16][C][T]       V = B^T d B   per 4x4 input window (stride 2, halo 1)
-//   wino_out  : M [16][C][T], bias       -> y_l (N,C,H_l,W_l)  Y = A^T m A   per tile (2x2 outputs) [+bias] [ReLU]
-//   wino_out_t: dy_l                     -> dM [16][C][T]      dM = A dy A^T (adjoint of wino_out, weight gradient)
+//   wino_in   : x_l (N,C,H_l,W_l)        -> V [C][16][T]       V = B^T d B   per 4x4 input window (stride 2, halo 1)
+//   wino_out  : M [C][16][T], bias       -> y_l (N,C,H_l,W_l)  Y = A^T m A   per tile (2x2 outputs) [+bias] [ReLU]
+//   wino_out_t: dy_l                     -> dM [C][16][T]      dM = A dy A^T (adjoint of wino_out, weight gradient)
 //   wino_in_dual: dy_l -> V(flip) and dM in one pass over dy (the two operands of the backward pass)
 // Every module on the path applies ONE filter to all pyramid levels, and a Winograd tile does not care which level it
 // came from: the tiles of all L levels are concatenated along T (level l starts at an even offset), so one conv over
 // the pyramid is one transform launch + one batched GEMM + one transform launch, and p6/p7 (1.6 % of the pixels, but a
 // third of the launches on the per-level library path) ride along for free.  Tile index is the fastest axis everywhere:
-// all global accesses are coalesced along x and nothing is transposed (GEMM orientation U[16][Co][Ci] @ V[16][Ci][T]).
+// all global accesses are coalesced along x and nothing is transposed.  The frequency planes of one channel are adjacent
+// ([C][nf][T]: the GEMM of frequency f sees a (C x T) matrix with row stride nf*T) -- a workgroup's nf output chunks then
+// lie within one 45 KB..1.6 MB neighbourhood instead of nf planes 88 MB apart (measured 4.6 -> 5.2 TB/s on the p3 input
+// transform, tools/lab/wino4_lab.hip).
 // The input gradient is the same pipeline on dy with the 180-degree rotated, (Co,Ci)-transposed filter; the rotation
 // is a permutation of the 16 frequencies (flip = 1), so the host reuses U.
 #include "common.h"
@@ -30,7 +33,8 @@ struct WinoArgs {
     float* buf_out2;                        // [16][C][T] (dual)
     const float* bias;
     long long tile_off[LGD_MAX_LEVELS];     // first tile of the level (even)
-    long long T;                            // total tiles incl. per-level padding to an even count
+    long long T;                            // total tiles incl. per-level padding (even count for tile 2, multiple of 4 for tile 4)
+    long long cs;                           // channel stride of the frequency buffers = nf * T  (layout [C][nf][T])
     unsigned blk_off[LGD_MAX_LEVELS + 1];   // first workgroup of the level
     int H[LGD_MAX_LEVELS], W[LGD_MAX_LEVELS], TH[LGD_MAX_LEVELS], TW[LGD_MAX_LEVELS], pair[LGD_MAX_LEVELS];
     int L, N, C, flip, relu;
@@ -56,6 +60,7 @@ __device__ __forceinline__ void bt4(const float* d, float* o) {
 }
 
 typedef float wino_vf2 __attribute__((ext_vector_type(2)));
+typedef float wino_vf4 __attribute__((ext_vector_type(4)));
 
 // V / dM / M are written once and read once by a GEMM that streams 0.7 GB: non-temporal on both sides
 // (measured on the p3 input transform: 171 -> 153 us from the store hint alone)
@@ -81,14 +86,14 @@ __device__ __forceinline__ void wino_in_body(const WinoArgs& a, int l) {
     const long long units = (long long)a.N * TH * TWP;
     const long long u = (long long)(blockIdx.x - a.blk_off[l]) * 256 + threadIdx.x;
     const int c = blockIdx.y;
-    const size_t plane = (size_t)a.C * a.T;
+    const size_t plane = (size_t)a.T;
     if (u >= units) {
         // an odd tile count is padded by one all-zero tile so that every level starts on an even tile
         if (PAIR == 1 && u == units && (units & 1)) {
             const size_t t = (size_t)a.tile_off[l] + units;
             for (int f = 0; f < 16; ++f) {
-                a.buf_out[(size_t)f * plane + (size_t)c * a.T + t] = 0.f;
-                if (DUAL) a.buf_out2[(size_t)f * plane + (size_t)c * a.T + t] = 0.f;
+                a.buf_out[(size_t)f * plane + (size_t)c * a.cs + t] = 0.f;
+                if (DUAL) a.buf_out2[(size_t)f * plane + (size_t)c * a.cs + t] = 0.f;
             }
         }
         return;
@@ -140,7 +145,7 @@ __device__ __forceinline__ void wino_in_body(const WinoArgs& a, int l) {
         }
     }
     const size_t t = (size_t)a.tile_off[l] + ((size_t)n * TH + ty) * TW + tx;
-    float* o = a.buf_out + (size_t)c * a.T + t;
+    float* o = a.buf_out + (size_t)c * a.cs + t;
     float v[4][4][PAIR];
     #pragma unroll
     for (int q = 0; q < PAIR; ++q) {
@@ -164,7 +169,7 @@ __device__ __forceinline__ void wino_in_body(const WinoArgs& a, int l) {
         #pragma unroll
         for (int j = 0; j < 4; ++j) store_freq<PAIR>(o + (size_t)freq(i, j, a.flip) * plane, v[i][j]);
     if constexpr (DUAL) {
-        float* o2 = a.buf_out2 + (size_t)c * a.T + t;
+        float* o2 = a.buf_out2 + (size_t)c * a.cs + t;
         float w[4][4][PAIR];
         #pragma unroll
         for (int q = 0; q < PAIR; ++q) {
@@ -200,8 +205,8 @@ __device__ __forceinline__ void wino_out_body(const WinoArgs& a, int l) {
     const int c = blockIdx.y;
     const int txp = (int)(u % TWP), ty = (int)((u / TWP) % TH), n = (int)(u / ((long long)TWP * TH));
     const int tx = txp * PAIR;
-    const size_t plane = (size_t)a.C * a.T;
-    const float* m = a.buf_in + (size_t)c * a.T + (size_t)a.tile_off[l] + ((size_t)n * TH + ty) * TW + tx;
+    const size_t plane = (size_t)a.T;
+    const float* m = a.buf_in + (size_t)c * a.cs + (size_t)a.tile_off[l] + ((size_t)n * TH + ty) * TW + tx;
     float q[4][4][PAIR];
     #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -265,8 +270,8 @@ __global__ __launch_bounds__(256) void wino_out_t_kernel(WinoArgs a) {
     const long long units = (long long)a.N * TH * TW;
     const long long u = (long long)(blockIdx.x - a.blk_off[l]) * 256 + threadIdx.x;
     const int c = blockIdx.y;
-    const size_t plane = (size_t)a.C * a.T;
-    float* o = a.buf_out + (size_t)c * a.T + (size_t)a.tile_off[l] + u;
+    const size_t plane = (size_t)a.T;
+    float* o = a.buf_out + (size_t)c * a.cs + (size_t)a.tile_off[l] + u;
     if (u >= units) {
         if (u == units && (units & 1))
             for (int f = 0; f < 16; ++f) o[(size_t)f * plane] = 0.f;
@@ -325,15 +330,32 @@ __device__ __forceinline__ void a6(const float* g, float* r) {
     r[0] = g[0]; r[1] = e + o; r[2] = e - o; r[3] = e4 + o2; r[4] = e4 - o2; r[5] = g[3];
 }
 
+// The nf = 36 values of the workgroup's 256 tiles go through LDS so that every frequency plane is written / read as ONE
+// 1 KB run (float4 per lane) instead of 256 B per wave; level tile counts are padded to a multiple of 4 with zero tiles.
+__device__ __forceinline__ void stage_store36(const float* lds, float* dst, size_t plane, long long t0, long long tend) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    #pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int f = wave + 4 * k;
+        const float4 v = *reinterpret_cast<const float4*>(&lds[f * 256 + lane * 4]);
+        if (t0 + lane * 4 < tend) {  // tend is a multiple of 4
+            wino_vf4 q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+            __builtin_nontemporal_store(q, reinterpret_cast<wino_vf4*>(dst + (size_t)f * plane + lane * 4));
+        }
+    }
+}
+
 template <bool VEC, bool DUAL, bool MASK>
-__device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l) {
+__device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
-    const long long units = (long long)a.N * TH * TW;
-    const long long u = (long long)(blockIdx.x - a.blk_off[l]) * 256 + threadIdx.x;
-    if (u >= units) return;
+    const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
+    const long long t0 = (long long)(blockIdx.x - a.blk_off[l]) * 256;
+    const long long u = t0 + threadIdx.x;
+    const bool on = u < units;
+    const long long uu = on ? u : units - 1;
     const int c = blockIdx.y;
-    const size_t plane = (size_t)a.C * a.T;
-    const int tx = (int)(u % TW), ty = (int)((u / TW) % TH), n = (int)(u / ((long long)TW * TH));
+    const size_t plane = (size_t)a.T;
+    const int tx = (int)(uu % TW), ty = (int)((uu / TW) % TH), n = (int)(uu / ((long long)TW * TH));
     const size_t img = ((size_t)n * a.C + c) * H * W;
     const float* p = a.maps_in[l] + img;
     const float* pm = MASK ? a.mask_ref[l] + img : nullptr;
@@ -352,12 +374,13 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l) {
                 const float4 k = yok ? *reinterpret_cast<const float4*>(pm + ro + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
                 m.x = k.x > 0.f ? m.x : 0.f; m.y = k.y > 0.f ? m.y : 0.f; m.z = k.z > 0.f ? m.z : 0.f; m.w = k.w > 0.f ? m.w : 0.f;
             }
+            // halo columns = the neighbour lanes' edge values (same image row unless first / last tile of the row)
             float e0 = __shfl_up(m.w, 1), e5 = __shfl_down(m.x, 1);
             if (lane == 0 && tx != 0) {
                 e0 = yok ? row[x0] : 0.f;
                 if constexpr (MASK) { if (yok) e0 = pm[ro + x0] > 0.f ? e0 : 0.f; }
             }
-            if (lane == 63 && tx != TW - 1) {
+            if ((lane == 63 || u + 1 >= units) && tx != TW - 1) {
                 e5 = yok ? row[x0 + 5] : 0.f;
                 if constexpr (MASK) { if (yok) e5 = pm[ro + x0 + 5] > 0.f ? e5 : 0.f; }
             }
@@ -375,8 +398,8 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l) {
             }
         }
     }
-    const size_t t = (size_t)a.tile_off[l] + u;
-    float* o = a.buf_out + (size_t)c * a.T + t;
+    const size_t base = (size_t)c * a.cs + (size_t)a.tile_off[l] + t0;
+    const long long tend = padded - t0;  // tiles of this workgroup that exist (incl. zero pad tiles), relative to t0
     {
         float r[6][6];
         #pragma unroll
@@ -392,12 +415,13 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l) {
             float w[6];
             bt6(r[i], w);
             #pragma unroll
-            for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(w[j], o + (size_t)(6 * i + j) * plane);
+            for (int j = 0; j < 6; ++j) lds[(6 * i + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
         }
     }
+    __syncthreads();
+    stage_store36(lds, a.buf_out + base, plane, 0, tend);
     if constexpr (DUAL) {
         // dM = A g A^T with g = the tile's own 4x4 block = window rows/cols 1..4 (zero beyond the map)
-        float* o2 = a.buf_out2 + (size_t)c * a.T + t;
         float r[6][4];
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -407,38 +431,56 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l) {
             #pragma unroll
             for (int i = 0; i < 6; ++i) r[i][j] = w[i];
         }
+        __syncthreads();
         #pragma unroll
         for (int i = 0; i < 6; ++i) {
             float w[6];
             a6(r[i], w);
             #pragma unroll
-            for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(w[j], o2 + (size_t)(6 * i + j) * plane);
+            for (int j = 0; j < 6; ++j) lds[(6 * i + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
         }
+        __syncthreads();
+        stage_store36(lds, a.buf_out2 + base, plane, 0, tend);
     }
 }
 
 template <bool DUAL, bool MASK>
 __global__ __launch_bounds__(256) void wino4_in_kernel(WinoArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[36 * 256];
     const int l = wino_level(a);
-    if (a.pair[l]) wino4_in_body<true, DUAL, MASK>(a, l);
-    else wino4_in_body<false, DUAL, MASK>(a, l);
+    if (a.pair[l]) wino4_in_body<true, DUAL, MASK>(a, l, lds);
+    else wino4_in_body<false, DUAL, MASK>(a, l, lds);
 }
 
-template <bool VEC>
-__device__ __forceinline__ void wino4_out_body(const WinoArgs& a, int l) {
+template <bool VEC, bool STAGE>
+__device__ __forceinline__ void wino4_out_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
-    const long long u = (long long)(blockIdx.x - a.blk_off[l]) * 256 + threadIdx.x;
-    if (u >= (long long)a.N * TH * TW) return;
+    const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
+    const long long t0 = (long long)(blockIdx.x - a.blk_off[l]) * 256;
+    const long long u = t0 + threadIdx.x;
     const int c = blockIdx.y;
+    const size_t plane = (size_t)a.T;
+    const float* m = a.buf_in + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0;
+    if constexpr (STAGE) {   // the workgroup's 36 x 1 KB runs -> LDS
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        #pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int f = wave + 4 * k;
+            wino_vf4 q; q.x = q.y = q.z = q.w = 0.f;
+            if (t0 + lane * 4 < padded) q = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(m + (size_t)f * plane + lane * 4));
+            *reinterpret_cast<float4*>(&lds[f * 256 + lane * 4]) = make_float4(q.x, q.y, q.z, q.w);
+        }
+        __syncthreads();
+    }
+    if (u >= units) return;
     const int tx = (int)(u % TW), ty = (int)((u / TW) % TH), n = (int)(u / ((long long)TW * TH));
-    const size_t plane = (size_t)a.C * a.T;
-    const float* m = a.buf_in + (size_t)c * a.T + (size_t)a.tile_off[l] + u;
     float r[4][6];
     #pragma unroll
     for (int j = 0; j < 6; ++j) {  // columns: A^T m
         float col[6];
         #pragma unroll
-        for (int i = 0; i < 6; ++i) col[i] = __builtin_nontemporal_load(m + (size_t)(6 * i + j) * plane);
+        for (int i = 0; i < 6; ++i)
+            col[i] = STAGE ? lds[(6 * i + j) * 256 + threadIdx.x] : __builtin_nontemporal_load(m + (size_t)(6 * i + j) * plane + threadIdx.x);
         float w[4];
         at6(col, w);
         r[0][j] = w[0]; r[1][j] = w[1]; r[2][j] = w[2]; r[3][j] = w[3];
@@ -463,25 +505,29 @@ __device__ __forceinline__ void wino4_out_body(const WinoArgs& a, int l) {
     }
 }
 
+template <bool STAGE>
 __global__ __launch_bounds__(256) void wino4_out_kernel(WinoArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[STAGE ? 36 * 256 : 4];
     const int l = wino_level(a);
-    if (a.pair[l]) wino4_out_body<true>(a, l);
-    else wino4_out_body<false>(a, l);
+    if (a.pair[l]) wino4_out_body<true, STAGE>(a, l, lds);
+    else wino4_out_body<false, STAGE>(a, l, lds);
 }
 
 // dM = A dy A^T alone
 __global__ __launch_bounds__(256) void wino4_out_t_kernel(WinoArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[36 * 256];
     const int l = wino_level(a);
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
-    const long long u = (long long)(blockIdx.x - a.blk_off[l]) * 256 + threadIdx.x;
-    if (u >= (long long)a.N * TH * TW) return;
+    const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
+    const long long t0 = (long long)(blockIdx.x - a.blk_off[l]) * 256;
+    const long long u = t0 + threadIdx.x;
+    const bool on = u < units;
+    const long long uu = on ? u : units - 1;
     const int c = blockIdx.y;
-    const size_t plane = (size_t)a.C * a.T;
-    const int tx = (int)(u % TW), ty = (int)((u / TW) % TH), n = (int)(u / ((long long)TW * TH));
+    const int tx = (int)(uu % TW), ty = (int)((uu / TW) % TH), n = (int)(uu / ((long long)TW * TH));
     const size_t img = ((size_t)n * a.C + c) * H * W;
     const float* p = a.maps_in[l] + img;
     const float* pm = a.mask_ref[l] ? a.mask_ref[l] + img : nullptr;
-    float* o = a.buf_out + (size_t)c * a.T + (size_t)a.tile_off[l] + u;
     float r[6][4];
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -505,12 +551,14 @@ __global__ __launch_bounds__(256) void wino4_out_t_kernel(WinoArgs a) {
         float w[6];
         a6(r[i], w);
         #pragma unroll
-        for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(w[j], o + (size_t)(6 * i + j) * plane);
+        for (int j = 0; j < 6; ++j) lds[(6 * i + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
     }
+    __syncthreads();
+    stage_store36(lds, a.buf_out + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0, (size_t)a.T, 0, padded - t0);
 }
 
 static long long level_tiles(int N, int H, int W, int tile) {
-    if (tile == 4) return (long long)N * ((H + 3) / 4) * ((W + 3) / 4);
+    if (tile == 4) return (((long long)N * ((H + 3) / 4) * ((W + 3) / 4)) + 3) & ~3LL;
     const long long t = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
     return t + (t & 1);
 }
@@ -540,6 +588,7 @@ static int wino_fill(WinoArgs& a, const int32_t* level_hw, int L, int N, int C, 
     }
     a.blk_off[L] = blk;
     a.T = off;
+    a.cs = (long long)(tile + 2) * (tile + 2) * off;
     *blocks = blk;
     return LGD_OK;
 }
@@ -599,7 +648,9 @@ int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host
         a.maps_out[l] = y_host[l];
     }
     a.buf_in = M; a.bias = bias; a.relu = relu ? 1 : 0;
-    if (tile == 4) { LGD_LAUNCH("wino_out_kernel", lgd::wino4_out_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
+    // reads of M: direct 256 B non-temporal runs (STAGE = false); staging the 36 x 1 KB runs through LDS as the input
+    // transform does for its stores measured slower here (110 vs 124 us HBM-cold on the pyramid)
+    if (tile == 4) { LGD_LAUNCH("wino_out_kernel", lgd::wino4_out_kernel<false>, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
     else { LGD_LAUNCH("wino_out_kernel", lgd::wino_out_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
     return lgd::check_launch();
 }

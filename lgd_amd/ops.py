@@ -649,6 +649,12 @@ def _wino_gg(device, tile):
     return _WINO_GG[key]
 
 
+def _freq_buf(nf, C, T, device):
+    """frequency buffer in the kernels' layout [C][nf][T], returned as its (nf, C, T) view: the per-frequency GEMMs see
+    (C x T) matrices with row stride nf*T (a plain leading dimension for the BLAS), nothing is copied."""
+    return torch.empty((C, nf, T), dtype=torch.float32, device=device).permute(1, 0, 2)
+
+
 class _Conv3x3(torch.autograd.Function):
     """nn.Conv2d(Ci, Co, 3, stride 1, padding 1) [+ ReLU] with one filter over L maps (the pyramid levels) in the
     minimal-filtering form F(tile x tile, 3x3), tile = 4 (default) or 2: HIP data transforms (lgd_wino_in / lgd_wino_out /
@@ -670,13 +676,13 @@ class _Conv3x3(torch.autograd.Function):
         hw = hip.int_array([d for x in xs for d in x.shape[2:]])
         T = lib.lgd_wino_tiles(hw, L, N, tile)
         U = torch.mm(_wino_gg(dev, tile), w.view(Co * Ci, 9).t()).view(nf, Co, Ci)
-        V = torch.empty((nf, Ci, T), dtype=torch.float32, device=dev)
+        V = _freq_buf(nf, Ci, T, dev)
         hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
         fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
         _count_bytes("wino_in_kernel", (px + fb) * Ci)
         _count_bytes("wino_out_kernel", (px + fb) * Co)
-        M = torch.bmm(U, V)
+        M = torch.bmm(U, V, out=_freq_buf(nf, Co, T, dev))
         ys = [torch.empty((N, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
         hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(b) if b is not None else None, hw, L, N, Co, tile, 0, int(relu),
                                    hip.ptr_array(ys), hip.stream_ptr()), "lgd_wino_out")
@@ -708,11 +714,11 @@ class _Conv3x3(torch.autograd.Function):
             else:  # transform of the rotated, (Co,Ci)-transposed filter
                 wr = Uw.flip(2, 3).transpose(0, 1).reshape(Ci * Co, 9)
                 Ut, flip = torch.mm(_wino_gg(dev, tile), wr.t()).view(nf, Ci, Co), 0
-            Vd = torch.empty((nf, Co, T), dtype=torch.float32, device=dev)
-            dM = torch.empty_like(Vd) if need_w else None
+            Vd = _freq_buf(nf, Co, T, dev)
+            dM = _freq_buf(nf, Co, T, dev) if need_w else None
             hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, hw, L, N, Co, tile, flip, hip.ptr(Vd),
                                       hip.ptr(dM) if need_w else None, hip.stream_ptr()), "lgd_wino_in")
-            Md = torch.bmm(Ut, Vd)
+            Md = torch.bmm(Ut, Vd, out=_freq_buf(nf, Ci, T, dev))
             del Vd
             dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
             hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, flip, 0, hip.ptr_array(dxs), hip.stream_ptr()),
@@ -720,7 +726,7 @@ class _Conv3x3(torch.autograd.Function):
             del Md
         elif need_w:
             _count_bytes("wino_out_t_kernel", pdy + fb * Co)
-            dM = torch.empty((nf, Co, T), dtype=torch.float32, device=dev)
+            dM = _freq_buf(nf, Co, T, dev)
             hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
                       "lgd_wino_out_t")
         if need_w:

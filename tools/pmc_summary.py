@@ -39,6 +39,9 @@ TIMER_NAMES = {
     "rowln_kernel<0>": ["rowln_kernel"], "rowln_kernel<1>": ["rowln_bwd_kernel"],
     "wino_in_kernel<false, false>": ["wino_in_kernel"], "wino_in_kernel<false, true>": ["wino_in_kernel"],
     "wino_in_kernel<true, false>": ["wino_in_dual_kernel"], "wino_in_kernel<true, true>": ["wino_in_dual_kernel"],
+    "wino4_in_kernel<false, false>": ["wino_in_kernel"], "wino4_in_kernel<false, true>": ["wino_in_kernel"],
+    "wino4_in_kernel<true, false>": ["wino_in_dual_kernel"], "wino4_in_kernel<true, true>": ["wino_in_dual_kernel"],
+    "wino4_out_kernel": ["wino_out_kernel"], "wino4_out_t_kernel": ["wino_out_t_kernel"],
 }
 
 
