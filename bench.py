@@ -163,13 +163,15 @@ def main():
             if name in alg:
                 kernels[name]["alg_bytes"] = alg[name]
                 kernels[name]["GBps"] = alg[name] / (1e-3 * ms / n) / 1e9
+        is_cfg1 = (os.path.abspath(args.config) == os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml") and Bg == 8
+                   and (args.height, args.width) == (800, 1333))
         hbm_bound = [k for k in kernels if k in alg and not k.startswith("focal")]  # focal is exp/log bound, reported but not the roofline line
         dom = max(hbm_bound, key=lambda k: kernels[k]["total_ms"], default=None)
         roofline = None
         if dom:
             traffic = None
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tf):
+            if os.path.exists(tf) and is_cfg1:  # the counters were collected on configs[1]
                 traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
             roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,

@@ -133,6 +133,57 @@ __global__ __launch_bounds__(256) void wino4_in(const float* __restrict__ x, flo
   }
 }
 
+// staged variants on the [c][f][t] layout: NT threads per block, PH phases of 36/PH planes each (LDS = 36/PH * NT * 4 B)
+template <int NT, int PH>
+__global__ __launch_bounds__(NT) void wino4_in_staged(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W) {
+    const int TH = H / 4, TW = W / 4;
+    const long long T = (long long)N * TH * TW;
+    const int c = blockIdx.y;
+    constexpr int NPL = 36 / PH;
+    __shared__ __attribute__((aligned(16))) float lds[NPL * NT];
+    const long long t0 = (long long)blockIdx.x * NT;
+    const long long u = t0 + threadIdx.x;
+    const bool on = u < T;
+    const long long uu = on ? u : T - 1;
+    const int tx = (int)(uu % TW), ty = (int)((uu / TW) % TH), n = (int)(uu / ((long long)TW * TH));
+    const float* p = x + ((size_t)n * C + c) * H * W;
+    float d[6][6];
+    load_window(p, H, W, TW, tx, ty, d);
+    float r[6][6];
+    #pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float w[6]; bt6(col, w);
+        #pragma unroll
+        for (int i = 0; i < 6; ++i) r[i][j] = w[i];
+    }
+    float* dst = V + (size_t)c * 36 * T + t0;
+    constexpr int NW = NT / 64, RUN4 = NT / 4;  // float4 per plane run
+    #pragma unroll
+    for (int ph = 0; ph < PH; ++ph) {
+        if (ph) __syncthreads();
+        #pragma unroll
+        for (int ii = 0; ii < 6 / PH; ++ii) {
+            const int i = ph * (6 / PH) + ii;
+            float w[6]; bt6(r[i], w);
+            #pragma unroll
+            for (int j = 0; j < 6; ++j) lds[(6 * ii + j) * NT + threadIdx.x] = w[j];
+        }
+        __syncthreads();
+        // NPL planes x RUN4 float4: thread k handles float4 index k, k+NT, ...
+        #pragma unroll
+        for (int k = 0; k < NPL * RUN4 / NT; ++k) {
+            const int idx = k * NT + threadIdx.x;
+            const int f = idx / RUN4, q4 = idx % RUN4;
+            const float4 v = *reinterpret_cast<const float4*>(&lds[f * NT + q4 * 4]);
+            if (t0 + q4 * 4 + 3 < T) {
+                vf4 q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+                __builtin_nontemporal_store(q, reinterpret_cast<vf4*>(dst + (size_t)(ph * NPL + f) * T + q4 * 4));
+            }
+        }
+    }
+}
+
 int main() {
     const int N = 8, C = 256, H = 100, W = 168;
     const size_t nx = (size_t)N * C * H * W, T = (size_t)N * (H / 4) * (W / 4), nv = 36 * (size_t)C * T;
@@ -155,9 +206,8 @@ int main() {
     run("B LDS-staged 1 KB stores", [&](float* x, float* v) { wino4_in<1><<<dim3((unsigned)((T + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
     run("A layout [c][f][t]", [&](float* x, float* v) { wino4_in<0, 1><<<dim3((unsigned)((T + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
     run("B layout [c][f][t]", [&](float* x, float* v) { wino4_in<1, 1><<<dim3((unsigned)((T + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
-    run("A 4 x 256 tiles per block", [&](float* x, float* v) { wino4_in<0, 0, 4><<<dim3((unsigned)((T + 1023) / 1024), C), 256>>>(x, v, N, C, H, W); });
-    run("B 4 x 256 tiles per block", [&](float* x, float* v) { wino4_in<1, 0, 4><<<dim3((unsigned)((T + 1023) / 1024), C), 256>>>(x, v, N, C, H, W); });
-    run("B [c][f][t] 4 x 256 tiles per block", [&](float* x, float* v) { wino4_in<1, 1, 4><<<dim3((unsigned)((T + 1023) / 1024), C), 256>>>(x, v, N, C, H, W); });
+#define ST(NT, PH) run("staged [c][f][t] NT=" #NT " PH=" #PH, [&](float* x, float* v) { wino4_in_staged<NT, PH><<<dim3((unsigned)((T + NT - 1) / NT), C), NT>>>(x, v, N, C, H, W); })
+    ST(256, 1); ST(256, 2); ST(256, 3); ST(128, 1); ST(128, 2); ST(512, 1); ST(512, 2); ST(64, 1);
     run("C two tiles/thread float2", [&](float* x, float* v) { wino4_in<2><<<dim3((unsigned)((T / 2 + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
     return 0;
 }

@@ -41,7 +41,9 @@ TIMER_NAMES = {
     "wino_in_kernel<true, false>": ["wino_in_dual_kernel"], "wino_in_kernel<true, true>": ["wino_in_dual_kernel"],
     "wino4_in_kernel<false, false>": ["wino_in_kernel"], "wino4_in_kernel<false, true>": ["wino_in_kernel"],
     "wino4_in_kernel<true, false>": ["wino_in_dual_kernel"], "wino4_in_kernel<true, true>": ["wino_in_dual_kernel"],
-    "wino4_out_kernel": ["wino_out_kernel"], "wino4_out_t_kernel": ["wino_out_t_kernel"],
+    "wino4_out_kernel": ["wino_out_kernel"], "wino4_out_kernel<false>": ["wino_out_kernel"], "wino4_out_kernel<true>": ["wino_out_kernel"],
+    "bias_act_kernel<4>": ["bias_act_kernel"], "bias_act_kernel<1>": ["bias_act_kernel"],
+    "relu_mask_kernel<4>": ["relu_mask_kernel"], "relu_mask_kernel<1>": ["relu_mask_kernel"], "wino4_out_t_kernel": ["wino_out_t_kernel"],
 }
 
 
