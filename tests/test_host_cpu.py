@@ -194,3 +194,34 @@ def test_dcnv2_config_builds():
     assert "student.raw_backbone.res3.0.conv2_offset.weight" in keys and "student.raw_backbone.res5.2.conv2_offset.bias" in keys
     assert "student.raw_backbone.res2.0.conv2_offset.weight" not in keys
     assert m.state_dict()["student.raw_backbone.res4.22.conv2_offset.weight"].shape == (27, 256, 3, 3)
+
+
+@pytest.mark.parametrize("tile", [2, 4])
+def test_winograd_matrices_define_the_convolution(tile):
+    """host side of K8: the filter-transform matrix G the wrapper ships (ops._WINO_G, as kron(G, G)) together with the
+    B^T / A^T the transforms hard-code (restated here) satisfies the minimal-filtering identity
+    A^T [ (G g G^T) * (B^T d B) ] A == valid 3x3 correlation of the (tile+2)^2 window, in fp64."""
+    from lgd_amd import ops
+    if tile == 2:
+        BT = [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]]
+        AT = [[1, 1, 1, 0], [0, 1, -1, -1]]
+    else:
+        BT = [[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+              [0, 4, 0, -5, 0, 1]]
+        AT = [[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]]
+    BT, AT = torch.tensor(BT, dtype=torch.float64), torch.tensor(AT, dtype=torch.float64)
+    G = torch.tensor(ops._WINO_G[tile], dtype=torch.float64)
+    n = tile + 2
+    gen = torch.Generator().manual_seed(3)
+    d = torch.randn(n, n, dtype=torch.float64, generator=gen)
+    g = torch.randn(3, 3, dtype=torch.float64, generator=gen)
+    U = (torch.kron(G, G) @ g.reshape(9)).reshape(n, n)          # what ops._wino_gg applies to the flattened filter
+    assert torch.allclose(U, G @ g @ G.t(), atol=1e-12)
+    y = AT @ (U * (BT @ d @ BT.t())) @ AT.t()
+    ref = torch.nn.functional.conv2d(d[None, None], g[None, None])[0, 0]
+    assert torch.allclose(y, ref, atol=1e-10)
+    # the adjoint used for the weight gradient: frequency (1,1) of A g A^T is the plain sum of the tile's gradient
+    gy = torch.randn(tile, tile, dtype=torch.float64, generator=gen)
+    dM = AT.t() @ gy @ AT
+    assert abs(float(dM[1, 1] - gy.sum())) < 1e-12
+    assert 1 * n + 1 == tile + 3  # ... which ops._Conv3x3.backward indexes as dM[tile + 3]

@@ -255,3 +255,38 @@ def test_full_size_properties():
     r = geom.rects()
     cnt = torch.where(r[..., 1] >= r[..., 0], (r[..., 1] - r[..., 0] + 1) * (r[..., 3] - r[..., 2] + 1), torch.zeros_like(r[..., 0]))
     assert torch.equal(ones[..., 0], cnt.float())              # box sum of ones == pixel count of the bit-exact rectangle
+
+
+def test_full_size_conv3x3_properties():
+    """the Winograd convolution at BASELINE config-2 size (B=8, whole pyramid, 256 -> 256): agrees with the library's direct
+    convolution (same fp32 inputs, a different summation order) within 5e-5; is linear in the input; an impulse filter
+    (centre tap = identity matrix) reproduces the input; <conv(x), g> == <x, conv^T(g)> (backward is the exact adjoint)."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    B, C = 8, 256
+    level_hw = synth.pyramid_shapes(800, 1344)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    xs = [torch.randn(B, C, h, w, device=DEV, generator=g) for h, w in level_hw]
+    w = torch.randn(C, C, 3, 3, device=DEV, generator=g) * 0.02
+    b = torch.randn(C, device=DEV, generator=g) * 0.1
+    ys = ops.conv3x3_levels(xs, w, b)
+    for x, y in zip(xs, ys):
+        ref = F.conv2d(x, w, b, 1, 1)
+        assert float((y - ref).abs().max()) <= 5e-5 * float(ref.abs().max())
+    x2 = [torch.randn_like(x) for x in xs]
+    y2 = ops.conv3x3_levels(x2, w, None)
+    y12 = ops.conv3x3_levels([2.0 * p - q for p, q in zip(xs, x2)], w, None)
+    y1 = ops.conv3x3_levels(xs, w, None)
+    for p, q, r in zip(y1, y2, y12):
+        assert cm.rel_err(r, 2.0 * p - q) < 2e-5
+    wi = torch.zeros(C, C, 3, 3, device=DEV)
+    wi[torch.arange(C), torch.arange(C), 1, 1] = 1.0
+    for x, y in zip(xs, ops.conv3x3_levels(xs, wi, None)):
+        assert float((y - x).abs().max()) <= 2e-5 * float(x.abs().max())
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    gy = [torch.randn_like(y) for y in ys]
+    out = ops.conv3x3_levels(xr, w, None)
+    torch.autograd.backward(out, gy)
+    lhs = sum(float((o.detach().double() * q.double()).sum()) for o, q in zip(out, gy))
+    rhs = sum(float((x.detach().double() * x.grad.double()).sum()) for x in xr)
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
