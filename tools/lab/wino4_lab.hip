@@ -134,14 +134,17 @@ __global__ __launch_bounds__(256) void wino4_in(const float* __restrict__ x, flo
 }
 
 // staged variants on the [c][f][t] layout: NT threads per block, PH phases of 36/PH planes each (LDS = 36/PH * NT * 4 B)
-template <int NT, int PH>
+template <int NT, int PH, int G = 0, bool SWAP = false>
 __global__ __launch_bounds__(NT) void wino4_in_staged(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W) {
     const int TH = H / 4, TW = W / 4;
     const long long T = (long long)N * TH * TW;
-    const int c = blockIdx.y;
+    const int c = SWAP ? blockIdx.x : blockIdx.y;
     constexpr int NPL = 36 / PH;
     __shared__ __attribute__((aligned(16))) float lds[NPL * NT];
-    const long long t0 = (long long)blockIdx.x * NT;
+    // G > 0: workgroups are dealt round-robin to the 8 XCDs; give each XCD runs of G consecutive tile blocks
+    long long lb = SWAP ? blockIdx.y : blockIdx.x;
+    if (G > 0) { const long long xcd = lb % 8, idx = lb / 8; lb = ((idx / G) * 8 + xcd) * G + idx % G; }
+    const long long t0 = lb * NT;
     const long long u = t0 + threadIdx.x;
     const bool on = u < T;
     const long long uu = on ? u : T - 1;
@@ -207,7 +210,10 @@ int main() {
     run("A layout [c][f][t]", [&](float* x, float* v) { wino4_in<0, 1><<<dim3((unsigned)((T + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
     run("B layout [c][f][t]", [&](float* x, float* v) { wino4_in<1, 1><<<dim3((unsigned)((T + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
 #define ST(NT, PH) run("staged [c][f][t] NT=" #NT " PH=" #PH, [&](float* x, float* v) { wino4_in_staged<NT, PH><<<dim3((unsigned)((T + NT - 1) / NT), C), NT>>>(x, v, N, C, H, W); })
-    ST(256, 1); ST(256, 2); ST(256, 3); ST(128, 1); ST(128, 2); ST(512, 1); ST(512, 2); ST(64, 1);
+    ST(256, 1); ST(256, 3);
+#define STG(NT, PH, G) run("staged NT=" #NT " PH=" #PH " XCD runs G=" #G, [&](float* x, float* v) { const unsigned nb = (unsigned)((T + NT - 1) / NT); wino4_in_staged<NT, PH, G><<<dim3((nb + 8 * G - 1) / (8 * G) * (8 * G), C), NT>>>(x, v, N, C, H, W); })
+    run("staged NT=256 PH=1 channel-fastest dispatch", [&](float* x, float* v) { wino4_in_staged<256, 1, 0, true><<<dim3(C, (unsigned)((T + 255) / 256)), 256>>>(x, v, N, C, H, W); });
+    run("staged NT=256 PH=3 channel-fastest dispatch", [&](float* x, float* v) { wino4_in_staged<256, 3, 0, true><<<dim3(C, (unsigned)((T + 255) / 256)), 256>>>(x, v, N, C, H, W); });
     run("C two tiles/thread float2", [&](float* x, float* v) { wino4_in<2><<<dim3((unsigned)((T / 2 + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
     return 0;
 }

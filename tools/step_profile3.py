@@ -14,10 +14,10 @@ from lgd_amd.data import synthetic_batch  # noqa: E402
 from lgd_amd.distillator import build_model  # noqa: E402
 from lgd_amd.engine import Trainer  # noqa: E402
 
-cfg = config.setup_cfg(os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", "cuda"])
+cfg = config.setup_cfg(os.path.join(ROOT, "configs", sys.argv[1] if len(sys.argv) > 1 else "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", "cuda"])
 model = build_model(cfg)
 tr = Trainer(cfg, model)
-data = synthetic_batch(8, 800, 1333, 10, seed=1)
+data = synthetic_batch(int(sys.argv[2]) if len(sys.argv) > 2 else 8, 800, 1333, 10, seed=1)
 for i in range(4):
     tr.step(data, 40000 + i)
 torch.cuda.synchronize()
