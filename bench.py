@@ -195,6 +195,7 @@ def main():
                                       args.height, args.width, Hp, Wp, args.boxes, "on" if ctx else "off", args.phase),
                        "yaml": os.path.relpath(args.config, ROOT), "global_batch": world * Bg, "parallelism": "dp%d" % world},
             "losses": {k: round(v, 6) for k, v in metrics.items()},
+            "hbm_peak_alloc_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
