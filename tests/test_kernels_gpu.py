@@ -512,6 +512,9 @@ def test_gn_relu_mask_pool_fused_fwd_bwd(cfg):
     (2, 64, 96, [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)], True, True),   # a pyramid: one filter over 5 levels
     (1, 64, 36, [(13, 21), (7, 11), (4, 6)], True, False),                    # odd levels + narrow output (bbox_pred)
     (2, 64, 1, [(8, 12), (4, 6)], True, False),                               # single output channel (centerness)
+    (1, 3, 5, [(5, 7)], True, True),                                          # tiny channel counts
+    (1, 8, 8, [(16, 16), (12, 8), (9, 9), (8, 4), (5, 3), (4, 4), (2, 2), (1, 1)], False, True),  # LGD_MAX_LEVELS levels
+    (2, 16, 16, [(67, 260)], True, False),                                    # > 256 tiles per row block, W % 4 == 0, H odd
 ])
 def test_conv3x3_winograd_fwd_bwd(N, Ci, Co, hws, bias, relu, tile):
     """F(2x2,3x3) / F(4x4,3x3) transforms + GEMMs against the direct convolution in fp64 (what the oracle runs:
