@@ -263,6 +263,18 @@ int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, i
                      void* stream);
 int lgd_relu_mask_bwd(const float* y, const float* dy, long long total, float* dx, void* stream);
 
+/* ------------------------------------------------------------------ anchor <-> ground-truth matching of the student loss
+ * [ref: distillator.py:96-112 -> student.losses on student AND teacher features; detectron2 RetinaNet.label_anchors /
+ *  Matcher semantics: IoU thresholds [lo, hi] -> labels {0, -1, 1}, allow_low_quality_matches,
+ *  background -> num_classes, ignore -> -1, every anchor also gets the box of its arg-max ground truth]
+ * anchors (R,4) xyxy; gt_boxes (T,4) / gt_classes (T, int64) concatenated image-major with img_off (B+1, device int32);
+ * best_ws: T uint32 scratch; labels (B,R) int64; matched_boxes (B,R,4) fp32.  Two launches for the whole mini-batch, the
+ * IoU matrix is never materialised; integer results are bit-identical to the elementwise fp32 definition.
+ */
+int lgd_anchor_match(const float* anchors, int R, const float* gt_boxes, const int64_t* gt_classes, const int32_t* img_off,
+                     int B, int T, float iou_lo, float iou_hi, int num_classes, int allow_low_quality, uint32_t* best_ws,
+                     int64_t* labels, float* matched_boxes, void* stream);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench.py)
  * When enabled every kernel launch of this library is bracketed by a HIP event pair recorded on
  * the launch stream.  lgd_timing_collect waits for the recorded events, sums the elapsed time per

@@ -24,15 +24,17 @@ struct PrepArgs {
 // empty set returns hi < lo.  One WAVE evaluates one box axis: lane j tests coordinates j, j+64, ... and the
 // interval ends come from the ballots (no serial loop over the pixels).
 __device__ __forceinline__ void axis_interval(float a, float b, float ratio, int n, int lane, int& lo, int& hi) {
-    const float a1 = __fmul_rn(a, ratio);       // box_tensor[:, [0,2]] * r_w  (utils.py:69)
-    const float b1 = __fmul_rn(b, ratio);
-    const float c = __fmul_rn(__fadd_rn(a1, b1), 0.5f);  // (x1 + x2) * 0.5     (utils.py:73)
-    const float s = __fsub_rn(b1, a1);                   // x2 - x1             (utils.py:77)
+    // plain operators under the file-scope contract(off): the header intrinsics (__fmul_rn, ...) are inline functions
+    // compiled with the default fp-contract=fast and were fused into v_fma after inlining (a*r + b1 in ONE rounding)
+    const float a1 = a * ratio;        // box_tensor[:, [0,2]] * r_w  (utils.py:69)
+    const float b1 = b * ratio;
+    const float c = (a1 + b1) * 0.5f;  // (x1 + x2) * 0.5             (utils.py:73)
+    const float s = b1 - a1;           // x2 - x1                     (utils.py:77)
     lo = n;
     hi = -1;
     for (int p0 = 0; p0 < n; p0 += 64) {
         const int p = p0 + lane;
-        const float d = __fdiv_rn(fabsf(__fsub_rn(c, (float)p)), s);  // utils.py:87
+        const float d = fabsf(c - (float)p) / s;  // utils.py:87 ('/' = correctly rounded division)
         // false for NaN (0/0) and +inf (x/0): zero-extent boxes are empty
         const unsigned long long m = __ballot(p < n && d <= 0.5f);
         if (m) {

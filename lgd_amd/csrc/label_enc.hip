@@ -35,24 +35,23 @@ __global__ __launch_bounds__(256) void box_desc_kernel(DescArgs a) {
     int cls = -1;
     if (n == 0) {                       // label_encoder.py:64-66 substitute box, class vector all zero
         x1 = 0.f; y1 = 0.f; x2 = 1.f; y2 = 1.f;
-        if (a.wh_format) { x2 = __fsub_rn(__fadd_rn(x1, 1.f), 1.f); y2 = __fsub_rn(__fadd_rn(y1, 1.f), 1.f); }
+        if (a.wh_format) { x2 = (x1 + 1.f) - 1.f; y2 = (y1 + 1.f) - 1.f; }
     } else if (j == n) {                // label_encoder.py:75-77 context box, class vector all zero
         x1 = 0.f; y1 = 0.f; x2 = (float)a.img_w; y2 = (float)a.img_h;
     } else {
         const float4 v = reinterpret_cast<const float4*>(a.boxes_in)[i0 + j];
         x1 = v.x; y1 = v.y; x2 = v.z; y2 = v.w;
-        if (a.wh_format) { x2 = __fsub_rn(__fadd_rn(x1, v.z), 1.f); y2 = __fsub_rn(__fadd_rn(y1, v.w), 1.f); }  // utils.py:26-38
+        if (a.wh_format) { x2 = (x1 + v.z) - 1.f; y2 = (y1 + v.w) - 1.f; }  // utils.py:26-38
         cls = a.classes[i0 + j];
     }
     const float mw = (float)(a.img_w - 1), mh = (float)(a.img_h - 1);   // utils.py:40-51
     x1 = fminf(fmaxf(x1, 0.f), mw); x2 = fminf(fmaxf(x2, 0.f), mw);
     y1 = fminf(fmaxf(y1, 0.f), mh); y2 = fminf(fmaxf(y2, 0.f), mh);
     if (lane == 0) reinterpret_cast<float4*>(a.boxes_out)[t] = make_float4(x1, y1, x2, y2);
-    const float nb[4] = {__fdiv_rn(x1, (float)a.img_w), __fdiv_rn(y1, (float)a.img_h),
-                         __fdiv_rn(x2, (float)a.img_w), __fdiv_rn(y2, (float)a.img_h)};   // label_encoder.py:88-89
+    const float nb[4] = {x1 / (float)a.img_w, y1 / (float)a.img_h, x2 / (float)a.img_w, y2 / (float)a.img_h};   // label_encoder.py:88-89
     for (int d = lane; d < D; d += 64) {
         const float v = d < 4 ? nb[d] : ((d - 4) == cls ? 1.f : 0.f);
-        a.desc[(size_t)t * D + d] = __fadd_rn(__fmul_rn(2.f, v), -1.f);  // range_scaling [0,1] -> [-1,1]
+        a.desc[(size_t)t * D + d] = 2.f * v - 1.f;  // plain operators under contract(off): one rounding per torch op  // range_scaling [0,1] -> [-1,1]
     }
 }
 

@@ -799,6 +799,30 @@ class Conv3x3(torch.nn.Conv2d):
 
 
 # ------------------------------------------------------------------------------------------------ timing
+# ------------------------------------------------------------------------------------------------ anchor matching
+def anchor_match(anchors, gt_boxes, gt_classes, counts, iou_lo, iou_hi, num_classes, allow_low_quality=True, img_off=None):
+    """detectron2 Matcher + label assignment for the whole mini-batch in two launches (no IoU matrix):
+    anchors (R,4), gt_boxes (T,4) / gt_classes (T,) concatenated image-major, counts = boxes per image.
+    Returns labels (B,R) int64 (class id, num_classes = background, -1 = ignore) and matched boxes (B,R,4)."""
+    hip.require_gpu(anchors)
+    anchors = hip.dense_f32(anchors)
+    B, R, T = len(counts), anchors.shape[0], int(sum(counts))
+    dev = anchors.device
+    if img_off is None:
+        img_off = torch.tensor(_offsets(counts), dtype=torch.int32).to(dev, non_blocking=True)
+    labels = torch.empty((B, R), dtype=torch.int64, device=dev)
+    matched = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
+    if T:
+        gt_boxes = hip.dense_f32(gt_boxes)
+        gt_classes = gt_classes.to(torch.int64).contiguous()
+        ws = torch.empty((T,), dtype=torch.int32, device=dev)
+    hip.check(hip.load().lgd_anchor_match(hip.ptr(anchors), R, hip.ptr(gt_boxes) if T else None,
+                                          hip.ptr(gt_classes) if T else None, hip.ptr(img_off), B, T, float(iou_lo), float(iou_hi),
+                                          int(num_classes), int(bool(allow_low_quality)), hip.ptr(ws) if T else None,
+                                          hip.ptr(labels), hip.ptr(matched), hip.stream_ptr()), "lgd_anchor_match")
+    return labels, matched
+
+
 # ------------------------------------------------------------------------------------------------ student conv epilogues
 class _BiasAct(torch.autograd.Function):
     """relu(x + bias[c] (+ residual)) in one pass; backward = the ReLU mask of the saved output on the incoming gradient

@@ -233,6 +233,20 @@ class RetinaNetCT(nn.Module):
         background -> num_classes, ignore -> -1.  All images in one batched IoU when they have
         the same number of boxes is not assumed: the loop is over images, tensors stay on device."""
         A = torch.cat(anchors, 0)
+        lo, hi = self.iou_thresholds
+        if A.is_cuda and tuple(self.iou_labels) == (0, -1, 1):  # the whole mini-batch in two HIP launches, no IoU matrix
+            counts = [len(inst) for inst in gt_instances]
+            if sum(counts):
+                gb = torch.cat([inst.gt_boxes.tensor for inst in gt_instances if len(inst)], 0)
+                gc = torch.cat([inst.gt_classes for inst in gt_instances if len(inst)], 0)
+            else:
+                gb = gc = None
+            labels, matched = ops.anchor_match(A, gb, gc, counts, lo, hi, self.num_classes, True)
+            return list(labels.unbind(0)), list(matched.unbind(0))
+        return self._label_anchors_torch(A, gt_instances)
+
+    def _label_anchors_torch(self, A, gt_instances):
+        """the same matching as elementwise torch ops per image (CPU tests; the HIP path is checked against it)."""
         gt_labels, gt_boxes = [], []
         lo, hi = self.iou_thresholds
         for inst in gt_instances:

@@ -76,6 +76,42 @@ def test_rects_adversarial_boundaries():
     assert np.array_equal(geom.rects().cpu().numpy(), _norm_rects(_oracle_rects(boxlists, (H, W), level_hw)))
 
 
+def test_rects_inexact_ratios_random():
+    """3000 random boxes at level sizes whose ratios to the image are NOT powers of two (13/800, 97/777, ...): every
+    product a*r rounds, so a fused multiply-add anywhere in the predicate (e.g. (a*r + b*r) in one rounding) shifts
+    interval ends -- the kernel must round once per reference op (the header intrinsics __fmul_rn/... did get contracted
+    after inlining; the predicate is written with plain operators under `#pragma clang fp contract(off)`)."""
+    H, W = 777, 1001
+    level_hw = [(97, 125), (49, 63), (13, 17), (7, 9), (3, 5)]
+    rng = np.random.default_rng(11)
+    boxlists = []
+    for b in range(30):
+        bl = []
+        for _ in range(100):
+            x1, y1 = rng.uniform(0, W - 2), rng.uniform(0, H - 2)
+            bl.append([float(np.float32(x1)), float(np.float32(y1)), float(np.float32(min(W - 1, x1 + rng.uniform(0.5, W / 1.5)))),
+                       float(np.float32(min(H - 1, y1 + rng.uniform(0.5, H / 1.5))))])
+        boxlists.append(bl)
+    # adversarial: left / top edges that land (to within an ulp) ON a pixel coordinate of some level after scaling, where
+    # |c - p| / s == 0.5 in exact arithmetic and the outcome is decided by the rounding of each single operation
+    adv = []
+    for (h, w) in level_hw:
+        rw, rh = np.float32(w) / np.float32(W), np.float32(h) / np.float32(H)
+        for p in range(1, min(w, h) - 1, max(1, min(w, h) // 12)):
+            for du in (-1, 0, 1):
+                ax = np.float32(p / float(rw))
+                ay = np.float32(p / float(rh))
+                ax = np.nextafter(ax, np.float32(np.inf if du > 0 else -np.inf)) if du else ax
+                ay = np.nextafter(ay, np.float32(np.inf if du > 0 else -np.inf)) if du else ay
+                bx = np.float32(min(W - 1, float(ax) + rng.uniform(3, W / 3)))
+                by = np.float32(min(H - 1, float(ay) + rng.uniform(3, H / 3)))
+                adv.append([float(ax), float(ay), float(bx), float(by)])
+    for i in range(0, len(adv), 100):
+        boxlists.append(adv[i:i + 100])
+    geom = _geom(boxlists, (H, W), level_hw)
+    assert np.array_equal(geom.rects().cpu().numpy(), _norm_rects(_oracle_rects(boxlists, (H, W), level_hw)))
+
+
 # ------------------------------------------------------------------------------------------- mask pool / render
 def _random_case(B, H, W, counts, level_hw, C=256, seed=0, ctx=False):
     rng = np.random.default_rng(seed)
@@ -625,3 +661,47 @@ def test_conv1x1_weight_grad_by_gemm():
     assert float((y.detach().double() - yr.detach()).abs().max()) <= FTOL * float(yr.detach().abs().max())
     assert float((x.grad.double() - xr.grad).abs().max()) <= FTOL * float(xr.grad.abs().max())
     assert float((w.grad.double() - wr.grad).abs().max()) <= FTOL * float(wr.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------- anchor matching
+def test_anchor_match_equals_elementwise_definition():
+    """lgd_anchor_match vs the per-image torch restatement of detectron2's Matcher on config-2 anchors (R = 201,600):
+    labels and matched boxes identical, incl. an image without ground truth, a box touching no anchor (its all-zero IoU
+    row makes every anchor a low-quality positive, as in the definition), duplicate boxes (first arg-max) and boxes whose
+    IoU with some anchor sits exactly on a threshold."""
+    import types
+    from lgd_amd import ops
+    from lgd_amd.student import retinanet as rn
+    gen = rn.AnchorGenerator([[32.0 * 2 ** (i + j / 3) for j in range(3)] for i in range(5)], [[0.5, 1.0, 2.0]],
+                             [8, 16, 32, 64, 128])
+    level_hw = synth.pyramid_shapes(800, 1344)
+    feats = [torch.zeros(1, 1, h, w, device=DEV) for h, w in level_hw]
+    anchors = gen(feats)
+    A = torch.cat(anchors, 0)
+    gts = synth.synth_gt(4, 800, 1344, 10, seed=3)
+    boxes = [torch.from_numpy(b).to(DEV) for b, _ in gts]
+    classes = [torch.from_numpy(c).to(DEV) for _, c in gts]
+    boxes[1], classes[1] = boxes[1][:0], classes[1][:0]                                 # empty image
+    boxes[2] = torch.cat([boxes[2], boxes[2][:1], A[1234:1235], A[150000:150001] * 1.0])   # duplicate + boxes equal to anchors
+    classes[2] = torch.cat([classes[2], classes[2][:1] + 1, classes[2][:2]])
+    boxes[3] = torch.cat([boxes[3][:3], torch.tensor([[5000.0, 5000.0, 5010.0, 5010.0]], device=DEV)])  # touches no anchor
+    classes[3] = classes[3][:4]
+
+    class Inst:
+        def __init__(self, b, c):
+            self.gt_boxes, self.gt_classes = types.SimpleNamespace(tensor=b), c
+
+        def __len__(self):
+            return self.gt_boxes.tensor.shape[0]
+    insts = [Inst(b, c) for b, c in zip(boxes, classes)]
+    host = types.SimpleNamespace(iou_thresholds=[0.4, 0.5], iou_labels=[0, -1, 1], num_classes=80)
+    ref_l, ref_b = rn.RetinaNetCT._label_anchors_torch(host, A, insts)
+    counts = [len(i) for i in insts]
+    got_l, got_b = ops.anchor_match(A, torch.cat([b for b in boxes if len(b)]), torch.cat([c for c in classes if len(c)]),
+                                    counts, 0.4, 0.5, 80, True)
+    for i in range(4):
+        assert torch.equal(got_l[i], ref_l[i]), i
+        assert torch.equal(got_b[i], ref_b[i]), i
+    assert int((got_l[0] >= 0).sum()) > 0 and int(((got_l[0] >= 0) & (got_l[0] < 80)).sum()) > 0
+    assert bool((got_l[1] == 80).all())                       # no ground truth: all background
+    assert bool(((got_l[3] >= 0) & (got_l[3] < 80)).all())    # the all-zero IoU row: every anchor positive (definition)
