@@ -275,6 +275,21 @@ int lgd_anchor_match(const float* anchors, int R, const float* gt_boxes, const i
                      int B, int T, float iou_lo, float iou_hi, int num_classes, int allow_low_quality, uint32_t* best_ws,
                      int64_t* labels, float* matched_boxes, void* stream);
 
+/* ------------------------------------------------------------------ box-regression loss on the head's raw NCHW deltas
+ * [ref: distillator.py:107-112 -> student.losses -> detectron2 RetinaNet.losses: smooth_l1(pred_deltas[pos],
+ *  Box2BoxTransform(weights).get_deltas(anchors, matched_gt)[pos], beta, reduction="sum")]
+ * deltas_host: L device pointers to (N, A*4, H_l, W_l); labels_host: the int32 label planes (N, A, H_l, W_l) of the focal
+ * loss (positives: 0 <= label < K); anchors (R,4) ordered (level, y, x, a); matched_boxes (N,R,4) from lgd_anchor_match;
+ * ws: lgd_box_reg_ws_doubles(...) doubles; loss: 1 fp32.  backward writes dense gradients (zeros off the positives).
+ */
+size_t lgd_box_reg_ws_doubles(const int32_t* level_hw_host, int L, int N, int A);
+int lgd_box_reg_loss_fwd(const float* const* deltas_host, const int32_t* const* labels_host, const int32_t* level_hw_host, int L,
+                         int N, int A, int K, const float* anchors, const float* matched_boxes, int R, float beta,
+                         const float* weights4_host, double* ws, float* loss, void* stream);
+int lgd_box_reg_loss_bwd(const float* const* deltas_host, const int32_t* const* labels_host, const int32_t* level_hw_host, int L,
+                         int N, int A, int K, const float* anchors, const float* matched_boxes, int R, float beta,
+                         const float* weights4_host, const float* grad_loss, float* const* grad_deltas_host, void* stream);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench.py)
  * When enabled every kernel launch of this library is bracketed by a HIP event pair recorded on
  * the launch stream.  lgd_timing_collect waits for the recorded events, sums the elapsed time per

@@ -63,6 +63,9 @@ SIGNATURES = {
     "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_relu_mask_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_anchor_match": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_box_reg_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
+    "lgd_box_reg_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_box_reg_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
     "lgd_timing_enable": (c_i, [c_i]),
     "lgd_timing_collect": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_i]),
 }

@@ -622,6 +622,57 @@ def focal_loss_sum(raw_logits, label_planes, A, K, alpha, gamma):
     return _FocalSum.apply(int(A), int(K), float(alpha), float(gamma), len(raw_logits), *raw_logits, *label_planes)
 
 
+class _BoxRegSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, K, beta, weights, n_levels, anchors, matched, *tensors):
+        lib = hip.load()
+        deltas = [hip.dense_f32(t) for t in tensors[:n_levels]]
+        labels = list(tensors[n_levels:])
+        hip.require_gpu(*deltas, *labels)
+        anchors, matched = hip.dense_f32(anchors), hip.dense_f32(matched)
+        N, R = deltas[0].shape[0], anchors.shape[0]
+        for x, y in zip(deltas, labels):
+            if x.shape[0] != N or x.shape[1] != A * 4 or y.dtype != torch.int32 or tuple(y.shape) != (N, A) + tuple(x.shape[-2:]) \
+                    or not y.is_contiguous():
+                raise hip.LgdHipError("box-reg loss: deltas (N,A*4,H,W) / int32 labels (N,A,H,W) expected, got %s / %s %s"
+                                      % (tuple(x.shape), tuple(y.shape), y.dtype))
+        if tuple(matched.shape) != (N, R, 4):
+            raise hip.LgdHipError("box-reg loss: matched boxes (N,R,4) expected, got %s" % (tuple(matched.shape),))
+        hw = hip.int_array([v for m in deltas for v in m.shape[-2:]])
+        w4 = (ctypes.c_float * 4)(*[float(v) for v in weights])
+        dev = deltas[0].device
+        ws = torch.empty(lib.lgd_box_reg_ws_doubles(hw, n_levels, N, A), dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        hip.check(lib.lgd_box_reg_loss_fwd(hip.ptr_array(deltas), hip.ptr_array(labels), hw, n_levels, N, A, K, hip.ptr(anchors),
+                                           hip.ptr(matched), R, float(beta), ctypes.cast(w4, ctypes.c_void_p), hip.ptr(ws),
+                                           hip.ptr(loss), hip.stream_ptr()), "lgd_box_reg_loss_fwd")
+        ctx.save_for_backward(anchors, matched, *deltas, *labels)
+        ctx.meta = (A, K, float(beta), [float(v) for v in weights], n_levels, N, R, hw)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = hip.load()
+        A, K, beta, weights, L, N, R, hw = ctx.meta
+        anchors, matched = ctx.saved_tensors[:2]
+        deltas, labels = ctx.saved_tensors[2:2 + L], ctx.saved_tensors[2 + L:]
+        w4 = (ctypes.c_float * 4)(*weights)
+        g = g.contiguous().to(torch.float32)
+        grads = [torch.empty_like(x) for x in deltas]
+        hip.check(lib.lgd_box_reg_loss_bwd(hip.ptr_array(deltas), hip.ptr_array(labels), hw, L, N, A, K, hip.ptr(anchors),
+                                           hip.ptr(matched), R, beta, ctypes.cast(w4, ctypes.c_void_p), hip.ptr(g),
+                                           hip.ptr_array(grads), hip.stream_ptr()), "lgd_box_reg_loss_bwd")
+        return (None, None, None, None, None, None, None, *grads, *([None] * L))
+
+
+def box_reg_loss_sum(raw_deltas, label_planes, anchors, matched_boxes, A, K, beta, weights=(1.0, 1.0, 1.0, 1.0)):
+    """sum over positive anchors of smooth-L1(pred deltas, Box2BoxTransform deltas of the matched box), evaluated in place on
+    the head's raw (N, A*4, H, W) outputs with the focal loss's int32 label planes; anchors (R,4), matched_boxes (N,R,4)."""
+    raw_deltas, label_planes = list(raw_deltas), list(label_planes)
+    return _BoxRegSum.apply(int(A), int(K), float(beta), tuple(weights), len(raw_deltas), anchors, matched_boxes,
+                            *raw_deltas, *label_planes)
+
+
 def label_planes(labels, level_hw, A):
     """(N, R) integer anchor labels ordered (level, y, x, a) -> per level (N, A, H, W) int32 planes."""
     out, off = [], 0

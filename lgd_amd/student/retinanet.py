@@ -273,31 +273,35 @@ class RetinaNetCT(nn.Module):
         calls this twice per iteration (student and teacher features, distillator.py:110)."""
         labels = torch.stack(gt_labels)  # (B,R)
         A = torch.cat(anchors, 0)
-        gt_deltas = box_deltas(A[None], torch.stack(gt_boxes), self.bbox_reg_weights)
         valid = labels >= 0
         pos = valid & (labels != self.num_classes)
         num_pos = pos.sum().to(torch.float32)
         self.loss_normalizer = (self.loss_normalizer_momentum * self.loss_normalizer
                                 + (1 - self.loss_normalizer_momentum) * num_pos.clamp(min=1.0)).detach()
-        deltas = torch.cat(list(pred_anchor_deltas), 1)
-        raw = getattr(pred_logits, "raw", None)
-        if raw is not None and raw[0].is_cuda:  # fused HIP kernel on the head's NCHW output (no permute copy, no one-hot)
+        raw, raw_d = getattr(pred_logits, "raw", None), getattr(pred_anchor_deltas, "raw", None)
+        if raw is not None and raw_d is not None and raw[0].is_cuda:
+            # fused HIP kernels on the head's NCHW outputs: no permute copies, no one-hot, no target deltas for all anchors
             from .. import ops
+            nA = raw[0].shape[1] // self.num_classes
             key = (id(gt_labels[0]), len(gt_labels))
-            if getattr(self, "_label_plane_key", None) != key:  # student and teacher passes share the same labels
+            if getattr(self, "_label_plane_key", None) != key:  # student and teacher passes share the same targets
                 hw = [tuple(x.shape[-2:]) for x in raw]
-                self._label_planes = ops.label_planes(labels, hw, raw[0].shape[1] // self.num_classes)
+                self._label_planes = ops.label_planes(labels, hw, nA)
+                self._matched = torch.stack(gt_boxes)
                 self._label_plane_key = key
-            loss_cls = ops.focal_loss_sum(raw, self._label_planes, raw[0].shape[1] // self.num_classes, self.num_classes,
-                                          self.focal_loss_alpha, self.focal_loss_gamma)
+            loss_cls = ops.focal_loss_sum(raw, self._label_planes, nA, self.num_classes, self.focal_loss_alpha, self.focal_loss_gamma)
+            loss_box = ops.box_reg_loss_sum(raw_d, self._label_planes, A, self._matched, nA, self.num_classes,
+                                            self.smooth_l1_beta, self.bbox_reg_weights)
         else:
+            gt_deltas = box_deltas(A[None], torch.stack(gt_boxes), self.bbox_reg_weights)
+            deltas = torch.cat(list(pred_anchor_deltas), 1)
             loss_cls = sigmoid_focal_sum(torch.cat(list(pred_logits), 1), labels, valid, self.num_classes,
                                          self.focal_loss_alpha, self.focal_loss_gamma)
-        diff = (deltas - torch.where(pos[..., None], gt_deltas, deltas.detach())).abs()
-        if self.smooth_l1_beta >= 1e-5:
-            b = self.smooth_l1_beta
-            diff = torch.where(diff < b, 0.5 * diff * diff / b, diff - 0.5 * b)
-        loss_box = (diff * pos[..., None].to(diff.dtype)).sum()
+            diff = (deltas - torch.where(pos[..., None], gt_deltas, deltas.detach())).abs()
+            if self.smooth_l1_beta >= 1e-5:
+                b = self.smooth_l1_beta
+                diff = torch.where(diff < b, 0.5 * diff * diff / b, diff - 0.5 * b)
+            loss_box = (diff * pos[..., None].to(diff.dtype)).sum()
         return {"loss_cls": loss_cls / self.loss_normalizer, "loss_box_reg": loss_box / self.loss_normalizer}
 
     def forward(self, batched_inputs):

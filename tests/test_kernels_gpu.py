@@ -705,3 +705,40 @@ def test_anchor_match_equals_elementwise_definition():
     assert int((got_l[0] >= 0).sum()) > 0 and int(((got_l[0] >= 0) & (got_l[0] < 80)).sum()) > 0
     assert bool((got_l[1] == 80).all())                       # no ground truth: all background
     assert bool(((got_l[3] >= 0) & (got_l[3] < 80)).all())    # the all-zero IoU row: every anchor positive (definition)
+
+
+@pytest.mark.parametrize("beta", [0.0, 0.11])
+def test_box_reg_loss_sum_fwd_bwd(beta):
+    """fused box-regression loss on the head's raw (N, A*4, H, W) deltas vs the elementwise restatement
+    (target deltas for all anchors, permute + cat, masked smooth-L1): value and gradient."""
+    from lgd_amd import ops
+    from lgd_amd.student import retinanet as rn
+    N, A, K = 2, 3, 5
+    level_hw = [(6, 8), (3, 4), (2, 2)]
+    R = sum(h * w * A for h, w in level_hw)
+    rng = np.random.default_rng(5)
+    anc = rng.uniform(0, 60, (R, 2)).astype(np.float32)
+    anchors = torch.from_numpy(np.concatenate([anc, anc + rng.uniform(4, 40, (R, 2)).astype(np.float32)], 1)).to(DEV)
+    mb = rng.uniform(0, 60, (N, R, 2)).astype(np.float32)
+    matched = torch.from_numpy(np.concatenate([mb, mb + rng.uniform(4, 40, (N, R, 2)).astype(np.float32)], 2)).to(DEV)
+    labels = torch.from_numpy(rng.choice(np.array([-1, K, K, K, 0, 2, 4]), size=(N, R))).to(DEV)
+    raw = [torch.from_numpy(synth.det_uniform((N, A * 4, h, w), 940 + i, -1.0, 1.0)).to(DEV).requires_grad_(True)
+           for i, (h, w) in enumerate(level_hw)]
+    planes = ops.label_planes(labels, level_hw, A)
+    wts = (1.0, 1.0, 2.0, 2.0)
+    loss = ops.box_reg_loss_sum(raw, planes, anchors, matched, A, K, beta, wts)
+    loss.backward()
+    got = [r.grad.clone() for r in raw]
+    for r in raw:
+        r.grad = None
+    deltas = torch.cat([rn.permute_to_N_HWA_K(r, 4) for r in raw], 1)
+    pos = (labels >= 0) & (labels != K)
+    gt = rn.box_deltas(anchors[None], matched, wts)
+    diff = (deltas - torch.where(pos[..., None], gt, deltas.detach())).abs()
+    if beta >= 1e-5:
+        diff = torch.where(diff < beta, 0.5 * diff * diff / beta, diff - 0.5 * beta)
+    ref = (diff * pos[..., None].to(diff.dtype)).sum()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    for g, r in zip(got, raw):
+        assert float((g - r.grad).abs().max()) <= 1e-5
