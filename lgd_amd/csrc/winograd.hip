@@ -483,26 +483,38 @@ __device__ __forceinline__ void wino4_out_body(const WinoArgs& a, int l, float* 
     const int c = blockIdx.y;
     const size_t plane = (size_t)a.T;
     const float* m = a.buf_in + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0;
-    if constexpr (STAGE) {   // the workgroup's 36 x 1 KB runs -> LDS
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float mm[6][6];
+    if constexpr (STAGE) {   // 1 KB runs of two frequency rows (12 planes, 12 KB) at a time through LDS
         #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int f = wave + 4 * k;
-            wino_vf4 q; q.x = q.y = q.z = q.w = 0.f;
-            if (t0 + lane * 4 < padded) q = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(m + (size_t)f * plane + lane * 4));
-            *reinterpret_cast<float4*>(&lds[f * 256 + lane * 4]) = make_float4(q.x, q.y, q.z, q.w);
+        for (int ph = 0; ph < 3; ++ph) {
+            if (ph) __syncthreads();
+            #pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = k * 256 + threadIdx.x, f = idx >> 6, q4 = idx & 63;
+                wino_vf4 q; q.x = q.y = q.z = q.w = 0.f;
+                if (t0 + q4 * 4 < padded)
+                    q = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(m + (size_t)(12 * ph + f) * plane + q4 * 4));
+                *reinterpret_cast<float4*>(&lds[f * 256 + q4 * 4]) = make_float4(q.x, q.y, q.z, q.w);
+            }
+            __syncthreads();
+            #pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+                #pragma unroll
+                for (int j = 0; j < 6; ++j) mm[2 * ph + ii][j] = lds[(6 * ii + j) * 256 + threadIdx.x];
         }
-        __syncthreads();
     }
     if (u >= units) return;
+    if constexpr (!STAGE) {
+        #pragma unroll
+        for (int i = 0; i < 6; ++i)
+            #pragma unroll
+            for (int j = 0; j < 6; ++j) mm[i][j] = __builtin_nontemporal_load(m + (size_t)(6 * i + j) * plane + threadIdx.x);
+    }
     const int tx = (int)(u % TW), ty = (int)((u / TW) % TH), n = (int)(u / ((long long)TW * TH));
     float r[4][6];
     #pragma unroll
     for (int j = 0; j < 6; ++j) {  // columns: A^T m
-        float col[6];
-        #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            col[i] = STAGE ? lds[(6 * i + j) * 256 + threadIdx.x] : __builtin_nontemporal_load(m + (size_t)(6 * i + j) * plane + threadIdx.x);
+        const float col[6] = {mm[0][j], mm[1][j], mm[2][j], mm[3][j], mm[4][j], mm[5][j]};
         float w[4];
         at6(col, w);
         r[0][j] = w[0]; r[1][j] = w[1]; r[2][j] = w[2]; r[3][j] = w[3];
@@ -529,7 +541,7 @@ __device__ __forceinline__ void wino4_out_body(const WinoArgs& a, int l, float* 
 
 template <bool STAGE>
 __global__ __launch_bounds__(256) void wino4_out_kernel(WinoArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[STAGE ? 36 * 256 : 4];
+    __shared__ __attribute__((aligned(16))) float lds[STAGE ? 12 * 256 : 4];
     const int l = wino_level(a);
     if (a.pair[l]) wino4_out_body<true, STAGE>(a, l, lds);
     else wino4_out_body<false, STAGE>(a, l, lds);
@@ -670,9 +682,10 @@ int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host
         a.maps_out[l] = y_host[l];
     }
     a.buf_in = M; a.bias = bias; a.relu = relu ? 1 : 0;
-    // reads of M: direct 256 B non-temporal runs (STAGE = false); staging the 36 x 1 KB runs through LDS as the input
-    // transform does for its stores measured slower here (110 vs 124 us HBM-cold on the pyramid)
-    if (tile == 4) { LGD_LAUNCH("wino_out_kernel", lgd::wino4_out_kernel<false>, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
+    // reads of M staged through LDS two frequency rows (12 KB) at a time: 1 KB runs instead of 256 B per wave, measured
+    // 83 -> 77 us in the step (HBM-cold 109 -> 100 us = 6.0 TB/s); a 36-plane slab (36 KB, a third of the resident
+    // workgroups) was slower than the direct loads (124 us)
+    if (tile == 4) { LGD_LAUNCH("wino_out_kernel", lgd::wino4_out_kernel<true>, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
     else { LGD_LAUNCH("wino_out_kernel", lgd::wino_out_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
     return lgd::check_launch();
 }
