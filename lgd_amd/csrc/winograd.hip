@@ -346,10 +346,17 @@ __device__ __forceinline__ void stage_store36(const float* lds, float* dst, size
 }
 
 // 12 planes (two rows of the 6x6 frequency grid) x 256 tiles: 768 float4, three per thread; f0 = first plane of the slab
+#ifndef LGD_WINO_NR
+#define LGD_WINO_NR 2
+#endif
+constexpr int kNR = LGD_WINO_NR;  // frequency rows staged per phase by the input transform
+
+template <int NP = 12>
 __device__ __forceinline__ void stage_store12(const float* lds, float* dst, size_t plane, int f0, long long tend) {
     #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < (NP * 64 + 255) / 256; ++k) {
         const int idx = k * 256 + threadIdx.x, f = idx >> 6, q4 = idx & 63;
+        if (idx >= NP * 64) break;
         const float4 v = *reinterpret_cast<const float4*>(&lds[f * 256 + q4 * 4]);
         if (q4 * 4 < tend) {  // tend is a multiple of 4
             wino_vf4 q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
@@ -426,17 +433,17 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
         // rows: (B^T d) B, staged two frequency rows (12 planes, 12 KB) at a time: 3x the resident workgroups of a
         // 36-plane slab (4 % faster on the p3 transform, tools/lab/wino4_lab.hip)
         #pragma unroll
-        for (int ph = 0; ph < 3; ++ph) {
+        for (int ph = 0; ph < 6 / kNR; ++ph) {
             if (ph) __syncthreads();
             #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
+            for (int ii = 0; ii < kNR; ++ii) {
                 float w[6];
-                bt6(r[2 * ph + ii], w);
+                bt6(r[kNR * ph + ii], w);
                 #pragma unroll
                 for (int j = 0; j < 6; ++j) lds[(6 * ii + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
             }
             __syncthreads();
-            stage_store12(lds, a.buf_out + base, plane, 12 * ph, tend);
+            stage_store12<6 * kNR>(lds, a.buf_out + base, plane, 6 * kNR * ph, tend);
         }
     }
     if constexpr (DUAL) {
@@ -451,17 +458,17 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
             for (int i = 0; i < 6; ++i) r[i][j] = w[i];
         }
         #pragma unroll
-        for (int ph = 0; ph < 3; ++ph) {
+        for (int ph = 0; ph < 6 / kNR; ++ph) {
             __syncthreads();
             #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
+            for (int ii = 0; ii < kNR; ++ii) {
                 float w[6];
-                a6(r[2 * ph + ii], w);
+                a6(r[kNR * ph + ii], w);
                 #pragma unroll
                 for (int j = 0; j < 6; ++j) lds[(6 * ii + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
             }
             __syncthreads();
-            stage_store12(lds, a.buf_out2 + base, plane, 12 * ph, tend);
+            stage_store12<6 * kNR>(lds, a.buf_out2 + base, plane, 6 * kNR * ph, tend);
         }
     }
 }
