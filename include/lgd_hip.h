@@ -290,6 +290,18 @@ int lgd_box_reg_loss_bwd(const float* const* deltas_host, const int32_t* const* 
                          int N, int A, int K, const float* anchors, const float* matched_boxes, int R, float beta,
                          const float* weights4_host, const float* grad_loss, float* const* grad_deltas_host, void* stream);
 
+/* ------------------------------------------------------------------ modulated deformable 3x3 convolution (DCNv2, config 5)
+ * [ref: configs/Distillation/RetinaNet/retinanet_R_101_dcnv2_*.yaml:7-8 -> detectron2 ModulatedDeformConv]
+ * lgd_dcn_im2col: col[n][c*9+k][y*Wo+x] = mask[n,k,y,x] * bilinear(x[n,c], y*s - p + ky*d + off[n,2k,y,x], x*s - p + kx*d + off[n,2k+1,y,x])
+ *   (zero outside the map; mask may be NULL = 1); the convolution is then W (O x C*9) @ col, a library GEMM issued by the host.
+ * lgd_dcn_col2im: from d col (same layout) the gradients dx (N,C,H,W; zeroed here, atomic scatter), d offset (N,18,Ho,Wo) and
+ *   d mask (N,9,Ho,Wo; ignored when mask is NULL).  Ho = (H + 2p - 2d - 1)/s + 1, likewise Wo.
+ */
+int lgd_dcn_im2col(const float* x, const float* offset, const float* mask, int N, int C, int H, int W, int stride, int pad,
+                   int dilation, float* col, void* stream);
+int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const float* dcol, int N, int C, int H, int W,
+                   int stride, int pad, int dilation, float* dx, float* doffset, float* dmask, void* stream);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench.py)
  * When enabled every kernel launch of this library is bracketed by a HIP event pair recorded on
  * the launch stream.  lgd_timing_collect waits for the recorded events, sums the elapsed time per

@@ -1,0 +1,144 @@
+// Modulated deformable 3x3 convolution (DCNv2) of BASELINE config 5 (RetinaNet R-101-DCNv2)  
+//   [ref: configs/Distillation/RetinaNet/retinanet_R_101_dcnv2_*.yaml:7-8 DEFORM_ON_PER_STAGE / DEFORM_MODULATED ->
+//    detectron2 ModulatedDeformConv]:
+//   out[n,o,y,x] = sum_{c,k} W[o,c,k] * mask[n,k,y,x] * bilinear(in[n,c], y*s - p + ky*d + dy_k, x*s - p + kx*d + dx_k)
+// with zero padding outside the input and offsets stored as (dy, dx) channel pairs per tap k = ky*3 + kx.
+// The per-tap grid_sample formulation costs 9 sampling passes + their autograd per conv (8 ms per conv at res3, 250 ms of
+// the 300 ms step).  Here the sampling is one gather kernel that writes the column matrix col (N, C*9, Ho*Wo) once; the
+// channel contraction is a library GEMM (W (O x C*9) @ col), and the backward is one kernel that turns d col into dx
+// (atomic scatter of the bilinear weights), d offset and d mask (register sums over the channels, no atomics).
+#include "common.h"
+
+namespace lgd {
+
+struct DcnArgs {
+    const float* x;       // (N, C, H, W)
+    const float* offset;  // (N, 18, Ho, Wo)
+    const float* mask;    // (N, 9, Ho, Wo) or null (unmodulated: 1)
+    float* col;           // (N, C*9, Ho*Wo)
+    const float* dcol;    // backward input, same layout as col
+    float* dx;            // (N, C, H, W), zero-initialised by the caller
+    float* doffset;       // (N, 18, Ho, Wo)
+    float* dmask;         // (N, 9, Ho, Wo) or null
+    int N, C, H, W, Ho, Wo, stride, pad, dil;
+};
+
+struct Bilin { int y0, x0; float wy1, wx1; bool in; };
+__device__ __forceinline__ Bilin bilin_setup(float py, float px, int H, int W) {
+    Bilin b;
+    b.in = py > -1.f && px > -1.f && py < (float)H && px < (float)W;
+    const float fy = floorf(py), fx = floorf(px);
+    b.y0 = (int)fy; b.x0 = (int)fx;
+    b.wy1 = py - fy; b.wx1 = px - fx;
+    return b;
+}
+__device__ __forceinline__ float at(const float* p, int y, int x, int H, int W) {
+    return (y >= 0 && y < H && x >= 0 && x < W) ? p[(size_t)y * W + x] : 0.f;
+}
+
+// thread per (n, c, pixel): 9 taps
+__global__ __launch_bounds__(256) void dcn_im2col_kernel(DcnArgs a) {
+    const int HoWo = a.Ho * a.Wo;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.N * a.C * HoWo) return;
+    const int pix = (int)(i % HoWo), c = (int)((i / HoWo) % a.C), n = (int)(i / ((long long)HoWo * a.C));
+    const int ho = pix / a.Wo, wo = pix % a.Wo;
+    const float* px_ = a.x + ((size_t)n * a.C + c) * a.H * a.W;
+    const float* off = a.offset + (size_t)n * 18 * HoWo + pix;
+    const float* msk = a.mask ? a.mask + (size_t)n * 9 * HoWo + pix : nullptr;
+    float* o = a.col + ((size_t)n * a.C + c) * 9 * HoWo + pix;
+    #pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int ky = k / 3, kx = k % 3;
+        const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + off[(size_t)(2 * k) * HoWo];
+        const float pxx = (float)(wo * a.stride - a.pad + kx * a.dil) + off[(size_t)(2 * k + 1) * HoWo];
+        float v = 0.f;
+        const Bilin b = bilin_setup(py, pxx, a.H, a.W);
+        if (b.in) {
+            const float wy0 = 1.f - b.wy1, wx0 = 1.f - b.wx1;
+            v = wy0 * (wx0 * at(px_, b.y0, b.x0, a.H, a.W) + b.wx1 * at(px_, b.y0, b.x0 + 1, a.H, a.W))
+              + b.wy1 * (wx0 * at(px_, b.y0 + 1, b.x0, a.H, a.W) + b.wx1 * at(px_, b.y0 + 1, b.x0 + 1, a.H, a.W));
+            if (msk) v *= msk[(size_t)k * HoWo];
+        }
+        o[(size_t)k * HoWo] = v;
+    }
+}
+
+// thread per (n, tap, pixel): loops over the channels; dx by atomic scatter, d offset / d mask in registers
+__global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
+    const int HoWo = a.Ho * a.Wo;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.N * 9 * HoWo) return;
+    const int pix = (int)(i % HoWo), k = (int)((i / HoWo) % 9), n = (int)(i / ((long long)HoWo * 9));
+    const int ho = pix / a.Wo, wo = pix % a.Wo, ky = k / 3, kx = k % 3;
+    const float* off = a.offset + (size_t)n * 18 * HoWo + pix;
+    const float m = a.mask ? a.mask[((size_t)n * 9 + k) * HoWo + pix] : 1.f;
+    const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + off[(size_t)(2 * k) * HoWo];
+    const float pxx = (float)(wo * a.stride - a.pad + kx * a.dil) + off[(size_t)(2 * k + 1) * HoWo];
+    const Bilin b = bilin_setup(py, pxx, a.H, a.W);
+    float gy = 0.f, gx = 0.f, gm = 0.f;
+    if (b.in) {
+        const float wy0 = 1.f - b.wy1, wx0 = 1.f - b.wx1;
+        const bool y0ok = b.y0 >= 0 && b.y0 < a.H, y1ok = b.y0 + 1 >= 0 && b.y0 + 1 < a.H;
+        const bool x0ok = b.x0 >= 0 && b.x0 < a.W, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < a.W;
+        const size_t o00 = (size_t)b.y0 * a.W + b.x0;
+        for (int c = 0; c < a.C; ++c) {
+            const size_t plane = ((size_t)n * a.C + c) * a.H * a.W;
+            const float* p = a.x + plane;
+            float* dp = a.dx + plane;
+            const float g = a.dcol[(((size_t)n * a.C + c) * 9 + k) * HoWo + pix];
+            const float v00 = (y0ok && x0ok) ? p[o00] : 0.f, v01 = (y0ok && x1ok) ? p[o00 + 1] : 0.f;
+            const float v10 = (y1ok && x0ok) ? p[o00 + a.W] : 0.f, v11 = (y1ok && x1ok) ? p[o00 + a.W + 1] : 0.f;
+            const float gmk = g * m;
+            if (y0ok && x0ok) atomicAdd(dp + o00, gmk * wy0 * wx0);
+            if (y0ok && x1ok) atomicAdd(dp + o00 + 1, gmk * wy0 * b.wx1);
+            if (y1ok && x0ok) atomicAdd(dp + o00 + a.W, gmk * b.wy1 * wx0);
+            if (y1ok && x1ok) atomicAdd(dp + o00 + a.W + 1, gmk * b.wy1 * b.wx1);
+            gy += gmk * (wx0 * (v10 - v00) + b.wx1 * (v11 - v01));
+            gx += gmk * (wy0 * (v01 - v00) + b.wy1 * (v11 - v10));
+            gm += g * (wy0 * (wx0 * v00 + b.wx1 * v01) + b.wy1 * (wx0 * v10 + b.wx1 * v11));
+        }
+    }
+    a.doffset[((size_t)n * 18 + 2 * k) * HoWo + pix] = gy;
+    a.doffset[((size_t)n * 18 + 2 * k + 1) * HoWo + pix] = gx;
+    if (a.dmask) a.dmask[((size_t)n * 9 + k) * HoWo + pix] = gm;
+}
+
+static int dcn_fill(DcnArgs& a, const float* x, const float* offset, const float* mask, int N, int C, int H, int W, int stride,
+                    int pad, int dil) {
+    if (!x || !offset || N < 1 || C < 1 || H < 1 || W < 1 || stride < 1 || dil < 1 || pad < 0) return LGD_EINVAL;
+    a.x = x; a.offset = offset; a.mask = mask; a.N = N; a.C = C; a.H = H; a.W = W; a.stride = stride; a.pad = pad; a.dil = dil;
+    a.Ho = (H + 2 * pad - dil * 2 - 1) / stride + 1;
+    a.Wo = (W + 2 * pad - dil * 2 - 1) / stride + 1;
+    a.col = nullptr; a.dcol = nullptr; a.dx = nullptr; a.doffset = nullptr; a.dmask = nullptr;
+    return (a.Ho < 1 || a.Wo < 1) ? LGD_EINVAL : LGD_OK;
+}
+
+}  // namespace lgd
+
+extern "C" {
+
+int lgd_dcn_im2col(const float* x, const float* offset, const float* mask, int N, int C, int H, int W, int stride, int pad,
+                   int dilation, float* col, void* stream) {
+    lgd::DcnArgs a;
+    if (!col || lgd::dcn_fill(a, x, offset, mask, N, C, H, W, stride, pad, dilation) != LGD_OK) return LGD_EINVAL;
+    a.col = col;
+    const long long total = (long long)N * C * a.Ho * a.Wo;
+    LGD_LAUNCH("dcn_im2col_kernel", lgd::dcn_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return lgd::check_launch();
+}
+
+int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const float* dcol, int N, int C, int H, int W,
+                   int stride, int pad, int dilation, float* dx, float* doffset, float* dmask, void* stream) {
+    lgd::DcnArgs a;
+    if (!dcol || !dx || !doffset || (mask && !dmask) || lgd::dcn_fill(a, x, offset, mask, N, C, H, W, stride, pad, dilation) != LGD_OK)
+        return LGD_EINVAL;
+    a.dcol = dcol; a.dx = dx; a.doffset = doffset; a.dmask = mask ? dmask : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return LGD_ELAUNCH;
+    const long long total = (long long)N * 9 * a.Ho * a.Wo;
+    LGD_LAUNCH("dcn_col2im_kernel", lgd::dcn_col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    return lgd::check_launch();
+}
+
+}  // extern "C"

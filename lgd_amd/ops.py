@@ -874,6 +874,63 @@ def anchor_match(anchors, gt_boxes, gt_classes, counts, iou_lo, iou_hi, num_clas
     return labels, matched
 
 
+# ------------------------------------------------------------------------------------------------ DCNv2 (config 5)
+class _DeformConv(torch.autograd.Function):
+    """modulated deformable 3x3 convolution: one gather kernel builds the column matrix, the channel contraction is a library
+    GEMM; backward = GEMM for d col, one kernel for dx / d offset / d mask, GEMM for dW (the column matrix is kept)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, bias, stride, padding, dilation):
+        hip.require_gpu(x, offset, weight)
+        lib = hip.load()
+        x, offset, weight = hip.dense_f32(x), hip.dense_f32(offset), hip.dense_f32(weight)
+        mask = hip.dense_f32(mask) if mask is not None else None
+        N, C, H, W = x.shape
+        O = weight.shape[0]
+        Ho = (H + 2 * padding - 2 * dilation - 1) // stride + 1
+        Wo = (W + 2 * padding - 2 * dilation - 1) // stride + 1
+        if tuple(weight.shape[1:]) != (C, 3, 3) or tuple(offset.shape) != (N, 18, Ho, Wo):
+            raise hip.LgdHipError("deform conv: weight (O,C,3,3) / offset (N,18,Ho,Wo) expected, got %s / %s"
+                                  % (tuple(weight.shape), tuple(offset.shape)))
+        col = torch.empty((N, C * 9, Ho * Wo), dtype=torch.float32, device=x.device)
+        hip.check(lib.lgd_dcn_im2col(hip.ptr(x), hip.ptr(offset), hip.ptr(mask) if mask is not None else None, N, C, H, W,
+                                     stride, padding, dilation, hip.ptr(col), hip.stream_ptr()), "lgd_dcn_im2col")
+        out = torch.matmul(weight.view(O, C * 9), col).view(N, O, Ho, Wo)
+        if bias is not None:
+            out = out + bias.view(1, -1, 1, 1)
+        ctx.save_for_backward(x, offset, mask, weight, col)
+        ctx.geom = (stride, padding, dilation, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, offset, mask, weight, col = ctx.saved_tensors
+        stride, padding, dilation, has_bias = ctx.geom
+        lib = hip.load()
+        N, C, H, W = x.shape
+        O = weight.shape[0]
+        dy = hip.dense_f32(dy).view(N, O, -1)
+        dx = doff = dmask = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
+            dcol = torch.matmul(weight.view(O, C * 9).t(), dy)
+            dx = torch.empty_like(x)
+            doff = torch.empty_like(offset)
+            dmask = torch.empty_like(mask) if mask is not None else None
+            hip.check(lib.lgd_dcn_col2im(hip.ptr(x), hip.ptr(offset), hip.ptr(mask) if mask is not None else None, hip.ptr(dcol),
+                                         N, C, H, W, stride, padding, dilation, hip.ptr(dx), hip.ptr(doff),
+                                         hip.ptr(dmask) if dmask is not None else None, hip.stream_ptr()), "lgd_dcn_col2im")
+        if ctx.needs_input_grad[3]:
+            dw = torch.bmm(dy, col.transpose(1, 2)).sum(0).view_as(weight)
+        if has_bias and ctx.needs_input_grad[4]:
+            db = dy.sum((0, 2))
+        return dx, doff, dmask, dw, db, None, None, None
+
+
+def deform_conv3x3(x, offset, mask, weight, bias=None, stride=1, padding=1, dilation=1):
+    """DCNv2 (mask given) / DCNv1 (mask None) 3x3 convolution on the GPU."""
+    return _DeformConv.apply(x, offset, mask, weight, bias, int(stride), int(padding), int(dilation))
+
+
 # ------------------------------------------------------------------------------------------------ student conv epilogues
 class _BiasAct(torch.autograd.Function):
     """relu(x + bias[c] (+ residual)) in one pass; backward = the ReLU mask of the saved output on the incoming gradient

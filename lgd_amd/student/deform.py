@@ -5,9 +5,9 @@ detectron2's ModulatedDeformConv CUDA op is not available in this environment].
 Restated from the public DCNv2 definition ([d2-memory]):
     out[n, o, y, x] = sum_{c, k} W[o, c, k] * mask[n, k, y, x] * bilinear(in[n, c], y*s - p + ky*d + dy_k, x*s - p + kx*d + dx_k)
 with zero padding outside the input, offsets stored as (dy, dx) channel pairs per tap k = ky*3 + kx.
-Implemented with bilinear `grid_sample` per tap followed by ONE GEMM over (C_in * 9); autograd supplies the
-backward.  A fused HIP kernel for the sampling is the scheduled follow-up: this version is
-correct and differentiable, not fast."""
+On the GPU: `ops.deform_conv3x3` (HIP gather kernel -> column matrix -> library GEMM; backward kernel for dx / d offset /
+d mask).  The restatement below (bilinear `grid_sample` per tap + ONE GEMM, autograd backward) is the CPU form the HIP
+path is tested against."""
 import torch
 import torch.nn.functional as F
 
@@ -15,6 +15,14 @@ import torch.nn.functional as F
 def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, padding=1, dilation=1):
     """x (N,C,H,W); offset (N, 2*K, Ho, Wo) with K = kh*kw, channel 2k = dy_k, 2k+1 = dx_k; mask (N, K, Ho, Wo);
     weight (O, C, kh, kw)."""
+    if x.is_cuda and x.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3):  # fused gather kernel + library GEMM
+        from .. import ops
+        return ops.deform_conv3x3(x, offset, mask, weight, bias, stride, padding, dilation)
+    return modulated_deform_conv2d_torch(x, offset, mask, weight, bias, stride, padding, dilation)
+
+
+def modulated_deform_conv2d_torch(x, offset, mask, weight, bias=None, stride=1, padding=1, dilation=1):
+    """the same operator as elementwise torch ops (any device): what the HIP path is tested against."""
     N, C, H, W = x.shape
     O, _, kh, kw = weight.shape
     Ho = (H + 2 * padding - dilation * (kh - 1) - 1) // stride + 1

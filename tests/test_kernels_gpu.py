@@ -742,3 +742,33 @@ def test_box_reg_loss_sum_fwd_bwd(beta):
     assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
     for g, r in zip(got, raw):
         assert float((g - r.grad).abs().max()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------- DCNv2 (config 5)
+@pytest.mark.parametrize("N,C,O,H,W,stride,dil,modulated", [(2, 6, 5, 9, 11, 1, 1, True), (1, 8, 4, 12, 10, 2, 1, True),
+                                                            (2, 4, 6, 7, 7, 1, 2, True), (1, 5, 3, 8, 9, 1, 1, False)])
+def test_deform_conv3x3_fwd_bwd(N, C, O, H, W, stride, dil, modulated):
+    """lgd_dcn_im2col / col2im + GEMMs vs the per-tap grid_sample restatement (itself checked against the DCNv2 definition in
+    tests/test_host_cpu.py): output and all five gradients; offsets large enough to sample outside the map."""
+    from lgd_amd import ops
+    from lgd_amd.student.deform import modulated_deform_conv2d_torch
+    pad = dil
+    Ho, Wo = (H + 2 * pad - 2 * dil - 1) // stride + 1, (W + 2 * pad - 2 * dil - 1) // stride + 1
+    mk = lambda shp, seed, lo, hi: torch.from_numpy(synth.det_uniform(shp, seed, lo, hi)).to(DEV)
+    x, off = mk((N, C, H, W), 951, -1.0, 1.0), mk((N, 18, Ho, Wo), 952, -2.5, 2.5)
+    m = mk((N, 9, Ho, Wo), 953, 0.0, 1.0) if modulated else None
+    w, b, gy = mk((O, C, 3, 3), 954, -0.5, 0.5), mk((O,), 955, -0.5, 0.5), mk((N, O, Ho, Wo), 956, -1.0, 1.0)
+    leaves = [t for t in (x, off, m, w, b) if t is not None]
+    for t in leaves:
+        t.requires_grad_(True)
+    y = ops.deform_conv3x3(x, off, m, w, b, stride, pad, dil)
+    y.backward(gy)
+    got = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    ones = torch.ones((N, 9, Ho, Wo), device=DEV)
+    yr = modulated_deform_conv2d_torch(x, off, m if modulated else ones, w, b, stride, pad, dil)
+    yr.backward(gy)
+    assert float((y - yr).detach().abs().max()) <= 1e-4 * float(yr.detach().abs().max())
+    for g, t, name in zip(got, leaves, ("x", "offset", "mask", "weight", "bias") if modulated else ("x", "offset", "weight", "bias")):
+        assert float((g - t.grad).abs().max()) <= 2e-4 * float(t.grad.abs().max()) + 1e-6, name
