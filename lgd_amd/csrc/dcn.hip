@@ -21,6 +21,7 @@ struct DcnArgs {
     float* doffset;       // (N, 18, Ho, Wo)
     float* dmask;         // (N, 9, Ho, Wo) or null
     int N, C, H, W, Ho, Wo, stride, pad, dil;
+    int cchunk;           // channels per blockIdx.y slice of the backward kernel (C if not split)
 };
 
 struct Bilin { int y0, x0; float wy1, wx1; bool in; };
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(DcnArgs a) {
     }
 }
 
-// thread per (n, tap, pixel): loops over the channels; dx by atomic scatter, d offset / d mask in registers
+// thread per (n, tap, pixel) and channel slice (blockIdx.y): loops over the slice's channels; dx by atomic scatter, d offset /
+// d mask summed in registers (one atomic per slice when the channels are split to fill the GPU on the small stages)
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
     const int HoWo = a.Ho * a.Wo;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -82,7 +84,8 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
         const bool y0ok = b.y0 >= 0 && b.y0 < a.H, y1ok = b.y0 + 1 >= 0 && b.y0 + 1 < a.H;
         const bool x0ok = b.x0 >= 0 && b.x0 < a.W, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < a.W;
         const size_t o00 = (size_t)b.y0 * a.W + b.x0;
-        for (int c = 0; c < a.C; ++c) {
+        const int c0 = blockIdx.y * a.cchunk, c1 = min(a.C, c0 + a.cchunk);
+        for (int c = c0; c < c1; ++c) {
             const size_t plane = ((size_t)n * a.C + c) * a.H * a.W;
             const float* p = a.x + plane;
             float* dp = a.dx + plane;
@@ -90,18 +93,24 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
             const float v00 = (y0ok && x0ok) ? p[o00] : 0.f, v01 = (y0ok && x1ok) ? p[o00 + 1] : 0.f;
             const float v10 = (y1ok && x0ok) ? p[o00 + a.W] : 0.f, v11 = (y1ok && x1ok) ? p[o00 + a.W + 1] : 0.f;
             const float gmk = g * m;
-            if (y0ok && x0ok) atomicAdd(dp + o00, gmk * wy0 * wx0);
-            if (y0ok && x1ok) atomicAdd(dp + o00 + 1, gmk * wy0 * b.wx1);
-            if (y1ok && x0ok) atomicAdd(dp + o00 + a.W, gmk * b.wy1 * wx0);
-            if (y1ok && x1ok) atomicAdd(dp + o00 + a.W + 1, gmk * b.wy1 * b.wx1);
+            if (y0ok && x0ok) unsafeAtomicAdd(dp + o00, gmk * wy0 * wx0);
+            if (y0ok && x1ok) unsafeAtomicAdd(dp + o00 + 1, gmk * wy0 * b.wx1);
+            if (y1ok && x0ok) unsafeAtomicAdd(dp + o00 + a.W, gmk * b.wy1 * wx0);
+            if (y1ok && x1ok) unsafeAtomicAdd(dp + o00 + a.W + 1, gmk * b.wy1 * b.wx1);
             gy += gmk * (wx0 * (v10 - v00) + b.wx1 * (v11 - v01));
             gx += gmk * (wy0 * (v01 - v00) + b.wy1 * (v11 - v10));
             gm += g * (wy0 * (wx0 * v00 + b.wx1 * v01) + b.wy1 * (wx0 * v10 + b.wx1 * v11));
         }
     }
-    a.doffset[((size_t)n * 18 + 2 * k) * HoWo + pix] = gy;
-    a.doffset[((size_t)n * 18 + 2 * k + 1) * HoWo + pix] = gx;
-    if (a.dmask) a.dmask[((size_t)n * 9 + k) * HoWo + pix] = gm;
+    float* oy = a.doffset + ((size_t)n * 18 + 2 * k) * HoWo + pix;
+    float* om = a.dmask ? a.dmask + ((size_t)n * 9 + k) * HoWo + pix : nullptr;
+    if (gridDim.y == 1) {
+        oy[0] = gy; oy[HoWo] = gx;
+        if (om) om[0] = gm;
+    } else if (b.in) {  // outputs zeroed by the host entry
+        unsafeAtomicAdd(oy, gy); unsafeAtomicAdd(oy + HoWo, gx);
+        if (om) unsafeAtomicAdd(om, gm);
+    }
 }
 
 static int dcn_fill(DcnArgs& a, const float* x, const float* offset, const float* mask, int N, int C, int H, int W, int stride,
@@ -110,7 +119,7 @@ static int dcn_fill(DcnArgs& a, const float* x, const float* offset, const float
     a.x = x; a.offset = offset; a.mask = mask; a.N = N; a.C = C; a.H = H; a.W = W; a.stride = stride; a.pad = pad; a.dil = dil;
     a.Ho = (H + 2 * pad - dil * 2 - 1) / stride + 1;
     a.Wo = (W + 2 * pad - dil * 2 - 1) / stride + 1;
-    a.col = nullptr; a.dcol = nullptr; a.dx = nullptr; a.doffset = nullptr; a.dmask = nullptr;
+    a.col = nullptr; a.dcol = nullptr; a.dx = nullptr; a.doffset = nullptr; a.dmask = nullptr; a.cchunk = C;
     return (a.Ho < 1 || a.Wo < 1) ? LGD_EINVAL : LGD_OK;
 }
 
@@ -137,7 +146,16 @@ int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return LGD_ELAUNCH;
     const long long total = (long long)N * 9 * a.Ho * a.Wo;
-    LGD_LAUNCH("dcn_col2im_kernel", lgd::dcn_col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    // split the channel loop until ~0.5 M threads are in flight (res5 has only 19 K (n, tap, pixel) triples)
+    int slices = (int)((500000 + total - 1) / total);
+    slices = slices < 1 ? 1 : (slices > C / 8 ? (C / 8 > 0 ? C / 8 : 1) : slices);
+    a.cchunk = (C + slices - 1) / slices;
+    slices = (C + a.cchunk - 1) / a.cchunk;
+    if (slices > 1) {
+        if (hipMemsetAsync(doffset, 0, (size_t)N * 18 * a.Ho * a.Wo * sizeof(float), st) != hipSuccess) return LGD_ELAUNCH;
+        if (a.dmask && hipMemsetAsync(dmask, 0, (size_t)N * 9 * a.Ho * a.Wo * sizeof(float), st) != hipSuccess) return LGD_ELAUNCH;
+    }
+    LGD_LAUNCH("dcn_col2im_kernel", lgd::dcn_col2im_kernel, dim3((unsigned)((total + 255) / 256), slices), dim3(256), 0, st, a);
     return lgd::check_launch();
 }
 
