@@ -195,6 +195,7 @@ def main():
                                       args.height, args.width, Hp, Wp, args.boxes, "on" if ctx else "off", args.phase),
                        "yaml": os.path.relpath(args.config, ROOT), "global_batch": world * Bg, "parallelism": "dp%d" % world},
             "losses": {k: round(v, 6) for k, v in metrics.items()},
+            "gemm_solution_table_loaded": bool(ops._TUNED_GEMM), "conv3x3": "winograd F(%dx%d,3x3)" % (ops._WINO_TILE, ops._WINO_TILE) if ops._WINO_ON else "library",
             "hbm_peak_alloc_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "roofline": roofline,
         }
