@@ -10,10 +10,15 @@ One step = student forward -> dynamic teacher -> head re-run on teacher features
 (8 images/GPU of 800x1333 padded to 800x1344, 10 GT boxes each, context box on).
 Weak scaling: the per-GPU batch is fixed, `value` = all images of all ranks / max-over-ranks time.
 
+Timing protocol: W warm-up steps, then K steps bracketed by barrier + synchronize give `value` / `ms_per_step` (no per-kernel
+instrumentation inside that region); then a SECOND pass of K steps with a HIP event pair around every launch of the library
+(recorded on the launch stream) and around the Winograd GEMMs gives the per-kernel numbers.
+
 Extra objects on the JSON line (task statement section 4):
-  roofline     -- dominant hand-written HIP kernel of the step: algorithmic bytes per launch / mean launch time,
-                  measured live with HIP events on the launch stream inside the timed region
-  cpu_baseline -- the CPU oracle (oracle/lgd_oracle.py, kind "port") timed on the host cores, rank 0, N=1 only
+  roofline      -- dominant hand-written HIP kernel of the step (HBM bound): algorithmic bytes per launch / mean launch time
+  roofline_mfma -- the Winograd channel GEMMs (library, fp32 MFMA): FLOP per launch / mean launch time vs the 157.3 TF peak
+  cpu_baseline  -- the CPU oracle (oracle/lgd_oracle.py, kind "port") timed on the host cores, rank 0, N=1 only, with
+                   `gpu_same_path`: the product's SAME sub-path (teacher + adapter + distill loss, fwd+bwd) timed on the GPU
 """
 import argparse
 import json
@@ -27,7 +32,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), same guide
 
 
 def parse():
@@ -44,6 +50,7 @@ def parse():
                     help="training phase to time: distill = steady state (distill on, backbone training; 150k of the "
                          "180k iterations), nondistill = iterations 20k-30k, frozen = first 20k iterations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
     ap.add_argument("--cpu-sample-images", type=int, default=1)
     return ap.parse_args()
 
@@ -77,11 +84,53 @@ def cpu_baseline(args, n_boxes, ctx, budget_s=20.0):
         dt += run(B, H, W)
         reps += 1
     B *= reps
-    return {"value": B / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+    return {"value": B / dt, "unit": "images/sec", "cores": threads, "kind": "port", "gpu_same_path": gpu_lgd_only(args, n_boxes, ctx),
             "sample": "oracle LGD path only (dynamic teacher fwd + adapter + distill loss, fwd+bwd; no student "
                       "backbone/head: the reference's detectron2 student is not runnable), %d image(s) of %dx%d, "
                       "%d GT boxes, %.1f s on %d threads (host has %d logical CPUs)"
                       % (B, H, W, n_boxes, dt, threads, os.cpu_count() or 1)}
+
+
+def gpu_lgd_only(args, n_boxes, ctx, steps=10):
+    """the product's DynamicTeacher + adapter + distill loss, forward + backward, on the GPU: the SAME sub-path and inputs the
+    CPU baseline times (no student backbone / head), full batch, so that the two numbers can be compared like for like."""
+    from lgd_amd import config, ops, synth
+    from lgd_amd.adapters import SequentialConvs
+    from lgd_amd.dynamic_teacher import DynamicTeacher
+    from lgd_amd.structures import Boxes, ImageList, Instances
+    from oracle import lgd_oracle as O  # parameter names / shapes only
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B = args.batch_per_gpu
+    H, W = (args.height + 31) // 32 * 32, (args.width + 31) // 32 * 32
+    cfg = config.setup_cfg(args.config, ["MODEL.DEVICE", str(dev)])
+    teacher = DynamicTeacher(cfg)
+    teacher.load_state_dict({k: torch.from_numpy(v) for k, v in synth.closed_form_params(O.teacher_param_shapes()).items()})
+    adapter = SequentialConvs(cfg)
+    adapter.load_state_dict({k: torch.from_numpy(v) for k, v in synth.closed_form_params(O.adapter_param_shapes()).items()})
+    teacher.to(dev).train()
+    adapter.to(dev).train()
+    feats = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in synth.synth_features(B, H, W, seed=3).items()}
+    gt = synth.synth_gt(B, H, W, n_boxes, seed=0)
+    bi = [{"image": torch.zeros(3, H, W), "instances": Instances((H, W), gt_boxes=Boxes(torch.from_numpy(b)), gt_classes=torch.from_numpy(c))}
+          for b, c in gt]
+    images = ImageList(torch.zeros(B, 3, H, W, device=dev), [(H, W)] * B)
+    keys = sorted(feats)
+
+    def step():
+        tea, _, _ = teacher((bi, images, None, feats))
+        stu = adapter.levels([feats[k] for k in keys])
+        loss = ops.distill_in_mse(stu, [tea[k] for k in keys], 1.0) + sum(t.mean() for t in tea.values())
+        loss.backward()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": B / dt, "unit": "images/sec", "ms_per_step": 1e3 * dt,
+            "sample": "product DynamicTeacher + adapter + distill loss fwd+bwd, %d images of %dx%d, %d GT boxes, %d steps" % (B, H, W, n_boxes, steps)}
 
 
 def main():
@@ -129,20 +178,34 @@ def main():
         trainer.step(data, it0 + i)
     trainer.fetch_metrics()
     sync()
-    ops.kernel_timer_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.step(data, it0 + args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    ktimes = ops.kernel_timer_collect()
-    kbytes = ops.kernel_alg_bytes()  # shape-varying kernels (Winograd transforms): bytes summed over the timed launches
-    ops.kernel_timer_enable(False)
     metrics = trainer.fetch_metrics()  # raises on non-finite losses
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # second pass, instrumented: an event pair around every launch of the library and around the Winograd GEMMs
+    ktimes, kbytes, kflops, dt_instr = {}, {}, {}, None
+    if not args.no_kernel_timing:  # every rank steps (the gradient all-reduce is collective); rank 0 carries the timers
+        if rank == 0:
+            ops.kernel_timer_enable(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            trainer.step(data, it0 + args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        dt_instr = time.perf_counter() - t1
+        if rank == 0:
+            ktimes = ops.kernel_timer_collect()
+            kbytes = ops.kernel_alg_bytes()   # shape-varying kernels (Winograd transforms): bytes summed over the timed launches
+            kflops = ops.kernel_gemm_flops()
+            ops.kernel_timer_enable(False)
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         Hp, Wp = (args.height + 31) // 32 * 32, (args.width + 31) // 32 * 32
@@ -158,26 +221,47 @@ def main():
         alg.update({"focal_fwd_kernel": 80 * Pf + Pf, "focal_bwd_kernel": 2 * 80 * Pf + Pf})
         alg.update({k: v / max(ktimes[k][0], 1) for k, v in kbytes.items() if k in ktimes})  # mean bytes per launch
         kernels = {}
-        for name, (n, ms) in ktimes.items():
-            kernels[name] = {"launches": n, "avg_us": 1e3 * ms / max(n, 1), "total_ms": ms}
+        for name, (n, ms, lo, hi) in ktimes.items():
+            kernels[name] = {"launches": n, "avg_us": 1e3 * ms / max(n, 1), "min_us": 1e3 * lo, "max_us": 1e3 * hi, "total_ms": ms}
             if name in alg:
                 kernels[name]["alg_bytes"] = alg[name]
                 kernels[name]["GBps"] = alg[name] / (1e-3 * ms / n) / 1e9
+            if name in kflops:
+                kernels[name]["TFLOPs"] = kflops[name] / (1e-3 * ms) / 1e12
         is_cfg1 = (os.path.abspath(args.config) == os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml") and Bg == 8
                    and (args.height, args.width) == (800, 1333))
         hbm_bound = [k for k in kernels if k in alg and not k.startswith("focal")]  # focal is exp/log bound, reported but not the roofline line
         dom = max(hbm_bound, key=lambda k: kernels[k]["total_ms"], default=None)
-        roofline = None
+        roofline = roofline_mfma = None
         if dom:
             traffic = None
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tf) and is_cfg1:  # the counters were collected on configs[1]
                 traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
-                        "alg_bytes_per_launch": alg[dom], "avg_launch_us": kernels[dom]["avg_us"],
-                        "all_hip_kernels": {k: {"avg_us": round(v["avg_us"], 2), "GBps": round(v.get("GBps", 0.0), 1),
-                                                "launches_per_step": v["launches"] / args.steps} for k, v in kernels.items()}}
+            k = kernels[dom]
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
+                        "traffic_source": "static profile: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                          "over this command, not re-measured in this run)" if traffic is not None else None,
+                        "alg_bytes_per_launch": alg[dom], "avg_launch_us": k["avg_us"], "min_launch_us": k["min_us"],
+                        "max_launch_us": k["max_us"],
+                        "all_hip_kernels": {n: {"avg_us": round(v["avg_us"], 2), "min_us": round(v["min_us"], 2),
+                                                "max_us": round(v["max_us"], 2), "GBps": round(v.get("GBps", 0.0), 1),
+                                                "launches_per_step": v["launches"] / args.steps}
+                                            for n, v in kernels.items() if not n.startswith("wino_gemm")}}
+        gemms = {n: v for n, v in kernels.items() if n.startswith("wino_gemm")}
+        if gemms:
+            tot_ms = sum(v["total_ms"] for v in gemms.values())
+            tot_fl = sum(kflops[n] for n in gemms)
+            n_l = sum(v["launches"] for v in gemms.values())
+            ach = tot_fl / (1e-3 * tot_ms) / 1e12
+            roofline_mfma = {"bound": "mfma", "kernel": "Winograd channel GEMMs (library fp32 MFMA via torch.bmm: forward, input-gradient, "
+                             "weight-gradient)", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "flop_per_launch": tot_fl / n_l,
+                             "avg_launch_us": 1e3 * tot_ms / n_l, "ms_per_step": tot_ms / args.steps,
+                             "by_kind": {n: {"TFLOPs": round(v["TFLOPs"], 1), "avg_us": round(v["avg_us"], 1), "min_us": round(v["min_us"], 1),
+                                             "max_us": round(v["max_us"], 1), "launches_per_step": v["launches"] / args.steps}
+                                         for n, v in gemms.items()}}
         arch = cfg.MODEL.META_ARCHITECTURE.replace("Distillator", "")
         default_cfg = os.path.abspath(args.config) == os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml")
         out = {
@@ -195,9 +279,11 @@ def main():
                                       args.height, args.width, Hp, Wp, args.boxes, "on" if ctx else "off", args.phase),
                        "yaml": os.path.relpath(args.config, ROOT), "global_batch": world * Bg, "parallelism": "dp%d" % world},
             "losses": {k: round(v, 6) for k, v in metrics.items()},
-            "gemm_solution_table_loaded": bool(ops._TUNED_GEMM), "conv3x3": "winograd F(%dx%d,3x3)" % (ops._WINO_TILE, ops._WINO_TILE) if ops._WINO_ON else "library",
+            "gemm_solution_table_loaded": bool(trainer.tuned_gemms), "conv3x3": "winograd F(%dx%d,3x3)" % (ops._WINO_TILE, ops._WINO_TILE) if ops._WINO_ON else "library",
             "hbm_peak_alloc_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-            "roofline": roofline,
+            "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,
+            "head_pass": "single (student + teacher pyramids in one pass)" if getattr(model, "fused_head_pass", False) else "two passes",
+            "roofline": roofline, "roofline_mfma": roofline_mfma,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.boxes, ctx)

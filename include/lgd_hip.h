@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define LGD_MAX_LEVELS 8
+/* maps per call: 5 pyramid levels, or the 2 x 5 maps of the single head pass over student + teacher features */
+#define LGD_MAX_LEVELS 16
 
 #define LGD_OK 0
 #define LGD_EINVAL (-1)   /* bad argument (null pointer, L > LGD_MAX_LEVELS, C % 4 != 0, ...) */
@@ -140,6 +141,25 @@ int lgd_gn1_stats(const float* const* x_host, const int32_t* level_hw_host, int 
 int lgd_gn1_bwd(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L,
                 int B, int C, int relu, const float* stats, double* ws, float* bstats,
                 float* const* dx_host, void* stream);
+
+/* ------------------------------------------------------------------ GroupNorm(G groups, per-channel affine) [+ReLU] (FCOS towers)
+ * [ref: models/customized_detectors/thirdparty_heads/fcos.py:455-470 (tower = conv3x3, GroupNorm(32, C), ReLU), 520-531
+ *  (the towers are applied to every level)]  y = gamma[c] * (x - mean_{b,g}) * rsqrt(var_{b,g} + 1e-5) + beta[c] over each
+ * sample's group of C/G adjacent channel planes (biased variance), optionally followed by ReLU; all maps in one call.
+ * gamma / beta: [C] or NULL (1 / 0).
+ *   ws        : fp64 workspace, lgd_gn_group_ws_doubles(...) entries (shared by fwd and bwd)
+ *   stats     : fp32 [L*B*G][2] (mean, rstd), written by fwd, read by bwd
+ *   bstats    : fp32 [L*B*G][2] scratch of the backward
+ *   plane_sums: fp32 [L*B*C][2] per (map, sample, channel): sum g, sum g*xhat with g = dy * [y > 0] when relu;
+ *               dbeta[c] / dgamma[c] are their sums over maps and samples (added by the host binding)
+ * backward: dx = rstd * (gamma*g - mean_grp(gamma*g) - xhat * mean_grp(gamma*g*xhat)).
+ */
+size_t lgd_gn_group_ws_doubles(const int32_t* level_hw_host, int L, int B, int C);
+int lgd_gn_group_fwd(const float* const* x_host, const int32_t* level_hw_host, int L, int B, int C, int G, const float* gamma,
+                     const float* beta, int relu, double* ws, float* stats, float* const* y_host, void* stream);
+int lgd_gn_group_bwd(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L, int B, int C,
+                     int G, const float* gamma, const float* beta, int relu, const float* stats, double* ws, float* bstats,
+                     float* plane_sums, float* const* dx_host, void* stream);
 
 /* ------------------------------------------------------------------ K3b: ReLU(x + ctx[b,c]) epilogue of the rendering
  * [ref: dynamic_teacher.py:151  F.relu(inst_featmap + ctx_feature[:, :, None, None])]
@@ -253,6 +273,23 @@ int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host
 int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const int32_t* level_hw_host, int L,
                    int N, int C, int tile, float* dM, void* stream);
 
+/* ------------------------------------------------------------------ FCOS ground-truth assignment
+ * [ref: models/customized_detectors/thirdparty_heads/fcos.py:177-284  FCOS.get_ground_truth]
+ * One launch for the mini-batch.  shifts: (R,2) location centres (x,y) of all levels concatenated (level l owns
+ * level_locs_host[l] consecutive rows); per level: the regression range [size_lo, size_hi] (OBJECT_SIZES_OF_INTEREST,
+ * fcos.py:248-252) and the centre-sampling radius in pixels (stride * CENTER_SAMPLING_RADIUS, fcos.py:228; ignored when
+ * center_sampling = 0: a location is then a candidate anywhere strictly inside the box, fcos.py:244-246).
+ * gt_boxes (T,4) / gt_classes (T,) int64 image-major, img_off (B+1) int32 (device).  Per (image, location): the candidate
+ * box of minimal area (first index on ties, fcos.py:254-259) -> class id (num_classes = background), (l,t,r,b) distances to
+ * the matched box (box 0 of the image when there is no candidate, as gt_boxes[argmin] does), centerness
+ * sqrt(clamp(min(l,r)/max(l,r),0) * clamp(min(t,b)/max(t,b),0)) (fcos.py:268-276).  Images without boxes: background / zeros.
+ * Outputs: classes (B,R) int64, deltas (B,R,4) fp32, centerness (B,R) fp32 -- bit-identical to the elementwise definition.
+ */
+int lgd_fcos_targets(const float* shifts, const int32_t* level_locs_host, const float* size_lo_host, const float* size_hi_host,
+                     const float* radius_px_host, int L, int R, const float* gt_boxes, const int64_t* gt_classes,
+                     const int32_t* img_off, int B, int T, int num_classes, int center_sampling, int64_t* out_classes,
+                     float* out_deltas, float* out_centerness, void* stream);
+
 /* ------------------------------------------------------------------ conv epilogues of the student (FrozenBN folded)
  * [ref: the detectron2 BottleneckBlock of the reference's student: conv -> FrozenBN (a per-channel
  *  affine, folded into the conv weights + bias) [-> += shortcut] -> relu]
@@ -309,6 +346,9 @@ int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const
  * name; returns the number of names written. */
 int lgd_timing_enable(int on);
 int lgd_timing_collect(char* names, size_t names_len, double* total_ms, int32_t* launches, int max_entries);
+/* same, plus the shortest / longest launch of every kernel name (ms) */
+int lgd_timing_collect_ex(char* names, size_t names_len, double* total_ms, double* min_ms, double* max_ms, int32_t* launches,
+                          int max_entries);
 
 #ifdef __cplusplus
 }

@@ -37,20 +37,23 @@ int lgd_timing_enable(int on) {
     return LGD_OK;
 }
 
-int lgd_timing_collect(char* names, size_t names_len, double* total_ms, int32_t* launches, int max_entries) {
+static int collect(char* names, size_t names_len, double* total_ms, double* min_ms, double* max_ms, int32_t* launches,
+                   int max_entries) {
     std::vector<lgd::Rec> recs;
     {
         std::lock_guard<std::mutex> lk(lgd::g_mu);
         recs.swap(lgd::g_recs);
     }
-    std::map<std::string, std::pair<double, int>> acc;
+    struct Acc { double sum = 0, mn = 1e300, mx = 0; int n = 0; };
+    std::map<std::string, Acc> acc;
     for (auto& r : recs) {
         (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             auto& e = acc[r.name];
-            e.first += ms;
-            e.second += 1;
+            e.sum += ms; e.n += 1;
+            if (ms < e.mn) e.mn = ms;
+            if (ms > e.mx) e.mx = ms;
         }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -61,11 +64,22 @@ int lgd_timing_collect(char* names, size_t names_len, double* total_ms, int32_t*
         if (n >= max_entries || off + kv.first.size() + 1 > names_len) break;
         std::memcpy(names + off, kv.first.c_str(), kv.first.size() + 1);
         off += kv.first.size() + 1;
-        total_ms[n] = kv.second.first;
-        launches[n] = kv.second.second;
+        total_ms[n] = kv.second.sum;
+        if (min_ms) min_ms[n] = kv.second.mn;
+        if (max_ms) max_ms[n] = kv.second.mx;
+        launches[n] = kv.second.n;
         ++n;
     }
     return n;
+}
+
+int lgd_timing_collect(char* names, size_t names_len, double* total_ms, int32_t* launches, int max_entries) {
+    return collect(names, names_len, total_ms, nullptr, nullptr, launches, max_entries);
+}
+
+int lgd_timing_collect_ex(char* names, size_t names_len, double* total_ms, double* min_ms, double* max_ms, int32_t* launches,
+                          int max_entries) {
+    return collect(names, names_len, total_ms, min_ms, max_ms, launches, max_entries);
 }
 
 }  // extern "C"

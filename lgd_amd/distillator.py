@@ -6,14 +6,29 @@ from .registry import META_ARCH_REGISTRY
 
 
 class _Distillator(BaseDistillator):
+    """Training forward [ref: distillator.py:39-68 / 216-243]: student -> dynamic teacher -> student head on the teacher
+    features -> distillation loss.  The student's own head pass does not feed the teacher, so it is deferred until the
+    teacher features exist and the head then runs ONCE over both pyramids (`student.predict_pair`, SURVEY.md section 8 f-1);
+    `forward_student` / `forward_teacher` keep the reference's two-pass signatures for callers that use them directly."""
+
     def __init__(self, cfg=None):
         super().__init__(cfg)
         self.flag_seg_map = cfg.MODEL.DISTILLATOR.LABEL_ENCODER.LOAD_LABELMAP
+        self.fused_head_pass = True  # False: the reference's literal two head passes (tests compare the two)
 
     def forward_student(self, batched_inputs, **kwargs):
         return self.student(batched_inputs)
 
     def forward(self, batched_inputs, **kwargs):
+        if self.training and self.fused_head_pass:
+            s = self.student
+            r_features, features, images, gt_instances = s.backbone_features(batched_inputs)
+            features_tea, inst_labels, geom = self.teacher((batched_inputs, images, r_features, features))
+            losses, losses_tea = self._pair_losses([features[f] for f in s.head_in_features],
+                                                   [features_tea[f] for f in s.head_in_features], gt_instances)
+            losses.update({k + ".tea": v for k, v in losses_tea.items()})
+            losses.update(self.distill_loss({"stu": features, "tea": features_tea}, images, batched_inputs, geom, inst_labels))
+            return losses
         if self.training:
             losses, r_features, features, images, gt = self.forward_student(batched_inputs)
             losses_tea, _, features_tea, geom, inst_labels = self.forward_teacher(
@@ -34,6 +49,15 @@ class _Distillator(BaseDistillator):
 class DistillatorRetinaNet(_Distillator):
     _gt_kw = "gt_labels_boxes"
 
+    def _pair_losses(self, feats_stu, feats_tea, gt_instances):
+        """student.losses on both halves of one head pass; student first, so the EMA loss normaliser advances in the
+        reference's order (student forward, then forward_teacher: distillator.py:44-52, 110)."""
+        s = self.student
+        anchors, (logits, deltas), (logits_t, deltas_t) = s.predict_pair(feats_stu, feats_tea)
+        gt_labels, gt_boxes = s.label_anchors(anchors, gt_instances)
+        return (s.losses(anchors, logits, gt_labels, deltas, gt_boxes),
+                s.losses(anchors, logits_t, gt_labels, deltas_t, gt_boxes))
+
     def forward_teacher(self, batched_inputs, **kwargs):
         """[ref: distillator.py:96-114]"""
         images, r_features, features = kwargs["images"], kwargs["r_features"], kwargs["features"]
@@ -52,6 +76,12 @@ class DistillatorRetinaNet(_Distillator):
 @META_ARCH_REGISTRY.register()
 class DistillatorFCOS(_Distillator):
     _gt_kw = "gt_targets"
+
+    def _pair_losses(self, feats_stu, feats_tea, gt_instances):
+        s = self.student
+        shifts, out_s, out_t = s.predict_pair(feats_stu, feats_tea)
+        gt = s.get_ground_truth(shifts, gt_instances)
+        return s.losses(*gt, *out_s), s.losses(*gt, *out_t)
 
     def forward_teacher(self, batched_inputs, **kwargs):
         """[ref: distillator.py:277-297]"""

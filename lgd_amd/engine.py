@@ -9,10 +9,12 @@ MI355X-first differences (behaviour-preserving):
     all-reducing and then discarding the gradients (train.py:205-207) -- SGD skips the same
     parameters (grad None), the backward pass and the gradient buckets shrink;
   * parameters that can never receive a gradient (global_ctx_proj_1D without a context box) are
-    frozen statically, so DDP runs with a static graph instead of find_unused_parameters=True;
+    frozen statically, so DDP runs with find_unused_parameters=False (no per-iteration graph walk);
+    `static_graph` stays off: the distill-flag switch changes which edges reach the backbone;
   * works at world size 1 (the reference dereferences `model.module` unconditionally).
 """
 import bisect
+import math
 import os
 
 import torch
@@ -34,12 +36,35 @@ def warmup_multistep_factor(it, steps, gamma, warmup_factor, warmup_iters, warmu
     return w * gamma ** bisect.bisect_right(list(steps), it)
 
 
-def build_distillator_lr_scheduler(solver, optimizer):
-    """[ref: utils/build.py:531-553]"""
+def _warmup_factor(it, warmup_factor, warmup_iters, warmup_method):
+    if it >= warmup_iters:
+        return 1.0
+    if warmup_method == "constant":
+        return warmup_factor
+    if warmup_method == "linear":
+        a = it / warmup_iters
+        return warmup_factor * (1 - a) + a
+    raise ValueError("Unknown warmup method: {}".format(warmup_method))
+
+
+def warmup_cosine_factor(it, max_iters, warmup_factor, warmup_iters, warmup_method="linear"):
+    """detectron2 WarmupCosineLR multiplier ([d2-memory]): warmup * 0.5 * (1 + cos(pi * it / max_iters))."""
+    return _warmup_factor(it, warmup_factor, warmup_iters, warmup_method) * 0.5 * (1.0 + math.cos(math.pi * it / max_iters))
+
+
+def build_distillator_lr_scheduler(solver, optimizer, max_iter=None):
+    """[ref: utils/build.py:531-553]; `max_iter` backs WarmupCosineLR when the sub-solver has no MAX_ITER of its own
+    (the reference reads solver.MAX_ITER, which its default sub-config does not define)."""
     name = solver.LR_SCHEDULER_NAME
     if name == "WarmupMultiStepLR":
         f = lambda it: warmup_multistep_factor(it, solver.STEPS, solver.GAMMA, solver.WARMUP_FACTOR,  # noqa: E731
                                                solver.WARMUP_ITERS, solver.WARMUP_METHOD)
+        return torch.optim.lr_scheduler.LambdaLR(optimizer, f)
+    if name == "WarmupCosineLR":
+        total = getattr(solver, "MAX_ITER", None) or max_iter
+        if not total:
+            raise ValueError("WarmupCosineLR needs MAX_ITER")
+        f = lambda it: warmup_cosine_factor(it, total, solver.WARMUP_FACTOR, solver.WARMUP_ITERS, solver.WARMUP_METHOD)  # noqa: E731
         return torch.optim.lr_scheduler.LambdaLR(optimizer, f)
     raise ValueError("Unknown LR sheduler: {}".format(name))
 
@@ -72,20 +97,47 @@ def build_distillator_optimizer(cfg, network):
             return torch.optim.AdamW(params, solver.BASE_LR, betas=(0.9, 0.999), weight_decay=solver.WEIGHT_DECAY,
                                      foreach=True)
         raise NotImplementedError("no optimizer type %s" % solver.OPTIMIZER)
-    # every parameter is registered (also currently-frozen backbone ones: SGD skips grad-less params)
-    stu = [p for p in _all_params([net.student, net.adapter]) if not getattr(p, "_lgd_never_trained", False)]
-    tea = [p for p in _all_params([net.teacher]) if not getattr(p, "_lgd_never_trained", False)]
-    return make(d.STUDENT.SOLVER, stu), make(d.TEACHER.SOLVER, tea)
+    # the reference registers every parameter that requires grad at build time -- including the ones that never receive a
+    # gradient (global_ctx_proj_1D without a context box; SGD skips grad-less params) and the phase-frozen backbone -- in
+    # named_parameters order, one param group each (utils/build.py:494-512).  Same parameters, same order here, but ONE group
+    # per optimizer so that the multi-tensor update is a handful of launches instead of ~10 per parameter;
+    # Trainer.state_dict()/load_state_dict() convert to / from the reference's one-group-per-parameter layout.
+    return make(d.STUDENT.SOLVER, _all_params([net.student, net.adapter])), make(d.TEACHER.SOLVER, _all_params([net.teacher]))
 
 
 def _all_params(modules):
     seen, out = set(), []
     for m in modules:
         for p in m.parameters():
-            if id(p) not in seen and (p.requires_grad or getattr(p, "_lgd_phase_frozen", False)):
+            if id(p) not in seen and (p.requires_grad or getattr(p, "_lgd_phase_frozen", False)
+                                      or getattr(p, "_lgd_never_trained", False)):
                 seen.add(id(p))
                 out.append(p)
     return out
+
+
+def optimizer_state_to_reference(sd):
+    """one param group per parameter, as the reference's optimizers store it (utils/build.py:494-512)."""
+    out = {"state": sd["state"], "param_groups": []}
+    for g in sd["param_groups"]:
+        for i in g["params"]:
+            out["param_groups"].append({**{k: v for k, v in g.items() if k != "params"}, "params": [i]})
+    return out
+
+
+def optimizer_state_from_reference(sd, optimizer):
+    """merge a one-group-per-parameter state_dict into this optimizer's group layout (hyper-parameters of the first group:
+    the reference gives every parameter the same lr / weight decay)."""
+    mine = optimizer.state_dict()["param_groups"]
+    if len(sd["param_groups"]) == len(mine):
+        return sd
+    flat = [i for g in sd["param_groups"] for i in g["params"]]
+    if len(mine) != 1 or len(flat) != len(mine[0]["params"]):
+        raise ValueError("optimizer state has %d parameters in %d groups, expected %d parameters"
+                         % (len(flat), len(sd["param_groups"]), sum(len(g["params"]) for g in mine)))
+    g0 = sd["param_groups"][0]
+    merged = {**mine[0], **{k: v for k, v in g0.items() if k != "params"}, "params": flat}
+    return {"state": sd["state"], "param_groups": [merged]}
 
 
 def freeze_static_unused(model):
@@ -119,11 +171,17 @@ class Trainer:
         self.model = model
         self._set_backbone_frozen(0 < self.d.PRE_FREEZE_STUDENT_BACKBONE_ITERS)
         self.stu_optimizer, self.tea_optimizer = build_distillator_optimizer(cfg, model)
-        self.stu_scheduler = build_distillator_lr_scheduler(self.d.STUDENT.SOLVER, self.stu_optimizer)
-        self.tea_scheduler = build_distillator_lr_scheduler(self.d.TEACHER.SOLVER, self.tea_optimizer)
+        self.stu_scheduler = build_distillator_lr_scheduler(self.d.STUDENT.SOLVER, self.stu_optimizer, self.max_iter)
+        self.tea_scheduler = build_distillator_lr_scheduler(self.d.TEACHER.SOLVER, self.tea_optimizer, self.max_iter)
         self.clip = cfg.SOLVER.CLIP_GRADIENTS
         self.iteration = 0
         self._log_acc, self._log_n = None, 0
+        self._finite = None  # device-side AND of isfinite(total loss) over the steps since the last check
+        if self.device.type == "cuda":
+            from . import ops
+            self.tuned_gemms = ops.enable_tuned_gemms()  # opt-in here (not an import side effect): lookup-only solution table
+        else:
+            self.tuned_gemms = False
 
     # ---- phases ----------------------------------------------------------------------------
     def _set_backbone_frozen(self, frozen):
@@ -164,6 +222,8 @@ class Trainer:
         self.model.train()
         loss_dict = self.model(data)
         losses = sum(loss_dict.values())
+        ok = torch.isfinite(losses.detach())  # the reference asserts this every iteration (train.py:194); here: no host sync
+        self._finite = ok if self._finite is None else self._finite & ok
         self.stu_optimizer.zero_grad(set_to_none=True)
         self.tea_optimizer.zero_grad(set_to_none=True)
         losses.backward()  # DDP: bucketed RCCL all-reduce over xGMI overlaps with this
@@ -182,21 +242,40 @@ class Trainer:
         return loss_dict
 
     def _clip(self):
-        """detectron2 default CLIP_TYPE='value', CLIP_VALUE=1.0: element-wise clamp of every gradient."""
+        """detectron2 maybe_add_gradient_clipping: per PARAMETER, CLIP_TYPE 'value' (default, CLIP_VALUE 1.0) = element-wise
+        clamp, 'norm' = clip_grad_norm_ of each parameter on its own [d2-memory]; multi-tensor forms, no host sync."""
         grads = [p.grad for g in self.stu_optimizer.param_groups + self.tea_optimizer.param_groups
                  for p in g["params"] if p.grad is not None]
+        if not grads:
+            return
+        v = float(self.clip.CLIP_VALUE)
         if self.clip.CLIP_TYPE == "value":
-            v = float(self.clip.CLIP_VALUE)
             torch._foreach_clamp_min_(grads, -v)
             torch._foreach_clamp_max_(grads, v)
         else:
-            torch.nn.utils.clip_grad_norm_([p for g in self.stu_optimizer.param_groups + self.tea_optimizer.param_groups
-                                            for p in g["params"]], float(self.clip.CLIP_VALUE), float(self.clip.NORM_TYPE))
+            norms = torch._foreach_norm(grads, float(self.clip.NORM_TYPE))
+            coef = [torch.clamp(v / (n + 1e-6), max=1.0) for n in norms]
+            torch._foreach_mul_(grads, coef)
+
+    def check_finite(self):
+        """raise if any total loss since the last check was non-finite (ONE host sync; call before saving a checkpoint)."""
+        if self._finite is None:
+            return
+        if self.distributed:
+            f = self._finite.to(torch.float32)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            ok = bool(f.item() > 0)
+        else:
+            ok = bool(self._finite.item())
+        self._finite = None
+        if not ok:
+            raise FloatingPointError("non-finite total loss at or before iteration %d" % (self.iteration - 1))
 
     def fetch_metrics(self):
         """Mean of every loss since the last call, averaged over ranks (ONE all-reduce, ONE host copy),
         plus total_loss / stu_lr / tea_lr  [ref: train.py:196-199, 212-213 scalar names].  Raises if a loss went
         non-finite (the reference asserts every iteration, train.py:194)."""
+        self.check_finite()
         if self._log_acc is None:
             return {}
         v = self._log_acc / self._log_n
@@ -214,15 +293,17 @@ class Trainer:
         return out
 
     def state_dict(self):
-        """checkpoint payload with the reference's keys [ref: train.py:155-157]."""
-        return {"model": self.raw_model.state_dict(), "stu_optimizer": self.stu_optimizer.state_dict(),
-                "tea_optimizer": self.tea_optimizer.state_dict(), "stu_scheduler": self.stu_scheduler.state_dict(),
+        """checkpoint payload with the reference's keys and optimizer layout [ref: train.py:155-157, utils/build.py:494-512]."""
+        return {"model": self.raw_model.state_dict(),
+                "stu_optimizer": optimizer_state_to_reference(self.stu_optimizer.state_dict()),
+                "tea_optimizer": optimizer_state_to_reference(self.tea_optimizer.state_dict()),
+                "stu_scheduler": self.stu_scheduler.state_dict(),
                 "tea_scheduler": self.tea_scheduler.state_dict(), "iteration": self.iteration - 1}
 
     def load_state_dict(self, sd):
         self.raw_model.load_state_dict(sd["model"])
-        self.stu_optimizer.load_state_dict(sd["stu_optimizer"])
-        self.tea_optimizer.load_state_dict(sd["tea_optimizer"])
+        self.stu_optimizer.load_state_dict(optimizer_state_from_reference(sd["stu_optimizer"], self.stu_optimizer))
+        self.tea_optimizer.load_state_dict(optimizer_state_from_reference(sd["tea_optimizer"], self.tea_optimizer))
         self.stu_scheduler.load_state_dict(sd["stu_scheduler"])
         self.tea_scheduler.load_state_dict(sd["tea_scheduler"])
         self.iteration = sd.get("iteration", -1) + 1

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -41,6 +41,10 @@ SIGNATURES = {
     "lgd_gn_pool_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn_pool_bwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn1_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gn_group_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
+    "lgd_gn_group_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gn_group_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_fcos_targets": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_ctx_relu_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_ctx_relu_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_gemm_batch": (c_i, [c_fp, c_i, c_fp]),
@@ -70,6 +74,7 @@ SIGNATURES = {
     "lgd_dcn_col2im": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_timing_enable": (c_i, [c_i]),
     "lgd_timing_collect": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_i]),
+    "lgd_timing_collect_ex": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_fp, c_fp, c_i]),
 }
 
 

@@ -291,6 +291,54 @@ def gn_relu_mask_pool(geom, xs):
     return _GnReluPool.apply(geom, *xs)
 
 
+class _GroupNormRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, groups, relu, weight, bias, *xs):
+        lib = hip.load()
+        hip.require_gpu(*xs)
+        xs = [hip.dense_f32(x) for x in xs]
+        L = len(xs)
+        B, C, hw = _levels_meta(xs)
+        weight = hip.dense_f32(weight) if weight is not None else None
+        bias = hip.dense_f32(bias) if bias is not None else None
+        dev = xs[0].device
+        ws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)
+        stats = torch.empty((L * B * groups, 2), dtype=torch.float32, device=dev)
+        ys = [torch.empty_like(x) for x in xs]
+        hip.check(lib.lgd_gn_group_fwd(hip.ptr_array(xs), hw, L, B, C, groups, hip.ptr(weight) if weight is not None else None,
+                                       hip.ptr(bias) if bias is not None else None, int(relu), hip.ptr(ws), hip.ptr(stats),
+                                       hip.ptr_array(ys), hip.stream_ptr()), "lgd_gn_group_fwd")
+        ctx.save_for_backward(stats, weight, bias, *xs)
+        ctx.meta = (groups, bool(relu), L, B, C, hw)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = hip.load()
+        groups, relu, L, B, C, hw = ctx.meta
+        stats, weight, bias, *xs = ctx.saved_tensors
+        dys = [hip.dense_f32(d) for d in dys]
+        dev = xs[0].device
+        ws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)
+        bstats = torch.empty((L * B * groups, 2), dtype=torch.float32, device=dev)
+        psums = torch.empty((L * B, C, 2), dtype=torch.float32, device=dev)
+        dxs = [torch.empty_like(x) for x in xs]
+        hip.check(lib.lgd_gn_group_bwd(hip.ptr_array(xs), hip.ptr_array(dys), hw, L, B, C, groups,
+                                       hip.ptr(weight) if weight is not None else None, hip.ptr(bias) if bias is not None else None,
+                                       int(relu), hip.ptr(stats), hip.ptr(ws), hip.ptr(bstats), hip.ptr(psums), hip.ptr_array(dxs),
+                                       hip.stream_ptr()), "lgd_gn_group_bwd")
+        s = psums.sum(0) if (weight is not None or bias is not None) else None
+        dw = s[:, 1].contiguous() if weight is not None and ctx.needs_input_grad[2] else None
+        db = s[:, 0].contiguous() if bias is not None and ctx.needs_input_grad[3] else None
+        return (None, None, dw, db, *dxs)
+
+
+def group_norm_relu(xs, groups, weight=None, bias=None, relu=True):
+    """nn.GroupNorm(groups, C)(x) [+ ReLU] with ONE module applied to a list of maps (B,C,H_l,W_l) in one call
+    [ref: thirdparty_heads/fcos.py:455-470 tower layers]."""
+    return list(_GroupNormRelu.apply(int(groups), bool(relu), weight, bias, *xs))
+
+
 class _CtxRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cvec, *xs):
@@ -733,7 +781,7 @@ class _Conv3x3(torch.autograd.Function):
         fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
         _count_bytes("wino_in_kernel", (px + fb) * Ci)
         _count_bytes("wino_out_kernel", (px + fb) * Co)
-        M = torch.bmm(U, V, out=_freq_buf(nf, Co, T, dev))
+        M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
         ys = [torch.empty((N, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
         hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(b) if b is not None else None, hw, L, N, Co, tile, 0, int(relu),
                                    hip.ptr_array(ys), hip.stream_ptr()), "lgd_wino_out")
@@ -769,7 +817,7 @@ class _Conv3x3(torch.autograd.Function):
             dM = _freq_buf(nf, Co, T, dev) if need_w else None
             hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, hw, L, N, Co, tile, flip, hip.ptr(Vd),
                                       hip.ptr(dM) if need_w else None, hip.stream_ptr()), "lgd_wino_in")
-            Md = torch.bmm(Ut, Vd, out=_freq_buf(nf, Ci, T, dev))
+            Md = _timed_bmm("wino_gemm_dx", Ut, Vd, out=_freq_buf(nf, Ci, T, dev))
             del Vd
             dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
             hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, flip, 0, hip.ptr_array(dxs), hip.stream_ptr()),
@@ -781,7 +829,7 @@ class _Conv3x3(torch.autograd.Function):
             hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
                       "lgd_wino_out_t")
         if need_w:
-            dU = torch.bmm(dM, V.transpose(1, 2))
+            dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
             dw = torch.mm(_wino_gg(dev, tile).t(), dU.view(nf, Co * Ci)).t().reshape(Co, Ci, 3, 3)
             if has_bias and ctx.needs_input_grad[1]:
                 # A's row of the interpolation point 1 is all ones: that frequency of dM = A g A^T is the tile's gradient sum
@@ -801,17 +849,37 @@ def enable_tuned_gemms(path=None):
     path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
     if not os.path.exists(path):
         return False
+    global _TUNED_GEMM
     import torch.cuda.tunable as tunable
     tunable.enable(True)
     tunable.tuning_enable(False)
-    return bool(tunable.read_file(path))
+    _TUNED_GEMM = bool(tunable.read_file(path))  # TunableOp rejects a table whose validators (ROCm / BLAS versions) differ
+    if not _TUNED_GEMM:
+        tunable.enable(False)
+    return _TUNED_GEMM
 
 
-_TUNED_GEMM = enable_tuned_gemms()
+_TUNED_GEMM = False  # set by enable_tuned_gemms(); Trainer / bench.py opt in, importing this module changes nothing
 _WINO_TILE = int(os.environ.get("LGD_WINO_TILE", "4"))  # output tile of the minimal-filtering form: 4 -> F(4x4,3x3), 2 -> F(2x2,3x3)
 _WINO_MIN_TILES = int(os.environ.get("LGD_WINO_MIN_TILES", "2000"))
 _WINO_MIN_CH = int(os.environ.get("LGD_WINO_MIN_CH", "64"))
 _WINO_ON = os.environ.get("LGD_WINO", "1") != "0"
+
+
+def conv3x3_backend(winograd=None, min_tiles=None, tile=None):
+    """run-time form of the LGD_WINO / LGD_WINO_MIN_TILES / LGD_WINO_TILE debug switches (tests force the Winograd kernels
+    onto small problems, or the library convolutions onto large ones); returns the previous (winograd, min_tiles, tile)."""
+    global _WINO_ON, _WINO_MIN_TILES, _WINO_TILE
+    prev = (_WINO_ON, _WINO_MIN_TILES, _WINO_TILE)
+    if winograd is not None:
+        _WINO_ON = bool(winograd)
+    if min_tiles is not None:
+        _WINO_MIN_TILES = int(min_tiles)
+    if tile is not None:
+        if int(tile) not in (2, 4):
+            raise ValueError("tile must be 2 or 4")
+        _WINO_TILE = int(tile)
+    return prev
 
 
 def _wino_ok(xs, w):
@@ -872,6 +940,34 @@ def anchor_match(anchors, gt_boxes, gt_classes, counts, iou_lo, iou_hi, num_clas
                                           int(num_classes), int(bool(allow_low_quality)), hip.ptr(ws) if T else None,
                                           hip.ptr(labels), hip.ptr(matched), hip.stream_ptr()), "lgd_anchor_match")
     return labels, matched
+
+
+def fcos_targets(shifts, strides, sizes_of_interest, gt_boxes, gt_classes, counts, num_classes, radius, img_off=None):
+    """FCOS ground-truth assignment for the mini-batch in one launch [ref: thirdparty_heads/fcos.py:177-284]: shifts = list of
+    per-level (HW,2) centres; gt_boxes (T,4) / gt_classes (T,) concatenated image-major (None when T = 0), counts = boxes
+    per image.  Returns classes (B,R) int64 (num_classes = background), ltrb deltas (B,R,4), centerness (B,R)."""
+    hip.require_gpu(*shifts)
+    dev = shifts[0].device
+    pts = hip.dense_f32(torch.cat(list(shifts), 0))
+    L, R, B, T = len(shifts), pts.shape[0], len(counts), int(sum(counts))
+    if img_off is None:
+        img_off = torch.tensor(_offsets(counts), dtype=torch.int32).to(dev, non_blocking=True)
+    locs = hip.int_array([s.shape[0] for s in shifts])
+    fa = lambda v: (ctypes.c_float * len(v))(*[float(x) for x in v])  # noqa: E731
+    lo, hi = fa([s[0] for s in sizes_of_interest]), fa([s[1] for s in sizes_of_interest])
+    rad = fa([float(st) * float(radius) for st in strides])
+    cls = torch.empty((B, R), dtype=torch.int64, device=dev)
+    deltas = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
+    ctr = torch.empty((B, R), dtype=torch.float32, device=dev)
+    if T:
+        gt_boxes = hip.dense_f32(gt_boxes)
+        gt_classes = gt_classes.to(torch.int64).contiguous()
+    c = lambda a: ctypes.cast(a, ctypes.c_void_p)  # noqa: E731
+    hip.check(hip.load().lgd_fcos_targets(hip.ptr(pts), c(locs), c(lo), c(hi), c(rad), L, R, hip.ptr(gt_boxes) if T else None,
+                                          hip.ptr(gt_classes) if T else None, hip.ptr(img_off), B, T, int(num_classes),
+                                          int(radius > 0), hip.ptr(cls), hip.ptr(deltas), hip.ptr(ctr), hip.stream_ptr()),
+              "lgd_fcos_targets")
+    return cls, deltas, ctr
 
 
 # ------------------------------------------------------------------------------------------------ DCNv2 (config 5)
@@ -968,13 +1064,8 @@ class _BiasAct(torch.autograd.Function):
 
 
 def bias_act(x, bias=None, residual=None, relu=True):
-    """relu(x + bias.view(1,-1,1,1) + residual) for NCHW fp32 maps on the GPU (plain torch ops elsewhere)."""
-    if x.is_cuda and x.dtype == torch.float32:
-        return _BiasAct.apply(x, bias, residual, bool(relu))
-    y = x if bias is None else x + bias.view(1, -1, 1, 1)
-    if residual is not None:
-        y = y + residual
-    return F.relu(y) if relu else y
+    """relu(x + bias.view(1,-1,1,1) + residual) for NCHW fp32 maps in one pass."""
+    return _BiasAct.apply(x, bias, residual, bool(relu))
 
 
 class _Conv1x1(torch.autograd.Function):
@@ -1027,6 +1118,8 @@ def kernel_timer_enable(on):
     _TIMER_ON = bool(on)
     if on:
         _ALG_BYTES.clear()
+        _GEMM_FLOPS.clear()
+        _GEMM_EVENTS.clear()
 
 
 def kernel_alg_bytes():
@@ -1035,17 +1128,49 @@ def kernel_alg_bytes():
 
 
 def kernel_timer_collect():
-    """{kernel name: (launches, total_ms)} since the last collect (synchronises the recorded events)."""
+    """{kernel name: (launches, total_ms, min_ms, max_ms)} since the last collect (synchronises the recorded events); the
+    library GEMMs of the Winograd convolutions (torch.bmm, timed with events on torch's current stream = their launch
+    stream) appear as 'wino_gemm_fwd' / 'wino_gemm_dx' / 'wino_gemm_dw'."""
     import ctypes
     lib = hip.load()
-    names = ctypes.create_string_buffer(4096)
-    ms = (ctypes.c_double * 64)()
-    cnt = (ctypes.c_int32 * 64)()
-    n = lib.lgd_timing_collect(names, 4096, ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p), 64)
+    names = ctypes.create_string_buffer(8192)
+    ms, mn, mx = (ctypes.c_double * 128)(), (ctypes.c_double * 128)(), (ctypes.c_double * 128)()
+    cnt = (ctypes.c_int32 * 128)()
+    c = lambda a: ctypes.cast(a, ctypes.c_void_p)  # noqa: E731
+    n = lib.lgd_timing_collect_ex(names, 8192, c(ms), c(mn), c(mx), c(cnt), 128)
     out, off = {}, 0
     raw = names.raw
     for i in range(n):
         end = raw.index(b"\0", off)
-        out[raw[off:end].decode()] = (int(cnt[i]), float(ms[i]))
+        out[raw[off:end].decode()] = (int(cnt[i]), float(ms[i]), float(mn[i]), float(mx[i]))
         off = end + 1
+    if _GEMM_EVENTS:
+        torch.cuda.synchronize()
+        for name, a, b in _GEMM_EVENTS:
+            t = a.elapsed_time(b)
+            n0, s0, lo, hi = out.get(name, (0, 0.0, 1e300, 0.0))
+            out[name] = (n0 + 1, s0 + t, min(lo, t), max(hi, t))
+        _GEMM_EVENTS.clear()
     return out
+
+
+_GEMM_EVENTS = []
+_GEMM_FLOPS = {}
+
+
+def _timed_bmm(name, a, b, out=None):
+    """torch.bmm, bracketed by an event pair on the current stream while the kernel timer is on (bench.py's MFMA roofline)."""
+    if not _TIMER_ON:
+        return torch.bmm(a, b, out=out) if out is not None else torch.bmm(a, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = torch.bmm(a, b, out=out) if out is not None else torch.bmm(a, b)
+    e1.record()
+    _GEMM_EVENTS.append((name, e0, e1))
+    _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + 2 * a.shape[0] * a.shape[1] * a.shape[2] * b.shape[2]
+    return r
+
+
+def kernel_gemm_flops():
+    """{gemm name: floating-point operations summed over the launches since kernel_timer_enable(True)}."""
+    return dict(_GEMM_FLOPS)

@@ -14,9 +14,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..registry import CUSTOMIZED_DETECTORS_REGISTRY
 from ..structures import ImageList
-from .retinanet import batched_nms, build_resnet_fpn, sigmoid_focal_sum
-
-INF = float("inf")
+from .retinanet import batched_nms, build_resnet_fpn
 
 
 class Scale(nn.Module):
@@ -56,15 +54,19 @@ class FCOSHead(nn.Module):
         self.scales = nn.ModuleList([Scale(1.0) for _ in self.fpn_strides])
 
     def forward(self, features):
-        # the towers share their filters across levels: every conv is ONE pass over the concatenated pyramid
+        """features: the L pyramid levels, or 2L maps (student + teacher pyramids, one pass).  Every tower layer is ONE
+        Winograd conv over all maps + ONE fused GroupNorm(32)+ReLU call over all maps."""
+        nl = len(self.fpn_strides)
         c = b = list(features)
         for i in range(0, len(self.cls_subnet), 3):
-            c = [self.cls_subnet[i + 2](self.cls_subnet[i + 1](t)) for t in self.cls_subnet[i].levels(c)]
-            b = [self.bbox_subnet[i + 2](self.bbox_subnet[i + 1](t)) for t in self.bbox_subnet[i].levels(b)]
+            gc, gb = self.cls_subnet[i + 1], self.bbox_subnet[i + 1]
+            c = ops.group_norm_relu(self.cls_subnet[i].levels(c), gc.num_groups, gc.weight, gc.bias, relu=True)
+            b = ops.group_norm_relu(self.bbox_subnet[i].levels(b), gb.num_groups, gb.weight, gb.bias, relu=True)
         logits = self.cls_score.levels(c)
         ctr = self.centerness.levels(b if self.centerness_on_reg else c)
         reg = []
-        for lvl, r in enumerate(self.bbox_pred.levels(b)):
+        for i, r in enumerate(self.bbox_pred.levels(b)):
+            lvl = i % nl
             r = self.scales[lvl](r)
             reg.append(F.relu(r) * self.fpn_strides[lvl] if self.norm_reg_targets else torch.exp(r))
         return logits, reg, ctr
@@ -149,65 +151,38 @@ class FCOSCT(nn.Module):
 
     @torch.no_grad()
     def get_ground_truth(self, shifts, targets):
-        """centre sampling + scale ranges + min-area tie break [ref: thirdparty_heads/fcos.py:177-284]."""
-        all_shifts = torch.cat(shifts, 0)  # (R,2)
-        soi = torch.cat([all_shifts.new_tensor(s)[None].expand(len(sh), -1) for sh, s in zip(shifts, self.object_sizes_of_interest)], 0)
-        gt_classes, gt_deltas, gt_ctr = [], [], []
-        for t in targets:
-            if len(t) == 0:
-                gt_classes.append(torch.full((len(all_shifts),), self.num_classes, dtype=torch.int64, device=all_shifts.device))
-                gt_deltas.append(torch.zeros((len(all_shifts), 4), device=all_shifts.device))
-                gt_ctr.append(torch.zeros((len(all_shifts),), device=all_shifts.device))
-                continue
-            gb = t.gt_boxes.tensor  # (M,4)
-            deltas = torch.cat((all_shifts[None] - gb[:, None, :2], gb[:, None, 2:] - all_shifts[None]), -1)  # (M,R,4) ltrb
-            if self.center_sampling_radius > 0:
-                centers = (gb[:, :2] + gb[:, 2:]) / 2
-                inside = []
-                for stride, sh in zip(self.fpn_strides, shifts):
-                    rad = stride * self.center_sampling_radius
-                    cb = torch.cat((torch.max(centers - rad, gb[:, :2]), torch.min(centers + rad, gb[:, 2:])), -1)
-                    cd = torch.cat((sh[None] - cb[:, None, :2], cb[:, None, 2:] - sh[None]), -1)
-                    inside.append(cd.min(-1).values > 0)
-                inside = torch.cat(inside, 1)
-            else:
-                inside = deltas.min(-1).values > 0
-            mx = deltas.max(-1).values
-            cared = (mx >= soi[None, :, 0]) & (mx <= soi[None, :, 1])
-            area = ((gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1]))[:, None].expand(-1, len(all_shifts))
-            area = torch.where(inside & cared, area, torch.full_like(area, INF))
-            min_area, idx = area.min(0)
-            d = torch.cat((all_shifts - gb[idx][:, :2], gb[idx][:, 2:] - all_shifts), -1)
-            cls = t.gt_classes[idx].to(torch.int64)
-            cls = torch.where(min_area == INF, torch.full_like(cls, self.num_classes), cls)
-            lr, tb = d[:, [0, 2]], d[:, [1, 3]]
-            ctr = torch.sqrt((lr.min(-1).values / lr.max(-1).values).clamp(min=0) * (tb.min(-1).values / tb.max(-1).values).clamp(min=0))
-            gt_classes.append(cls)
-            gt_deltas.append(d)
-            gt_ctr.append(ctr)
-        return torch.stack(gt_classes), torch.stack(gt_deltas), torch.stack(gt_ctr)
+        """centre sampling + scale ranges + min-area tie break for the whole mini-batch in ONE HIP launch
+        [ref: thirdparty_heads/fcos.py:177-284] -> (gt_classes (B,R), gt_shifts_deltas (B,R,4), gt_centerness (B,R))."""
+        counts = [len(t) for t in targets]
+        if sum(counts):
+            gb = torch.cat([t.gt_boxes.tensor for t in targets if len(t)], 0)
+            gc = torch.cat([t.gt_classes for t in targets if len(t)], 0)
+        else:
+            gb = gc = None
+        return ops.fcos_targets(shifts, self.fpn_strides, self.object_sizes_of_interest, gb, gc, counts, self.num_classes,
+                                self.center_sampling_radius)
+
+    @staticmethod
+    def reduce_counts(counts):
+        """rank-mean of (num_fg, sum of foreground centerness): ONE packed all-reduce instead of the reference's two
+        scalar ones (fcos.py:141,143)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(counts)
+            counts = counts / dist.get_world_size()
+        return counts
 
     def losses(self, gt_classes, gt_shifts_deltas, gt_centerness, pred_class_logits, pred_shift_deltas, pred_centerness):
-        """[ref: thirdparty_heads/fcos.py:107-175] without boolean-index gathers / host syncs."""
-        logits = None if pred_class_logits[0].is_cuda else _flatten_levels(pred_class_logits, self.num_classes)
+        """[ref: thirdparty_heads/fcos.py:107-175] without boolean-index gathers / host syncs; the focal loss is the fused
+        HIP kernel on the raw (N, K, H, W) logits."""
         deltas = _flatten_levels(pred_shift_deltas, 4)
         ctr = _flatten_levels(pred_centerness, 1).squeeze(-1)
-        valid = gt_classes >= 0
-        fg = valid & (gt_classes != self.num_classes)
+        fg = (gt_classes >= 0) & (gt_classes != self.num_classes)
         gt_ctr = torch.where(fg, gt_centerness, torch.zeros_like(gt_centerness))
-        counts = torch.stack((fg.sum().to(torch.float32), gt_ctr.sum()))
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(counts)  # one packed all-reduce instead of two (fcos.py:141,143)
-            counts = counts / dist.get_world_size()
+        counts = self.reduce_counts(torch.stack((fg.sum().to(torch.float32), gt_ctr.sum())))
         num_fg, num_targets = counts[0].clamp(min=1.0), counts[1].clamp(min=1.0)
-        if pred_class_logits[0].is_cuda:  # fused HIP kernel on the raw (N, K, H, W) outputs
-            from .. import ops
-            hw = [tuple(x.shape[-2:]) for x in pred_class_logits]
-            loss_cls = ops.focal_loss_sum(pred_class_logits, ops.label_planes(gt_classes, hw, 1), 1, self.num_classes,
-                                          self.focal_loss_alpha, self.focal_loss_gamma) / num_fg
-        else:
-            loss_cls = sigmoid_focal_sum(logits, gt_classes, valid, self.num_classes, self.focal_loss_alpha,
-                                         self.focal_loss_gamma) / num_fg
+        hw = [tuple(x.shape[-2:]) for x in pred_class_logits]
+        loss_cls = ops.focal_loss_sum(pred_class_logits, ops.label_planes(gt_classes, hw, 1), 1, self.num_classes,
+                                      self.focal_loss_alpha, self.focal_loss_gamma) / num_fg
         safe_t = torch.where(fg[..., None], gt_shifts_deltas, torch.ones_like(gt_shifts_deltas))
         safe_p = torch.where(fg[..., None], deltas, torch.ones_like(deltas))
         loss_box = (torch.where(fg, giou_ltrb_loss(safe_p, safe_t) * gt_ctr, torch.zeros_like(gt_ctr))).sum() / num_targets
@@ -215,17 +190,30 @@ class FCOSCT(nn.Module):
         loss_ctr = torch.where(fg, bce, torch.zeros_like(bce)).sum() / num_fg
         return {"loss_cls": loss_cls, "loss_box_reg": loss_box, "loss_centerness": loss_ctr}
 
-    def forward(self, batched_inputs):
-        """[ref: customized_detectors/fcos.py:36-63]"""
+    def backbone_features(self, batched_inputs):
+        """bottom-up + FPN only (see RetinaNetCT.backbone_features)."""
         images = self.preprocess_image(batched_inputs)
         raw_features = self.raw_backbone(images.tensor)
         features = self.fpn(raw_features)
-        features = [features[f] for f in self.in_features]
-        shifts, box_cls, box_delta, box_center = self.predict(features)
-        features = dict(zip(self.in_features, features))
+        features = {f: features[f] for f in self.in_features}
+        gt_instances = None
         if self.training:
             assert "instances" in batched_inputs[0], "Instance annotations are missing in training!"
             gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        return raw_features, features, images, gt_instances
+
+    def predict_pair(self, feats_a, feats_b):
+        """predict() on two pyramids with ONE head pass (see RetinaNetCT.predict_pair):
+        shifts, (cls_a, delta_a, center_a), (cls_b, delta_b, center_b)."""
+        L = len(feats_a)
+        cls, reg, ctr = self.head(list(feats_a) + list(feats_b))
+        return self.shift_generator(feats_a), (cls[:L], reg[:L], ctr[:L]), (cls[L:], reg[L:], ctr[L:])
+
+    def forward(self, batched_inputs):
+        """[ref: customized_detectors/fcos.py:36-63]"""
+        raw_features, features, images, gt_instances = self.backbone_features(batched_inputs)
+        shifts, box_cls, box_delta, box_center = self.predict([features[f] for f in self.in_features])
+        if self.training:
             gt = self.get_ground_truth(shifts, gt_instances)
             losses = self.losses(*gt, box_cls, box_delta, box_center)
             return losses, raw_features, features, images, gt

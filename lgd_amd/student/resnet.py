@@ -45,16 +45,11 @@ class ConvBN(nn.Conv2d):
         w = self.weight * scale.view(-1, 1, 1, 1)
         if self._plain3x3 and residual is None:  # 3x3 / stride 1: Winograd transforms + GEMMs (bias + ReLU fused in the output transform)
             return ops.conv3x3(x, w, shift, relu=relu)
-        if x.is_cuda:
-            if self._pointwise:
-                y = ops.conv1x1(x, w)
-            else:
-                y = F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
-            return ops.bias_act(y, shift, residual, relu)
-        y = F.conv2d(x, w, shift, self.stride, self.padding, self.dilation, self.groups)
-        if residual is not None:
-            y = y + residual
-        return F.relu_(y) if relu else y
+        if self._pointwise:
+            y = ops.conv1x1(x, w)
+        else:
+            y = F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
+        return ops.bias_act(y, shift, residual, relu)
 
 
 class Bottleneck(nn.Module):

@@ -8,7 +8,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..registry import CUSTOMIZED_DETECTORS_REGISTRY
@@ -95,16 +94,6 @@ def pairwise_iou(a, b):
     return torch.where(inter > 0, inter / (area_a[:, None] + area_b[None, :] - inter), torch.zeros_like(inter))
 
 
-def box_deltas(src, dst, weights=(1.0, 1.0, 1.0, 1.0)):
-    """Box2BoxTransform.get_deltas"""
-    sw, sh = src[..., 2] - src[..., 0], src[..., 3] - src[..., 1]
-    sx, sy = src[..., 0] + 0.5 * sw, src[..., 1] + 0.5 * sh
-    dw, dh = dst[..., 2] - dst[..., 0], dst[..., 3] - dst[..., 1]
-    dx, dy = dst[..., 0] + 0.5 * dw, dst[..., 1] + 0.5 * dh
-    wx, wy, ww, wh = weights
-    return torch.stack((wx * (dx - sx) / sw, wy * (dy - sy) / sh, ww * torch.log(dw / sw), wh * torch.log(dh / sh)), -1)
-
-
 def apply_deltas(deltas, boxes, weights=(1.0, 1.0, 1.0, 1.0), clamp=math.log(1000.0 / 16)):
     w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
     cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
@@ -112,19 +101,6 @@ def apply_deltas(deltas, boxes, weights=(1.0, 1.0, 1.0, 1.0), clamp=math.log(100
     dw, dh = (deltas[:, 2] / weights[2]).clamp(max=clamp), (deltas[:, 3] / weights[3]).clamp(max=clamp)
     pcx, pcy, pw, ph = dx * w + cx, dy * h + cy, torch.exp(dw) * w, torch.exp(dh) * h
     return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), 1)
-
-
-def sigmoid_focal_sum(logits, labels, valid, num_classes, alpha, gamma):
-    """sum over valid anchors and classes of fvcore's sigmoid focal loss, the one-hot target given
-    implicitly by integer labels (num_classes = background).  logits (B,R,K), labels (B,R)."""
-    t = (labels[..., None] == torch.arange(num_classes, device=labels.device)).to(logits.dtype)
-    p = torch.sigmoid(logits)
-    ce = F.binary_cross_entropy_with_logits(logits, t, reduction="none")
-    p_t = p * t + (1 - p) * (1 - t)
-    loss = ce * (1 - p_t) ** gamma
-    if alpha >= 0:
-        loss = (alpha * t + (1 - alpha) * (1 - t)) * loss
-    return (loss * valid[..., None].to(loss.dtype)).sum()
 
 
 class HeadOutputs(list):
@@ -229,92 +205,92 @@ class RetinaNetCT(nn.Module):
 
     @torch.no_grad()
     def label_anchors(self, anchors, gt_instances):
-        """IoU matcher, thresholds [0.4,0.5] -> labels [0,-1,1], low-quality matches allowed;
-        background -> num_classes, ignore -> -1.  All images in one batched IoU when they have
-        the same number of boxes is not assumed: the loop is over images, tensors stay on device."""
+        """detectron2 Matcher (thresholds [0.4,0.5] -> labels [0,-1,1], low-quality matches allowed; background ->
+        num_classes, ignore -> -1) for the whole mini-batch in two HIP launches, no IoU matrix, tensors stay on the device
+        [call site ref: retinanet.py:66-67].  The int32 label planes the fused loss kernels read are built here, once per
+        iteration, and shared by the student and the teacher `losses()` calls."""
+        if tuple(self.iou_labels) != (0, -1, 1):
+            raise ValueError("IOU_LABELS %s not supported (shipped configs use [0, -1, 1])" % (self.iou_labels,))
         A = torch.cat(anchors, 0)
         lo, hi = self.iou_thresholds
-        if A.is_cuda and tuple(self.iou_labels) == (0, -1, 1):  # the whole mini-batch in two HIP launches, no IoU matrix
-            counts = [len(inst) for inst in gt_instances]
-            if sum(counts):
-                gb = torch.cat([inst.gt_boxes.tensor for inst in gt_instances if len(inst)], 0)
-                gc = torch.cat([inst.gt_classes for inst in gt_instances if len(inst)], 0)
-            else:
-                gb = gc = None
-            labels, matched = ops.anchor_match(A, gb, gc, counts, lo, hi, self.num_classes, True)
-            return list(labels.unbind(0)), list(matched.unbind(0))
-        return self._label_anchors_torch(A, gt_instances)
-
-    def _label_anchors_torch(self, A, gt_instances):
-        """the same matching as elementwise torch ops per image (CPU tests; the HIP path is checked against it)."""
-        gt_labels, gt_boxes = [], []
-        lo, hi = self.iou_thresholds
-        for inst in gt_instances:
-            if len(inst) == 0:
-                gt_labels.append(torch.full((A.shape[0],), self.num_classes, dtype=torch.int64, device=A.device))
-                gt_boxes.append(torch.zeros_like(A))
-                continue
-            gb = inst.gt_boxes.tensor
-            iou = pairwise_iou(gb, A)
-            vals, idx = iou.max(0)
-            l0, l1, l2 = (torch.full_like(idx, v) for v in self.iou_labels)
-            lab = torch.where(vals >= hi, l2, torch.where(vals >= lo, l1, l0))
-            best_per_gt = iou.max(1, keepdim=True)[0]
-            lab = torch.where((iou == best_per_gt).any(0), torch.ones_like(lab), lab)  # allow_low_quality_matches
-            cls = inst.gt_classes[idx].to(torch.int64)
-            cls = torch.where(lab == 0, torch.full_like(cls, self.num_classes), cls)
-            cls = torch.where(lab == -1, torch.full_like(cls, -1), cls)
-            gt_labels.append(cls)
-            gt_boxes.append(gb[idx])
+        counts = [len(inst) for inst in gt_instances]
+        if sum(counts):
+            gb = torch.cat([inst.gt_boxes.tensor for inst in gt_instances if len(inst)], 0)
+            gc = torch.cat([inst.gt_classes for inst in gt_instances if len(inst)], 0)
+        else:
+            gb = gc = None
+        labels, matched = ops.anchor_match(A, gb, gc, counts, lo, hi, self.num_classes, True)
+        gt_labels, gt_boxes = list(labels.unbind(0)), list(matched.unbind(0))
+        self._remember_targets(gt_labels, labels, matched)
         return gt_labels, gt_boxes
+
+    def _remember_targets(self, gt_labels, labels, matched):
+        """this iteration's stacked targets.  The cache holds a strong reference to the first label tensor and is matched
+        by identity (`is`), so a recycled object address can never alias a later batch's targets."""
+        self._target_cache = {"src": gt_labels[0], "n": len(gt_labels), "labels": labels, "matched": matched,
+                              "hw": None, "planes": None}
+
+    def _targets_for(self, gt_labels, gt_boxes, raw):
+        """stacked labels / matched boxes / int32 label planes for these targets (built once, shared by both losses() calls)."""
+        c = getattr(self, "_target_cache", None)
+        if c is None or c["src"] is not gt_labels[0] or c["n"] != len(gt_labels):
+            self._remember_targets(gt_labels, torch.stack(gt_labels), torch.stack(gt_boxes))
+            c = self._target_cache
+        hw = [tuple(x.shape[-2:]) for x in raw]
+        if c["planes"] is None or c["hw"] != hw:
+            c["planes"], c["hw"] = ops.label_planes(c["labels"], hw, raw[0].shape[1] // self.num_classes), hw
+        return c
 
     def losses(self, anchors, pred_logits, gt_labels, pred_anchor_deltas, gt_boxes):
         """[d2-memory RetinaNet.losses]; the EMA normaliser advances on EVERY call -- the distillator
-        calls this twice per iteration (student and teacher features, distillator.py:110)."""
-        labels = torch.stack(gt_labels)  # (B,R)
+        calls this twice per iteration (student and teacher features, distillator.py:110).
+        Fused HIP kernels on the head's raw NCHW outputs: no permute copies, no one-hot, no target deltas for all anchors,
+        no host sync (d2 calls `.item()` on the positive count)."""
+        raw, raw_d = getattr(pred_logits, "raw", None), getattr(pred_anchor_deltas, "raw", None)
+        if raw is None or raw_d is None:
+            raise TypeError("losses() expects the HeadOutputs returned by predict()")
+        c = self._targets_for(gt_labels, gt_boxes, raw)
+        labels = c["labels"]
         A = torch.cat(anchors, 0)
-        valid = labels >= 0
-        pos = valid & (labels != self.num_classes)
-        num_pos = pos.sum().to(torch.float32)
+        num_pos = ((labels >= 0) & (labels != self.num_classes)).sum().to(torch.float32)
         self.loss_normalizer = (self.loss_normalizer_momentum * self.loss_normalizer
                                 + (1 - self.loss_normalizer_momentum) * num_pos.clamp(min=1.0)).detach()
-        raw, raw_d = getattr(pred_logits, "raw", None), getattr(pred_anchor_deltas, "raw", None)
-        if raw is not None and raw_d is not None and raw[0].is_cuda:
-            # fused HIP kernels on the head's NCHW outputs: no permute copies, no one-hot, no target deltas for all anchors
-            from .. import ops
-            nA = raw[0].shape[1] // self.num_classes
-            key = (id(gt_labels[0]), len(gt_labels))
-            if getattr(self, "_label_plane_key", None) != key:  # student and teacher passes share the same targets
-                hw = [tuple(x.shape[-2:]) for x in raw]
-                self._label_planes = ops.label_planes(labels, hw, nA)
-                self._matched = torch.stack(gt_boxes)
-                self._label_plane_key = key
-            loss_cls = ops.focal_loss_sum(raw, self._label_planes, nA, self.num_classes, self.focal_loss_alpha, self.focal_loss_gamma)
-            loss_box = ops.box_reg_loss_sum(raw_d, self._label_planes, A, self._matched, nA, self.num_classes,
-                                            self.smooth_l1_beta, self.bbox_reg_weights)
-        else:
-            gt_deltas = box_deltas(A[None], torch.stack(gt_boxes), self.bbox_reg_weights)
-            deltas = torch.cat(list(pred_anchor_deltas), 1)
-            loss_cls = sigmoid_focal_sum(torch.cat(list(pred_logits), 1), labels, valid, self.num_classes,
-                                         self.focal_loss_alpha, self.focal_loss_gamma)
-            diff = (deltas - torch.where(pos[..., None], gt_deltas, deltas.detach())).abs()
-            if self.smooth_l1_beta >= 1e-5:
-                b = self.smooth_l1_beta
-                diff = torch.where(diff < b, 0.5 * diff * diff / b, diff - 0.5 * b)
-            loss_box = (diff * pos[..., None].to(diff.dtype)).sum()
+        nA = raw[0].shape[1] // self.num_classes
+        loss_cls = ops.focal_loss_sum(raw, c["planes"], nA, self.num_classes, self.focal_loss_alpha, self.focal_loss_gamma)
+        loss_box = ops.box_reg_loss_sum(raw_d, c["planes"], A, c["matched"], nA, self.num_classes,
+                                        self.smooth_l1_beta, self.bbox_reg_weights)
         return {"loss_cls": loss_cls / self.loss_normalizer, "loss_box_reg": loss_box / self.loss_normalizer}
 
-    def forward(self, batched_inputs):
-        """[ref: retinanet.py:45-81]"""
+    def backbone_features(self, batched_inputs):
+        """bottom-up + FPN only (no head pass): (raw_features, features dict, images, gt_instances | None).  The
+        distillator defers the student's head pass until the teacher features exist and runs the head ONCE over both
+        (ref: distillator.py:107-112 re-runs student.predict on the teacher features)."""
         images = self.preprocess_image(batched_inputs)
         raw_features = self.raw_backbone(images.tensor)
         features = self.fpn(raw_features)
-        features = [features[f] for f in self.head_in_features]
-        anchors, pred_logits, pred_anchor_deltas = self.predict(features)
-        features = dict(zip(self.head_in_features, features))
+        features = {f: features[f] for f in self.head_in_features}
+        gt_instances = None
         if self.training:
             assert "instances" in batched_inputs[0], "Instance annotations are missing in training!"
             gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        return raw_features, features, images, gt_instances
+
+    def predict_pair(self, feats_a, feats_b):
+        """predict() on two pyramids with ONE head pass: the 2 x L maps go through every tower conv as one Winograd problem
+        (one filter transform, one GEMM per frequency over both pyramids' tiles, one weight-gradient GEMM), no concat copy.
+        Returns anchors, (logits_a, deltas_a), (logits_b, deltas_b)."""
+        L = len(feats_a)
+        anchors = self.anchor_generator(feats_a)
+        logits, deltas = self.head(list(feats_a) + list(feats_b))
+        K = self.num_classes
+        return (anchors, (HeadOutputs(logits[:L], K), HeadOutputs(deltas[:L], 4)),
+                (HeadOutputs(logits[L:], K), HeadOutputs(deltas[L:], 4)))
+
+    def forward(self, batched_inputs):
+        """[ref: retinanet.py:45-81]"""
+        raw_features, features, images, gt_instances = self.backbone_features(batched_inputs)
+        anchors, pred_logits, pred_anchor_deltas = self.predict([features[f] for f in self.head_in_features])
+        if self.training:
             gt_labels, gt_boxes = self.label_anchors(anchors, gt_instances)
             losses = self.losses(anchors, pred_logits, gt_labels, pred_anchor_deltas, gt_boxes)
             return losses, raw_features, features, images, (gt_labels, gt_boxes)

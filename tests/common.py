@@ -16,7 +16,16 @@ CASES = {
     "c1_ctx_stuguided": (2, 512, 512, True, "stuGuided", "x1y1x2y2", 1.0, 11),
     "c1b_noctx_labelguided_wh": (3, 384, 512, False, "labelGuided", "x1y1wh", 1.0, 11),
     "c1c_noctx_stuguided": (2, 320, 480, False, "stuGuided", "x1y1x2y2", 2.5, 13),
+    # the full BASELINE shape (configs 2 / 3), B=2, 10 boxes/img; losses stored, no gradients
+    "c2_full_ctx_800x1344": (2, 800, 1344, True, "stuGuided", "x1y1x2y2", 1.0, 17),
+    "c3_full_noctx_800x1344": (2, 800, 1344, False, "stuGuided", "x1y1x2y2", 1.0, 19),
 }
+FULL_STRIDE = 997
+SMALL_CASES = [k for k in CASES if "_full_" not in k]
+
+
+def stride_of(name):
+    return FULL_STRIDE if "_full_" in name else SAMPLE_STRIDE
 
 
 def golden(name):
@@ -34,6 +43,8 @@ def case_gt(name):
         gt = synth.synth_gt(2, 320, 480, 6, seed=4)
     elif name == "c2_masks_800x1344":
         gt = synth.synth_gt(8, 800, 1344, 10, seed=0)
+    elif "_full_" in name:
+        gt = synth.synth_gt(2, 800, 1344, 10, seed=0)
     else:
         raise KeyError(name)
     return [(torch.from_numpy(b.copy()), torch.from_numpy(c.copy())) for b, c in gt]
@@ -65,9 +76,9 @@ def rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def sample(t):
+def sample(t, stride=SAMPLE_STRIDE):
     f = t.detach().reshape(-1).double().cpu()
-    return f[::SAMPLE_STRIDE].float().numpy(), float(f.sum()), float((f * f).sum())
+    return f[::stride].float().numpy(), float(f.sum()), float((f * f).sum())
 
 
 def kink_robust_close(a, b, tol=1e-4, max_outlier_frac=5e-4, max_rel=2e-2):

@@ -23,6 +23,8 @@ from oracle import lgd_oracle as O  # noqa: E402
 
 torch.set_num_threads(8)
 SAMPLE_STRIDE = 37
+ONLY = set()  # --only a,b: regenerate just these cases
+FULL_STRIDE = 997  # full-size cases (11.5 M teacher-feature elements)
 
 
 class _Boxes:
@@ -53,9 +55,9 @@ def load_params(module, shapes, gain=1.0):
     return sd
 
 
-def sample(t):
+def sample(t, stride=SAMPLE_STRIDE):
     f = t.detach().reshape(-1).double()
-    return dict(s=f[::SAMPLE_STRIDE].float().numpy(), sum=np.float64(f.sum()), sq=np.float64((f * f).sum()))
+    return dict(s=f[::stride].float().numpy(), sum=np.float64(f.sum()), sq=np.float64((f * f).sum()))
 
 
 def pack_rects(masks_level, hw):
@@ -76,7 +78,11 @@ def pack_rects(masks_level, hw):
 
 
 def run_teacher_case(ref, name, B, H, W, gt, add_ctx, interact, box_format="x1y1x2y2", with_grads=False, coef=1.0,
-                     feat_seed=11):
+                     feat_seed=11, stride=SAMPLE_STRIDE, full_small_levels=True, with_loss=False):
+    """with_grads: distill losses + total loss + gradients; with_loss: the losses only (full-size cases: no backward);
+    stride: sampling stride of the stored teacher features; full_small_levels: also store p6/p7 and their masks whole."""
+    if ONLY and name not in ONLY:
+        return
     cfg = make_cfg(add_ctx=add_ctx, interact=interact, box_format=box_format, coef=coef)
     teacher = ref.DynamicTeacher(cfg)
     load_params(teacher, O.teacher_param_shapes())
@@ -120,13 +126,13 @@ def run_teacher_case(ref, name, B, H, W, gt, add_ctx, interact, box_format="x1y1
         out["app_" + k] = app_outs[i].detach().numpy()
         if attn_outs:
             out["attn_" + k] = attn_outs[i].detach().numpy()
-        if k in ("p6", "p7"):
+        if k in ("p6", "p7") and full_small_levels:
             out["tea_full_" + k] = tea[k].detach().numpy()
             out["mask_bits_" + k] = np.packbits(torch.cat(list(masks[i]), 0).numpy().astype(np.uint8), axis=None)
-        s = sample(tea[k])
+        s = sample(tea[k], stride)
         out["tea_s_" + k], out["tea_sum_" + k], out["tea_sq_" + k] = s["s"], s["sum"], s["sq"]
 
-    if with_grads:
+    if with_grads or with_loss:
         # loss = loss_distill(flag=1) + sum(teacher feats * probe)   (SURVEY.md section 8c viii)
         class D(ref.BaseDistillator):
             def __init__(self):
@@ -144,6 +150,10 @@ def run_teacher_case(ref, name, B, H, W, gt, add_ctx, interact, box_format="x1y1
         probe = {k: torch.from_numpy(synth.det_uniform(tuple(tea[k].shape), 900 + i, -1e-3, 1e-3)) for i, k in enumerate(keys)}
         total = loss + sum((tea[k] * probe[k]).sum() for k in keys)
         out["total_loss"] = np.float64(total.item())
+        if not with_grads:
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "T=%d" % int(out["counts"].sum()), "saved", len(out), "arrays (no grads)")
+            return
         total.backward()
         for k in keys:
             g = sample(feats[k].grad)
@@ -160,6 +170,8 @@ def run_teacher_case(ref, name, B, H, W, gt, add_ctx, interact, box_format="x1y1
 
 def run_mask_case(ref, name, H, W, gt, add_ctx):
     """masks only at a BASELINE config-2 shape: rect bounds for every (level, box)."""
+    if ONLY and name not in ONLY:
+        return
     descs, boxlists, _ = ref.box_descriptor_encode([b["instances"] for b in to_batched_inputs(gt, H, W)], H, W, 80,
                                                    "one_hot", "x1y1x2y2", add_ctx)
     out = {"counts": np.array([len(b) for b in boxlists], np.int32),
@@ -174,6 +186,8 @@ def run_mask_case(ref, name, H, W, gt, add_ctx):
 
 def run_distill_case(ref, name, B, H, W, coef):
     """BaseDistillator.distill alone on independent closed-form student/teacher pyramids."""
+    if ONLY and name not in ONLY:
+        return
     cfg = make_cfg(coef=coef)
 
     class D(ref.BaseDistillator):
@@ -234,10 +248,18 @@ def main():
     # mask-only at the config-2 shape (800x1344), random + table boxes
     gt2 = synth.synth_gt(8, 800, 1344, 10, seed=0)
     run_mask_case(ref, "c2_masks_800x1344", 800, 1344, gt2, True)
+    # the full BASELINE shape, B=2 800x1344, 10 boxes/img: config 2 (ctx=YES) and config 3 (ctx=NO)
+    gt_f = synth.synth_gt(2, 800, 1344, 10, seed=0)
+    run_teacher_case(ref, "c2_full_ctx_800x1344", 2, 800, 1344, gt_f, True, "stuGuided", with_loss=True, feat_seed=17,
+                     stride=FULL_STRIDE, full_small_levels=False)
+    run_teacher_case(ref, "c3_full_noctx_800x1344", 2, 800, 1344, gt_f, False, "stuGuided", with_loss=True, feat_seed=19,
+                     stride=FULL_STRIDE, full_small_levels=False)
     # distill alone
     run_distill_case(ref, "distill_c1", 2, 512, 512, coef=1.0)
     run_distill_case(ref, "distill_coef", 2, 256, 320, coef=0.37)
 
 
 if __name__ == "__main__":
+    if "--only" in sys.argv:
+        ONLY = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     main()

@@ -75,15 +75,9 @@ def _worker(rank, world, port, q):
         dist.all_gather(gathered, w)
         same = all(torch.equal(gathered[0], g) for g in gathered)
         # FCOS packed all-reduce of (num_fg, sum centerness): both ranks must use the rank-AVERAGED counts
-        from types import SimpleNamespace
         from lgd_amd.student.fcos import FCOSCT
-        obj = SimpleNamespace(num_classes=3, focal_loss_alpha=0.25, focal_loss_gamma=2.0)
-        R = 6
-        gt_cls = torch.full((1, R), 3, dtype=torch.int64)
-        gt_cls[0, :rank + 1] = 0  # rank 0: 1 foreground, rank 1: 2 foreground
-        out = FCOSCT.losses(obj, gt_cls, torch.ones(1, R, 4), torch.full((1, R), 0.5),
-                            [torch.zeros(1, 3, 1, R)], [torch.ones(1, 4, 1, R)], [torch.zeros(1, 1, 1, R)])
-        q.put((rank, flags, frozen, metrics, same, float(out["loss_centerness"])))
+        counts = FCOSCT.reduce_counts(torch.tensor([float(rank + 1), 0.5 * (rank + 1)]))  # rank 0: 1 fg, rank 1: 2 fg
+        q.put((rank, flags, frozen, metrics, same, counts.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -105,6 +99,67 @@ def test_ddp_gloo_world2():
         assert frozen == [True, True, False, False, False, False]  # train.py:205-207 with PRE_FREEZE...=2
         assert same                                    # replicas stay identical (gradients were averaged)
     assert res[0][3] == res[1][3]                      # metrics are rank-averaged by the single all-reduce
-    import math
-    # centerness BCE at logit 0 = ln 2 per foreground; normaliser = mean foreground count over ranks = 1.5
-    assert abs(res[0][5] - 1 * math.log(2) / 1.5) < 1e-6 and abs(res[1][5] - 2 * math.log(2) / 1.5) < 1e-6
+    assert res[0][5] == [1.5, 0.75] and res[1][5] == [1.5, 0.75]  # one packed all-reduce, mean over ranks
+
+
+def _real_tree_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lgd_amd import config
+        from lgd_amd.distillator import build_model
+        from lgd_amd.engine import Trainer
+        from torch.nn.parallel import DistributedDataParallel
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_fcos_r50.yaml"),
+                               ["MODEL.DEVICE", "cpu", "MODEL.DISTILLATOR.PRE_NONDISTILL_ITERS", "3",
+                                "MODEL.DISTILLATOR.PRE_FREEZE_STUDENT_BACKBONE_ITERS", "2", "SOLVER.MAX_ITER", "100"])
+        torch.manual_seed(0)
+        model = build_model(cfg)  # the REAL DistillatorFCOS module tree: aliased FPN, frozen stem/res2, never-trained ctx proj
+
+        # the HIP kernels have no CPU form, so the forward is replaced by a loss that touches exactly the parameters the real
+        # forward trains in each phase (rank-dependent, so that unsynchronised replicas would drift apart)
+        def forward(data):
+            scale = float(data)
+            tot = sum((p.float() ** 2).sum() for p in model.parameters() if p.requires_grad)
+            return {"loss_cls": tot * scale * 1e-3, "loss_distill": tot * (1e-4 if model.distill_flag else 0.0)}
+        model.forward = forward
+        tr = Trainer(cfg, model, device=torch.device("cpu"))
+        assert isinstance(tr.model, DistributedDataParallel)
+        assert not model.teacher.global_ctx_proj_1D.weight.requires_grad  # no context box: frozen statically
+        ddps, frozen = [], []
+        for it in range(5):
+            tr.step(rank + 1.0, it)
+            ddps.append(id(tr.model))
+            frozen.append(not model.student.raw_backbone.res5[0].conv1.weight.requires_grad)
+        m = tr.fetch_metrics()
+        w = torch.cat([p.detach().reshape(-1)[:64] for p in model.parameters()])
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        n_alias = sum(1 for n, _ in model.named_parameters(remove_duplicate=False) if n.startswith("student.fpn."))
+        q.put((rank, all(torch.equal(ws[0], x) for x in ws), frozen, len(set(ddps)), m["loss_cls"], n_alias))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_gloo_world2_real_module_tree():
+    """the real Trainer over the real DistillatorFCOS parameter tree under DDP (gloo, world 2): the aliased FPN module
+    (`student.backbone` is `student.fpn`), FREEZE_AT parameters, the statically frozen `global_ctx_proj_1D` and the
+    phase-frozen backbone all go through reducer construction / rebuild; replicas fed different data stay identical."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_real_tree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, same, frozen, n_ddp, loss_cls, n_alias in res:
+        assert same
+        assert frozen == [True, True, False, False, False]
+        assert n_ddp == 2          # one reducer per backbone phase
+        assert n_alias > 0         # the alias really is registered twice
+    assert res[0][4] == res[1][4]  # rank-averaged metric

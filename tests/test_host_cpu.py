@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from lgd_amd import config, registry
-from lgd_amd.engine import warmup_multistep_factor
+from lgd_amd.engine import warmup_cosine_factor, warmup_multistep_factor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -124,6 +124,147 @@ def test_warmup_multistep_schedule():
     assert f(119999) == 1.0 and abs(f(120000) - 0.1) < 1e-12 and abs(f(160000) - 0.01) < 1e-12
 
 
+def test_warmup_cosine_schedule():
+    """[ref: utils/build.py:544-551 WarmupCosineLR]"""
+    import math
+    f = lambda it: warmup_cosine_factor(it, 1000, 1e-3, 100, "linear")  # noqa: E731
+    assert abs(f(0) - 1e-3) < 1e-12 and abs(f(500) - 0.5) < 1e-12 and abs(f(1000)) < 1e-12
+    assert abs(f(50) - (1e-3 * 0.5 + 0.5) * 0.5 * (1 + math.cos(math.pi * 0.05))) < 1e-12
+    from lgd_amd.engine import build_distillator_lr_scheduler
+    cfg = config.setup_cfg(None, ["MODEL.DISTILLATOR.STUDENT.SOLVER.LR_SCHEDULER_NAME", "WarmupCosineLR",
+                                  "MODEL.DISTILLATOR.STUDENT.SOLVER.WARMUP_FACTOR", "0.001",
+                                  "MODEL.DISTILLATOR.STUDENT.SOLVER.WARMUP_ITERS", "100",
+                                  "MODEL.DISTILLATOR.STUDENT.SOLVER.WARMUP_METHOD", "linear"])
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], 0.1)
+    sch = build_distillator_lr_scheduler(cfg.MODEL.DISTILLATOR.STUDENT.SOLVER, opt, max_iter=1000)
+    for _ in range(500):
+        opt.step()
+        sch.step()
+    assert abs(opt.param_groups[0]["lr"] - 0.05) < 1e-9
+
+
+def test_optimizer_layout_matches_reference_and_round_trips():
+    """[ref: utils/build.py:494-512] one param group per parameter, every parameter that requires grad at build time in
+    named_parameters order -- incl. the never-trained global_ctx_proj_1D; Trainer.state_dict() writes that layout and
+    load_state_dict() reads it back into the fused single-group optimizers."""
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    cfg = config.setup_cfg(os.path.join(ROOT, "configs", "lgd_fcos_r50.yaml"), ["MODEL.DEVICE", "cpu"])  # ctx box off
+    m = build_model(cfg)
+    tr = Trainer(cfg, m, device=torch.device("cpu"), distributed=False)
+    want_tea = [n for n, _ in m.teacher.named_parameters()]
+    assert not m.teacher.global_ctx_proj_1D.weight.requires_grad  # frozen statically (never receives a gradient)
+    assert len(tr.tea_optimizer.param_groups) == 1 and len(tr.tea_optimizer.param_groups[0]["params"]) == len(want_tea)
+    seen, want_stu = set(), []
+    for mod in (m.student, m.adapter):
+        for n, p in mod.named_parameters():
+            if id(p) not in seen and (p.requires_grad or getattr(p, "_lgd_phase_frozen", False)):
+                seen.add(id(p))
+                want_stu.append(p)
+    assert [id(p) for p in tr.stu_optimizer.param_groups[0]["params"]] == [id(p) for p in want_stu]
+    for p in tr.tea_optimizer.param_groups[0]["params"][:3]:  # give some state to carry
+        p.grad = torch.ones_like(p)
+    tr.tea_optimizer.step()
+    sd = tr.state_dict()
+    assert len(sd["tea_optimizer"]["param_groups"]) == len(want_tea)
+    assert all(len(g["params"]) == 1 and g["weight_decay"] == 1e-4 for g in sd["tea_optimizer"]["param_groups"])
+    assert [g["params"][0] for g in sd["tea_optimizer"]["param_groups"]] == list(range(len(want_tea)))
+    tr2 = Trainer(cfg, build_model(cfg), device=torch.device("cpu"), distributed=False)
+    tr2.load_state_dict(sd)
+    st = tr2.tea_optimizer.state_dict()
+    assert len(st["param_groups"]) == 1 and sorted(st["state"]) == [0, 1, 2]
+    assert torch.equal(st["state"][0]["momentum_buffer"], tr.tea_optimizer.state_dict()["state"][0]["momentum_buffer"])
+
+
+def test_reference_checkpoint_loader(tmp_path):
+    """a detectron2 DetectionCheckpointer file written under the reference's key names (section 8c):
+    alias copies of the FPN, `module.` prefix, persisted pixel/anchor buffers, numpy payloads; and a Caffe2-named ImageNet
+    backbone pickle (`MODEL.WEIGHTS: detectron2://ImageNetPretrained/MSRA/R-50.pkl`)."""
+    import pickle
+    import numpy as np
+    from lgd_amd.checkpoint import load_checkpoint, load_model_state
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    cfg = config.setup_cfg(os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", "cpu"])
+    torch.manual_seed(1)
+    src = build_model(cfg)
+    tr = Trainer(cfg, src, device=torch.device("cpu"), distributed=False)
+    tr.iteration = 1235
+    sd = tr.state_dict()
+    model_sd = {}
+    for i, (k, v) in enumerate(sd["model"].items()):
+        model_sd["module." + k] = v.numpy().copy() if i % 7 == 0 else v.clone()
+    model_sd["module.student.pixel_mean"] = torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)
+    model_sd["module.student.pixel_std"] = torch.ones(3, 1, 1)
+    for i in range(5):
+        model_sd["module.student.anchor_generator.cell_anchors.%d" % i] = torch.zeros(9, 4)
+    model_sd["module.student.some_new_head.weight"] = torch.zeros(3)
+    f = tmp_path / "model_0001234.pth"
+    torch.save({**sd, "model": model_sd}, str(f))
+    torch.manual_seed(2)
+    dst = build_model(cfg)
+    tr2 = Trainer(cfg, dst, device=torch.device("cpu"), distributed=False)
+    rep = load_checkpoint(str(f), dst, tr2, resume=True)
+    assert rep.missing == [] and rep.unexpected == ["student.some_new_head.weight"] and len(rep.ignored) == 7
+    assert rep.alias_conflicts == [] and tr2.iteration == 1235
+    for (n, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), n
+    # the two FPN names are one module here: loading either copy fills both; a file whose copies disagree is reported
+    only_fpn = {k: v for k, v in sd["model"].items() if not k.startswith("student.backbone.")}
+    rep = load_model_state(build_model(cfg), only_fpn)
+    assert rep.missing == []
+    bad = dict(sd["model"])
+    bad["student.fpn.fpn_lateral3.bias"] = bad["student.fpn.fpn_lateral3.bias"] + 1.0
+    assert load_model_state(build_model(cfg), bad).alias_conflicts == ["student.fpn.fpn_lateral3.bias"]
+    with pytest.raises(ValueError):
+        load_model_state(build_model(cfg), {"teacher.local_inst_proj_1D.weight": torch.zeros(3, 3)})
+    # Caffe2-named backbone pickle
+    bb = {k[len("student.raw_backbone."):]: v for k, v in sd["model"].items() if k.startswith("student.raw_backbone.")}
+    c2 = {"fc1000_w": np.zeros((1000, 2048), np.float32), "fc1000_b": np.zeros(1000, np.float32)}
+    for k, v in bb.items():
+        if k.endswith(("running_mean", "running_var")) or "conv2_offset" in k:
+            continue
+        n = k.replace(".norm.weight", "_bn_s").replace(".norm.bias", "_bn_b").replace(".weight", "_w").replace(".bias", "_b")
+        n = n.replace("stem.conv1_bn", "res_conv1_bn").replace("stem.conv1", "conv1")
+        for d2, cc in (("shortcut", "branch1"), ("conv1", "branch2a"), ("conv2", "branch2b"), ("conv3", "branch2c")):
+            n = n.replace("." + d2, "_" + cc) if n.startswith("res") else n
+        n = n.replace(".", "_", 1) if n.startswith("res") and not n.startswith("res_conv1") else n
+        c2[n] = v.numpy()
+    pk = tmp_path / "R-50.pkl"
+    with open(str(pk), "wb") as fh:
+        pickle.dump({"model": c2, "__author__": "Caffe2", "matching_heuristics": True}, fh)
+    torch.manual_seed(3)
+    fresh = build_model(cfg)
+    rep = load_checkpoint(str(pk), fresh)
+    assert rep.unexpected == [] and len(rep.loaded) == len(c2) - 2
+    assert torch.equal(fresh.state_dict()["student.raw_backbone.res4.5.conv3.weight"], sd["model"]["student.raw_backbone.res4.5.conv3.weight"])
+    assert torch.equal(fresh.state_dict()["student.raw_backbone.stem.conv1.norm.bias"], sd["model"]["student.raw_backbone.stem.conv1.norm.bias"])
+    assert all(not k.startswith("student.raw_backbone.") or k.endswith(("running_mean", "running_var")) for k in rep.missing)
+
+
+def test_clip_and_finite_flag_cpu():
+    """per-parameter gradient clipping (d2 maybe_add_gradient_clipping, 'norm' type) and the sync-free non-finite flag
+    (the reference asserts isfinite every iteration, train.py:194)."""
+    from types import SimpleNamespace
+    from lgd_amd.engine import Trainer
+    t = Trainer.__new__(Trainer)
+    a, b = torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(2))
+    a.grad, b.grad = torch.full((4,), 3.0), torch.tensor([0.1, 0.0])
+    t.stu_optimizer, t.tea_optimizer = torch.optim.SGD([a], 0.1), torch.optim.SGD([b], 0.1)
+    t.clip = SimpleNamespace(CLIP_TYPE="norm", CLIP_VALUE=1.0, NORM_TYPE=2.0)
+    t._clip()
+    assert abs(float(a.grad.norm()) - 1.0) < 1e-5 and torch.equal(b.grad, torch.tensor([0.1, 0.0]))  # each on its own
+    t.clip = SimpleNamespace(CLIP_TYPE="value", CLIP_VALUE=0.05, NORM_TYPE=2.0)
+    t._clip()
+    assert float(b.grad.max()) == pytest.approx(0.05)
+    t.distributed, t.iteration = False, 7
+    t._finite = torch.tensor(True) & torch.isfinite(torch.tensor(float("nan")))
+    with pytest.raises(FloatingPointError):
+        t.check_finite()
+    t._finite = torch.tensor(True)
+    t.check_finite()
+
+
 def test_synthetic_batch_format():
     from lgd_amd.data import synthetic_batch
     b = synthetic_batch(2, 64, 96, 3, seed=1)
@@ -133,33 +274,65 @@ def test_synthetic_batch_format():
     assert torch.equal(b[1]["image"], again[1]["image"])  # hash-based: reproducible everywhere
 
 
-def test_retinanet_anchor_labels_and_losses_cpu():
-    """student-side restatement (parity unpinned): self-consistency of anchors, matching and the sync-free losses."""
-    from lgd_amd.student.retinanet import AnchorGenerator, box_deltas, apply_deltas, pairwise_iou, sigmoid_focal_sum
+def test_retinanet_anchors_and_student_restatements_cpu():
+    """student side (parity unpinned): anchor grid of the product, and the restatements in
+    oracle/student_oracle.py (what the HIP kernels are held to) against hand-computed cases."""
+    from lgd_amd.student.retinanet import AnchorGenerator, apply_deltas, pairwise_iou
+    from oracle import student_oracle as SO
     ag = AnchorGenerator([[32, 40.3, 50.8]], [[0.5, 1.0, 2.0]], [8])
     a = ag([torch.zeros(1, 1, 4, 6)])[0]
     assert a.shape == (4 * 6 * 9, 4)
     assert torch.allclose(a[0], torch.tensor([-22.6274, -11.3137, 22.6274, 11.3137]), atol=1e-3)  # size 32, ratio .5 at (0,0)
     assert torch.allclose(a[9, :2] - a[0, :2], torch.tensor([8.0, 0.0]))                           # next cell along x
     gt = torch.tensor([[4.0, 4.0, 40.0, 30.0]])
-    d = box_deltas(a, gt.expand_as(a))
+    d = SO.box2box_deltas(a, gt.expand_as(a))
     assert torch.allclose(apply_deltas(d, a), gt.expand_as(a), atol=1e-3)
-    assert abs(float(pairwise_iou(gt, gt)) - 1.0) < 1e-6
+    assert abs(float(pairwise_iou(gt, gt)) - 1.0) < 1e-6 and abs(float(SO.pairwise_iou(gt, gt)) - 1.0) < 1e-6
+    # focal: explicit one-hot formula
     logits = torch.randn(2, 7, 5)
     labels = torch.tensor([[0, 5, 5, -1, 2, 5, 5], [5, 5, 5, 5, 5, 5, 4]])
-    valid = labels >= 0
-    got = sigmoid_focal_sum(logits, labels, valid, 5, 0.25, 2.0)
+    got = SO.sigmoid_focal_sum(logits, labels, 5, 0.25, 2.0)
     t = torch.nn.functional.one_hot(labels.clamp(min=0), 6)[..., :5].float()
     p = torch.sigmoid(logits)
     ce = torch.nn.functional.binary_cross_entropy_with_logits(logits, t, reduction="none")
-    ref = ((0.25 * t + 0.75 * (1 - t)) * ce * (1 - (p * t + (1 - p) * (1 - t))) ** 2)[valid].sum()
+    ref = ((0.25 * t + 0.75 * (1 - t)) * ce * (1 - (p * t + (1 - p) * (1 - t))) ** 2)[labels >= 0].sum()
     assert abs(float(got - ref)) < 1e-5
+    # matcher: IoU 1.0 -> positive; 0.45 -> ignore; 0.1 -> background, unless it is some GT's best anchor (low-quality match)
+    anchors = torch.tensor([[0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 10.0, 4.5], [100.0, 100.0, 110.0, 110.0], [50.0, 50.0, 60.0, 60.0]])
+    g = [(torch.tensor([[0.0, 0.0, 10.0, 10.0], [50.0, 50.0, 60.0, 51.0]]), torch.tensor([3, 9]))]
+    lab, mb = SO.label_anchors(anchors, g, 80)
+    assert lab[0].tolist() == [3, -1, 80, 9]  # anchor 3 has IoU 0.1 with GT 1 but is its best anchor
+    assert torch.equal(mb[0][0], g[0][0][0]) and torch.equal(mb[0][3], g[0][0][1])
+    lab, mb = SO.label_anchors(anchors, [(torch.zeros(0, 4), torch.zeros(0, dtype=torch.int64))], 80)
+    assert lab[0].tolist() == [80] * 4 and float(mb[0].abs().max()) == 0.0
+    # box-regression loss: one positive anchor, |pred - target| summed over 4 coordinates
+    deltas = torch.zeros(1, 4, 4)
+    tgt = SO.box2box_deltas(anchors[0], torch.tensor([1.0, 1.0, 9.0, 11.0]))
+    loss = SO.box_reg_sum(deltas, torch.tensor([[3, 80, 80, -1]]), anchors, torch.tensor([[[1.0, 1.0, 9.0, 11.0]] * 4]), 80, 0.0)
+    assert abs(float(loss) - float(tgt.abs().sum())) < 1e-6
+
+
+def test_fcos_target_restatement_cpu():
+    """oracle/student_oracle.py::fcos_targets on hand cases [ref: thirdparty_heads/fcos.py:177-284]."""
+    from oracle import student_oracle as SO
+    shifts = [torch.tensor([[4.0, 4.0], [12.0, 4.0], [4.0, 12.0], [12.0, 12.0]]), torch.tensor([[8.0, 8.0]])]
+    big = torch.tensor([[0.0, 0.0, 16.0, 16.0]])
+    # level 0 accepts max-ltrb in [-1, 64]: all four locations are inside the centre-sampling box (8 +- 12, clipped to the box)
+    c, d, t = SO.fcos_targets(shifts, [8, 16], [[-1, 64], [64, 1e9]], [(big, torch.tensor([7]))], 80, 1.5)
+    assert c[0].tolist() == [7, 7, 7, 7, 80]       # level 1 needs max-ltrb >= 64
+    assert d[0, 0].tolist() == [4.0, 4.0, 12.0, 12.0] and abs(float(t[0, 0]) - 1.0 / 3.0) < 1e-6
+    # a smaller box covering location 0 wins it (min area); radius 0 = anywhere strictly inside the box
+    two = torch.tensor([[0.0, 0.0, 16.0, 16.0], [2.0, 2.0, 7.0, 7.0]])
+    c, d, _ = SO.fcos_targets(shifts, [8, 16], [[-1, 64], [64, 1e9]], [(two, torch.tensor([7, 9]))], 80, 0.0)
+    assert c[0].tolist() == [9, 7, 7, 7, 80] and d[0, 0].tolist() == [2.0, 2.0, 3.0, 3.0]
+    c, d, t = SO.fcos_targets(shifts, [8, 16], [[-1, 64], [64, 1e9]], [(torch.zeros(0, 4), torch.zeros(0, dtype=torch.int64))], 80, 1.5)
+    assert c[0].tolist() == [80] * 5 and float(d.abs().max()) == 0.0 and float(t.abs().max()) == 0.0
 
 
 def test_modulated_deform_conv_matches_definition():
     """DCNv2 (BASELINE config 5): zero offsets + unit mask == plain conv; random offsets == direct bilinear sampling."""
     import torch.nn.functional as F
-    from lgd_amd.student.deform import modulated_deform_conv2d
+    from oracle.student_oracle import modulated_deform_conv2d
     torch.manual_seed(0)
     x, w, b = torch.randn(2, 5, 9, 11), torch.randn(7, 5, 3, 3), torch.randn(7)
     for stride in (1, 2):

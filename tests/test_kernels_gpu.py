@@ -8,6 +8,7 @@ import torch
 import common as cm
 from lgd_amd import synth
 from oracle import lgd_oracle as O
+from oracle import student_oracle as SO
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -382,10 +383,9 @@ def test_gemm_batch_strided():
 @pytest.mark.parametrize("N,A,K,level_hw,gamma", [(2, 9, 80, [(16, 20), (8, 10), (3, 5)], 2.0), (3, 1, 80, [(25, 42), (7, 11)], 2.0),
                                                   (1, 3, 7, [(9, 13)], 1.5)])
 def test_focal_loss_sum_fwd_bwd(N, A, K, level_hw, gamma):
-    """vs the torch restatement of fvcore's sigmoid_focal_loss (lgd_amd.student.retinanet.sigmoid_focal_sum)
+    """vs the torch restatement of fvcore's sigmoid_focal_loss (oracle/student_oracle.py::sigmoid_focal_sum)
     evaluated on the permuted (N, HWA, K) layout with explicit one-hot semantics."""
     from lgd_amd import ops
-    from lgd_amd.student.retinanet import permute_to_N_HWA_K, sigmoid_focal_sum
     rng = np.random.default_rng(3)
     R = sum(h * w * A for h, w in level_hw)
     labels = torch.from_numpy(rng.integers(-1, K + 1, size=(N, R)))  # -1 ignore, K background
@@ -394,7 +394,7 @@ def test_focal_loss_sum_fwd_bwd(N, A, K, level_hw, gamma):
     planes = ops.label_planes(labels.to(DEV), level_hw, A)
     loss = ops.focal_loss_sum(rg, planes, A, K, 0.25, gamma)
     rc = [x.clone().requires_grad_(True) for x in raw]
-    ref = sigmoid_focal_sum(torch.cat([permute_to_N_HWA_K(x, K) for x in rc], 1), labels, labels >= 0, K, 0.25, gamma)
+    ref = SO.sigmoid_focal_sum(torch.cat([SO.flatten_head_output(x, K) for x in rc], 1), labels, K, 0.25, gamma)
     assert abs(loss.item() - ref.item()) / ref.item() < 1e-5
     (loss * 0.37).backward()
     (ref * 0.37).backward()
@@ -669,7 +669,6 @@ def test_anchor_match_equals_elementwise_definition():
     labels and matched boxes identical, incl. an image without ground truth, a box touching no anchor (its all-zero IoU
     row makes every anchor a low-quality positive, as in the definition), duplicate boxes (first arg-max) and boxes whose
     IoU with some anchor sits exactly on a threshold."""
-    import types
     from lgd_amd import ops
     from lgd_amd.student import retinanet as rn
     gen = rn.AnchorGenerator([[32.0 * 2 ** (i + j / 3) for j in range(3)] for i in range(5)], [[0.5, 1.0, 2.0]],
@@ -687,16 +686,8 @@ def test_anchor_match_equals_elementwise_definition():
     boxes[3] = torch.cat([boxes[3][:3], torch.tensor([[5000.0, 5000.0, 5010.0, 5010.0]], device=DEV)])  # touches no anchor
     classes[3] = classes[3][:4]
 
-    class Inst:
-        def __init__(self, b, c):
-            self.gt_boxes, self.gt_classes = types.SimpleNamespace(tensor=b), c
-
-        def __len__(self):
-            return self.gt_boxes.tensor.shape[0]
-    insts = [Inst(b, c) for b, c in zip(boxes, classes)]
-    host = types.SimpleNamespace(iou_thresholds=[0.4, 0.5], iou_labels=[0, -1, 1], num_classes=80)
-    ref_l, ref_b = rn.RetinaNetCT._label_anchors_torch(host, A, insts)
-    counts = [len(i) for i in insts]
+    ref_l, ref_b = SO.label_anchors(A, list(zip(boxes, classes)), 80, (0.4, 0.5), (0, -1, 1))
+    counts = [len(b) for b in boxes]
     got_l, got_b = ops.anchor_match(A, torch.cat([b for b in boxes if len(b)]), torch.cat([c for c in classes if len(c)]),
                                     counts, 0.4, 0.5, 80, True)
     for i in range(4):
@@ -712,7 +703,6 @@ def test_box_reg_loss_sum_fwd_bwd(beta):
     """fused box-regression loss on the head's raw (N, A*4, H, W) deltas vs the elementwise restatement
     (target deltas for all anchors, permute + cat, masked smooth-L1): value and gradient."""
     from lgd_amd import ops
-    from lgd_amd.student import retinanet as rn
     N, A, K = 2, 3, 5
     level_hw = [(6, 8), (3, 4), (2, 2)]
     R = sum(h * w * A for h, w in level_hw)
@@ -731,13 +721,7 @@ def test_box_reg_loss_sum_fwd_bwd(beta):
     got = [r.grad.clone() for r in raw]
     for r in raw:
         r.grad = None
-    deltas = torch.cat([rn.permute_to_N_HWA_K(r, 4) for r in raw], 1)
-    pos = (labels >= 0) & (labels != K)
-    gt = rn.box_deltas(anchors[None], matched, wts)
-    diff = (deltas - torch.where(pos[..., None], gt, deltas.detach())).abs()
-    if beta >= 1e-5:
-        diff = torch.where(diff < beta, 0.5 * diff * diff / beta, diff - 0.5 * beta)
-    ref = (diff * pos[..., None].to(diff.dtype)).sum()
+    ref = SO.box_reg_sum(torch.cat([SO.flatten_head_output(r, 4) for r in raw], 1), labels, anchors, matched, K, beta, wts)
     ref.backward()
     assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
     for g, r in zip(got, raw):
@@ -751,7 +735,6 @@ def test_deform_conv3x3_fwd_bwd(N, C, O, H, W, stride, dil, modulated):
     """lgd_dcn_im2col / col2im + GEMMs vs the per-tap grid_sample restatement (itself checked against the DCNv2 definition in
     tests/test_host_cpu.py): output and all five gradients; offsets large enough to sample outside the map."""
     from lgd_amd import ops
-    from lgd_amd.student.deform import modulated_deform_conv2d_torch
     pad = dil
     Ho, Wo = (H + 2 * pad - 2 * dil - 1) // stride + 1, (W + 2 * pad - 2 * dil - 1) // stride + 1
     mk = lambda shp, seed, lo, hi: torch.from_numpy(synth.det_uniform(shp, seed, lo, hi)).to(DEV)
@@ -767,8 +750,119 @@ def test_deform_conv3x3_fwd_bwd(N, C, O, H, W, stride, dil, modulated):
     for t in leaves:
         t.grad = None
     ones = torch.ones((N, 9, Ho, Wo), device=DEV)
-    yr = modulated_deform_conv2d_torch(x, off, m if modulated else ones, w, b, stride, pad, dil)
+    yr = SO.modulated_deform_conv2d(x, off, m if modulated else ones, w, b, stride, pad, dil)
     yr.backward(gy)
     assert float((y - yr).detach().abs().max()) <= 1e-4 * float(yr.detach().abs().max())
     for g, t, name in zip(got, leaves, ("x", "offset", "mask", "weight", "bias") if modulated else ("x", "offset", "weight", "bias")):
         assert float((g - t.grad).abs().max()) <= 2e-4 * float(t.grad.abs().max()) + 1e-6, name
+
+
+# ------------------------------------------------------------------------------------------- f-1 losses at the BASELINE config-2 size
+def test_detection_losses_full_size():
+    """focal / box-regression / anchor matching at configs[1] size: 8 images, 201,600 anchors x 80 classes, 10 GT boxes each,
+    against the restatements (oracle/student_oracle.py) evaluated image by image on the GPU's torch ops (the restatement of a
+    whole batch would need 8 x 201,600 x 80 one-hot tensors several times over)."""
+    from lgd_amd import ops
+    from lgd_amd.student import retinanet as rn
+    N, A, K = 8, 9, 80
+    level_hw = synth.pyramid_shapes(800, 1344)
+    gen = rn.AnchorGenerator([[32.0 * 2 ** (i + j / 3) for j in range(3)] for i in range(5)], [[0.5, 1.0, 2.0]], [8, 16, 32, 64, 128])
+    anchors = torch.cat(gen([torch.zeros(1, 1, h, w, device=DEV) for h, w in level_hw]), 0)
+    R = anchors.shape[0]
+    assert R == 201600
+    gts = synth.synth_gt(N, 800, 1344, 10, seed=7)
+    boxes = [torch.from_numpy(b).to(DEV) for b, _ in gts]
+    classes = [torch.from_numpy(c).to(DEV) for _, c in gts]
+    labels, matched = ops.anchor_match(anchors, torch.cat(boxes), torch.cat(classes), [len(b) for b in boxes], 0.4, 0.5, K, True)
+    ref_l, ref_b = SO.label_anchors(anchors, list(zip(boxes, classes)), K)
+    assert torch.equal(labels, torch.stack(ref_l)) and torch.equal(matched, torch.stack(ref_b))
+    g = torch.Generator(device=DEV).manual_seed(5)
+    logits = [(torch.randn(N, A * K, h, w, device=DEV, generator=g) * 3 - 4).requires_grad_(True) for h, w in level_hw]
+    deltas = [(torch.randn(N, A * 4, h, w, device=DEV, generator=g) * 0.5).requires_grad_(True) for h, w in level_hw]
+    planes = ops.label_planes(labels, level_hw, A)
+    lc = ops.focal_loss_sum(logits, planes, A, K, 0.25, 2.0)
+    lb = ops.box_reg_loss_sum(deltas, planes, anchors, matched, A, K, 0.0)
+    (lc * 0.01 + lb * 0.1).backward()
+    got_c, got_b = [x.grad.clone() for x in logits], [x.grad.clone() for x in deltas]
+    ref_c = ref_bx = 0.0
+    for n in range(N):  # image by image: bounded memory
+        lg = [x.detach()[n:n + 1].clone().requires_grad_(True) for x in logits]
+        dl = [x.detach()[n:n + 1].clone().requires_grad_(True) for x in deltas]
+        rc = SO.sigmoid_focal_sum(torch.cat([SO.flatten_head_output(x, K) for x in lg], 1), labels[n:n + 1], K, 0.25, 2.0)
+        rb = SO.box_reg_sum(torch.cat([SO.flatten_head_output(x, 4) for x in dl], 1), labels[n:n + 1], anchors, matched[n:n + 1], K, 0.0)
+        (rc * 0.01 + rb * 0.1).backward()
+        ref_c, ref_bx = ref_c + rc.item(), ref_bx + rb.item()
+        for l in range(len(level_hw)):
+            assert cm.rel_err(got_c[l][n], lg[l].grad[0]) < FTOL, (n, l)
+            assert float((got_b[l][n] - dl[l].grad[0]).abs().max()) <= 1e-6, (n, l)
+    assert abs(lc.item() - ref_c) <= 2e-5 * abs(ref_c)
+    assert abs(lb.item() - ref_bx) <= 2e-5 * abs(ref_bx)
+
+
+# ------------------------------------------------------------------------------------------- FCOS tower GroupNorm(32)+ReLU
+@pytest.mark.parametrize("B,C,G,level_hw,relu,affine", [(2, 256, 32, [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)], True, True),
+                                                        (3, 64, 8, [(13, 21), (7, 11)], True, True),
+                                                        (1, 32, 32, [(70, 64)], False, True), (2, 16, 1, [(9, 9)], True, False)])
+def test_group_norm_relu_fwd_bwd(B, C, G, level_hw, relu, affine):
+    """lgd_gn_group_* (one module over a list of maps, shared gamma/beta) vs F.group_norm [+ relu] in fp64 on the same
+    inputs: outputs, input gradients, gamma / beta gradients summed over all maps."""
+    from lgd_amd import ops
+    xs = [torch.from_numpy(synth.det_uniform((B, C, h, w), 1300 + i, -2.0, 3.0)).to(DEV).requires_grad_(True) for i, (h, w) in enumerate(level_hw)]
+    gys = [torch.from_numpy(synth.det_uniform((B, C, h, w), 1320 + i, -1.0, 1.0)).to(DEV) for i, (h, w) in enumerate(level_hw)]
+    ga = torch.from_numpy(synth.det_uniform((C,), 1340, 0.5, 1.5)).to(DEV).requires_grad_(True) if affine else None
+    be = torch.from_numpy(synth.det_uniform((C,), 1341, -0.5, 0.5)).to(DEV).requires_grad_(True) if affine else None
+    ys = ops.group_norm_relu(xs, G, ga, be, relu=relu)
+    torch.autograd.backward(ys, gys)
+    x64 = [x.detach().double().requires_grad_(True) for x in xs]
+    ga64 = ga.detach().double().requires_grad_(True) if affine else None
+    be64 = be.detach().double().requires_grad_(True) if affine else None
+    ref = [SO.group_norm_relu(x, G, ga64, be64, relu) for x in x64]
+    torch.autograd.backward(ref, [g.double() for g in gys])
+    for y, r, x, xr in zip(ys, ref, xs, x64):
+        assert cm.rel_err(y, r) < FTOL
+        ok, msg = cm.kink_robust_close(x.grad, xr.grad, tol=1e-4, max_outlier_frac=1e-3, max_rel=5e-3)
+        assert ok, msg
+    if affine:
+        assert cm.rel_err(ga.grad, ga64.grad) < 1e-4 and cm.rel_err(be.grad, be64.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- FCOS target assignment
+@pytest.mark.parametrize("radius", [1.5, 0.0])
+def test_fcos_targets_bit_exact(radius):
+    """lgd_fcos_targets vs the elementwise restatement of FCOS.get_ground_truth [ref: thirdparty_heads/fcos.py:177-284] at
+    the config-3 shape (22,400 locations): classes, ltrb deltas and centerness bit-identical; an image without boxes, a
+    crowded image, nested boxes of equal centre (min-area tie break), duplicate boxes (first index wins)."""
+    from lgd_amd import ops
+    level_hw = synth.pyramid_shapes(800, 1344)
+    strides = [8, 16, 32, 64, 128]
+    soi = [[-1, 64], [64, 128], [128, 256], [256, 512], [512, float("inf")]]
+    shifts = []
+    for (h, w), s in zip(level_hw, strides):
+        sx = torch.arange(0, w * s, s, dtype=torch.float32, device=DEV) + 0.5 * s
+        sy = torch.arange(0, h * s, s, dtype=torch.float32, device=DEV) + 0.5 * s
+        yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+        shifts.append(torch.stack((xx.reshape(-1), yy.reshape(-1)), 1))
+    gts = synth.synth_gt(4, 800, 1344, 10, seed=9)
+    boxes = [torch.from_numpy(b).to(DEV) for b, _ in gts]
+    classes = [torch.from_numpy(c).to(DEV) for _, c in gts]
+    boxes[1], classes[1] = boxes[1][:0], classes[1][:0]
+    nested = torch.tensor([[200.0, 200.0, 600.0, 500.0], [300.0, 275.0, 500.0, 425.0], [300.0, 275.0, 500.0, 425.0]], device=DEV)
+    boxes[2] = torch.cat([boxes[2], nested])
+    classes[2] = torch.cat([classes[2], torch.tensor([3, 4, 5], device=DEV)])
+    rng = np.random.default_rng(2)
+    x1, y1 = rng.uniform(0, 1200, 60), rng.uniform(0, 700, 60)
+    crowd = np.stack([x1, y1, np.minimum(1343, x1 + rng.uniform(8, 500, 60)), np.minimum(799, y1 + rng.uniform(8, 400, 60))], 1)
+    boxes[3] = torch.tensor(crowd, dtype=torch.float32, device=DEV)
+    classes[3] = torch.from_numpy(rng.integers(0, 80, 60)).to(DEV)
+    counts = [len(b) for b in boxes]
+    cls, dl, ct = ops.fcos_targets(shifts, strides, soi, torch.cat(boxes), torch.cat(classes), counts, 80, radius)
+    # the restatement on the CPU: torch's arg-min returns the FIRST minimal index there (ties: duplicate boxes)
+    rc, rd, rt = SO.fcos_targets([s.cpu() for s in shifts], strides, soi, [(b.cpu(), c.cpu()) for b, c in zip(boxes, classes)], 80, radius)
+    cls, dl, ct = cls.cpu(), dl.cpu(), ct.cpu()
+    assert torch.equal(cls, rc)
+    assert torch.equal(dl, rd)
+    fg = rc != 80
+    assert int(fg.sum()) > 100
+    assert torch.equal(ct[fg], rt[fg])
+    assert torch.equal(torch.nan_to_num(ct, nan=-1.0), torch.nan_to_num(rt, nan=-1.0))
+    assert bool((cls[1] == 80).all()) and float(dl[1].abs().max()) == 0.0

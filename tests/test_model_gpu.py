@@ -38,10 +38,17 @@ def _teacher(name):
     return t.to(DEV).train()
 
 
-@pytest.fixture(scope="module", params=list(cm.CASES))
+# every golden case on the Winograd kernels (forced: the small cases have fewer tiles than the production threshold), the
+# small ones once more on the library convolutions (LGD_WINO=0 back-end)
+_RUNS = [(n, "winograd") for n in cm.CASES] + [(n, "library") for n in cm.SMALL_CASES]
+
+
+@pytest.fixture(scope="module", params=_RUNS, ids=["%s-%s" % r for r in _RUNS])
 def run(request):
+    from lgd_amd import ops
     from lgd_amd.structures import ImageList
-    name = request.param
+    name, backend = request.param
+    prev = ops.conv3x3_backend(winograd=(backend == "winograd"), min_tiles=0)
     B, H, W, ctx, interact, fmt, coef, _ = cm.CASES[name]
     teacher = _teacher(name)
     feats = {k: v.to(DEV).requires_grad_(True) for k, v in cm.case_feats(name).items()}
@@ -49,10 +56,18 @@ def run(request):
     bi = _batched_inputs(cm.case_gt(name), H, W)
     cap = {}
     h = teacher.label_encoder_.register_forward_hook(lambda m, i, o: cap.__setitem__("le", o))
-    tea, inst_labels, geom = teacher((bi, images, None, feats))
-    h.remove()
-    return dict(name=name, g=cm.golden(name), teacher=teacher, feats=feats, tea=tea, geom=geom, le=cap["le"], coef=coef,
-                inst_labels=inst_labels)
+    # the same taps tests/golden/make_golden.py puts on the reference: output of aggregate_per_level and of the MHA
+    real_pool, real_mha = ops.gn_relu_mask_pool, ops.mha_blockdiag
+    ops.gn_relu_mask_pool = lambda *a, **k: cap.setdefault("app", real_pool(*a, **k))
+    ops.mha_blockdiag = lambda *a, **k: cap.setdefault("att", real_mha(*a, **k))
+    try:
+        tea, inst_labels, geom = teacher((bi, images, None, feats))
+    finally:
+        ops.gn_relu_mask_pool, ops.mha_blockdiag = real_pool, real_mha
+        h.remove()
+    yield dict(name=name, backend=backend, g=cm.golden(name), teacher=teacher, feats=feats, tea=tea, geom=geom, le=cap["le"],
+               coef=coef, inst_labels=inst_labels, app=cap.get("app"), att=cap.get("att"), stride=cm.stride_of(name))
+    ops.conv3x3_backend(*prev)
 
 
 def test_label_encoder_and_geometry(run):
@@ -62,6 +77,7 @@ def test_label_encoder_and_geometry(run):
     assert np.array_equal(boxes.cpu().double().numpy(), g["boxlists"])  # clamped boxes: bit-exact
     assert cm.rel_err(embed, g["label_embed"]) < TOL
     assert cm.rel_err(m1.reshape(-1)[::cm.SAMPLE_STRIDE], g["stn_desc_sample"]) < TOL
+    assert cm.rel_err(m2.reshape(-1)[::cm.SAMPLE_STRIDE], g["stn_feat_sample"]) < TOL
     rects = run["geom"].rects().cpu().numpy()
     for i, k in enumerate(O.LEVELS):
         ref = g["rects_" + k].copy()
@@ -71,13 +87,23 @@ def test_label_encoder_and_geometry(run):
     assert np.array_equal(lab, g["inst_labels"])
 
 
+def test_appearance_and_attention_match_reference(run):
+    """the HIP mask pooling (fused GN+ReLU+pool) and block-diagonal MHA against the reference's own intermediate tensors
+    (golden app_* = aggregate_per_level output, attn_* = nn.MultiheadAttention output, per level)."""
+    g = run["g"]
+    assert run["app"] is not None and run["att"] is not None
+    for i, k in enumerate(O.LEVELS):
+        assert cm.rel_err(run["app"][i], g["app_" + k]) < TOL, k
+        assert cm.rel_err(run["att"][i], g["attn_" + k]) < TOL, k
+
+
 def test_teacher_features_match_reference(run):
     g, tea = run["g"], run["tea"]
     for k in O.LEVELS:
-        s, _, sq = cm.sample(tea[k])
+        s, _, sq = cm.sample(tea[k], run["stride"])
         assert cm.rel_err(s, g["tea_s_" + k]) < TOL, k
         assert abs(sq - float(g["tea_sq_" + k])) / float(g["tea_sq_" + k]) < 2 * TOL, k
-        if k in ("p6", "p7"):
+        if k in ("p6", "p7") and "tea_full_" + k in g:
             assert cm.rel_err(tea[k], g["tea_full_" + k]) < TOL, k
 
 
@@ -105,32 +131,62 @@ def test_distill_loss_and_grads_match_reference(run):
     pr = cm.probes({k: tea[k] for k in O.LEVELS})
     total = loss + sum((tea[k] * pr[k].to(DEV)).sum() for k in O.LEVELS)
     assert abs(total.item() - float(g["total_loss"])) < TOL * abs(float(g["total_loss"])) + 1e-6
+    if "gfeat_s_p3" not in g:
+        return  # the full-size cases store the losses only
     total.backward()
+    report = []
     for k in O.LEVELS:
         s, _, sq = cm.sample(feats[k].grad)
-        # 1e-2, not 1e-4: ONE activation within an ulp of zero whose ReLU mask differs between the CPU
-        # reference and the GPU forward moves a level's gradient by ~sqrt(1/numel) (measured: 1 flip of 2,097,152
-        # at p3 -> 1.2e-3, 1 of 131,072 at p5 -> 3.0e-3; levels without a flip agree to 4e-6; tools/parity_diag5.py).
-        # Every kernel's backward is held to 2e-5 in tests/test_kernels_gpu.py.
-        assert cm.rel_err(s, g["gfeat_s_" + k]) < 1e-2, k
+        # Platform rounding at ReLU kinks: an activation within an ulp of zero can get a different mask here than in the CPU
+        # reference (measured: 1 flip of 2,097,152 at p3; the identical deviation appears when the ORACLE's own torch ops run
+        # on the GPU).  One flip moves the gradient in its receptive field (<= 7x7x256 elements ~ 0.6 % of a level) by ~1e-2
+        # relative; everything else agrees to ~1e-6.  So: >= 98 % of the sampled elements within 1e-4 (a systematically wrong
+        # gradient fails this), the whole level within 2e-2.
+        ok, msg = cm.kink_robust_close(s, g["gfeat_s_" + k], tol=1e-4, max_outlier_frac=2e-2, max_rel=2e-2)
+        report.append("%s: %s" % (k, msg))
+        assert ok, (k, msg)
+    print("feature-gradient parity:", "; ".join(report))
     named = list(teacher.named_parameters()) + [("adapter." + n, p) for n, p in d.adapter["distill"].named_parameters()]
+    worst_s = worst_q = 0.0
     for n, prm in named:
         if "gnone_" + n in g:
             assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n
             continue
         s, _, sq = cm.sample(prm.grad)
         ref_sq = float(g["gw_sq_" + n])
-        assert abs(sq - ref_sq) <= 4e-2 * ref_sq + 1e-12, n  # kink flips, see above
-        assert np.abs(s[:64] - g["gw_s_" + n]).max() <= 2e-2 * np.abs(g["gw_s_" + n]).max() + 1e-7, n
+        # a weight gradient sums over every position, so a handful of flipped masks moves it by ~1e-4 at most
+        dq = abs(sq - ref_sq) / (ref_sq + 1e-12)
+        ds = float(np.abs(s[:64] - g["gw_s_" + n]).max() / (np.abs(g["gw_s_" + n]).max() + 1e-7))
+        if ref_sq > 1e-10:  # adapter.4.bias sits right before an InstanceNorm: its gradient is analytically 0 (fp noise)
+            worst_s, worst_q = max(worst_s, ds), max(worst_q, dq)
+            assert dq <= 4e-3, (n, dq)
+            assert ds <= 2e-3, (n, ds)
+        else:
+            assert sq <= 1e-9, n
+    print("weight-gradient parity: worst sample dev %.2e, worst |g|^2 dev %.2e" % (worst_s, worst_q))
 
 
-@pytest.mark.parametrize("yaml_name,keys", [
-    ("lgd_retinanet_r50", {"loss_cls", "loss_box_reg", "loss_cls.tea", "loss_box_reg.tea", "loss_distill"}),
-    ("lgd_fcos_r50", {"loss_cls", "loss_box_reg", "loss_centerness", "loss_cls.tea", "loss_box_reg.tea",
-                      "loss_centerness.tea", "loss_distill"}),
-    ("lgd_retinanet_r101_dcnv2", {"loss_cls", "loss_box_reg", "loss_cls.tea", "loss_box_reg.tea", "loss_distill"}),
-])
-def test_meta_arch_train_step(yaml_name, keys):
+_RN_KEYS = {"loss_cls", "loss_box_reg", "loss_cls.tea", "loss_box_reg.tea", "loss_distill"}
+_FC_KEYS = _RN_KEYS | {"loss_centerness", "loss_centerness.tea"}
+
+
+@pytest.fixture
+def conv_backend(request):
+    """'winograd': winograd.hip forced onto the small test problems (production threshold: 2000 tiles); 'library': LGD_WINO=0."""
+    from lgd_amd import ops
+    prev = ops.conv3x3_backend(winograd=(request.param == "winograd"), min_tiles=0)
+    yield request.param
+    ops.conv3x3_backend(*prev)
+
+
+@pytest.mark.parametrize("yaml_name,keys,conv_backend", [
+    ("lgd_retinanet_r50", _RN_KEYS, "winograd"),
+    ("lgd_retinanet_r50", _RN_KEYS, "library"),
+    ("lgd_fcos_r50", _FC_KEYS, "winograd"),
+    ("lgd_retinanet_r101", _RN_KEYS, "winograd"),        # BASELINE configs[3] (per-rank workload of the DDP 8x run)
+    ("lgd_retinanet_r101_dcnv2", _RN_KEYS, "winograd"),  # BASELINE configs[4]
+], indirect=["conv_backend"])
+def test_meta_arch_train_step(yaml_name, keys, conv_backend):
     """one full training iteration (both optimizers) on a small synthetic batch; loss keys as in the reference
     [ref: distillator.py:66-68,110-112,292-295]."""
     import os
@@ -221,7 +277,8 @@ def test_teacher_edge_batch_vs_oracle():
         sum((tea[k] * pr[k].to(DEV)).sum() for k in O.LEVELS).backward()
         sum((ref[k] * pr[k]).sum() for k in O.LEVELS).backward()
         for k in O.LEVELS:
-            assert cm.rel_err(fg[k].grad, fc[k].grad) < 1e-2, (ctx, k)  # kink-limited, see test_distill_loss_and_grads...
+            ok, msg = cm.kink_robust_close(fg[k].grad, fc[k].grad, tol=1e-4, max_outlier_frac=2e-2, max_rel=2e-2)
+            assert ok, (ctx, k, msg)  # kink-limited, see test_distill_loss_and_grads_match_reference
 
 
 def test_full_size_properties():
@@ -290,3 +347,143 @@ def test_full_size_conv3x3_properties():
     lhs = sum(float((o.detach().double() * q.double()).sum()) for o, q in zip(out, gy))
     rhs = sum(float((x.detach().double() * x.grad.double()).sum()) for x in xr)
     assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+
+
+# ------------------------------------------------------------------------------------------- f-1: one head pass over student + teacher
+@pytest.mark.parametrize("yaml_name,conv_backend", [("lgd_retinanet_r50", "winograd"), ("lgd_fcos_r50", "winograd"),
+                                                    ("lgd_retinanet_r50", "library")], indirect=["conv_backend"])
+def test_single_head_pass_equals_two_passes(yaml_name, conv_backend):
+    """the head runs ONCE over the 2 x L maps of the student and teacher pyramids
+    (`student.predict_pair`) instead of twice [ref: distillator.py:88-91 + 107-112]: same loss values, same gradients."""
+    import os
+    from lgd_amd import config
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", yaml_name + ".yaml"), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    model = build_model(cfg).train()
+    model.distill_flag = 1
+    data = synthetic_batch(2, 256, 320, 5, seed=5)
+    res = {}
+    for fused in (True, False):
+        model.fused_head_pass = fused
+        if hasattr(model.student, "loss_normalizer"):
+            model.student.loss_normalizer.fill_(100.0)
+        model.zero_grad(set_to_none=True)
+        losses = model(data)
+        sum(losses.values()).backward()
+        res[fused] = ({k: float(v) for k, v in losses.items()},
+                      {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    la, lb = res[True][0], res[False][0]
+    assert set(la) == set(lb)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * abs(lb[k]) + 1e-7, (k, la[k], lb[k])
+    ga, gb = res[True][1], res[False][1]
+    assert set(ga) == set(gb)
+    for n in ga:
+        assert cm.rel_err(ga[n], gb[n]) < 1e-4 or float(gb[n].abs().max()) < 1e-9, n
+
+
+# ------------------------------------------------------------------------------------------- (e): the real model under torch.distributed / RCCL
+def _init_single_rank_nccl():
+    import socket
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+
+def test_trainer_step_under_single_rank_rccl():
+    """the REAL DistillatorRetinaNet wrapped in DistributedDataParallel over the `nccl` (= RCCL) backend [ref: train.py:279-281],
+    world size 1: three Trainer.steps across both phase switches (frozen backbone -> trainable rebuilds the reducer; distill
+    flag off -> on) must leave the same parameters as the non-DDP trainer started from the same weights."""
+    import copy
+    import os
+    import torch.distributed as dist
+    from lgd_amd import config
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    from torch.nn.parallel import DistributedDataParallel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    base = build_model(cfg)
+    twin = copy.deepcopy(base)
+    data = synthetic_batch(2, 256, 320, 5, seed=6)
+    its = (0, 25000, 40000)
+    plain = Trainer(cfg, base, distributed=False)
+    for it in its:
+        plain.step(data, it)
+    _init_single_rank_nccl()
+    try:
+        ddp = Trainer(cfg, twin, distributed=True)
+        assert isinstance(ddp.model, DistributedDataParallel)
+        first = ddp.model
+        for it in its:
+            ddp.step(data, it)
+        assert ddp.model is not first  # the frozen -> trainable switch rebuilt the reducer
+        m = ddp.fetch_metrics()        # one all-reduce over RCCL
+        assert all(np.isfinite(v) for v in m.values())
+    finally:
+        dist.destroy_process_group()
+    worst = 0.0
+    for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
+        worst = max(worst, float((a - b).abs().max() / (a.abs().max() + 1e-12)))
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
+    print("DDP(world 1, RCCL) vs plain trainer: worst relative parameter difference %.2e" % worst)
+
+
+def _nccl2_worker(rank, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=2, device_id=dev)
+    try:
+        from lgd_amd import config
+        from lgd_amd.data import synthetic_batch
+        from lgd_amd.distillator import build_model
+        from lgd_amd.engine import Trainer
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", "cuda:%d" % rank])
+        torch.manual_seed(0)
+        tr = Trainer(cfg, build_model(cfg), device=dev)
+        for it in (19999, 20000, 40000):
+            tr.step(synthetic_batch(1, 256, 320, 4, seed=10 + rank), it)
+        m = tr.fetch_metrics()
+        w = torch.cat([p.detach().reshape(-1) for p in tr.raw_model.parameters()])
+        ws = [torch.empty_like(w) for _ in range(2)]
+        dist.all_gather(ws, w)
+        q.put((rank, bool(torch.equal(ws[0], ws[1])), m["loss_distill"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_trainer_two_ranks_rccl():
+    """two processes, two GPUs, RCCL: replicas fed different images stay bit-identical (gradients were averaged) and report
+    the same rank-averaged metrics.  Skips on a single-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the driver's multi-GPU node)")
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl2_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=800) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == res[1][2]

@@ -67,10 +67,16 @@ def main():
     model.distill_flag = cfg.MODEL.DISTILLATOR.DISTILL_OFF  # train.py:266
     per_gpu = max(1, cfg.SOLVER.IMS_PER_BATCH // world)
     h, w = args.image_size
+    from lgd_amd.checkpoint import load_checkpoint
+    weights = cfg.MODEL.WEIGHTS if cfg.MODEL.WEIGHTS and os.path.isfile(cfg.MODEL.WEIGHTS) else None
+    if cfg.MODEL.WEIGHTS and weights is None and rank == 0:
+        print("MODEL.WEIGHTS %r is not a local file: starting from the constructed initialisation" % cfg.MODEL.WEIGHTS)
     if args.eval_only:
-        ck = latest_checkpoint(cfg.OUTPUT_DIR) if args.resume else (cfg.MODEL.WEIGHTS if os.path.exists(cfg.MODEL.WEIGHTS) else None)
+        ck = (latest_checkpoint(cfg.OUTPUT_DIR) if args.resume else None) or weights  # resume_or_load, train.py:270-272
         if ck:
-            model.load_state_dict(torch.load(ck, map_location=dev)["model"])
+            rep = load_checkpoint(ck, model)
+            if rank == 0:
+                print("loaded %s: %s" % (ck, rep))
         model.eval()
         with torch.no_grad():
             for probe in ([True, False] if cfg.MODEL.DISTILLATOR.EVAL_TEACHER else [False]):  # train.py:268-276
@@ -80,9 +86,16 @@ def main():
         return
     trainer = Trainer(cfg, model, device=dev)
     start = 0
-    if args.resume and latest_checkpoint(cfg.OUTPUT_DIR):
-        trainer.load_state_dict(torch.load(latest_checkpoint(cfg.OUTPUT_DIR), map_location=dev))
+    ck = latest_checkpoint(cfg.OUTPUT_DIR) if args.resume else None
+    if ck:  # [ref: train.py:159-161] resume: weights + both optimizers + both schedulers + iteration
+        rep = load_checkpoint(ck, model, trainer, resume=True)
         start = trainer.iteration
+    elif weights:  # fresh run from MODEL.WEIGHTS (ImageNet backbone pickle or a released LGD checkpoint): weights only
+        rep = load_checkpoint(weights, model)
+    if (ck or weights) and rank == 0:
+        print("loaded %s: %s" % (ck or weights, rep))
+        if rep.unexpected:
+            print("  unexpected keys:", rep.unexpected[:8], "..." if len(rep.unexpected) > 8 else "")
     max_iter = cfg.SOLVER.MAX_ITER if args.max_iter is None else min(cfg.SOLVER.MAX_ITER, args.max_iter)
     metrics_f = open(os.path.join(cfg.OUTPUT_DIR, "metrics.json"), "a") if rank == 0 and (os.makedirs(cfg.OUTPUT_DIR, exist_ok=True) or True) else None
     t0 = time.perf_counter()
@@ -97,8 +110,10 @@ def main():
                 metrics_f.flush()
                 print("iter %d  total_loss %.4f  %s  stu_lr %.6f  %.3f s/iter" % (
                     it, m["total_loss"], "  ".join("%s %.4f" % (k, v) for k, v in m.items() if k.startswith("loss")), m["stu_lr"], m["time"]))
-        if rank == 0 and ((it + 1) % cfg.SOLVER.CHECKPOINT_PERIOD == 0 or it == max_iter - 1):  # train.py:165-167,234
-            save_checkpoint(trainer, cfg.OUTPUT_DIR, "model_%07d.pth" % it if it != max_iter - 1 else "model_final.pth")
+        if (it + 1) % cfg.SOLVER.CHECKPOINT_PERIOD == 0 or it == max_iter - 1:  # train.py:165-167,234
+            trainer.check_finite()  # never write (and point last_checkpoint at) weights that went through a non-finite loss
+            if rank == 0:
+                save_checkpoint(trainer, cfg.OUTPUT_DIR, "model_%07d.pth" % it if it != max_iter - 1 else "model_final.pth")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
