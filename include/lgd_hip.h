@@ -264,14 +264,17 @@ int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* la
  * tile = 4: F(4x4,3x3): 36 frequencies (buffers [C][36][T]), windows 6x6 at stride 4, 4x4 outputs per tile,
  *   T = sum_l (N * ceil(H_l/4) * ceil(W_l/4) rounded up to a multiple of 4 with zero tiles); flip must be 0 -- the host transforms the rotated filter.
  *   0.56x the GEMM work and ~0.65x the transform traffic of tile = 2; fp32 rounding ~1e-5 of the output scale per
- *   convolution instead of ~6e-7. */
+ *   convolution instead of ~6e-7.
+ * relu_bits (tile = 4 only, may be NULL): [C][T] uint16, one entry per tile: bit 4*i+j set <=> output (i,j) of the tile is > 0.
+ *   lgd_wino_out writes it (with relu = 1); lgd_wino_in / lgd_wino_out_t take it INSTEAD of relu_ref_host as the gradient mask:
+ *   1 bit per pixel instead of re-reading the 4-byte forward output, and the forward output need not be kept for the backward. */
 size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N, int tile);
-int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, const int32_t* level_hw_host, int L, int N,
-                int C, int tile, int flip, float* V, float* dM, void* stream);
+int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, const uint16_t* relu_bits, const int32_t* level_hw_host,
+                int L, int N, int C, int tile, int flip, float* V, float* dM, void* stream);
 int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host, int L, int N, int C, int tile, int flip,
-                 int relu, float* const* y_host, void* stream);
-int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const int32_t* level_hw_host, int L,
-                   int N, int C, int tile, float* dM, void* stream);
+                 int relu, float* const* y_host, uint16_t* relu_bits, void* stream);
+int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const uint16_t* relu_bits,
+                   const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM, void* stream);
 
 /* ------------------------------------------------------------------ FCOS ground-truth assignment
  * [ref: models/customized_detectors/thirdparty_heads/fcos.py:177-284  FCOS.get_ground_truth]

@@ -70,10 +70,12 @@ __global__ __launch_bounds__(256) void fcos_target_kernel(FcosTargetArgs a) {
     a.out_cls[o] = best == INFINITY ? (int64_t)a.num_classes : a.classes[arg];
     reinterpret_cast<float4*>(a.out_delta)[o] = make_float4(bl, bt, br, bb);
     // clamp_(min=0) keeps NaN (0/0 on a zero-extent box), as torch does; such locations are never foreground
-    float q0 = fminf(bl, br) / fmaxf(bl, br), q1 = fminf(bt, bb) / fmaxf(bt, bb);
+    // division and square root through fp64: (float)((double)a / b) and (float)sqrt((double)x) ARE the correctly rounded fp32
+    // results (53 >= 2*24 + 2 bits), whatever the compiler's fp32 division / sqrt expansion does
+    float q0 = (float)((double)fminf(bl, br) / (double)fmaxf(bl, br)), q1 = (float)((double)fminf(bt, bb) / (double)fmaxf(bt, bb));
     q0 = q0 < 0.f ? 0.f : q0;
     q1 = q1 < 0.f ? 0.f : q1;
-    a.out_ctr[o] = sqrtf(q0 * q1);
+    a.out_ctr[o] = (float)sqrt((double)(q0 * q1));
 }
 
 }  // namespace lgd

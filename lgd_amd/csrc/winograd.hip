@@ -32,6 +32,8 @@ struct WinoArgs {
     float* buf_out;                         // [16][C][T]
     float* buf_out2;                        // [16][C][T] (dual)
     const float* bias;
+    unsigned short* bits_out;               // optional (tile 4, relu): [C][T] 16-bit ReLU masks of the tiles' 4x4 outputs, bit 4*i+j = y[i][j] > 0
+    const unsigned short* bits_in;          // optional (tile 4): the same table as the gradient mask of wino_in / wino_out_t
     long long tile_off[LGD_MAX_LEVELS];     // first tile of the level (even)
     long long T;                            // total tiles incl. per-level padding (even count for tile 2, multiple of 4 for tile 4)
     long long cs;                           // channel stride of the frequency buffers = nf * T  (layout [C][nf][T])
@@ -365,7 +367,9 @@ __device__ __forceinline__ void stage_store12(const float* lds, float* dst, size
     }
 }
 
-template <bool VEC, bool DUAL, bool MASK>
+// MASK: 0 = none; 1 = zero the gradient where the forward output y (mask_ref) is <= 0; 2 = the same mask from the 16-bit
+// per-tile table the forward output transform wrote (1 bit per pixel instead of re-reading the 4-byte output).
+template <bool VEC, bool DUAL, int MASK>
 __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
     const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
@@ -378,9 +382,27 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
     const int tx = (int)(uu % TW), ty = (int)((uu / TW) % TH), n = (int)(uu / ((long long)TW * TH));
     const size_t img = ((size_t)n * a.C + c) * H * W;
     const float* p = a.maps_in[l] + img;
-    const float* pm = MASK ? a.mask_ref[l] + img : nullptr;
+    const float* pm = MASK == 1 ? a.mask_ref[l] + img : nullptr;
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const int lane = threadIdx.x & 63;
+    // MASK == 2: this tile's, the upper and the lower tile's masks (rows -1 / 0..3 / 4 of the window), and the same three of
+    // the left and right neighbour tiles (columns -1 and 4) from the neighbour lanes; only the wave's end lanes load them
+    unsigned mc[3] = {0u, 0u, 0u}, ml[3] = {0u, 0u, 0u}, mr[3] = {0u, 0u, 0u};
+    const unsigned short* pb = MASK == 2 ? a.bits_in + (size_t)c * plane + (size_t)a.tile_off[l] : nullptr;
+    if constexpr (MASK == 2) {
+        const bool up = ty > 0, dn = ty < TH - 1;
+        mc[1] = pb[uu];
+        mc[0] = up ? pb[uu - TW] : 0u;
+        mc[2] = dn ? pb[uu + TW] : 0u;
+        #pragma unroll
+        for (int k = 0; k < 3; ++k) { ml[k] = __shfl_up(mc[k], 1); mr[k] = __shfl_down(mc[k], 1); }
+        if (lane == 0 && tx != 0) {
+            ml[1] = pb[uu - 1]; ml[0] = up ? pb[uu - TW - 1] : 0u; ml[2] = dn ? pb[uu + TW - 1] : 0u;
+        }
+        if ((lane == 63 || u + 1 >= units) && tx != TW - 1) {
+            mr[1] = pb[uu + 1]; mr[0] = up ? pb[uu - TW + 1] : 0u; mr[2] = dn ? pb[uu + TW + 1] : 0u;
+        }
+    }
     float d[6][6];
     #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -388,21 +410,29 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
         const bool yok = y >= 0 && y < H;
         const size_t ro = (size_t)(yok ? y : 0) * W;
         const float* row = p + ro;
+        // window row i lives in tile-row r of family f (0: upper tile, 1: this tile, 2: lower tile)
+        const int f = i == 0 ? 0 : (i == 5 ? 2 : 1), r = i == 0 ? 3 : (i == 5 ? 0 : i - 1);
         if constexpr (VEC) {
             float4 m = yok ? *reinterpret_cast<const float4*>(row + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (MASK) {
+            if constexpr (MASK == 1) {
                 const float4 k = yok ? *reinterpret_cast<const float4*>(pm + ro + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
                 m.x = k.x > 0.f ? m.x : 0.f; m.y = k.y > 0.f ? m.y : 0.f; m.z = k.z > 0.f ? m.z : 0.f; m.w = k.w > 0.f ? m.w : 0.f;
+            }
+            if constexpr (MASK == 2) {
+                const unsigned nib = mc[f] >> (4 * r);
+                m.x = (nib & 1u) ? m.x : 0.f; m.y = (nib & 2u) ? m.y : 0.f; m.z = (nib & 4u) ? m.z : 0.f; m.w = (nib & 8u) ? m.w : 0.f;
             }
             // halo columns = the neighbour lanes' edge values (same image row unless first / last tile of the row)
             float e0 = __shfl_up(m.w, 1), e5 = __shfl_down(m.x, 1);
             if (lane == 0 && tx != 0) {
                 e0 = yok ? row[x0] : 0.f;
-                if constexpr (MASK) { if (yok) e0 = pm[ro + x0] > 0.f ? e0 : 0.f; }
+                if constexpr (MASK == 1) { if (yok) e0 = pm[ro + x0] > 0.f ? e0 : 0.f; }
+                if constexpr (MASK == 2) e0 = ((ml[f] >> (4 * r + 3)) & 1u) ? e0 : 0.f;
             }
             if ((lane == 63 || u + 1 >= units) && tx != TW - 1) {
                 e5 = yok ? row[x0 + 5] : 0.f;
-                if constexpr (MASK) { if (yok) e5 = pm[ro + x0 + 5] > 0.f ? e5 : 0.f; }
+                if constexpr (MASK == 1) { if (yok) e5 = pm[ro + x0 + 5] > 0.f ? e5 : 0.f; }
+                if constexpr (MASK == 2) e5 = ((mr[f] >> (4 * r)) & 1u) ? e5 : 0.f;
             }
             if (tx == 0) e0 = 0.f;
             if (tx == TW - 1) e5 = 0.f;
@@ -413,7 +443,12 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
                 const int x = x0 + j;
                 const bool ok = yok && x >= 0 && x < W;
                 float e = ok ? row[x] : 0.f;
-                if constexpr (MASK) { if (ok) e = pm[ro + x] > 0.f ? e : 0.f; }
+                if constexpr (MASK == 1) { if (ok) e = pm[ro + x] > 0.f ? e : 0.f; }
+                if constexpr (MASK == 2) {
+                    const unsigned w16 = j == 0 ? ml[f] : (j == 5 ? mr[f] : mc[f]);
+                    const int cc = j == 0 ? 3 : (j == 5 ? 0 : j - 1);
+                    e = ((w16 >> (4 * r + cc)) & 1u) ? e : 0.f;
+                }
                 d[i][j] = e;
             }
         }
@@ -473,7 +508,7 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
     }
 }
 
-template <bool DUAL, bool MASK>
+template <bool DUAL, int MASK>
 __global__ __launch_bounds__(256) void wino4_in_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[12 * 256];
     const int l = wino_level(a);
@@ -529,12 +564,18 @@ __device__ __forceinline__ void wino4_out_body(const WinoArgs& a, int l, float* 
     const float b = a.bias ? a.bias[c] : 0.f;
     float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
     const int oy = 4 * ty, ox = 4 * tx;
+    unsigned bits = 0u;
     #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float y[4];
         at6(r[i], y);
         #pragma unroll
-        for (int j = 0; j < 4; ++j) { y[j] += b; if (a.relu) y[j] = fmaxf(y[j], 0.f); }
+        for (int j = 0; j < 4; ++j) {
+            y[j] += b;
+            if (a.relu) y[j] = fmaxf(y[j], 0.f);
+            bits |= (y[j] > 0.f ? 1u : 0u) << (4 * i + j);
+        }
+        if (i == 3 && a.bits_out) a.bits_out[(size_t)c * plane + (size_t)a.tile_off[l] + u] = (unsigned short)bits;
         if (oy + i >= H) continue;
         float* row = p + (size_t)(oy + i) * W + ox;
         if constexpr (VEC) {
@@ -569,6 +610,7 @@ __global__ __launch_bounds__(256) void wino4_out_t_kernel(WinoArgs a) {
     const size_t img = ((size_t)n * a.C + c) * H * W;
     const float* p = a.maps_in[l] + img;
     const float* pm = a.mask_ref[l] ? a.mask_ref[l] + img : nullptr;
+    const unsigned mb = a.bits_in ? a.bits_in[(size_t)c * (size_t)a.T + (size_t)a.tile_off[l] + uu] : 0xffffu;
     float r[6][4];
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -580,6 +622,7 @@ __global__ __launch_bounds__(256) void wino4_out_t_kernel(WinoArgs a) {
             const size_t at = (size_t)y * W + x;
             float e = ok ? p[at] : 0.f;
             if (ok && pm) e = pm[at] > 0.f ? e : 0.f;
+            e = ((mb >> (4 * i + j)) & 1u) ? e : 0.f;
             col[i] = e;
         }
         float w[6];
@@ -609,7 +652,7 @@ static int wino_fill(WinoArgs& a, const int32_t* level_hw, int L, int N, int C, 
     if (!level_hw || L < 1 || L > LGD_MAX_LEVELS || N < 1 || C < 1 || C > 65535 || (tile != 2 && tile != 4) || (tile == 4 && flip))
         return LGD_EINVAL;
     a.L = L; a.N = N; a.C = C; a.flip = flip ? 1 : 0; a.relu = 0;
-    a.bias = nullptr; a.buf_in = nullptr; a.buf_out = a.buf_out2 = nullptr;
+    a.bias = nullptr; a.buf_in = nullptr; a.buf_out = a.buf_out2 = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
     long long off = 0;
     unsigned blk = 0;
     for (int l = 0; l < LGD_MAX_LEVELS; ++l) {
@@ -645,11 +688,13 @@ size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N, int tile) {
     return (size_t)t;
 }
 
-int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, const int32_t* level_hw_host, int L, int N,
-                int C, int tile, int flip, float* V, float* dM, void* stream) {
+int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, const uint16_t* relu_bits, const int32_t* level_hw_host,
+                int L, int N, int C, int tile, int flip, float* V, float* dM, void* stream) {
     lgd::WinoArgs a;
     unsigned blocks;
     if (!x_host || !V || lgd::wino_fill(a, level_hw_host, L, N, C, flip, 0, tile, &blocks) != LGD_OK) return LGD_EINVAL;
+    if (relu_bits && (relu_ref_host || tile != 4)) return LGD_EINVAL;
+    a.bits_in = relu_bits;
     for (int l = 0; l < L; ++l) {
         if (!x_host[l] || (relu_ref_host && !relu_ref_host[l])) return LGD_EINVAL;
         a.maps_in[l] = x_host[l];
@@ -661,11 +706,13 @@ int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, c
     const bool mask = relu_ref_host != nullptr;
     if (tile == 4) {
         if (dM) {
-            if (mask) { LGD_LAUNCH("wino_in_dual_kernel", (lgd::wino4_in_kernel<true, true>), grid, block, 0, st, a); }
-            else { LGD_LAUNCH("wino_in_dual_kernel", (lgd::wino4_in_kernel<true, false>), grid, block, 0, st, a); }
+            if (relu_bits) { LGD_LAUNCH("wino_in_dual_kernel", (lgd::wino4_in_kernel<true, 2>), grid, block, 0, st, a); }
+            else if (mask) { LGD_LAUNCH("wino_in_dual_kernel", (lgd::wino4_in_kernel<true, 1>), grid, block, 0, st, a); }
+            else { LGD_LAUNCH("wino_in_dual_kernel", (lgd::wino4_in_kernel<true, 0>), grid, block, 0, st, a); }
         } else {
-            if (mask) { LGD_LAUNCH("wino_in_kernel", (lgd::wino4_in_kernel<false, true>), grid, block, 0, st, a); }
-            else { LGD_LAUNCH("wino_in_kernel", (lgd::wino4_in_kernel<false, false>), grid, block, 0, st, a); }
+            if (relu_bits) { LGD_LAUNCH("wino_in_kernel", (lgd::wino4_in_kernel<false, 2>), grid, block, 0, st, a); }
+            else if (mask) { LGD_LAUNCH("wino_in_kernel", (lgd::wino4_in_kernel<false, 1>), grid, block, 0, st, a); }
+            else { LGD_LAUNCH("wino_in_kernel", (lgd::wino4_in_kernel<false, 0>), grid, block, 0, st, a); }
         }
     } else {
         if (dM) {
@@ -680,10 +727,12 @@ int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, c
 }
 
 int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host, int L, int N, int C, int tile, int flip,
-                 int relu, float* const* y_host, void* stream) {
+                 int relu, float* const* y_host, uint16_t* relu_bits, void* stream) {
     lgd::WinoArgs a;
     unsigned blocks;
     if (!M || !y_host || lgd::wino_fill(a, level_hw_host, L, N, C, flip, 0, tile, &blocks) != LGD_OK) return LGD_EINVAL;
+    if (relu_bits && tile != 4) return LGD_EINVAL;
+    a.bits_out = relu_bits;
     for (int l = 0; l < L; ++l) {
         if (!y_host[l]) return LGD_EINVAL;
         a.maps_out[l] = y_host[l];
@@ -697,11 +746,13 @@ int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host
     return lgd::check_launch();
 }
 
-int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const int32_t* level_hw_host, int L,
-                   int N, int C, int tile, float* dM, void* stream) {
+int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const uint16_t* relu_bits,
+                   const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM, void* stream) {
     lgd::WinoArgs a;
     unsigned blocks;
     if (!dy_host || !dM || lgd::wino_fill(a, level_hw_host, L, N, C, 0, 1, tile, &blocks) != LGD_OK) return LGD_EINVAL;
+    if (relu_bits && (relu_ref_host || tile != 4)) return LGD_EINVAL;
+    a.bits_in = relu_bits;
     for (int l = 0; l < L; ++l) {
         if (!dy_host[l] || (relu_ref_host && !relu_ref_host[l])) return LGD_EINVAL;
         a.maps_in[l] = dy_host[l];

@@ -776,35 +776,40 @@ class _Conv3x3(torch.autograd.Function):
         T = lib.lgd_wino_tiles(hw, L, N, tile)
         U = torch.mm(_wino_gg(dev, tile), w.view(Co * Ci, 9).t()).view(nf, Co, Ci)
         V = _freq_buf(nf, Ci, T, dev)
-        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
+        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
         fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
         _count_bytes("wino_in_kernel", (px + fb) * Ci)
         _count_bytes("wino_out_kernel", (px + fb) * Co)
         M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
         ys = [torch.empty((N, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
+        # ReLU mask for the backward: 16 bits per 4x4 output tile written by the output transform (tile 4), so the backward reads
+        # 1 bit instead of 4 bytes per pixel and the forward output is not kept alive; tile 2 keeps the output itself
+        bits = torch.empty((Co, T), dtype=torch.int16, device=dev) if (relu and tile == 4) else None
         hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(b) if b is not None else None, hw, L, N, Co, tile, 0, int(relu),
-                                   hip.ptr_array(ys), hip.stream_ptr()), "lgd_wino_out")
+                                   hip.ptr_array(ys), hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
         need_w = ctx.needs_input_grad[0]
         # tile 2 reuses U for the input gradient (the filter rotation is a frequency permutation); tile 4 keeps w
-        ctx.save_for_backward(U if tile == 2 else w, V if need_w else None, *(ys if relu else []))
+        ctx.save_for_backward(U if tile == 2 else w, V if need_w else None, bits, *(ys if (relu and bits is None) else []))
         ctx.meta = (L, N, Ci, Co, hw, T, bool(relu), b is not None, [tuple(x.shape[2:]) for x in xs], tile, px, fb)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
-        Uw, V, *yref = ctx.saved_tensors
+        Uw, V, bits, *yref = ctx.saved_tensors
         L, N, Ci, Co, hw, T, relu, has_bias, shapes, tile, px, fb = ctx.meta
         lib = hip.load()
         dev = Uw.device
         nf = (tile + 2) ** 2
         dys = [hip.dense_f32(g) for g in dys]
         need_w, need_x = ctx.needs_input_grad[0], any(ctx.needs_input_grad[4:])
-        ref = hip.ptr_array(yref) if relu else None
+        ref = hip.ptr_array(yref) if (relu and bits is None) else None
+        pbits = hip.ptr(bits) if bits is not None else None
         dw = db = None
         dxs = [None] * L
         dM = None
-        pdy = px * Co * (2 if relu else 1)  # dy (+ the forward output as the ReLU mask)
+        # dy + the ReLU mask: the forward output again (tile 2) or 2 bytes per 16 pixels (tile 4)
+        pdy = px * Co * (2 if (relu and bits is None) else 1) + (2 * T * Co if bits is not None else 0)
         if need_x:
             _count_bytes("wino_in_dual_kernel" if need_w else "wino_in_kernel", pdy + fb * Co * (2 if need_w else 1))
             _count_bytes("wino_out_kernel", (px + fb) * Ci)
@@ -815,18 +820,18 @@ class _Conv3x3(torch.autograd.Function):
                 Ut, flip = torch.mm(_wino_gg(dev, tile), wr.t()).view(nf, Ci, Co), 0
             Vd = _freq_buf(nf, Co, T, dev)
             dM = _freq_buf(nf, Co, T, dev) if need_w else None
-            hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, hw, L, N, Co, tile, flip, hip.ptr(Vd),
+            hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, pbits, hw, L, N, Co, tile, flip, hip.ptr(Vd),
                                       hip.ptr(dM) if need_w else None, hip.stream_ptr()), "lgd_wino_in")
             Md = _timed_bmm("wino_gemm_dx", Ut, Vd, out=_freq_buf(nf, Ci, T, dev))
             del Vd
             dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-            hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, flip, 0, hip.ptr_array(dxs), hip.stream_ptr()),
+            hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, flip, 0, hip.ptr_array(dxs), None, hip.stream_ptr()),
                       "lgd_wino_out")
             del Md
         elif need_w:
             _count_bytes("wino_out_t_kernel", pdy + fb * Co)
             dM = _freq_buf(nf, Co, T, dev)
-            hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
+            hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, pbits, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
                       "lgd_wino_out_t")
         if need_w:
             dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
@@ -835,6 +840,8 @@ class _Conv3x3(torch.autograd.Function):
                 # A's row of the interpolation point 1 is all ones: that frequency of dM = A g A^T is the tile's gradient sum
                 db = dM[tile + 3].sum(1)
         elif has_bias and ctx.needs_input_grad[1]:
+            if bits is not None:
+                raise hip.LgdHipError("bias gradient without weight / input gradient is not used on the path")
             db = sum((g * (y > 0) if relu else g).sum((0, 2, 3)) for g, y in zip(dys, yref if relu else dys))
         return (dw, db, None, None, *dxs)
 

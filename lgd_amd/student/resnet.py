@@ -20,8 +20,16 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(c) - eps)
 
     def scale_shift(self):
-        scale = self.weight * (self.running_var + self.eps).rsqrt()
-        return scale, self.bias - self.running_mean * scale
+        """(scale, shift) of the frozen affine; the four buffers never change during training, so the pair is computed once
+        and reused until a buffer is written (load_state_dict / .to(): tracked by the tensors' identity and version counters)."""
+        bufs = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((id(b), b._version) for b in bufs)
+        if getattr(self, "_ss_key", None) != key:
+            with torch.no_grad():
+                scale = self.weight * (self.running_var + self.eps).rsqrt()
+                self._ss = (scale, self.bias - self.running_mean * scale)
+            self._ss_key = key
+        return self._ss
 
     def forward(self, x):
         scale, shift = self.scale_shift()
@@ -42,7 +50,15 @@ class ConvBN(nn.Conv2d):
         """conv -> FrozenBN [-> += residual] [-> ReLU]: the affine is folded into the filter; bias, residual and ReLU are ONE
         pass over the conv output (ops.bias_act) instead of three."""
         scale, shift = self.norm.scale_shift()
-        w = self.weight * scale.view(-1, 1, 1, 1)
+        if self.weight.requires_grad:
+            w = self.weight * scale.view(-1, 1, 1, 1)
+        else:  # frozen (FREEZE_AT prefix, or the backbone-freeze phase): the folded filter is reused until the weight is written
+            key = (id(self.weight), self.weight._version, id(scale))
+            if getattr(self, "_fold_key", None) != key:
+                with torch.no_grad():
+                    self._fold = self.weight * scale.view(-1, 1, 1, 1)
+                self._fold_key = key
+            w = self._fold
         if self._plain3x3 and residual is None:  # 3x3 / stride 1: Winograd transforms + GEMMs (bias + ReLU fused in the output transform)
             return ops.conv3x3(x, w, shift, relu=relu)
         if self._pointwise:

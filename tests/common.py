@@ -97,3 +97,23 @@ def kink_robust_close(a, b, tol=1e-4, max_outlier_frac=5e-4, max_rel=2e-2):
     bad = ((a - b).abs() > tol * (b.abs() + rms)).double().mean().item()
     rel = float((a - b).norm() / (b.norm() + 1e-30))
     return (bad <= max_outlier_frac and rel <= max_rel), "outlier frac %.2e (max %.0e), rel L2 %.2e (max %.0e)" % (bad, max_outlier_frac, rel, max_rel)
+
+
+def oracle_grads_on_device(name, device):
+    """the ORACLE's fp32 torch ops executed on `device` (the reference's own arithmetic on this platform): feature and
+    parameter gradients of  loss_distill(flag=1) + sum(teacher feats * probe)  for golden case `name`.
+    Used to calibrate model-level gradient bounds: a ReLU input within rounding noise of zero gets its backward mask from the
+    platform's summation order, so ANY fp32 evaluation on another platform (this one included) leaves the CPU reference's
+    gradient by ~1e-3 on the levels where that happens (measured on MI355X, tools/diag_grad_chain.py: oracle-fp32-on-GPU vs
+    fp64: 1e-3 at p3, 3..5e-3 at p5, 5e-6 at p4/p6/p7 -- and the HIP path shows the same numbers on the same levels)."""
+    B, H, W, ctx, interact, fmt, coef, _ = CASES[name]
+    p = {k: v.to(device).requires_grad_(True) for k, v in teacher_params().items()}
+    pa = {k: v.to(device).requires_grad_(True) for k, v in adapter_params().items()}
+    feats = {k: v.to(device).requires_grad_(True) for k, v in case_feats(name).items()}
+    tea, _, _ = O.teacher_forward(p, feats, case_gt(name), (H, W), ctx, interact, False, fmt)
+    loss = O.distill_loss(pa, feats, tea, coef, 1)
+    pr = probes(tea)
+    (loss + sum((tea[k] * pr[k].to(device)).sum() for k in tea)).backward()
+    grads = {n: v.grad for n, v in p.items()}
+    grads.update({"adapter." + n: v.grad for n, v in pa.items()})
+    return {k: feats[k].grad for k in feats}, grads

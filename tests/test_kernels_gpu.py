@@ -827,10 +827,15 @@ def test_group_norm_relu_fwd_bwd(B, C, G, level_hw, relu, affine):
 
 
 # ------------------------------------------------------------------------------------------- FCOS target assignment
+def counts_mask(counts, R):
+    """(B,R) bool: images that have ground truth (images without boxes get zero targets, not the formula)."""
+    return np.repeat((np.array(counts) > 0)[:, None], R, 1)
+
+
 @pytest.mark.parametrize("radius", [1.5, 0.0])
 def test_fcos_targets_bit_exact(radius):
     """lgd_fcos_targets vs the elementwise restatement of FCOS.get_ground_truth [ref: thirdparty_heads/fcos.py:177-284] at
-    the config-3 shape (22,400 locations): classes, ltrb deltas and centerness bit-identical; an image without boxes, a
+    the config-3 shape (22,400 locations): classes and ltrb deltas bit-identical, centerness = the IEEE value; an image without boxes, a
     crowded image, nested boxes of equal centre (min-area tie break), duplicate boxes (first index wins)."""
     from lgd_amd import ops
     level_hw = synth.pyramid_shapes(800, 1344)
@@ -863,6 +868,16 @@ def test_fcos_targets_bit_exact(radius):
     assert torch.equal(dl, rd)
     fg = rc != 80
     assert int(fg.sum()) > 100
-    assert torch.equal(ct[fg], rt[fg])
-    assert torch.equal(torch.nan_to_num(ct, nan=-1.0), torch.nan_to_num(rt, nan=-1.0))
+    # centerness: torch's CPU sqrt is not correctly rounded (2 of 273 foreground values of this very case differ from IEEE by
+    # one ulp), so the restatement is held to 1 ulp and the kernel to the IEEE evaluation (numpy) of the same formula
+    assert torch.allclose(ct[fg], rt[fg], rtol=2.4e-7, atol=0.0)
+    d = dl.numpy()
+    with np.errstate(all="ignore"):
+        q0 = np.minimum(d[..., 0], d[..., 2]) / np.maximum(d[..., 0], d[..., 2])
+        q1 = np.minimum(d[..., 1], d[..., 3]) / np.maximum(d[..., 1], d[..., 3])
+        ieee = np.sqrt(np.where(q0 < 0, np.float32(0), q0) * np.where(q1 < 0, np.float32(0), q1))
+    keep = cls.numpy() != 80
+    assert ieee.dtype == np.float32 and np.array_equal(ct.numpy()[keep], ieee[keep])
+    assert np.array_equal(np.nan_to_num(ct.numpy(), nan=-1.0)[counts_mask(counts, cls.shape[1])],
+                          np.nan_to_num(ieee, nan=-1.0)[counts_mask(counts, cls.shape[1])])
     assert bool((cls[1] == 80).all()) and float(dl[1].abs().max()) == 0.0
