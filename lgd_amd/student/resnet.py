@@ -45,8 +45,16 @@ class ConvBN(nn.Conv2d):
         self.norm = FrozenBatchNorm2d(cout)
         self._plain3x3 = (k == 3 and stride == 1 and padding == 1 and dilation == 1 and groups == 1)
         self._pointwise = (k == 1 and stride == 1 and padding == 0 and groups == 1)
+        # 1x1 / stride 2 (STRIDE_IN_1X1 bottlenecks, projection shortcuts) = take every other pixel, then a pointwise conv:
+        # forward, input and weight gradient then run as plain GEMMs instead of the library's strided implicit-GEMM kernels,
+        # whose weight gradient transposes both operands to NHWC first (4.5 ms/step at config 2)
+        self._pointwise_s2 = (k == 1 and stride == 2 and padding == 0 and groups == 1)
 
-    def forward(self, x, relu=False, residual=None):
+    @staticmethod
+    def subsample2(x):
+        return x[:, :, ::2, ::2].contiguous()
+
+    def forward(self, x, relu=False, residual=None, subsampled=False):
         """conv -> FrozenBN [-> += residual] [-> ReLU]: the affine is folded into the filter; bias, residual and ReLU are ONE
         pass over the conv output (ops.bias_act) instead of three."""
         scale, shift = self.norm.scale_shift()
@@ -61,7 +69,9 @@ class ConvBN(nn.Conv2d):
             w = self._fold
         if self._plain3x3 and residual is None:  # 3x3 / stride 1: Winograd transforms + GEMMs (bias + ReLU fused in the output transform)
             return ops.conv3x3(x, w, shift, relu=relu)
-        if self._pointwise:
+        if self._pointwise or self._pointwise_s2:
+            if self._pointwise_s2 and not subsampled:
+                x = self.subsample2(x)
             y = ops.conv1x1(x, w)
         else:
             y = F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
@@ -78,9 +88,12 @@ class Bottleneck(nn.Module):
         self.conv3 = ConvBN(mid, cout, 1)
 
     def forward(self, x):
-        out = self.conv1(x, relu=True)
+        shared = self.conv1._pointwise_s2 and self.shortcut is not None and self.shortcut._pointwise_s2
+        if shared:  # conv1 and the projection shortcut read the same every-other-pixel view of x: take it once
+            x = ConvBN.subsample2(x)
+        out = self.conv1(x, relu=True, subsampled=shared)
         out = self.conv2(out, relu=True)
-        sc = self.shortcut(x) if self.shortcut is not None else x
+        sc = self.shortcut(x, subsampled=shared) if self.shortcut is not None else x
         return self.conv3(out, relu=True, residual=sc)
 
 
@@ -97,7 +110,10 @@ class DeformBottleneck(Bottleneck):
 
     def forward(self, x):
         from .deform import modulated_deform_conv2d
-        out = self.conv1(x, relu=True)
+        shared = self.conv1._pointwise_s2 and self.shortcut is not None and self.shortcut._pointwise_s2
+        if shared:
+            x = ConvBN.subsample2(x)
+        out = self.conv1(x, relu=True, subsampled=shared)
         om = self.conv2_offset(out)
         if self.modulated:
             o1, o2, m = torch.chunk(om, 3, dim=1)
@@ -108,7 +124,7 @@ class DeformBottleneck(Bottleneck):
         scale, shift = c2.norm.scale_shift()
         out = modulated_deform_conv2d(out, offset, mask, c2.weight * scale.view(-1, 1, 1, 1), shift, c2.stride[0],
                                       c2.padding[0], c2.dilation[0])
-        sc = self.shortcut(x) if self.shortcut is not None else x
+        sc = self.shortcut(x, subsampled=shared) if self.shortcut is not None else x
         return self.conv3(F.relu_(out), relu=True, residual=sc)
 
 
