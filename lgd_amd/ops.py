@@ -305,6 +305,9 @@ class _GroupNormRelu(torch.autograd.Function):
         ws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)
         stats = torch.empty((L * B * groups, 2), dtype=torch.float32, device=dev)
         ys = [torch.empty_like(x) for x in xs]
+        nb = 4 * sum(x.numel() for x in xs)
+        _count_bytes("gn_group_stats_kernel", nb)
+        _count_bytes("gn_group_apply_kernel", 2 * nb)
         hip.check(lib.lgd_gn_group_fwd(hip.ptr_array(xs), hw, L, B, C, groups, hip.ptr(weight) if weight is not None else None,
                                        hip.ptr(bias) if bias is not None else None, int(relu), hip.ptr(ws), hip.ptr(stats),
                                        hip.ptr_array(ys), hip.stream_ptr()), "lgd_gn_group_fwd")
@@ -323,6 +326,9 @@ class _GroupNormRelu(torch.autograd.Function):
         bstats = torch.empty((L * B * groups, 2), dtype=torch.float32, device=dev)
         psums = torch.empty((L * B, C, 2), dtype=torch.float32, device=dev)
         dxs = [torch.empty_like(x) for x in xs]
+        nb = 4 * sum(x.numel() for x in xs)
+        _count_bytes("gn_group_bwd_stats_kernel", 2 * nb)
+        _count_bytes("gn_group_bwd_apply_kernel", 3 * nb)
         hip.check(lib.lgd_gn_group_bwd(hip.ptr_array(xs), hip.ptr_array(dys), hw, L, B, C, groups,
                                        hip.ptr(weight) if weight is not None else None, hip.ptr(bias) if bias is not None else None,
                                        int(relu), hip.ptr(stats), hip.ptr(ws), hip.ptr(bstats), hip.ptr(psums), hip.ptr_array(dxs),
@@ -1073,6 +1079,56 @@ class _BiasAct(torch.autograd.Function):
 def bias_act(x, bias=None, residual=None, relu=True):
     """relu(x + bias.view(1,-1,1,1) + residual) for NCHW fp32 maps in one pass."""
     return _BiasAct.apply(x, bias, residual, bool(relu))
+
+
+class _PointwiseConvBN(torch.autograd.Function):
+    """1x1 / stride 1 convolution with a folded frozen per-channel affine, as ONE autograd node:
+        out = relu?( conv(x, w * scale[:, None, None, None]) + shift[c] (+ residual) )
+    [d2-memory: conv -> FrozenBN (-> += shortcut) -> relu of the bottleneck blocks, SURVEY.md appendix A].  The filter fold, the
+    library GEMM, the bias / residual / ReLU epilogue kernel and, backward, the ReLU mask kernel, the input-gradient GEMM and the
+    weight gradient as per-image NT GEMMs on the NCHW maps run under a single node -- three autograd nodes and their host
+    bookkeeping less per convolution than fold * conv1x1 * bias_act, which is what bounds the step at 2 images per GPU."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, residual, relu):
+        hip.require_gpu(x, w)
+        lib = hip.load()
+        x = hip.dense_f32(x)
+        wf = w * scale.view(-1, 1, 1, 1)
+        y = F.conv2d(x, wf)
+        residual = hip.dense_f32(residual) if residual is not None else None
+        N, C = y.shape[0], y.shape[1]
+        out = torch.empty_like(y)
+        hip.check(lib.lgd_bias_act_fwd(hip.ptr(y), hip.ptr(shift), hip.ptr(residual) if residual is not None else None, N, C,
+                                       y.numel() // (N * C), int(relu), hip.ptr(out), hip.stream_ptr()), "lgd_bias_act_fwd")
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, wf, scale, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wf, scale, out = ctx.saved_tensors
+        dy = hip.dense_f32(dy)
+        if ctx.relu:
+            dz = torch.empty_like(dy)
+            hip.check(hip.load().lgd_relu_mask_bwd(hip.ptr(out), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
+                      "lgd_relu_mask_bwd")
+        else:
+            dz = dy
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dz, x, wf, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            N, Ci, Co = x.shape[0], x.shape[1], wf.shape[0]
+            dw = torch.bmm(dz.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2)).sum(0)
+            dw = (dw * scale.view(-1, 1)).view(Co, Ci, 1, 1)
+        return dx, dw, None, None, (dz if ctx.needs_input_grad[4] else None), None
+
+
+def pointwise_conv_bn(x, w, scale, shift, residual=None, relu=True):
+    """relu?(conv1x1(x, w * scale) + shift (+ residual)); scale / shift are the frozen affine of the FrozenBN that follows."""
+    return _PointwiseConvBN.apply(x, w, scale, shift, residual, bool(relu))
 
 
 class _Conv1x1(torch.autograd.Function):

@@ -58,6 +58,10 @@ class ConvBN(nn.Conv2d):
         """conv -> FrozenBN [-> += residual] [-> ReLU]: the affine is folded into the filter; bias, residual and ReLU are ONE
         pass over the conv output (ops.bias_act) instead of three."""
         scale, shift = self.norm.scale_shift()
+        if self._pointwise or self._pointwise_s2:  # fold + GEMM + epilogue (and their backward) as one autograd node
+            if self._pointwise_s2 and not subsampled:
+                x = self.subsample2(x)
+            return ops.pointwise_conv_bn(x, self.weight, scale, shift, residual, relu)
         if self.weight.requires_grad:
             w = self.weight * scale.view(-1, 1, 1, 1)
         else:  # frozen (FREEZE_AT prefix, or the backbone-freeze phase): the folded filter is reused until the weight is written
@@ -69,12 +73,7 @@ class ConvBN(nn.Conv2d):
             w = self._fold
         if self._plain3x3 and residual is None:  # 3x3 / stride 1: Winograd transforms + GEMMs (bias + ReLU fused in the output transform)
             return ops.conv3x3(x, w, shift, relu=relu)
-        if self._pointwise or self._pointwise_s2:
-            if self._pointwise_s2 and not subsampled:
-                x = self.subsample2(x)
-            y = ops.conv1x1(x, w)
-        else:
-            y = F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
+        y = F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
         return ops.bias_act(y, shift, residual, relu)
 
 

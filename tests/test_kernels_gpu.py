@@ -881,3 +881,40 @@ def test_fcos_targets_bit_exact(radius):
     assert np.array_equal(np.nan_to_num(ct.numpy(), nan=-1.0)[counts_mask(counts, cls.shape[1])],
                           np.nan_to_num(ieee, nan=-1.0)[counts_mask(counts, cls.shape[1])])
     assert bool((cls[1] == 80).all()) and float(dl[1].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------- student bottleneck: 1x1 conv + FrozenBN (+ residual) + ReLU
+@pytest.mark.parametrize("N,Ci,Co,H,W,relu,res", [(2, 64, 256, 20, 28, True, True), (3, 256, 64, 13, 21, True, False),
+                                                  (2, 128, 128, 8, 12, False, True), (1, 32, 48, 7, 11, False, False)])
+def test_pointwise_conv_bn_fwd_bwd(N, Ci, Co, H, W, relu, res):
+    """ops.pointwise_conv_bn (filter fold + library GEMM + lgd_bias_act / lgd_relu_mask epilogues as one autograd node) vs
+    conv2d -> per-channel affine (FrozenBN) -> (+ shortcut) -> relu in fp64: value and the gradients of x, w and the shortcut;
+    and the strided form: 1x1 / stride 2 == pointwise conv on every other pixel."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    mk = lambda shp, seed, lo, hi: torch.from_numpy(synth.det_uniform(shp, seed, lo, hi)).to(DEV)
+    x, w = mk((N, Ci, H, W), 1401, -1.0, 1.0).requires_grad_(True), mk((Co, Ci, 1, 1), 1402, -0.2, 0.2).requires_grad_(True)
+    scale, shift = mk((Co,), 1403, 0.5, 1.5), mk((Co,), 1404, -0.3, 0.3)
+    r = mk((N, Co, H, W), 1405, -1.0, 1.0).requires_grad_(True) if res else None
+    gy = mk((N, Co, H, W), 1406, -1.0, 1.0)
+    out = ops.pointwise_conv_bn(x, w, scale, shift, r, relu)
+    out.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    rd = r.detach().double().requires_grad_(True) if res else None
+    ref = F.conv2d(xd, wd) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if res:
+        ref = ref + rd
+    if relu:
+        ref = F.relu(ref)
+    ref.backward(gy.double())
+    assert cm.rel_err(out, ref) < FTOL
+    if relu:
+        assert float(((out > 0) != (ref > 0)).double().mean()) < 1e-4
+    assert cm.rel_err(x.grad, xd.grad) < 5e-5 and cm.rel_err(w.grad, wd.grad) < 5e-5
+    if res:
+        assert cm.rel_err(r.grad, rd.grad) < 5e-5
+    xs = mk((N, Ci, 2 * H - 1, 2 * W), 1407, -1.0, 1.0)
+    from lgd_amd.student.resnet import ConvBN
+    got = ops.pointwise_conv_bn(ConvBN.subsample2(xs), w.detach(), scale, shift, None, relu)
+    want = F.conv2d(xs.double(), w.detach().double(), stride=2) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    assert cm.rel_err(got, F.relu(want) if relu else want) < FTOL

@@ -12,9 +12,11 @@ from lgd_amd.data import synthetic_batch  # noqa: E402
 from lgd_amd.distillator import build_model  # noqa: E402
 from lgd_amd.engine import Trainer  # noqa: E402
 
-cfg = config.setup_cfg(os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", "cuda"])
+yaml = sys.argv[1] if len(sys.argv) > 1 else "lgd_retinanet_r50"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+cfg = config.setup_cfg(os.path.join(ROOT, "configs", yaml + ".yaml"), ["MODEL.DEVICE", "cuda"])
 tr = Trainer(cfg, build_model(cfg))
-data = synthetic_batch(8, 800, 1333, 10, seed=1, pin=True)
+data = synthetic_batch(B, 800, 1333, 10, seed=1, pin=True)
 for i in range(5):
     tr.step(data, 40000 + i)
 torch.cuda.synchronize()
@@ -28,5 +30,5 @@ for i in range(8):
     t2 = time.perf_counter()
     issue.append(t1 - t0)
     total.append(t2 - t0)
-print("host issue %.1f ms/step, issue+drain %.1f ms/step (GPU idle at start of each step in this measurement)"
+print(yaml, "B=%d:" % B, "host issue %.1f ms/step, issue+drain %.1f ms/step (GPU idle at start of each step in this measurement)"
       % (1e3 * sum(issue) / len(issue), 1e3 * sum(total) / len(total)))

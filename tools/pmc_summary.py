@@ -39,8 +39,11 @@ TIMER_NAMES = {
     "rowln_kernel<0>": ["rowln_kernel"], "rowln_kernel<1>": ["rowln_bwd_kernel"],
     "wino_in_kernel<false, false>": ["wino_in_kernel"], "wino_in_kernel<false, true>": ["wino_in_kernel"],
     "wino_in_kernel<true, false>": ["wino_in_dual_kernel"], "wino_in_kernel<true, true>": ["wino_in_dual_kernel"],
-    "wino4_in_kernel<false, false>": ["wino_in_kernel"], "wino4_in_kernel<false, true>": ["wino_in_kernel"],
-    "wino4_in_kernel<true, false>": ["wino_in_dual_kernel"], "wino4_in_kernel<true, true>": ["wino_in_dual_kernel"],
+    "wino4_in_kernel<false, 0>": ["wino_in_kernel"], "wino4_in_kernel<false, 1>": ["wino_in_kernel"], "wino4_in_kernel<false, 2>": ["wino_in_kernel"],
+    "wino4_in_kernel<true, 0>": ["wino_in_dual_kernel"], "wino4_in_kernel<true, 1>": ["wino_in_dual_kernel"], "wino4_in_kernel<true, 2>": ["wino_in_dual_kernel"],
+    "gg_stats_kernel<0>": ["gn_group_stats_kernel"], "gg_stats_kernel<1>": ["gn_group_bwd_stats_kernel"],
+    "gg_apply_kernel<0>": ["gn_group_apply_kernel"], "gg_apply_kernel<1>": ["gn_group_bwd_apply_kernel"],
+    "gg_finalize_kernel<0>": ["gn_group_finalize_kernel"], "gg_finalize_kernel<1>": ["gn_group_bwd_finalize_kernel"],
     "wino4_out_kernel": ["wino_out_kernel"], "wino4_out_kernel<false>": ["wino_out_kernel"], "wino4_out_kernel<true>": ["wino_out_kernel"],
     "bias_act_kernel<4>": ["bias_act_kernel"], "bias_act_kernel<1>": ["bias_act_kernel"],
     "relu_mask_kernel<4>": ["relu_mask_kernel"], "relu_mask_kernel<1>": ["relu_mask_kernel"], "wino4_out_t_kernel": ["wino_out_t_kernel"],
