@@ -51,6 +51,8 @@ def parse():
                          "180k iterations), nondistill = iterations 20k-30k, frozen = first 20k iterations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
+    ap.add_argument("--head-passes", type=int, default=1, choices=[1, 2],
+                    help="1 = one head pass over student + teacher pyramids (default); 2 = the reference's literal two passes")
     ap.add_argument("--cpu-sample-images", type=int, default=1)
     return ap.parse_args()
 
@@ -161,6 +163,7 @@ def main():
     cfg = config.setup_cfg(args.config, ["MODEL.DEVICE", "cuda:%d" % local_rank])
     torch.manual_seed(0)
     model = build_model(cfg)
+    model.fused_head_pass = args.head_passes == 1
     trainer = Trainer(cfg, model, device=dev, distributed=True if force_ddp else None)
     d = cfg.MODEL.DISTILLATOR
     it0 = {"distill": max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS),

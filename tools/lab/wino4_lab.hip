@@ -210,7 +210,7 @@ int main() {
     run("A layout [c][f][t]", [&](float* x, float* v) { wino4_in<0, 1><<<dim3((unsigned)((T + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
     run("B layout [c][f][t]", [&](float* x, float* v) { wino4_in<1, 1><<<dim3((unsigned)((T + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
 #define ST(NT, PH) run("staged [c][f][t] NT=" #NT " PH=" #PH, [&](float* x, float* v) { wino4_in_staged<NT, PH><<<dim3((unsigned)((T + NT - 1) / NT), C), NT>>>(x, v, N, C, H, W); })
-    ST(256, 1); ST(256, 3);
+    ST(256, 1); ST(256, 3); ST(256, 6); ST(512, 3); ST(512, 6); ST(1024, 3); ST(1024, 6); ST(128, 3); ST(128, 1);
 #define STG(NT, PH, G) run("staged NT=" #NT " PH=" #PH " XCD runs G=" #G, [&](float* x, float* v) { const unsigned nb = (unsigned)((T + NT - 1) / NT); wino4_in_staged<NT, PH, G><<<dim3((nb + 8 * G - 1) / (8 * G) * (8 * G), C), NT>>>(x, v, N, C, H, W); })
     run("staged NT=256 PH=1 channel-fastest dispatch", [&](float* x, float* v) { wino4_in_staged<256, 1, 0, true><<<dim3(C, (unsigned)((T + 255) / 256)), 256>>>(x, v, N, C, H, W); });
     run("staged NT=256 PH=3 channel-fastest dispatch", [&](float* x, float* v) { wino4_in_staged<256, 3, 0, true><<<dim3(C, (unsigned)((T + 255) / 256)), 256>>>(x, v, N, C, H, W); });
