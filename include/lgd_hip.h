@@ -255,9 +255,13 @@ int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* la
  *                   dM = A g A^T of the window's 2x2 centre (the two backward operands in one pass over dy)
  *   lgd_wino_out  : y  = A^T m A + bias (bias may be NULL) [then ReLU if relu], 2x2 outputs per tile, clipped to H x W
  *   lgd_wino_out_t: dM = A dy A^T alone, the adjoint of lgd_wino_out (weight gradient: dU[f] = dM[f] @ V[f]^T)
+ *   lgd_wino_in_t : dx = the adjoint of lgd_wino_in (tile = 4 only): overlap-add of B dV B^T over the 6x6 windows, written as a
+ *                   gather per 4x4 block (deterministic, no atomics).  With it the backward pass of a convolution expands dy ONCE:
+ *                   dM = out_t(dy), dV[f] = U[f]^T @ dM[f], dx = in_t(dV), dU[f] = dM[f] @ V[f]^T -- the autograd of the forward
+ *                   pipeline itself, 2.25 maps of frequency-buffer writes less than the rotated-filter form below.
  * relu_ref_host (may be NULL): the forward outputs y_l of a conv evaluated with relu = 1; the incoming gradient is
  *   zeroed where y_l <= 0 while it is read (the ReLU backward costs no pass of its own).
- * The input gradient is the same pipeline run on dy with the filter rotated by 180 degrees and transposed in (C', C).
+ * tile = 2 computes the input gradient as the same pipeline run on dy with the filter rotated by 180 degrees and transposed in (C', C).
  * tile = 2: F(2x2,3x3) as described (16 frequencies, windows 4x4 at stride 2); the rotation is the frequency
  *   permutation (0<->3 on both axes), applied by the transforms when flip = 1, so the host reuses U and only
  *   transposes it: dx = out(U[f]^T @ in(dy, flip=1), flip=1).
@@ -275,6 +279,7 @@ int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host
                  int relu, float* const* y_host, uint16_t* relu_bits, void* stream);
 int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const uint16_t* relu_bits,
                    const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM, void* stream);
+int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host, void* stream);
 
 /* ------------------------------------------------------------------ FCOS ground-truth assignment
  * [ref: models/customized_detectors/thirdparty_heads/fcos.py:177-284  FCOS.get_ground_truth]

@@ -595,10 +595,12 @@ __global__ __launch_bounds__(256) void wino4_out_kernel(WinoArgs a) {
     else wino4_out_body<false, STAGE>(a, l, lds);
 }
 
-// dM = A dy A^T alone
-__global__ __launch_bounds__(256) void wino4_out_t_kernel(WinoArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[36 * 256];
-    const int l = wino_level(a);
+// dM = A dy A^T alone: the ONE transform of dy the backward pass needs.  Both backward products hang off it --
+// dU[f] = dM[f] V[f]^T (weight gradient) and dV[f] = U[f]^T dM[f] (input gradient in the frequency domain, brought back by
+// wino4_in_t below) -- so dy is expanded once (2.25x) instead of twice (the rotated-filter form needs B^T dy B as well).
+// A tile's 4x4 block is four aligned float4 rows (W % 4 == 0); staged two frequency rows (12 KB) at a time like wino4_in.
+template <bool VEC>
+__device__ __forceinline__ void wino4_out_t_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
     const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
     const long long t0 = (long long)(blockIdx.x - a.blk_off[l]) * 256;
@@ -606,39 +608,182 @@ __global__ __launch_bounds__(256) void wino4_out_t_kernel(WinoArgs a) {
     const bool on = u < units;
     const long long uu = on ? u : units - 1;
     const int c = blockIdx.y;
+    const size_t plane = (size_t)a.T;
     const int tx = (int)(uu % TW), ty = (int)((uu / TW) % TH), n = (int)(uu / ((long long)TW * TH));
     const size_t img = ((size_t)n * a.C + c) * H * W;
     const float* p = a.maps_in[l] + img;
     const float* pm = a.mask_ref[l] ? a.mask_ref[l] + img : nullptr;
-    const unsigned mb = a.bits_in ? a.bits_in[(size_t)c * (size_t)a.T + (size_t)a.tile_off[l] + uu] : 0xffffu;
+    const unsigned mb = a.bits_in ? a.bits_in[(size_t)c * plane + (size_t)a.tile_off[l] + uu] : 0xffffu;
+    float g[4][4];
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = 4 * ty + i;
+        const bool yok = y < H;
+        const size_t ro = (size_t)(yok ? y : 0) * W + 4 * tx;
+        if constexpr (VEC) {
+            float4 m = yok ? ldg_stream4(p + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pm) {
+                const float4 k = yok ? *reinterpret_cast<const float4*>(pm + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
+                m.x = k.x > 0.f ? m.x : 0.f; m.y = k.y > 0.f ? m.y : 0.f; m.z = k.z > 0.f ? m.z : 0.f; m.w = k.w > 0.f ? m.w : 0.f;
+            }
+            g[i][0] = m.x; g[i][1] = m.y; g[i][2] = m.z; g[i][3] = m.w;
+        } else {
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = yok && 4 * tx + j < W;
+                float e = ok ? p[ro + j] : 0.f;
+                if (ok && pm) e = pm[ro + j] > 0.f ? e : 0.f;
+                g[i][j] = e;
+            }
+        }
+        const unsigned nib = mb >> (4 * i);
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) g[i][j] = ((nib >> j) & 1u) ? g[i][j] : 0.f;
+    }
     float r[6][4];
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float col[4];
-        #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int y = 4 * ty + i, x = 4 * tx + j;
-            const bool ok = y < H && x < W;
-            const size_t at = (size_t)y * W + x;
-            float e = ok ? p[at] : 0.f;
-            if (ok && pm) e = pm[at] > 0.f ? e : 0.f;
-            e = ((mb >> (4 * i + j)) & 1u) ? e : 0.f;
-            col[i] = e;
-        }
+        const float col[4] = {g[0][j], g[1][j], g[2][j], g[3][j]};
         float w[6];
         a6(col, w);
         #pragma unroll
         for (int i = 0; i < 6; ++i) r[i][j] = w[i];
     }
+    float* dst = a.buf_out + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0;
     #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        float w[6];
-        a6(r[i], w);
+    for (int ph = 0; ph < 3; ++ph) {
+        if (ph) __syncthreads();
         #pragma unroll
-        for (int j = 0; j < 6; ++j) lds[(6 * i + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
+        for (int ii = 0; ii < 2; ++ii) {
+            float w[6];
+            a6(r[2 * ph + ii], w);
+            #pragma unroll
+            for (int j = 0; j < 6; ++j) lds[(6 * ii + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
+        }
+        __syncthreads();
+        stage_store12<12>(lds, dst, plane, 12 * ph, padded - t0);
+    }
+}
+
+__global__ __launch_bounds__(256) void wino4_out_t_kernel(WinoArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[12 * 256];
+    const int l = wino_level(a);
+    if (a.pair[l]) wino4_out_t_body<true>(a, l, lds);
+    else wino4_out_t_body<false>(a, l, lds);
+}
+
+// dx = adjoint of wino4_in: the 6x6 windows Z_t = B G_t B^T (G = dV, B = (B^T)^T) of neighbouring tiles overlap by two
+// pixels and are summed where they do.  Written as a GATHER, one thread per tile producing its own 4x4 block of dx, so
+// nothing is exchanged or accumulated in memory: window row / column 0 of a tile depends only on frequency row / column 0
+// (B's row 0 is [4 0 0 0 0 0]) and window row / column 5 only on frequency row / column 5 ([0 0 0 0 0 1]), so the block needs,
+// besides the tile's own 36 values, 6 values of each edge neighbour and 1 of each corner neighbour (64 loads, the extra 28
+// from lines this workgroup or its neighbour streams anyway).  The 36 planes are read as 1 KB runs through 12 KB of LDS like
+// wino4_out; neighbour values come from the LDS slab when the neighbour tile is inside the workgroup's 256-tile run.
+//   z = B g:  z0 = 4 g0, z1 = 4(g2-g1) + 2(g4-g3) + 4 g5, z2 = -5 g0 - 4(g1+g2) - (g3+g4), z3 = (g1-g2) + 2(g3-g4) - 5 g5,
+//             z4 = g0+g1+g2+g3+g4, z5 = g5
+__device__ __forceinline__ void b6mid(const float* g, float* z) {   // z1..z4 (the rows / columns inside the tile's own block)
+    const float s12 = g[1] + g[2], d21 = g[2] - g[1], s34 = g[3] + g[4], d43 = g[4] - g[3];
+    z[0] = 4.f * d21 + 2.f * d43 + 4.f * g[5];
+    z[1] = -5.f * g[0] - 4.f * s12 - s34;
+    z[2] = -d21 - 2.f * d43 - 5.f * g[5];
+    z[3] = g[0] + s12 + s34;
+}
+
+// rows (2 PH, 2 PH + 1) of g added into z1..z4 = (B g)[1..4]: the frequency rows arrive two at a time (one LDS phase), so the
+// column pass accumulates instead of holding all 36 values (half the registers of the two-pass form)
+template <int PH>
+__device__ __forceinline__ void b6acc(float ga, float gb, float* z) {
+    if constexpr (PH == 0) { z[0] = -4.f * gb; z[1] = -5.f * ga - 4.f * gb; z[2] = gb; z[3] = ga + gb; }
+    if constexpr (PH == 1) { z[0] += 4.f * ga - 2.f * gb; z[1] -= 4.f * ga + gb; z[2] += 2.f * gb - ga; z[3] += ga + gb; }
+    if constexpr (PH == 2) { z[0] += 2.f * ga + 4.f * gb; z[1] -= ga; z[2] -= 2.f * ga + 5.f * gb; z[3] += ga; }
+}
+
+template <bool VEC, int PH>
+__device__ __forceinline__ void wino4_in_t_phase(const float* m, size_t plane, long long t0, long long padded, float* lds,
+                                                 int TW, bool hasL, bool hasR, bool hasU, bool hasD,
+                                                 float (&t)[4][6], float (&tl)[4], float (&tr)[4]) {
+    const int tid = threadIdx.x;
+    if (PH) __syncthreads();
+    #pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int idx = k * 256 + tid, f = idx >> 6, q4 = idx & 63;
+        wino_vf4 q; q.x = q.y = q.z = q.w = 0.f;
+        if (t0 + q4 * 4 < padded)
+            q = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(m + (size_t)(12 * PH + f) * plane + q4 * 4));
+        *reinterpret_cast<float4*>(&lds[f * 256 + q4 * 4]) = make_float4(q.x, q.y, q.z, q.w);
     }
     __syncthreads();
-    stage_store36(lds, a.buf_out + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0, (size_t)a.T, 0, padded - t0);
+    // value of local plane fl (global plane 12 PH + fl) of the tile d positions further along the level's tile run
+    auto fetch = [&](int fl, int d) -> float {
+        const int li = tid + d;
+        return (li >= 0 && li < 256) ? lds[fl * 256 + li] : m[(ptrdiff_t)((size_t)(12 * PH + fl) * plane) + li];
+    };
+    #pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        float z[4] = {t[0][b], t[1][b], t[2][b], t[3][b]};
+        b6acc<PH>(lds[b * 256 + tid], lds[(6 + b) * 256 + tid], z);
+        t[0][b] = z[0]; t[1][b] = z[1]; t[2][b] = z[2]; t[3][b] = z[3];
+    }
+    b6acc<PH>(hasL ? fetch(5, -1) : 0.f, hasL ? fetch(11, -1) : 0.f, tl);   // frequency column 5 of the left tile
+    b6acc<PH>(hasR ? fetch(0, 1) : 0.f, hasR ? fetch(6, 1) : 0.f, tr);      // frequency column 0 of the right tile
+    if constexpr (PH == 0) {   // frequency row 0 of the lower tile row -> its window row 0 = this block's row 3 (B[0][0] = 4)
+        #pragma unroll
+        for (int b = 0; b < 6; ++b) t[3][b] += 4.f * (hasD ? fetch(b, TW) : 0.f);
+        tl[3] += 4.f * ((hasD && hasL) ? fetch(5, TW - 1) : 0.f);
+        tr[3] += 4.f * ((hasD && hasR) ? fetch(0, TW + 1) : 0.f);
+    }
+    if constexpr (PH == 2) {   // frequency row 5 of the upper tile row -> its window row 5 = this block's row 0 (B[5][5] = 1)
+        #pragma unroll
+        for (int b = 0; b < 6; ++b) t[0][b] += hasU ? fetch(6 + b, -TW) : 0.f;
+        tl[0] += (hasU && hasL) ? fetch(11, -TW - 1) : 0.f;
+        tr[0] += (hasU && hasR) ? fetch(6, -TW + 1) : 0.f;
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void wino4_in_t_body(const WinoArgs& a, int l, float* lds) {
+    const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
+    const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
+    const long long t0 = (long long)(blockIdx.x - a.blk_off[l]) * 256;
+    const long long u = t0 + threadIdx.x;
+    const bool on = u < units;
+    const long long uu = on ? u : units - 1;
+    const int c = blockIdx.y;
+    const size_t plane = (size_t)a.T;
+    const int tx = (int)(uu % TW), ty = (int)((uu / TW) % TH), n = (int)(uu / ((long long)TW * TH));
+    const bool hasL = on && tx > 0, hasR = on && tx < TW - 1, hasU = on && ty > 0, hasD = on && ty < TH - 1;
+    const float* m = a.buf_in + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0;
+    // t[r][b]: window row r+1 (= block row r) of B G per frequency column b, incl. the vertical neighbours' rows;
+    // tl / tr: the same for frequency column 5 of the left tile / column 0 of the right tile
+    float t[4][6], tl[4], tr[4];
+    wino4_in_t_phase<VEC, 0>(m, plane, t0, padded, lds, TW, hasL, hasR, hasU, hasD, t, tl, tr);
+    wino4_in_t_phase<VEC, 1>(m, plane, t0, padded, lds, TW, hasL, hasR, hasU, hasD, t, tl, tr);
+    wino4_in_t_phase<VEC, 2>(m, plane, t0, padded, lds, TW, hasL, hasR, hasU, hasD, t, tl, tr);
+    if (!on) return;
+    float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
+    const int oy = 4 * ty, ox = 4 * tx;
+    #pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float y[4];
+        b6mid(t[r], y);         // rows: window columns 1..4 of (B G) B^T
+        y[0] += tl[r];          // the left tile's window column 5 (B[5][5] = 1)
+        y[3] += 4.f * tr[r];    // the right tile's window column 0 (B[0][0] = 4)
+        if (oy + r >= H) continue;
+        float* row = p + (size_t)(oy + r) * W + ox;
+        if constexpr (VEC) {
+            *reinterpret_cast<float4*>(row) = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) if (ox + j < W) row[j] = y[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino4_in_t_kernel(WinoArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[12 * 256];
+    const int l = wino_level(a);
+    if (a.pair[l]) wino4_in_t_body<true>(a, l, lds);
+    else wino4_in_t_body<false>(a, l, lds);
 }
 
 static long long level_tiles(int N, int H, int W, int tile) {
@@ -750,7 +895,7 @@ int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_hos
                    const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM, void* stream) {
     lgd::WinoArgs a;
     unsigned blocks;
-    if (!dy_host || !dM || lgd::wino_fill(a, level_hw_host, L, N, C, 0, 1, tile, &blocks) != LGD_OK) return LGD_EINVAL;
+    if (!dy_host || !dM || lgd::wino_fill(a, level_hw_host, L, N, C, 0, tile == 4 ? 0 : 1, tile, &blocks) != LGD_OK) return LGD_EINVAL;
     if (relu_bits && (relu_ref_host || tile != 4)) return LGD_EINVAL;
     a.bits_in = relu_bits;
     for (int l = 0; l < L; ++l) {
@@ -761,6 +906,19 @@ int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_hos
     a.buf_out = dM;
     if (tile == 4) { LGD_LAUNCH("wino_out_t_kernel", lgd::wino4_out_t_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
     else { LGD_LAUNCH("wino_out_t_kernel", lgd::wino_out_t_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
+    return lgd::check_launch();
+}
+
+int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!dV || !dx_host || tile != 4 || lgd::wino_fill(a, level_hw_host, L, N, C, 0, 0, tile, &blocks) != LGD_OK) return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) {
+        if (!dx_host[l]) return LGD_EINVAL;
+        a.maps_out[l] = dx_host[l];
+    }
+    a.buf_in = dV;
+    LGD_LAUNCH("wino_in_t_kernel", lgd::wino4_in_t_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 

@@ -795,17 +795,17 @@ class _Conv3x3(torch.autograd.Function):
         hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(b) if b is not None else None, hw, L, N, Co, tile, 0, int(relu),
                                    hip.ptr_array(ys), hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
         need_w = ctx.needs_input_grad[0]
-        # tile 2 reuses U for the input gradient (the filter rotation is a frequency permutation); tile 4 keeps w
-        ctx.save_for_backward(U if tile == 2 else w, V if need_w else None, bits, *(ys if (relu and bits is None) else []))
+        # the backward needs the transformed filter (tile 4: dV = U^T dM; tile 2: the rotation is a frequency permutation of U)
+        ctx.save_for_backward(U, V if need_w else None, bits, *(ys if (relu and bits is None) else []))
         ctx.meta = (L, N, Ci, Co, hw, T, bool(relu), b is not None, [tuple(x.shape[2:]) for x in xs], tile, px, fb)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
-        Uw, V, bits, *yref = ctx.saved_tensors
+        U, V, bits, *yref = ctx.saved_tensors
         L, N, Ci, Co, hw, T, relu, has_bias, shapes, tile, px, fb = ctx.meta
         lib = hip.load()
-        dev = Uw.device
+        dev = U.device
         nf = (tile + 2) ** 2
         dys = [hip.dense_f32(g) for g in dys]
         need_w, need_x = ctx.needs_input_grad[0], any(ctx.needs_input_grad[4:])
@@ -816,22 +816,31 @@ class _Conv3x3(torch.autograd.Function):
         dM = None
         # dy + the ReLU mask: the forward output again (tile 2) or 2 bytes per 16 pixels (tile 4)
         pdy = px * Co * (2 if (relu and bits is None) else 1) + (2 * T * Co if bits is not None else 0)
-        if need_x:
+        if tile == 4 and (need_x or need_w):
+            # the autograd of the forward pipeline itself: dy is expanded ONCE (dM = A dy A^T); the input gradient is
+            # dV[f] = U[f]^T dM[f] brought back by the adjoint of the input transform, the weight gradient dU[f] = dM[f] V[f]^T
+            _count_bytes("wino_out_t_kernel", pdy + fb * Co)
+            dM = _freq_buf(nf, Co, T, dev)
+            hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, pbits, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
+                      "lgd_wino_out_t")
+            if need_x:
+                _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
+                dV = _timed_bmm("wino_gemm_dx", U.transpose(1, 2).contiguous(), dM, out=_freq_buf(nf, Ci, T, dev))
+                dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
+                hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), hip.stream_ptr()), "lgd_wino_in_t")
+                del dV
+        elif need_x:
+            # tile 2: the same pipeline on dy with the rotated, transposed filter (a frequency permutation of U: flip = 1)
             _count_bytes("wino_in_dual_kernel" if need_w else "wino_in_kernel", pdy + fb * Co * (2 if need_w else 1))
             _count_bytes("wino_out_kernel", (px + fb) * Ci)
-            if tile == 2:
-                Ut, flip = Uw.transpose(1, 2), 1
-            else:  # transform of the rotated, (Co,Ci)-transposed filter
-                wr = Uw.flip(2, 3).transpose(0, 1).reshape(Ci * Co, 9)
-                Ut, flip = torch.mm(_wino_gg(dev, tile), wr.t()).view(nf, Ci, Co), 0
             Vd = _freq_buf(nf, Co, T, dev)
             dM = _freq_buf(nf, Co, T, dev) if need_w else None
-            hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, pbits, hw, L, N, Co, tile, flip, hip.ptr(Vd),
+            hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, pbits, hw, L, N, Co, tile, 1, hip.ptr(Vd),
                                       hip.ptr(dM) if need_w else None, hip.stream_ptr()), "lgd_wino_in")
-            Md = _timed_bmm("wino_gemm_dx", Ut, Vd, out=_freq_buf(nf, Ci, T, dev))
+            Md = _timed_bmm("wino_gemm_dx", U.transpose(1, 2), Vd, out=_freq_buf(nf, Ci, T, dev))
             del Vd
             dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-            hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, flip, 0, hip.ptr_array(dxs), None, hip.stream_ptr()),
+            hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, 1, 0, hip.ptr_array(dxs), None, hip.stream_ptr()),
                       "lgd_wino_out")
             del Md
         elif need_w:
@@ -846,9 +855,12 @@ class _Conv3x3(torch.autograd.Function):
                 # A's row of the interpolation point 1 is all ones: that frequency of dM = A g A^T is the tile's gradient sum
                 db = dM[tile + 3].sum(1)
         elif has_bias and ctx.needs_input_grad[1]:
-            if bits is not None:
+            if dM is not None:
+                db = dM[tile + 3].sum(1)
+            elif bits is not None:
                 raise hip.LgdHipError("bias gradient without weight / input gradient is not used on the path")
-            db = sum((g * (y > 0) if relu else g).sum((0, 2, 3)) for g, y in zip(dys, yref if relu else dys))
+            else:
+                db = sum((g * (y > 0) if relu else g).sum((0, 2, 3)) for g, y in zip(dys, yref if relu else dys))
         return (dw, db, None, None, *dxs)
 
 
