@@ -699,44 +699,75 @@ __device__ __forceinline__ void b6acc(float ga, float gb, float* z) {
 }
 
 template <bool VEC, int PH>
-__device__ __forceinline__ void wino4_in_t_phase(const float* m, size_t plane, long long t0, long long padded, float* lds,
+__device__ __forceinline__ void wino4_in_t_phase(const float* m, size_t plane, int nvalid, float* lds,
                                                  int TW, bool hasL, bool hasR, bool hasU, bool hasD,
                                                  float (&t)[4][6], float (&tl)[4], float (&tr)[4]) {
     const int tid = threadIdx.x;
+    const float* mp = m + (size_t)(12 * PH) * plane;   // wave-uniform base; everything below is a 32-bit offset from it
+    const int ip = (int)plane;                          // 12 planes of one channel: < 2^31 elements for any map that fits the HBM
     if (PH) __syncthreads();
+    wino_vf4 q[3];
     #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int idx = k * 256 + tid, f = idx >> 6, q4 = idx & 63;
-        wino_vf4 q; q.x = q.y = q.z = q.w = 0.f;
-        if (t0 + q4 * 4 < padded)
-            q = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(m + (size_t)(12 * PH + f) * plane + q4 * 4));
-        *reinterpret_cast<float4*>(&lds[f * 256 + q4 * 4]) = make_float4(q.x, q.y, q.z, q.w);
+        q[k].x = q[k].y = q[k].z = q[k].w = 0.f;
+        if (q4 * 4 < nvalid) q[k] = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(mp + (f * ip + q4 * 4)));
+    }
+    // Neighbour tiles outside the workgroup's 256-tile slab (the first / last TW+1 threads' vertical neighbours, thread 0's left
+    // and thread 255's right one) are loaded from memory HERE, together with the slab, so that their latency is not paid after
+    // the barrier.  Branch-free per lane: only the edge WAVES issue these loads (wave-uniform test); a lane of such a wave whose
+    // neighbour is inside the slab (or does not exist) re-reads its own tile -- a line the slab load touches anyway.
+    const int wb = tid & ~63, own = min(tid, nvalid - 1);
+    auto far = [&](int fl, int d, bool need) -> float {
+        const int li = tid + d;
+        return mp[fl * ip + ((need && (li < 0 || li >= 256)) ? li : own)];
+    };
+    // value of local plane fl (global plane 12 PH + fl) of the tile d positions further along the level's tile run
+    auto pick = [&](int fl, int d, bool need, float e) -> float {
+        const int li = tid + d;
+        const float v = lds[fl * 256 + min(max(li, 0), 255)];
+        return !need ? 0.f : ((li >= 0 && li < 256) ? v : e);
+    };
+    float eL0 = 0.f, eL1 = 0.f, eR0 = 0.f, eR1 = 0.f;
+    if (wb == 0) { eL0 = far(5, -1, hasL); eL1 = far(11, -1, hasL); }
+    if (wb == 192) { eR0 = far(0, 1, hasR); eR1 = far(6, 1, hasR); }
+    constexpr int vrow = PH == 2 ? 6 : 0;             // frequency row 5 (upper neighbour) lives in planes 6..11 of phase 2
+    const int vd = PH == 2 ? -TW : TW;                 // phase 0: frequency row 0 of the LOWER tile row; phase 2: row 5 of the UPPER one
+    const bool hasV = PH == 2 ? hasU : hasD;
+    float eV[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, eVl = 0.f, eVr = 0.f;
+    if constexpr (PH != 1) {
+        if (PH == 2 ? (wb - TW - 1 < 0) : (wb + 63 + TW + 1 >= 256)) {
+            #pragma unroll
+            for (int b = 0; b < 6; ++b) eV[b] = far(vrow + b, vd, hasV);
+            eVl = far(vrow + 5, vd - 1, hasV && hasL);
+            eVr = far(vrow, vd + 1, hasV && hasR);
+        }
+    }
+    #pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int idx = k * 256 + tid, f = idx >> 6, q4 = idx & 63;
+        *reinterpret_cast<float4*>(&lds[f * 256 + q4 * 4]) = make_float4(q[k].x, q[k].y, q[k].z, q[k].w);
     }
     __syncthreads();
-    // value of local plane fl (global plane 12 PH + fl) of the tile d positions further along the level's tile run
-    auto fetch = [&](int fl, int d) -> float {
-        const int li = tid + d;
-        return (li >= 0 && li < 256) ? lds[fl * 256 + li] : m[(ptrdiff_t)((size_t)(12 * PH + fl) * plane) + li];
-    };
     #pragma unroll
     for (int b = 0; b < 6; ++b) {
         float z[4] = {t[0][b], t[1][b], t[2][b], t[3][b]};
         b6acc<PH>(lds[b * 256 + tid], lds[(6 + b) * 256 + tid], z);
         t[0][b] = z[0]; t[1][b] = z[1]; t[2][b] = z[2]; t[3][b] = z[3];
     }
-    b6acc<PH>(hasL ? fetch(5, -1) : 0.f, hasL ? fetch(11, -1) : 0.f, tl);   // frequency column 5 of the left tile
-    b6acc<PH>(hasR ? fetch(0, 1) : 0.f, hasR ? fetch(6, 1) : 0.f, tr);      // frequency column 0 of the right tile
-    if constexpr (PH == 0) {   // frequency row 0 of the lower tile row -> its window row 0 = this block's row 3 (B[0][0] = 4)
+    b6acc<PH>(pick(5, -1, hasL, eL0), pick(11, -1, hasL, eL1), tl);   // frequency column 5 of the left tile
+    b6acc<PH>(pick(0, 1, hasR, eR0), pick(6, 1, hasR, eR1), tr);      // frequency column 0 of the right tile
+    if constexpr (PH == 0) {   // the lower tile's window row 0 = this block's row 3 (B[0][0] = 4)
         #pragma unroll
-        for (int b = 0; b < 6; ++b) t[3][b] += 4.f * (hasD ? fetch(b, TW) : 0.f);
-        tl[3] += 4.f * ((hasD && hasL) ? fetch(5, TW - 1) : 0.f);
-        tr[3] += 4.f * ((hasD && hasR) ? fetch(0, TW + 1) : 0.f);
+        for (int b = 0; b < 6; ++b) t[3][b] += 4.f * pick(b, vd, hasV, eV[b]);
+        tl[3] += 4.f * pick(5, vd - 1, hasV && hasL, eVl);
+        tr[3] += 4.f * pick(0, vd + 1, hasV && hasR, eVr);
     }
-    if constexpr (PH == 2) {   // frequency row 5 of the upper tile row -> its window row 5 = this block's row 0 (B[5][5] = 1)
+    if constexpr (PH == 2) {   // the upper tile's window row 5 = this block's row 0 (B[5][5] = 1)
         #pragma unroll
-        for (int b = 0; b < 6; ++b) t[0][b] += hasU ? fetch(6 + b, -TW) : 0.f;
-        tl[0] += (hasU && hasL) ? fetch(11, -TW - 1) : 0.f;
-        tr[0] += (hasU && hasR) ? fetch(6, -TW + 1) : 0.f;
+        for (int b = 0; b < 6; ++b) t[0][b] += pick(6 + b, vd, hasV, eV[b]);
+        tl[0] += pick(11, vd - 1, hasV && hasL, eVl);
+        tr[0] += pick(6, vd + 1, hasV && hasR, eVr);
     }
 }
 
@@ -756,9 +787,10 @@ __device__ __forceinline__ void wino4_in_t_body(const WinoArgs& a, int l, float*
     // t[r][b]: window row r+1 (= block row r) of B G per frequency column b, incl. the vertical neighbours' rows;
     // tl / tr: the same for frequency column 5 of the left tile / column 0 of the right tile
     float t[4][6], tl[4], tr[4];
-    wino4_in_t_phase<VEC, 0>(m, plane, t0, padded, lds, TW, hasL, hasR, hasU, hasD, t, tl, tr);
-    wino4_in_t_phase<VEC, 1>(m, plane, t0, padded, lds, TW, hasL, hasR, hasU, hasD, t, tl, tr);
-    wino4_in_t_phase<VEC, 2>(m, plane, t0, padded, lds, TW, hasL, hasR, hasU, hasD, t, tl, tr);
+    const int nvalid = (int)min(padded - t0, 256LL);   // tiles of the slab that exist (>= 4: a workgroup starts below `units`)
+    wino4_in_t_phase<VEC, 0>(m, plane, nvalid, lds, TW, hasL, hasR, hasU, hasD, t, tl, tr);
+    wino4_in_t_phase<VEC, 1>(m, plane, nvalid, lds, TW, hasL, hasR, hasU, hasD, t, tl, tr);
+    wino4_in_t_phase<VEC, 2>(m, plane, nvalid, lds, TW, hasL, hasR, hasU, hasD, t, tl, tr);
     if (!on) return;
     float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
     const int oy = 4 * ty, ox = 4 * tx;
@@ -779,7 +811,7 @@ __device__ __forceinline__ void wino4_in_t_body(const WinoArgs& a, int l, float*
     }
 }
 
-__global__ __launch_bounds__(256) void wino4_in_t_kernel(WinoArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void wino4_in_t_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[12 * 256];
     const int l = wino_level(a);
     if (a.pair[l]) wino4_in_t_body<true>(a, l, lds);

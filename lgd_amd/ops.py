@@ -760,108 +760,140 @@ def _freq_buf(nf, C, T, device):
     return torch.empty((C, nf, T), dtype=torch.float32, device=device).permute(1, 0, 2)
 
 
-class _Conv3x3(torch.autograd.Function):
-    """nn.Conv2d(Ci, Co, 3, stride 1, padding 1) [+ ReLU] with one filter over L maps (the pyramid levels) in the
-    minimal-filtering form F(tile x tile, 3x3), tile = 4 (default) or 2: HIP data transforms (lgd_wino_in / lgd_wino_out /
-    lgd_wino_out_t) around per-frequency channel GEMMs (hipBLASLt / rocBLAS fp32 MFMA through torch.bmm) over the
-    concatenated tiles of all levels.  Forward, input gradient and weight gradient all run at 1/4 (tile 4) or 4/9
-    (tile 2) of the direct multiplies; backward reads dy once."""
+class _Conv3x3K(torch.autograd.Function):
+    """K filters nn.Conv2d(Ci, Co_k, 3, stride 1, padding 1) [+ ReLU] applied to the SAME L maps (the pyramid levels; K = 1: one
+    conv, K = 2: e.g. the first convs of the cls / bbox towers, which read the same features) in the minimal-filtering form
+    F(tile x tile, 3x3), tile = 4 (default) or 2: HIP data transforms (lgd_wino_in / lgd_wino_out / lgd_wino_out_t /
+    lgd_wino_in_t) around per-frequency channel GEMMs (hipBLASLt / rocBLAS fp32 MFMA through torch.bmm) over the concatenated
+    tiles of all levels.  The input is transformed ONCE for all K filters (their U are stacked along C_out: one GEMM), and the
+    backward sums their input gradients inside the dV GEMM (K = sum Co_k) -- one adjoint input transform, no gradient-accumulation
+    pass.  Forward, input gradient and weight gradient all run at 1/4 (tile 4) or 4/9 (tile 2) of the direct multiplies.
+    apply(K, relu, tile, w_1, b_1, ..., w_K, b_K, x_1, ..., x_L) -> K * L maps, filter-major."""
 
     @staticmethod
-    def forward(ctx, w, b, relu, tile, *xs):
-        hip.require_gpu(w, *xs)
+    def forward(ctx, K, relu, tile, *args):
+        ws, bs, xs = list(args[0:2 * K:2]), list(args[1:2 * K:2]), list(args[2 * K:])
+        hip.require_gpu(*ws, *xs)
+        if K > 1 and tile != 4:
+            raise hip.LgdHipError("several filters on one input need tile = 4")
         lib = hip.load()
-        w = hip.dense_f32(w)
+        ws = [hip.dense_f32(w) for w in ws]
         xs = [hip.dense_f32(x) for x in xs]
-        b = hip.dense_f32(b) if b is not None else None
+        bs = [hip.dense_f32(b) if b is not None else None for b in bs]
         L, N, Ci = len(xs), xs[0].shape[0], xs[0].shape[1]
-        Co = w.shape[0]
-        dev = w.device
+        Cos = [w.shape[0] for w in ws]
+        Ct = sum(Cos)
+        dev = ws[0].device
         nf = (tile + 2) ** 2
         hw = hip.int_array([d for x in xs for d in x.shape[2:]])
         T = lib.lgd_wino_tiles(hw, L, N, tile)
-        U = torch.mm(_wino_gg(dev, tile), w.view(Co * Ci, 9).t()).view(nf, Co, Ci)
+        wcat = ws[0].view(Ct * Ci, 9) if K == 1 else torch.cat([w.view(-1, 9) for w in ws])
+        U = torch.mm(_wino_gg(dev, tile), wcat.t()).view(nf, Ct, Ci)
         V = _freq_buf(nf, Ci, T, dev)
         hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
         fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
         _count_bytes("wino_in_kernel", (px + fb) * Ci)
-        _count_bytes("wino_out_kernel", (px + fb) * Co)
-        M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
-        ys = [torch.empty((N, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
+        M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
         # ReLU mask for the backward: 16 bits per 4x4 output tile written by the output transform (tile 4), so the backward reads
         # 1 bit instead of 4 bytes per pixel and the forward output is not kept alive; tile 2 keeps the output itself
-        bits = torch.empty((Co, T), dtype=torch.int16, device=dev) if (relu and tile == 4) else None
-        hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(b) if b is not None else None, hw, L, N, Co, tile, 0, int(relu),
-                                   hip.ptr_array(ys), hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
-        need_w = ctx.needs_input_grad[0]
-        # the backward needs the transformed filter (tile 4: dV = U^T dM; tile 2: the rotation is a frequency permutation of U)
+        bits = torch.empty((Ct, T), dtype=torch.int16, device=dev) if (relu and tile == 4) else None
+        ys, c0 = [], 0
+        for k in range(K):   # one output transform per filter: its channels are a contiguous slab of M ([C][nf][T])
+            yk = [torch.empty((N, Cos[k]) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
+            _count_bytes("wino_out_kernel", (px + fb + (2 * T if bits is not None else 0)) * Cos[k])
+            hip.check(lib.lgd_wino_out(hip.ptr(M[:, c0]), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Cos[k], tile, 0, int(relu),
+                                       hip.ptr_array(yk), hip.ptr(bits[c0]) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
+            ys += yk
+            c0 += Cos[k]
+        need_w = any(ctx.needs_input_grad[3:3 + 2 * K:2])
+        # the backward needs the transformed filters (tile 4: dV = U^T dM; tile 2: the rotation is a frequency permutation of U)
         ctx.save_for_backward(U, V if need_w else None, bits, *(ys if (relu and bits is None) else []))
-        ctx.meta = (L, N, Ci, Co, hw, T, bool(relu), b is not None, [tuple(x.shape[2:]) for x in xs], tile, px, fb)
+        ctx.meta = (K, L, N, Ci, Cos, hw, T, bool(relu), [b is not None for b in bs], [tuple(x.shape[2:]) for x in xs], tile, px, fb)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
         U, V, bits, *yref = ctx.saved_tensors
-        L, N, Ci, Co, hw, T, relu, has_bias, shapes, tile, px, fb = ctx.meta
+        K, L, N, Ci, Cos, hw, T, relu, has_bias, shapes, tile, px, fb = ctx.meta
+        Ct = sum(Cos)
         lib = hip.load()
         dev = U.device
         nf = (tile + 2) ** 2
-        dys = [hip.dense_f32(g) for g in dys]
-        need_w, need_x = ctx.needs_input_grad[0], any(ctx.needs_input_grad[4:])
-        ref = hip.ptr_array(yref) if (relu and bits is None) else None
-        pbits = hip.ptr(bits) if bits is not None else None
-        dw = db = None
+        # an output nothing downstream used arrives as None
+        dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
+               for i, g in enumerate(dys)]
+        need_ws = list(ctx.needs_input_grad[3:3 + 2 * K:2])
+        need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[4:4 + 2 * K:2])]
+        need_w, need_x = any(need_ws), any(ctx.needs_input_grad[3 + 2 * K:])
+        dws, dbs = [None] * K, [None] * K
         dxs = [None] * L
         dM = None
-        # dy + the ReLU mask: the forward output again (tile 2) or 2 bytes per 16 pixels (tile 4)
-        pdy = px * Co * (2 if (relu and bits is None) else 1) + (2 * T * Co if bits is not None else 0)
-        if tile == 4 and (need_x or need_w):
+        if tile == 4 and (need_x or need_w or any(need_bs)):
             # the autograd of the forward pipeline itself: dy is expanded ONCE (dM = A dy A^T); the input gradient is
             # dV[f] = U[f]^T dM[f] brought back by the adjoint of the input transform, the weight gradient dU[f] = dM[f] V[f]^T
-            _count_bytes("wino_out_t_kernel", pdy + fb * Co)
-            dM = _freq_buf(nf, Co, T, dev)
-            hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, pbits, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
-                      "lgd_wino_out_t")
+            dM = _freq_buf(nf, Ct, T, dev)
+            c0 = 0
+            for k in range(K):
+                gk = dys[k * L:(k + 1) * L]
+                _count_bytes("wino_out_t_kernel", (px + fb + (2 * T if bits is not None else 0)) * Cos[k])
+                hip.check(lib.lgd_wino_out_t(hip.ptr_array(gk), None, hip.ptr(bits[c0]) if bits is not None else None, hw, L, N, Cos[k], tile,
+                                             hip.ptr(dM[:, c0]), hip.stream_ptr()), "lgd_wino_out_t")
+                c0 += Cos[k]
             if need_x:
                 _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
                 dV = _timed_bmm("wino_gemm_dx", U.transpose(1, 2).contiguous(), dM, out=_freq_buf(nf, Ci, T, dev))
                 dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
                 hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), hip.stream_ptr()), "lgd_wino_in_t")
                 del dV
-        elif need_x:
-            # tile 2: the same pipeline on dy with the rotated, transposed filter (a frequency permutation of U: flip = 1)
-            _count_bytes("wino_in_dual_kernel" if need_w else "wino_in_kernel", pdy + fb * Co * (2 if need_w else 1))
-            _count_bytes("wino_out_kernel", (px + fb) * Ci)
-            Vd = _freq_buf(nf, Co, T, dev)
+        elif tile == 2 and (need_x or need_w):
+            Co = Cos[0]
+            ref = hip.ptr_array(yref) if relu else None
+            pdy = px * Co * (2 if relu else 1)   # dy + the forward output as the ReLU mask
             dM = _freq_buf(nf, Co, T, dev) if need_w else None
-            hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, pbits, hw, L, N, Co, tile, 1, hip.ptr(Vd),
-                                      hip.ptr(dM) if need_w else None, hip.stream_ptr()), "lgd_wino_in")
-            Md = _timed_bmm("wino_gemm_dx", U.transpose(1, 2), Vd, out=_freq_buf(nf, Ci, T, dev))
-            del Vd
-            dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-            hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, 1, 0, hip.ptr_array(dxs), None, hip.stream_ptr()),
-                      "lgd_wino_out")
-            del Md
-        elif need_w:
-            _count_bytes("wino_out_t_kernel", pdy + fb * Co)
-            dM = _freq_buf(nf, Co, T, dev)
-            hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, pbits, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
-                      "lgd_wino_out_t")
+            if need_x:
+                # the same pipeline on dy with the rotated, transposed filter (a frequency permutation of U: flip = 1)
+                _count_bytes("wino_in_dual_kernel" if need_w else "wino_in_kernel", pdy + fb * Co * (2 if need_w else 1))
+                _count_bytes("wino_out_kernel", (px + fb) * Ci)
+                Vd = _freq_buf(nf, Co, T, dev)
+                hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, None, hw, L, N, Co, tile, 1, hip.ptr(Vd),
+                                          hip.ptr(dM) if need_w else None, hip.stream_ptr()), "lgd_wino_in")
+                Md = _timed_bmm("wino_gemm_dx", U.transpose(1, 2), Vd, out=_freq_buf(nf, Ci, T, dev))
+                del Vd
+                dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
+                hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, 1, 0, hip.ptr_array(dxs), None, hip.stream_ptr()),
+                          "lgd_wino_out")
+                del Md
+            else:
+                _count_bytes("wino_out_t_kernel", pdy + fb * Co)
+                hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, None, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
+                          "lgd_wino_out_t")
         if need_w:
             dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
-            dw = torch.mm(_wino_gg(dev, tile).t(), dU.view(nf, Co * Ci)).t().reshape(Co, Ci, 3, 3)
-            if has_bias and ctx.needs_input_grad[1]:
+            dw = torch.mm(_wino_gg(dev, tile).t(), dU.view(nf, Ct * Ci)).t().reshape(Ct, Ci, 3, 3)
+            c0 = 0
+            for k in range(K):
+                dws[k] = dw[c0:c0 + Cos[k]] if need_ws[k] else None
+                c0 += Cos[k]
+        if any(need_bs):
+            if dM is not None:
                 # A's row of the interpolation point 1 is all ones: that frequency of dM = A g A^T is the tile's gradient sum
                 db = dM[tile + 3].sum(1)
-        elif has_bias and ctx.needs_input_grad[1]:
-            if dM is not None:
-                db = dM[tile + 3].sum(1)
-            elif bits is not None:
-                raise hip.LgdHipError("bias gradient without weight / input gradient is not used on the path")
-            else:
+            else:  # tile 2, bias gradient alone
                 db = sum((g * (y > 0) if relu else g).sum((0, 2, 3)) for g, y in zip(dys, yref if relu else dys))
-        return (dw, db, None, None, *dxs)
+            c0 = 0
+            for k in range(K):
+                dbs[k] = db[c0:c0 + Cos[k]] if need_bs[k] else None
+                c0 += Cos[k]
+        return (None, None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
+
+
+class _Conv3x3:
+    """single-filter form of _Conv3x3K with the historical argument order: apply(w, b, relu, tile, *xs)."""
+
+    @staticmethod
+    def apply(w, b, relu, tile, *xs):
+        return _Conv3x3K.apply(1, bool(relu), tile, w, b, *xs)
 
 
 def enable_tuned_gemms(path=None):
@@ -922,6 +954,16 @@ def conv3x3_levels(xs, w, b=None, relu=False):
         return list(_Conv3x3.apply(w, b, bool(relu), _WINO_TILE, *xs))
     ys = [F.conv2d(x, w, b, 1, 1) for x in xs]
     return [F.relu_(y) for y in ys] if relu else ys
+
+
+def conv3x3_shared_input(xs, filters, relu=False):
+    """several 3x3 / stride 1 / padding 1 filters [(w, b), ...] [+ ReLU] on the SAME list of maps: one input transform, one
+    stacked GEMM, one adjoint input transform for the summed input gradient (see _Conv3x3K).  Returns one list of maps per filter."""
+    xs = list(xs)
+    if len(filters) > 1 and _WINO_TILE == 4 and all(_wino_ok(xs, w) for w, _ in filters):
+        ys = _Conv3x3K.apply(len(filters), bool(relu), 4, *[t for wb in filters for t in wb], *xs)
+        return [list(ys[k * len(xs):(k + 1) * len(xs)]) for k in range(len(filters))]
+    return [conv3x3_levels(xs, w, b, relu) for w, b in filters]
 
 
 def conv3x3(x, w, b=None, relu=False):

@@ -60,12 +60,22 @@ class FCOSHead(nn.Module):
         c = b = list(features)
         for i in range(0, len(self.cls_subnet), 3):
             gc, gb = self.cls_subnet[i + 1], self.bbox_subnet[i + 1]
-            c = ops.group_norm_relu(self.cls_subnet[i].levels(c), gc.num_groups, gc.weight, gc.bias, relu=True)
-            b = ops.group_norm_relu(self.bbox_subnet[i].levels(b), gb.num_groups, gb.weight, gb.bias, relu=True)
-        logits = self.cls_score.levels(c)
-        ctr = self.centerness.levels(b if self.centerness_on_reg else c)
+            if i == 0:  # the towers' first convs read the same maps: one input transform / stacked GEMM / summed input gradient
+                c, b = ops.conv3x3_shared_input(c, [(self.cls_subnet[0].weight, self.cls_subnet[0].bias),
+                                                    (self.bbox_subnet[0].weight, self.bbox_subnet[0].bias)])
+            else:
+                c, b = self.cls_subnet[i].levels(c), self.bbox_subnet[i].levels(b)
+            c = ops.group_norm_relu(c, gc.num_groups, gc.weight, gc.bias, relu=True)
+            b = ops.group_norm_relu(b, gb.num_groups, gb.weight, gb.bias, relu=True)
+        # centerness shares its input with bbox_pred (or cls_score): same sharing
+        if self.centerness_on_reg:
+            logits = self.cls_score.levels(c)
+            regs, ctr = ops.conv3x3_shared_input(b, [(self.bbox_pred.weight, self.bbox_pred.bias), (self.centerness.weight, self.centerness.bias)])
+        else:
+            regs = self.bbox_pred.levels(b)
+            logits, ctr = ops.conv3x3_shared_input(c, [(self.cls_score.weight, self.cls_score.bias), (self.centerness.weight, self.centerness.bias)])
         reg = []
-        for i, r in enumerate(self.bbox_pred.levels(b)):
+        for i, r in enumerate(regs):
             lvl = i % nl
             r = self.scales[lvl](r)
             reg.append(F.relu(r) * self.fpn_strides[lvl] if self.norm_reg_targets else torch.exp(r))

@@ -41,8 +41,10 @@ class RetinaNetHead(nn.Module):
 
     def forward(self, features):
         # the towers share their filters across levels: every conv is ONE pass over the concatenated pyramid, ReLU fused
-        c = b = list(features)
-        for i in range(0, len(self.cls_subnet), 2):
+        # the first convs of the two towers read the same maps: one input transform / stacked GEMM / summed input gradient
+        c0, b0 = self.cls_subnet[0], self.bbox_subnet[0]
+        c, b = ops.conv3x3_shared_input(list(features), [(c0.weight, c0.bias), (b0.weight, b0.bias)], relu=True)
+        for i in range(2, len(self.cls_subnet), 2):
             c = self.cls_subnet[i].levels(c, relu=True)
             b = self.bbox_subnet[i].levels(b, relu=True)
         return self.cls_score.levels(c), self.bbox_pred.levels(b)

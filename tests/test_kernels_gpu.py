@@ -615,6 +615,62 @@ def test_conv3x3_dispatch_and_partial_grads():
     assert float((bv.grad.double() - br.grad).abs().max()) <= 5e-5 * float(br.grad.abs().max())
 
 
+@pytest.mark.parametrize("N,Ci,Cos,hws,relu", [
+    (2, 64, (64, 64), [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)], True),     # the two towers' first convs over a pyramid
+    (1, 64, (4, 1), [(13, 21), (7, 11)], False),                                # FCOS bbox_pred + centerness (odd maps)
+    (2, 64, (40, 8, 24), [(25, 42), (13, 21)], True),                                     # three filters, uneven widths
+])
+def test_conv3x3_shared_input(N, Ci, Cos, hws, relu):
+    """K filters on the same maps through ONE input transform / stacked GEMM / adjoint input transform (_Conv3x3K) == K separate
+    convolutions in fp64: outputs, the SUMMED input gradient, every weight / bias gradient; a filter whose outputs are unused
+    (gradient None) contributes nothing."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    tol = 5e-5
+    prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=4)
+    try:
+        xs = [torch.from_numpy(synth.det_uniform((N, Ci, h, w), 931 + i, -2.0, 2.0)) for i, (h, w) in enumerate(hws)]
+        ws = [torch.from_numpy(synth.det_uniform((Co, Ci, 3, 3), 940 + k, -0.1, 0.1)) for k, Co in enumerate(Cos)]
+        bs = [torch.from_numpy(synth.det_uniform((Co,), 945 + k, -0.5, 0.5)) for k, Co in enumerate(Cos)]
+        gys = [[torch.from_numpy(synth.det_uniform((N, Co, h, w_), 960 + 10 * k + i, -1.0, 1.0)) for i, (h, w_) in enumerate(hws)]
+               for k, Co in enumerate(Cos)]
+        scale = lambda t: float(t.detach().abs().max()) + 1e-30
+        for used in (range(len(Cos)), [0]):   # all filters used; only the first one used downstream
+            xg = [x.to(DEV).requires_grad_(True) for x in xs]
+            wg = [w.to(DEV).requires_grad_(True) for w in ws]
+            bg = [b.to(DEV).requires_grad_(True) for b in bs]
+            ys = ops.conv3x3_shared_input(xg, list(zip(wg, bg)), relu=relu)
+            assert type(ys[0][0].grad_fn).__name__.startswith("_Conv3x3K")
+            torch.autograd.backward([y for k in used for y in ys[k]], [g.to(DEV) for k in used for g in gys[k]])
+            xr = [x.double().requires_grad_(True) for x in xs]
+            wr = [w.double().requires_grad_(True) for w in ws]
+            br = [b.double().requires_grad_(True) for b in bs]
+            yr = [[F.conv2d(x, w, b, 1, 1) for x in xr] for w, b in zip(wr, br)]
+            if relu:
+                # the fp64 reference takes the kernel's ReLU mask: a pre-activation within fp32 rounding of 0 may fall on either
+                # side, and one such flip moves a gradient by far more than the tolerance (the masks differ in < 1e-4 of the outputs)
+                for k in range(len(Cos)):
+                    for i in range(len(hws)):
+                        on = (ys[k][i].detach().cpu() > 0)
+                        assert float((on != (yr[k][i].detach() > 0)).double().mean()) < 1e-4
+                        yr[k][i] = yr[k][i] * on
+            torch.autograd.backward([y for k in used for y in yr[k]], [g.double() for k in used for g in gys[k]])
+            for k in range(len(Cos)):
+                for y, r in zip(ys[k], yr[k]):
+                    assert float((y.detach().cpu().double() - r.detach()).abs().max()) <= tol * scale(r)
+            gscale = max(scale(x.grad) for x in xr)
+            for x, r in zip(xg, xr):
+                assert float((x.grad.cpu().double() - r.grad).abs().max()) <= tol * gscale
+            for k in range(len(Cos)):
+                if k in used:
+                    assert float((wg[k].grad.cpu().double() - wr[k].grad).abs().max()) <= tol * scale(wr[k].grad)
+                    assert float((bg[k].grad.cpu().double() - br[k].grad).abs().max()) <= tol * scale(br[k].grad)
+                else:
+                    assert wg[k].grad is None or float(wg[k].grad.abs().max()) == 0.0
+    finally:
+        ops.conv3x3_backend(*prev)
+
+
 # ------------------------------------------------------------------------------------------- student conv epilogues
 @pytest.mark.parametrize("N,C,H,W,res,relu,bias_grad", [(2, 8, 6, 8, True, True, False), (1, 5, 3, 5, False, True, True),
                                                         (3, 16, 7, 4, True, False, True), (2, 4, 5, 5, False, False, False)])

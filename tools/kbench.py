@@ -70,9 +70,11 @@ alg = {"in_moments_kernel": 2 * P, "in_mse_bwd_kernel": 3 * P, "box_sum_kernel":
        "gn_pool_kernel": P, "gn_pool_bwd_stats_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
 tl = ops._WINO_TILE
 FB = 4 * (tl + 2) ** 2 * C * sum(B * ((h + tl - 1) // tl) * ((w + tl - 1) // tl) for h, w in level_hw)  # one frequency buffer
-alg.update({"wino_in_kernel": P + FB, "wino_out_kernel": P + FB, "wino_in_dual_kernel": 2 * P + 2 * FB})
+MB = 2 * C * (FB // (4 * (tl + 2) ** 2 * C))  # 16-bit ReLU mask per tile
+alg.update({"wino_in_kernel": P + FB, "wino_out_kernel": P + FB + MB, "wino_in_dual_kernel": P + MB + 2 * FB,
+            "wino_out_t_kernel": P + MB + FB, "wino_in_t_kernel": P + FB})
 res = {}
-for k, (n, ms) in sorted(t.items(), key=lambda kv: -kv[1][1]):
+for k, (n, ms, _lo, _hi) in sorted(t.items(), key=lambda kv: -kv[1][1]):
     us = 1e3 * ms / n
     res[k] = {"us": us, "GBps": alg[k] / us / 1e3 if k in alg else None}
     print("%-24s n=%3d avg %8.1f us   %s" % (k, n, us, ("%6.0f GB/s (%.0f%% of 8 TB/s)" % (alg[k] / us / 1e3, alg[k] / us / 1e3 / 80)) if k in alg else ""))
