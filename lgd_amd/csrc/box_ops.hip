@@ -12,9 +12,8 @@
 //     VALU add per element) and only then applies each active box's column interval; box_paint
 //     composes one row pattern per band and streams it to every row of the band;
 //   * lane n of the wave holds box n's rectangle/accumulator (64 boxes per pass), band activity is a
-//     single v_cmp ballot, box parameters travel by v_readlane, sums by DPP -- no LDS, no atomics,
-//     fixed reduction order (bit-reproducible run to run).
-#include <cstdlib>
+//     single v_cmp ballot, box parameters travel by v_readlane; a band's column sums become box sums through one
+//     wave-wide prefix sum (DPP) parked in wave-private LDS -- no atomics, fixed order (bit-reproducible run to run).
 #include "common.h"
 
 namespace lgd {
@@ -39,7 +38,7 @@ struct BoxArgs {
 
 struct Plane { int l, b, c, H, W, t0, n, nbp; const int32_t* rects; const int32_t* bands; };
 
-// ppb = planes per workgroup: 4 (one wave per plane, box_paint) or 1 (four waves share a plane, box_sum)
+// ppb = planes per workgroup (a multiple of 4): each of the four waves owns ppb/4 consecutive channel planes
 __device__ __forceinline__ Plane locate(const BoxArgs& a, int ppb) {
     Plane p;
     int slot = 0;
@@ -47,8 +46,7 @@ __device__ __forceinline__ Plane locate(const BoxArgs& a, int ppb) {
     for (int i = 1; i < LGD_MAX_LEVELS; ++i) slot += (i < a.L && (int)blockIdx.x >= a.blk0[i]) ? 1 : 0;
     const int l = a.lev[slot];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the plane bookkeeping on the scalar unit
-    // ppb planes per workgroup: each wave owns ppb/4 consecutive channel planes (ppb == 1: all four waves share one)
-    const int plane = ppb >= 4 ? ((int)blockIdx.x - a.blk0[slot]) * ppb + wave * (ppb / 4) : (int)blockIdx.x - a.blk0[slot];
+    const int plane = ((int)blockIdx.x - a.blk0[slot]) * ppb + wave * (ppb / 4);
     p.l = l; p.b = plane / a.C; p.c = plane % a.C;
     p.H = a.H[l]; p.W = a.W[l];
     p.t0 = __builtin_amdgcn_readfirstlane(a.img_off[p.b]);
@@ -80,88 +78,111 @@ __device__ __forceinline__ LaneBox load_lane_box(const Plane& p, int pass, int l
 }
 
 // ------------------------------------------------------------------------------------------- box_sum
-// One wave per plane.  Rows stream through a two-deep register pipeline of FIXED 4-row groups that ignores band
-// boundaries: every group is exactly 4 loads, so the compiler can keep one group in flight with a counted
-// s_waitcnt while the other is reduced (62 VGPRs -> 8 waves/SIMD: the whole grid is co-resident).  (The first
-// version loaded band by band and exposed one HBM latency per band: ~20 x 2.5 us per p3 wave, 3.3 TB/s.
-// Variable-length groups force s_waitcnt vmcnt(0) and serialise the pipeline again: 1.9 TB/s measured.)
-// Band bookkeeping happens at consume time with wave-uniform control flow; the band table and the rectangles
-// live in registers (lane k <- bands[k], lane n <- box n; v_readlane), so the loop touches memory only for rows.
-// Band flush: every active box adds one masked partial per lane into that lane's private LDS slot
-// sacc[box][lane] (conflict-free); the 64 -> 1 reductions happen once per (plane, box) at the end.
-// Measured alternatives that were SLOWER on MI355X (kept out): 4 waves per plane by row interleave or row quarters
-// (80-110 us: per-wave fixed costs x4), small levels dispatched first (56 us), an LDS-tiled variant with full-width
-// 1 KB loads and per-box rectangle sums out of LDS (101 us: 4x the load instructions on the small levels, same
-// VALU/SALU count).  SQ counters of this version: 18.5 M VALU + 14.3 M SALU instructions for 0.5 M loads per launch,
-// 28 % of wave cycles issuing, 26 % waiting on memory -- it is issue/latency-bound, not HBM-bound.
-// NP = channel planes per wave: planes c, c+1 of one image share every piece of bookkeeping (band walk, activity
-// ballots, box column tests, v_readlane traffic), which is what bounds this kernel -- not bytes.
+// One wave per NP channel planes (planes c, c+1 of one image share all band bookkeeping).  Rows stream through a two-deep register
+// pipeline of FIXED 4-row groups that ignores band boundaries: every group is exactly NP*4 loads, so the compiler keeps one group in
+// flight with a counted s_waitcnt while the other is reduced.  (Loading band by band exposed one HBM latency per band: ~20 x 2.5 us per
+// p3 wave, 3.3 TB/s; variable-length groups force s_waitcnt vmcnt(0): 1.9 TB/s.)  Band bookkeeping happens at consume time with
+// wave-uniform control flow; the band table and the rectangles live in registers (lane k <- bands[k], lane n <- box n).
+// Band flush = ONE wave-wide prefix sum of the band's column sums per plane (fp64 across lanes, fp32 inside a lane's VW columns),
+// parked in LDS; lane n then reads the prefix at its box's two column ends and adds the difference to box n's total in a register --
+// all (<= 64) boxes of the image at once, cost independent of how many are active.  (Round 1's flush added one masked partial per
+// ACTIVE box into LDS slots and reduced 64 -> 1 per box and plane at the end: same speed on box_sum, 8 % slower with the fused
+// GroupNorm + ReLU, whose extra arithmetic competes for the same issue slots.)
+// SQ counters (tools/sq_counters.sh): the kernel is ISSUE-bound, not HBM-bound -- 16 M VALU + 8 M SALU instructions per launch, the
+// resident waves' issue shares add up to one SIMD; a row of p3 fills 42 of 64 lanes, the small levels 11-21.  Measured and rejected:
+// splitting the rows of the big planes over the four waves of a workgroup (4x the waves, each with its own band walk and flushes):
+// 42 -> 51-55 us; 4 waves per plane by row interleave, small levels first, an LDS-tiled variant (round 1): all slower.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64m(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_incl_scan(double v) {
+    v += dpp_f64m<0x111, 0xf>(v);  // row_shr:1 .. 8: Kogge-Stone inside each row of 16 lanes (lanes without a source read 0)
+    v += dpp_f64m<0x112, 0xf>(v);
+    v += dpp_f64m<0x114, 0xf>(v);
+    v += dpp_f64m<0x118, 0xf>(v);
+    v += dpp_f64m<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_f64m<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_i32<0xB1>(v)); v = min(v, dpp_i32<0x4E>(v)); v = min(v, dpp_i32<0x141>(v)); v = min(v, dpp_i32<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    v = max(v, dpp_i32<0xB1>(v)); v = max(v, dpp_i32<0x4E>(v)); v = max(v, dpp_i32<0x141>(v)); v = max(v, dpp_i32<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+struct ScanScratch { double E[64]; float loc[256]; };   // per wave and plane: exclusive lane prefix, inclusive in-lane prefix by column
+
 template <int VW, int NP>
-__device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, float* sacc /* [NP][nb][64] of this wave */, int nb) {
+__device__ __forceinline__ void box_sum_scan(const BoxArgs& a, const Plane& p, ScanScratch* sc) {
     constexpr int G = 4;
     const int lane = threadIdx.x & 63;
     const size_t psz = (size_t)p.H * p.W;
     const float* __restrict__ src = a.in[p.l] + ((size_t)p.b * a.C + p.c) * psz;
-    const int npass = (p.n + nb - 1) / nb;   // nb = boxes per pass (LDS budget), <= 64
-    const int bandreg = lane < p.nbp ? p.bands[lane] : p.H;  // nbp <= 64 is the fast path
-    auto band = [&](int k) {  // wave-uniform by construction: say so, or every band test becomes an exec-masked vector loop
-        return __builtin_amdgcn_readfirstlane(p.nbp <= 64 ? __builtin_amdgcn_readlane(bandreg, k) : p.bands[k]);
+    const int npass = (p.n + 63) >> 6;
+    const int bandreg = lane < p.nbp ? p.bands[lane] : p.H;
+    auto band = [&](int k) {  // wave-uniform by construction
+        return __builtin_amdgcn_readfirstlane(p.nbp <= 64 ? __builtin_amdgcn_readlane(bandreg, k) : (k < p.nbp ? p.bands[k] : p.H));
     };
     const bool gn = a.gn_stats != nullptr;
     const float gmu = gn ? a.gn_stats[2 * (p.l * a.B + p.b)] : 0.f, grs = gn ? a.gn_stats[2 * (p.l * a.B + p.b) + 1] : 1.f;
     for (int pass = 0; pass < npass; ++pass) {
-        LaneBox bx{0, -1, 0, -1};
-        if (lane < nb) bx = load_lane_box_at(p, pass * nb + lane, a.skip_last);
-        for (int n = 0; n < NP * nb; ++n) sacc[n * 64 + lane] = 0.f;
-        // rows below ylo / above yhi are covered by no box of this pass: never fetched
-        int ylo = p.H, yhi = -1;
-        {
-            unsigned long long live = __ballot(bx.x1 >= bx.x0);
-            while (live) {
-                const int n = __builtin_ctzll(live);
-                live &= live - 1;
-                ylo = min(ylo, __builtin_amdgcn_readlane(bx.y0, n));
-                yhi = max(yhi, __builtin_amdgcn_readlane(bx.y1, n));
-            }
-        }
-        for (int xc = 0; yhi >= ylo && xc < p.W; xc += 64 * VW) {
+        const LaneBox bx = load_lane_box_at(p, pass * 64 + lane, a.skip_last);
+        const bool live = bx.x1 >= bx.x0 && bx.y1 >= bx.y0;
+        // rows any box of this pass covers: the others are never fetched
+        const int ra = __builtin_amdgcn_readfirstlane(wave_min_i(live ? bx.y0 : p.H));
+        const int rb = __builtin_amdgcn_readfirstlane(wave_max_i(live ? bx.y1 : -1) + 1);
+        double acc[NP];
+        #pragma unroll
+        for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+        for (int xc = 0; rb > ra && xc < p.W; xc += 64 * VW) {
             const int xl = xc + lane * VW;
             const bool on = xl < p.W;  // VW | W, so a lane's vector is wholly inside or outside the row
             const float* col = src + (on ? xl : 0);
-            auto band_act = [&](int ya) {
-                return __ballot(bx.x1 >= bx.x0 && bx.y0 <= ya && ya <= bx.y1 && bx.x1 >= xc && bx.x0 < xc + 64 * VW);
-            };
+            const bool inchunk = live && bx.x1 >= xc && bx.x0 < xc + 64 * VW;
             int k = 0;
-            while (band(k + 1) <= ylo) ++k;      // band containing ylo
+            while (band(k + 1) <= ra) ++k;       // band containing ra
             int yb = band(k + 1);
-            unsigned long long act = band_act(band(k));
+            bool mine = inchunk && bx.y0 <= ra && ra <= bx.y1;   // this lane's box is active in the current band
+            bool any = __ballot(mine) != 0ull;
             float cs[NP][VW];
             #pragma unroll
             for (int q = 0; q < NP; ++q)
                 #pragma unroll
                 for (int j = 0; j < VW; ++j) cs[q][j] = 0.f;
             auto flush = [&]() {
-                unsigned long long m = act;
-                while (m) {
-                    const int n = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int bx0 = __builtin_amdgcn_readlane(bx.x0, n), bx1 = __builtin_amdgcn_readlane(bx.x1, n);
-                    float part[NP];
-                    #pragma unroll
-                    for (int q = 0; q < NP; ++q) part[q] = 0.f;
-                    #pragma unroll
-                    for (int j = 0; j < VW; ++j) {
-                        const bool in = xl + j >= bx0 && xl + j <= bx1;
-                        #pragma unroll
-                        for (int q = 0; q < NP; ++q) part[q] += in ? cs[q][j] : 0.f;
-                    }
-                    #pragma unroll
-                    for (int q = 0; q < NP; ++q) sacc[(q * nb + n) * 64 + lane] += part[q];
-                }
+                if (!any) return;   // wave-uniform; cs is still zero
+                const int xa = max(bx.x0, xc) - xc, xb = min(bx.x1, xc + 64 * VW - 1) - xc;   // chunk-relative column ends
                 #pragma unroll
-                for (int q = 0; q < NP; ++q)
+                for (int q = 0; q < NP; ++q) {
+                    float pre[VW];
+                    pre[0] = cs[q][0];
+                    #pragma unroll
+                    for (int j = 1; j < VW; ++j) pre[j] = pre[j - 1] + cs[q][j];
+                    const double tot = (double)pre[VW - 1];
+                    sc[q].E[lane] = wave_incl_scan(tot) - tot;
+                    #pragma unroll
+                    for (int j = 0; j < VW; ++j) sc[q].loc[lane * VW + j] = pre[j];
                     #pragma unroll
                     for (int j = 0; j < VW; ++j) cs[q][j] = 0.f;
+                }
+                if (mine) {   // same wave: the LDS queue is in order, the writes above are visible
+                    #pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const double hi = sc[q].E[xb / VW] + (double)sc[q].loc[xb];
+                        const double lo = xa > 0 ? sc[q].E[(xa - 1) / VW] + (double)sc[q].loc[xa - 1] : 0.0;
+                        acc[q] += hi - lo;
+                    }
+                }
             };
             auto issue = [&](Vec<VW> (*v)[G], int y0) {  // always NP*G loads (rows clamped into the plane)
                 #pragma unroll
@@ -175,14 +196,15 @@ __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, 
                 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const int y = y0 + u;
-                    if (y <= yhi) {
+                    if (y < rb) {
                         while (y == yb) {  // wave-uniform: close the band, open the next
                             flush();
                             ++k;
                             yb = band(k + 1);
-                            act = band_act(y);
+                            mine = inchunk && bx.y0 <= y && y <= bx.y1;
+                            any = __ballot(mine) != 0ull;
                         }
-                        if (act && on) {
+                        if (any && on) {
                             #pragma unroll
                             for (int q = 0; q < NP; ++q)
                                 #pragma unroll
@@ -193,8 +215,8 @@ __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, 
                 }
             };
             Vec<VW> va[NP][G], vb[NP][G];
-            issue(va, ylo);
-            for (int y0 = ylo; y0 <= yhi; y0 += 2 * G) {
+            issue(va, ra);
+            for (int y0 = ra; y0 < rb; y0 += 2 * G) {
                 issue(vb, y0 + G);
                 consume(va, y0);
                 issue(va, y0 + 2 * G);
@@ -202,153 +224,99 @@ __device__ __forceinline__ void box_sum_plane(const BoxArgs& a, const Plane& p, 
             }
             flush();
         }
-        // one 64 -> 1 reduction per (plane, box) of the pass; lane n keeps box n's totals
-        float mine[NP];
-        #pragma unroll
-        for (int q = 0; q < NP; ++q) mine[q] = 0.f;
-        const int nlive = min(nb, p.n - pass * nb);
-        for (int n = 0; n < nlive; ++n) {
+        if (pass * 64 + lane < p.n) {
+            const float cnt = live ? (float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)) : 0.f;
             #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const float tot = wave_sum(sacc[(q * nb + n) * 64 + lane]);
-                if (lane == n) mine[q] = tot;
-            }
-        }
-        if (lane < nlive) {
-            const float cnt = (bx.x1 >= bx.x0) ? (float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)) : 0.f;
-            #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                float o = mine[q];
+                float o = (float)acc[q];
                 if (a.normalize) o = o / fmaxf(cnt, 1.f);  // [ref: dynamic_teacher.py:97-100]
-                a.pooled[((size_t)p.l * a.T + p.t0 + pass * nb + lane) * a.C + p.c + q] = o;
+                a.pooled[((size_t)p.l * a.T + p.t0 + pass * 64 + lane) * a.C + p.c + q] = o;
             }
         }
     }
 }
 
 template <int NP>  // channel planes per wave
-__global__ __launch_bounds__(256) void box_sum_kernel(BoxArgs a, int nb) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][NP][nb][64]
+__global__ __launch_bounds__(256) void box_sum_kernel(BoxArgs a) {
+    __shared__ ScanScratch sc[4][NP];
     const Plane p = locate(a, 4 * NP);
-    float* sacc = smem + (size_t)(threadIdx.x >> 6) * NP * nb * 64;
-    if ((p.W & 3) == 0) box_sum_plane<4, NP>(a, p, sacc, nb);
-    else if ((p.W & 1) == 0) box_sum_plane<2, NP>(a, p, sacc, nb);
-    else box_sum_plane<1, NP>(a, p, sacc, nb);
+    ScanScratch* mine = sc[threadIdx.x >> 6];
+    if ((p.W & 3) == 0) box_sum_scan<4, NP>(a, p, mine);
+    else if ((p.W & 1) == 0) box_sum_scan<2, NP>(a, p, mine);
+    else box_sum_scan<1, NP>(a, p, mine);
+}
+static void launch_box_sum(const char* name, const BoxArgs& a, int np, int nblk, hipStream_t s) {
+    if (np == 2) LGD_LAUNCH(name, box_sum_kernel<2>, dim3(nblk), dim3(256), 0, s, a);
+    else LGD_LAUNCH(name, box_sum_kernel<1>, dim3(nblk), dim3(256), 0, s, a);
 }
 
-// planes per wave: as many as the channel count allows (the shared bookkeeping is the cost centre)
-static int sum_planes(int C) {
-    const char* e = getenv("LGD_SUM_NP");
-    const int want = e ? atoi(e) : 2;
-    if (want >= 4 && C % 16 == 0) return 4;
-    if (want >= 2 && C % 8 == 0) return 2;
-    return 1;
-}
-static void launch_box_sum(const char* name, const BoxArgs& a, int np, int nblk, int nb, hipStream_t s) {
-    const size_t smem = (size_t)4 * np * nb * 64 * sizeof(float);
-    if (np == 4) LGD_LAUNCH(name, box_sum_kernel<4>, dim3(nblk), dim3(256), smem, s, a, nb);
-    else if (np == 2) LGD_LAUNCH(name, box_sum_kernel<2>, dim3(nblk), dim3(256), smem, s, a, nb);
-    else LGD_LAUNCH(name, box_sum_kernel<1>, dim3(nblk), dim3(256), smem, s, a, nb);
-}
-
-// ------------------------------------------------------------------------------------------- box_paint
-template <int VW>
-__device__ __forceinline__ void box_paint_plane(const BoxArgs& a, const Plane& p) {
+// ------------------------------------------------------------------------------------------- box_paint / gn_pool backward
+// One skeleton for the three kernels that apply a per-band ROW PATTERN pv[x] = sum of the values of the boxes covering (band, x):
+//   MODE 2  box_paint          dst = pv                                     (render fwd, mask pooling bwd; writes only)
+//   MODE 0  gn_pool bwd stats  per-plane sums of g and g*xhat, g = pv where relu(GN1(x)) > 0   (reads x)
+//   MODE 1  gn_pool bwd apply  dx = rstd * (g - m1 - xhat * m2)                                (reads x, writes dx)
+// d/dx of pool(relu(GN1(x))): dy = paint(dpool / count) restricted to y > 0, then the GroupNorm(1) backward with m1 = mean(g),
+// m2 = mean(g * xhat) over the sample; dy is never materialised.
+// Rows stream in fixed 4-row groups, two in flight, across band boundaries (the first version loaded band by band and paid one
+// HBM latency per band: ~20 bands x 2 us on a p3 plane, 0.38 of the HBM peak); the pattern is recomposed at a boundary by
+// wave-uniform control flow: 60 -> 50 us (stats), 84 -> 72 us (apply) HBM-cold.  Issue-bound like box_sum (20 M VALU + 13 M SALU
+// per launch); splitting the big planes' rows over four waves is slower here too (66 / 92 us).
+template <int VW, int MODE>
+__device__ __forceinline__ void paint_rows(const BoxArgs& a, const Plane& p) {
+    constexpr int G = 4;
     const int lane = threadIdx.x & 63;
-    float* __restrict__ dst = a.out[p.l] + ((size_t)p.b * a.C + p.c) * p.H * p.W;
+    const size_t base = ((size_t)p.b * a.C + p.c) * p.H * p.W;
+    const float* __restrict__ src = MODE != 2 ? a.gx[p.l] + base : nullptr;
+    float* __restrict__ dst = MODE != 0 ? a.out[p.l] + base : nullptr;
     const float* __restrict__ vals = a.vals + ((size_t)p.l * a.T + p.t0) * a.C + p.c;
+    const int seg = p.l * a.B + p.b;
+    float mu = 0.f, rs = 1.f, m1 = 0.f, m2 = 0.f;
+    if (MODE != 2) { mu = a.gn_stats[2 * seg]; rs = a.gn_stats[2 * seg + 1]; }
+    if (MODE == 1) { m1 = a.gn_bstats[2 * seg]; m2 = a.gn_bstats[2 * seg + 1]; }
+    const bool norm = MODE != 2 || a.normalize;
+    const int skip = MODE == 2 ? a.skip_last : 0;
     const int npass = (p.n + 63) >> 6;
-
     auto lane_val = [&](const LaneBox& bx, int pass) -> float {
-        const int n = pass * 64 + lane;
         float v = 0.f;
         if (bx.x1 >= bx.x0) {  // only live boxes are read (the skipped context row may hold anything)
-            v = vals[(size_t)n * a.C];
-            if (a.normalize) v = v / fmaxf((float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)), 1.f);
+            v = vals[(size_t)(pass * 64 + lane) * a.C];
+            if (norm) v = v / fmaxf((float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)), 1.f);
         }
         return v;
     };
     // common case (<= 64 boxes per image): rectangles and values stay in registers for the whole plane
-    LaneBox bx0 = load_lane_box(p, 0, lane, a.skip_last);
-    float val0 = lane_val(bx0, 0);
-
-    for (int xc = 0; xc < p.W; xc += 64 * VW) {
-        const int xl = xc + lane * VW;
-        const bool on = xl < p.W;
-        float* col = dst + xl;
-        for (int k = 0; k + 1 < p.nbp; ++k) {
-            const int ya = __builtin_amdgcn_readfirstlane(p.bands[k]), yb = __builtin_amdgcn_readfirstlane(p.bands[k + 1]);
-            Vec<VW> pv;
-            #pragma unroll
-            for (int j = 0; j < VW; ++j) pv.v[j] = 0.f;
-            for (int pass = 0; pass < npass; ++pass) {
-                LaneBox bx = bx0;
-                float val = val0;
-                if (pass > 0) { bx = load_lane_box(p, pass, lane, a.skip_last); val = lane_val(bx, pass); }
-                unsigned long long act = __ballot(bx.x1 >= bx.x0 && bx.y0 <= ya && ya <= bx.y1);
-                while (act) {
-                    const int n = __builtin_ctzll(act);
-                    act &= act - 1;
-                    const int q0 = __builtin_amdgcn_readlane(bx.x0, n), q1 = __builtin_amdgcn_readlane(bx.x1, n);
-                    const float v = readlane_f32(val, n);
-                    #pragma unroll
-                    for (int j = 0; j < VW; ++j) pv.v[j] += (xl + j >= q0 && xl + j <= q1) ? v : 0.f;
-                }
-            }
-            if (on) {
-                for (int y = ya; y < yb; ++y) vstore<VW>(col + (size_t)y * p.W, pv);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void box_paint_kernel(BoxArgs a) {
-    const Plane p = locate(a, 4);
-    if ((p.W & 3) == 0) box_paint_plane<4>(a, p);
-    else if ((p.W & 1) == 0) box_paint_plane<2>(a, p);
-    else box_paint_plane<1>(a, p);
-}
-
-// ------------------------------------------------------------------------------------------- gn_pool backward
-// d/dx of  pool(relu(GN1(x))):  dy = paint(dpool / count) restricted to y > 0, then the GroupNorm(1) backward
-// dx = rstd * (g - m1 - xhat * m2), m1 = mean(g), m2 = mean(g * xhat) over the sample.  dy is never materialised:
-// every band's row pattern pv is composed from the active boxes (as in box_paint) and applied while x streams by.
-//   MODE 0: per-plane partial sums of g and g*xhat (fp64) -> ws        (reads x once)
-//   MODE 1: dx                                                         (reads x once, writes dx)
-template <int VW, int MODE>
-__device__ __forceinline__ void gn_pool_bwd_plane(const BoxArgs& a, const Plane& p) {
-    const int lane = threadIdx.x & 63;
-    const size_t base = ((size_t)p.b * a.C + p.c) * p.H * p.W;
-    const float* __restrict__ src = a.gx[p.l] + base;
-    float* __restrict__ dst = MODE == 1 ? a.out[p.l] + base : nullptr;
-    const float* __restrict__ vals = a.vals + ((size_t)p.l * a.T + p.t0) * a.C + p.c;
-    const int seg = p.l * a.B + p.b;
-    const float mu = a.gn_stats[2 * seg], rs = a.gn_stats[2 * seg + 1];
-    float m1 = 0.f, m2 = 0.f;
-    if (MODE == 1) { m1 = a.gn_bstats[2 * seg]; m2 = a.gn_bstats[2 * seg + 1]; }
-    const int npass = (p.n + 63) >> 6;
-    auto lane_val = [&](const LaneBox& bx, int pass) -> float {
-        float v = 0.f;
-        if (bx.x1 >= bx.x0) v = vals[(size_t)(pass * 64 + lane) * a.C] / fmaxf((float)((bx.x1 - bx.x0 + 1) * (bx.y1 - bx.y0 + 1)), 1.f);
-        return v;
-    };
-    const LaneBox bx0 = load_lane_box(p, 0, lane, 0);
+    const LaneBox bx0 = load_lane_box(p, 0, lane, skip);
     const float val0 = lane_val(bx0, 0);
+    const int bandreg = lane < p.nbp ? p.bands[lane] : p.H;
+    auto band = [&](int k) {  // wave-uniform by construction
+        return __builtin_amdgcn_readfirstlane(p.nbp <= 64 ? __builtin_amdgcn_readlane(bandreg, k) : (k < p.nbp ? p.bands[k] : p.H));
+    };
+    // MODE 0 needs only the rows some box covers (g = 0 elsewhere); the writers cover the whole plane
+    int lo = 0, hi = p.H;
+    if (MODE == 0) {
+        int ylo = p.H, yhi = -1;
+        for (int pass = 0; pass < npass; ++pass) {
+            const LaneBox bx = pass ? load_lane_box(p, pass, lane, skip) : bx0;
+            const bool live = bx.x1 >= bx.x0 && bx.y1 >= bx.y0;
+            ylo = min(ylo, wave_min_i(live ? bx.y0 : p.H)); yhi = max(yhi, wave_max_i(live ? bx.y1 : -1));
+        }
+        lo = ylo; hi = max(yhi + 1, ylo);
+    }
+    const int ra = __builtin_amdgcn_readfirstlane(lo), rb = __builtin_amdgcn_readfirstlane(hi);
     double s1 = 0.0, s2 = 0.0;
-    for (int xc = 0; xc < p.W; xc += 64 * VW) {
+    for (int xc = 0; rb > ra && xc < p.W; xc += 64 * VW) {
         const int xl = xc + lane * VW;
         const bool on = xl < p.W;
-        const float* col = src + (on ? xl : 0);
-        for (int k = 0; k + 1 < p.nbp; ++k) {
-            const int ya = __builtin_amdgcn_readfirstlane(p.bands[k]), yb = __builtin_amdgcn_readfirstlane(p.bands[k + 1]);
-            float pv[VW];
+        float pv[VW];
+        bool any = false;
+        auto compose = [&](int ya) {   // the row pattern of the band that contains row ya
             #pragma unroll
             for (int j = 0; j < VW; ++j) pv[j] = 0.f;
-            bool any = false;
+            any = false;
             for (int pass = 0; pass < npass; ++pass) {
                 LaneBox bx = bx0;
                 float val = val0;
-                if (pass > 0) { bx = load_lane_box(p, pass, lane, 0); val = lane_val(bx, pass); }
+                if (pass > 0) { bx = load_lane_box(p, pass, lane, skip); val = lane_val(bx, pass); }
                 unsigned long long act = __ballot(bx.x1 >= bx.x0 && bx.y0 <= ya && ya <= bx.y1);
                 any |= act != 0ull;
                 while (act) {
@@ -360,27 +328,57 @@ __device__ __forceinline__ void gn_pool_bwd_plane(const BoxArgs& a, const Plane&
                     for (int j = 0; j < VW; ++j) pv[j] += (xl + j >= q0 && xl + j <= q1) ? v : 0.f;
                 }
             }
-            if (MODE == 0 && !any) continue;  // uncovered rows contribute g = 0 to both sums: not even read
-            if (!on) continue;
-            for (int y0 = ya; y0 < yb; y0 += 4) {
-                Vec<VW> v[4];
+        };
+        int k = 0;
+        while (band(k + 1) <= ra) ++k;
+        int yb = band(k + 1);
+        compose(ra);
+        if constexpr (MODE == 2) {
+            float* col = dst + xl;
+            for (int y = ra; y < rb;) {   // one row pattern per band, streamed to every row of the band
+                Vec<VW> o;
                 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = vload<VW>(col + (size_t)min(y0 + u, yb - 1) * p.W);
+                for (int j = 0; j < VW; ++j) o.v[j] = pv[j];
+                const int ye = min(yb, rb);
+                if (on) for (; y < ye; ++y) vstore<VW>(col + (size_t)y * p.W, o);
+                y = ye;
+                if (y < rb) { ++k; yb = band(k + 1); compose(y); }
+            }
+        } else {
+            const float* col = src + (on ? xl : 0);
+            auto issue = [&](Vec<VW>* v, int y0) {
                 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (y0 + u >= yb) continue;
-                    Vec<VW> o;
-                    float t1 = 0.f, t2 = 0.f;
-                    #pragma unroll
-                    for (int j = 0; j < VW; ++j) {
-                        const float xh = __fmul_rn(__fsub_rn(v[u].v[j], mu), rs);
-                        const float g = xh > 0.f ? pv[j] : 0.f;
-                        if (MODE == 0) { t1 += g; t2 = fmaf(g, xh, t2); }
-                        else o.v[j] = rs * (g - m1 - xh * m2);
+                for (int u = 0; u < G; ++u) v[u] = vload<VW>(col + (size_t)min(y0 + u, p.H - 1) * p.W);
+            };
+            auto consume = [&](Vec<VW>* v, int y0) {
+                #pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int y = y0 + u;
+                    if (y < rb) {
+                        if (y == yb) { while (band(k + 1) <= y) ++k; yb = band(k + 1); compose(y); }
+                        if (on && (MODE == 1 || any)) {
+                            Vec<VW> o;
+                            float t1 = 0.f, t2 = 0.f;
+                            #pragma unroll
+                            for (int j = 0; j < VW; ++j) {
+                                const float xh = __fmul_rn(__fsub_rn(v[u].v[j], mu), rs);
+                                const float g = xh > 0.f ? pv[j] : 0.f;
+                                if (MODE == 0) { t1 += g; t2 = fmaf(g, xh, t2); }
+                                else o.v[j] = rs * (g - m1 - xh * m2);
+                            }
+                            if (MODE == 0) { s1 += (double)t1; s2 += (double)t2; }
+                            else vstore<VW>(dst + xl + (size_t)y * p.W, o);
+                        }
                     }
-                    if (MODE == 0) { s1 += (double)t1; s2 += (double)t2; }
-                    else vstore<VW>(dst + xl + (size_t)(y0 + u) * p.W, o);
                 }
+            };
+            Vec<VW> va[G], vb[G];
+            issue(va, ra);
+            for (int y0 = ra; y0 < rb; y0 += 2 * G) {
+                issue(vb, y0 + G);
+                consume(va, y0);
+                issue(va, y0 + 2 * G);
+                consume(vb, y0 + G);
             }
         }
     }
@@ -393,12 +391,12 @@ __device__ __forceinline__ void gn_pool_bwd_plane(const BoxArgs& a, const Plane&
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void gn_pool_bwd_kernel(BoxArgs a) {
+template <int MODE>   // one wave per plane
+__global__ __launch_bounds__(256) void paint_kernel(BoxArgs a) {
     const Plane p = locate(a, 4);
-    if ((p.W & 3) == 0) gn_pool_bwd_plane<4, MODE>(a, p);
-    else if ((p.W & 1) == 0) gn_pool_bwd_plane<2, MODE>(a, p);
-    else gn_pool_bwd_plane<1, MODE>(a, p);
+    if ((p.W & 3) == 0) paint_rows<4, MODE>(a, p);
+    else if ((p.W & 1) == 0) paint_rows<2, MODE>(a, p);
+    else paint_rows<1, MODE>(a, p);
 }
 
 // per (level, image): fold the C per-plane partials -> m1 = mean(g), m2 = mean(g*xhat)
@@ -455,28 +453,26 @@ extern "C" {
 int lgd_box_sum(const float* const* feats_host, const int32_t* level_hw_host, int L, int B, int C, int T, int max_n,
                 const int32_t* img_off, const int32_t* geom, float* out, int normalize, int skip_last, void* stream) {
     lgd::BoxArgs a;
-    const int np = lgd::sum_planes(C);
+    const int np = C % 8 == 0 ? 2 : 1;   // channel planes per wave
     const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last, 4 * np);
     if (nblk < 0 || !feats_host || !out) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!feats_host[l]) return LGD_EINVAL; a.in[l] = feats_host[l]; }
     a.pooled = out;
     if (T == 0) return LGD_OK;
-    const int nb = max_n < 1 ? 1 : (max_n > 64 ? 64 : max_n);  // boxes per pass: 256 B of LDS per wave and box
-    lgd::launch_box_sum("box_sum_kernel", a, np, nblk, nb, (hipStream_t)stream);
+    lgd::launch_box_sum("box_sum_kernel", a, np, nblk, (hipStream_t)stream);
     return lgd::check_launch();
 }
 
 int lgd_gn_pool_fwd(const float* const* x_host, const float* gn_stats, const int32_t* level_hw_host, int L, int B, int C, int T,
                     int max_n, const int32_t* img_off, const int32_t* geom, float* out, void* stream) {
     lgd::BoxArgs a;
-    const int np = lgd::sum_planes(C);
+    const int np = C % 8 == 0 ? 2 : 1;
     const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, 1, 0, 4 * np);
     if (nblk < 0 || !x_host || !gn_stats || !out) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!x_host[l]) return LGD_EINVAL; a.in[l] = x_host[l]; }
     a.pooled = out; a.gn_stats = gn_stats;
     if (T == 0) return LGD_OK;
-    const int nb = max_n < 1 ? 1 : (max_n > 64 ? 64 : max_n);
-    lgd::launch_box_sum("gn_pool_kernel", a, np, nblk, nb, (hipStream_t)stream);
+    lgd::launch_box_sum("gn_pool_kernel", a, np, nblk, (hipStream_t)stream);
     return lgd::check_launch();
 }
 
@@ -492,9 +488,9 @@ int lgd_gn_pool_bwd(const float* const* x_host, const float* gn_stats, const flo
     }
     a.vals = dpool; a.gn_stats = gn_stats; a.gn_bstats = bstats; a.ws = ws;
     hipStream_t s = (hipStream_t)stream;
-    LGD_LAUNCH("gn_pool_bwd_stats_kernel", lgd::gn_pool_bwd_kernel<0>, dim3(nblk), dim3(256), 0, s, a);
+    LGD_LAUNCH("gn_pool_bwd_stats_kernel", lgd::paint_kernel<0>, dim3(nblk), dim3(256), 0, s, a);
     LGD_LAUNCH("gn_pool_bwd_finalize_kernel", lgd::gn_pool_bwd_finalize_kernel, dim3(L * B), dim3(256), 0, s, a, bstats);
-    LGD_LAUNCH("gn_pool_bwd_apply_kernel", lgd::gn_pool_bwd_kernel<1>, dim3(nblk), dim3(256), 0, s, a);
+    LGD_LAUNCH("gn_pool_bwd_apply_kernel", lgd::paint_kernel<1>, dim3(nblk), dim3(256), 0, s, a);
     return lgd::check_launch();
 }
 
@@ -506,7 +502,7 @@ int lgd_box_paint(const float* vals, const int32_t* level_hw_host, int L, int B,
     if (nblk < 0 || !outs_host || !vals) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!outs_host[l]) return LGD_EINVAL; a.out[l] = outs_host[l]; }
     a.vals = vals;
-    LGD_LAUNCH("box_paint_kernel", lgd::box_paint_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    LGD_LAUNCH("box_paint_kernel", lgd::paint_kernel<2>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 

@@ -34,7 +34,7 @@ TIMER_NAMES = {
     "gn_finalize_kernel<0>": ["gn_finalize_kernel"], "gn_finalize_kernel<1>": ["gn_bwd_finalize_kernel"],
     "ctx_relu_kernel<0>": ["ctx_relu_kernel"], "ctx_relu_kernel<1>": ["ctx_relu_bwd_kernel"],
     "focal_kernel<0>": ["focal_fwd_kernel"], "focal_kernel<1>": ["focal_bwd_kernel"],
-    "gn_pool_bwd_kernel<0>": ["gn_pool_bwd_stats_kernel"], "gn_pool_bwd_kernel<1>": ["gn_pool_bwd_apply_kernel"],
+    "paint_kernel<0>": ["gn_pool_bwd_stats_kernel"], "paint_kernel<1>": ["gn_pool_bwd_apply_kernel"], "paint_kernel<2>": ["box_paint_kernel"],
     "box_sum_kernel<1>": ["box_sum_kernel", "gn_pool_kernel"], "box_sum_kernel<2>": ["box_sum_kernel", "gn_pool_kernel"],
     "rowln_kernel<0>": ["rowln_kernel"], "rowln_kernel<1>": ["rowln_bwd_kernel"],
     "wino_in_kernel<false, false>": ["wino_in_kernel"], "wino_in_kernel<false, true>": ["wino_in_kernel"],
@@ -47,6 +47,7 @@ TIMER_NAMES = {
     "wino4_out_kernel": ["wino_out_kernel"], "wino4_out_kernel<false>": ["wino_out_kernel"], "wino4_out_kernel<true>": ["wino_out_kernel"],
     "bias_act_kernel<4>": ["bias_act_kernel"], "bias_act_kernel<1>": ["bias_act_kernel"],
     "relu_mask_kernel<4>": ["relu_mask_kernel"], "relu_mask_kernel<1>": ["relu_mask_kernel"], "wino4_out_t_kernel": ["wino_out_t_kernel"],
+    "wino4_in_t_kernel": ["wino_in_t_kernel"],
 }
 
 
