@@ -280,6 +280,12 @@ int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host
 int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const uint16_t* relu_bits,
                    const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM, void* stream);
 int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host, void* stream);
+/* lgd_wino_in_t followed by lgd_wino_out_t of the convolution that PRODUCED these maps, in one kernel (tile = 4): the backward link of a
+ * conv -> [ReLU] -> conv chain whose intermediate maps have no other consumer (the head towers, the adapter: distillator.py:107-109,
+ * sequential_convs.py:10-12).  dV: frequency-domain input gradient of the later conv; relu_bits: the earlier conv's mask table (NULL: no
+ * ReLU between them); dM: A (dx . mask) A^T of the earlier conv, same [C][36][T] layout.  The gradient map dx is never materialised. */
+int lgd_wino_in_t_out_t(const float* dV, const uint16_t* relu_bits, const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM,
+                        void* stream);
 
 /* ------------------------------------------------------------------ FCOS ground-truth assignment
  * [ref: models/customized_detectors/thirdparty_heads/fcos.py:177-284  FCOS.get_ground_truth]

@@ -26,7 +26,7 @@ class SequentialConvs(nn.Module):
     def levels(self, xs):
         """the adapter on a list of pyramid levels: each conv is one pass over the concatenated levels, ReLU fused."""
         a = self.adapter
-        return a[4].levels(a[2].levels(a[0].levels(xs, relu=True), relu=True))
+        return ops.conv3x3_chain(xs, [(a[i].weight, a[i].bias) for i in (0, 2, 4)], (True, True, False))
 
 
 def build_adapter(cfg):

@@ -888,6 +888,94 @@ class _Conv3x3K(torch.autograd.Function):
         return (None, None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
 
 
+class _Conv3x3Chain(torch.autograd.Function):
+    """K convolutions 3x3 / stride 1 / padding 1 in SEQUENCE over the same L maps, conv k [+ ReLU if relus[k]] feeding conv k+1 and
+    nothing else (the head towers after their first conv incl. the score conv, the adapter: distillator.py:107-109 ->
+    retinanet.py:36-43, sequential_convs.py:10-12).  The forward is the per-conv F(4x4,3x3) pipeline of _Conv3x3K.  The backward keeps
+    the gradient in the FREQUENCY domain across a link: dV_k = U_k^T dM_k goes through ONE kernel (lgd_wino_in_t_out_t: adjoint input
+    transform, ReLU mask of conv k-1, A . A^T) into dM_{k-1}; the intermediate gradient maps are neither written nor re-read (4.5
+    instead of 6.5 map transfers per link).  apply(K, relus, w_1, b_1, ..., w_K, b_K, x_1, ..., x_L) -> the L maps of the last conv."""
+
+    @staticmethod
+    def forward(ctx, K, relus, *args):
+        ws, bs, xs = list(args[0:2 * K:2]), list(args[1:2 * K:2]), list(args[2 * K:])
+        hip.require_gpu(*ws, *xs)
+        lib = hip.load()
+        tile, nf = 4, 36
+        ws = [hip.dense_f32(w) for w in ws]
+        xs = [hip.dense_f32(x) for x in xs]
+        bs = [hip.dense_f32(b) if b is not None else None for b in bs]
+        L, N = len(xs), xs[0].shape[0]
+        dev = ws[0].device
+        hw = hip.int_array([d for x in xs for d in x.shape[2:]])
+        shapes = [tuple(x.shape[2:]) for x in xs]
+        T = lib.lgd_wino_tiles(hw, L, N, tile)
+        px = 4 * N * sum(h * w_ for h, w_ in shapes)   # bytes of one channel of the maps
+        fb = 4 * nf * T                                # bytes of one channel of a frequency buffer
+        need_ws = list(ctx.needs_input_grad[2:2 + 2 * K:2])
+        saved, cur = [], xs
+        for k in range(K):
+            Co, Ci = ws[k].shape[0], ws[k].shape[1]
+            U = torch.mm(_wino_gg(dev, tile), ws[k].view(Co * Ci, 9).t()).view(nf, Co, Ci)
+            V = _freq_buf(nf, Ci, T, dev)
+            hip.check(lib.lgd_wino_in(hip.ptr_array(cur), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
+            _count_bytes("wino_in_kernel", (px + fb) * Ci)
+            M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
+            bits = torch.empty((Co, T), dtype=torch.int16, device=dev) if relus[k] else None
+            cur = [torch.empty((N, Co) + s, dtype=torch.float32, device=dev) for s in shapes]
+            _count_bytes("wino_out_kernel", (px + fb + (2 * T if bits is not None else 0)) * Co)
+            hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Co, tile, 0, int(relus[k]),
+                                       hip.ptr_array(cur), hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
+            del M
+            saved += [U, V if need_ws[k] else None, bits]
+        ctx.save_for_backward(*saved)
+        ctx.meta = (K, L, N, hw, T, shapes, [b is not None for b in bs], px, fb)
+        return tuple(cur)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved = ctx.saved_tensors
+        K, L, N, hw, T, shapes, has_bias, px, fb = ctx.meta
+        lib = hip.load()
+        tile, nf = 4, 36
+        dev = saved[0].device
+        need_ws = list(ctx.needs_input_grad[2:2 + 2 * K:2])
+        need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[3:3 + 2 * K:2])]
+        need_x = any(ctx.needs_input_grad[2 + 2 * K:])
+        dws, dbs, dxs = [None] * K, [None] * K, [None] * L
+        Co = saved[3 * (K - 1)].shape[1]
+        dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Co) + shapes[i], dtype=torch.float32, device=dev) for i, g in enumerate(dys)]
+        bits = saved[3 * (K - 1) + 2]
+        dM = _freq_buf(nf, Co, T, dev)
+        _count_bytes("wino_out_t_kernel", (px + fb + (2 * T if bits is not None else 0)) * Co)
+        hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), None, hip.ptr(bits) if bits is not None else None, hw, L, N, Co, tile, hip.ptr(dM),
+                                     hip.stream_ptr()), "lgd_wino_out_t")
+        for k in range(K - 1, -1, -1):
+            U, V = saved[3 * k], saved[3 * k + 1]
+            Co, Ci = U.shape[1], U.shape[2]
+            if need_ws[k]:
+                dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
+                dws[k] = torch.mm(_wino_gg(dev, tile).t(), dU.view(nf, Co * Ci)).t().reshape(Co, Ci, 3, 3)
+            if need_bs[k]:
+                dbs[k] = dM[tile + 3].sum(1)   # A's row of the interpolation point 1 is all ones: the tile's gradient sum
+            if k == 0 and not need_x:
+                break
+            dV = _timed_bmm("wino_gemm_dx", U.transpose(1, 2).contiguous(), dM, out=_freq_buf(nf, Ci, T, dev))
+            del dM
+            if k > 0:   # the link to conv k-1: dM_{k-1} = A (in_t(dV) . relu mask) A^T without the map in between
+                pb = saved[3 * (k - 1) + 2]
+                dM = _freq_buf(nf, Ci, T, dev)
+                _count_bytes("wino_in_t_out_t_kernel", (2 * fb + (2 * T if pb is not None else 0)) * Ci)
+                hip.check(lib.lgd_wino_in_t_out_t(hip.ptr(dV), hip.ptr(pb) if pb is not None else None, hw, L, N, Ci, tile, hip.ptr(dM),
+                                                  hip.stream_ptr()), "lgd_wino_in_t_out_t")
+            else:
+                _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
+                dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
+                hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), hip.stream_ptr()), "lgd_wino_in_t")
+            del dV
+        return (None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
+
+
 class _Conv3x3:
     """single-filter form of _Conv3x3K with the historical argument order: apply(w, b, relu, tile, *xs)."""
 
@@ -921,6 +1009,7 @@ _WINO_TILE = int(os.environ.get("LGD_WINO_TILE", "4"))  # output tile of the min
 _WINO_MIN_TILES = int(os.environ.get("LGD_WINO_MIN_TILES", "2000"))
 _WINO_MIN_CH = int(os.environ.get("LGD_WINO_MIN_CH", "64"))
 _WINO_ON = os.environ.get("LGD_WINO", "1") != "0"
+_CHAIN_ON = os.environ.get("LGD_CONV_CHAIN", "1") != "0"  # 0: every conv of a chain as its own autograd node (A/B measurements)
 
 
 def conv3x3_backend(winograd=None, min_tiles=None, tile=None):
@@ -964,6 +1053,18 @@ def conv3x3_shared_input(xs, filters, relu=False):
         ys = _Conv3x3K.apply(len(filters), bool(relu), 4, *[t for wb in filters for t in wb], *xs)
         return [list(ys[k * len(xs):(k + 1) * len(xs)]) for k in range(len(filters))]
     return [conv3x3_levels(xs, w, b, relu) for w, b in filters]
+
+
+def conv3x3_chain(xs, filters, relus):
+    """filters [(w, b), ...] applied in sequence to a list of maps, ReLU after conv k where relus[k]; the maps between two convs have no
+    other consumer, so the backward crosses each link in the frequency domain (see _Conv3x3Chain)."""
+    xs = list(xs)
+    relus = tuple(bool(r) for r in relus)
+    if _CHAIN_ON and len(filters) > 1 and _WINO_TILE == 4 and all(_wino_ok(xs, w) and w.shape[1] >= _WINO_MIN_CH for w, _ in filters):
+        return list(_Conv3x3Chain.apply(len(filters), relus, *[t for wb in filters for t in wb], *xs))
+    for (w, b), r in zip(filters, relus):
+        xs = conv3x3_levels(xs, w, b, r)
+    return xs
 
 
 def conv3x3(x, w, b=None, relu=False):

@@ -44,10 +44,13 @@ class RetinaNetHead(nn.Module):
         # the first convs of the two towers read the same maps: one input transform / stacked GEMM / summed input gradient
         c0, b0 = self.cls_subnet[0], self.bbox_subnet[0]
         c, b = ops.conv3x3_shared_input(list(features), [(c0.weight, c0.bias), (b0.weight, b0.bias)], relu=True)
-        for i in range(2, len(self.cls_subnet), 2):
-            c = self.cls_subnet[i].levels(c, relu=True)
-            b = self.bbox_subnet[i].levels(b, relu=True)
-        return self.cls_score.levels(c), self.bbox_pred.levels(b)
+        # the rest of each tower incl. its score conv is a chain whose intermediate maps nobody else reads: the backward crosses every
+        # conv -> ReLU -> conv link in the frequency domain (no gradient map written / re-read)
+        cl = [self.cls_subnet[i] for i in range(2, len(self.cls_subnet), 2)] + [self.cls_score]
+        bl = [self.bbox_subnet[i] for i in range(2, len(self.bbox_subnet), 2)] + [self.bbox_pred]
+        relus = [True] * (len(cl) - 1) + [False]
+        return (ops.conv3x3_chain(c, [(m.weight, m.bias) for m in cl], relus),
+                ops.conv3x3_chain(b, [(m.weight, m.bias) for m in bl], relus))
 
 
 class AnchorGenerator(nn.Module):

@@ -671,6 +671,65 @@ def test_conv3x3_shared_input(N, Ci, Cos, hws, relu):
         ops.conv3x3_backend(*prev)
 
 
+@pytest.mark.parametrize("N,Ci,Cos,hws,relus,bias,need_x", [
+    (2, 64, (64, 64, 64, 36), [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)], (True, True, True, False), True, True),   # a tower + score conv
+    (1, 64, (72, 64), [(13, 21), (7, 11)], (True, False), True, True),                                                # odd maps: tiles overhang
+    (2, 64, (64, 80, 64), [(25, 42)], (True, True, False), False, False),                                             # the adapter; detached input
+    (1, 64, (64, 64), [(12, 16), (6, 8)], (False, False), True, True),                                                # a link without ReLU
+])
+def test_conv3x3_chain(N, Ci, Cos, hws, relus, bias, need_x):
+    """conv -> [ReLU] -> conv -> ... as ONE autograd node whose backward crosses each link in the frequency domain
+    (lgd_wino_in_t_out_t) == the same convolutions as separate nodes (identical forward kernels, so identical ReLU masks): outputs
+    bit-equal, every gradient equal to rounding; and the chain against fp64 with the kink-robust criterion."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=4)
+    try:
+        xs = [torch.from_numpy(synth.det_uniform((N, Ci, h, w), 971 + i, -2.0, 2.0)) for i, (h, w) in enumerate(hws)]
+        cin = (Ci,) + tuple(Cos[:-1])
+        ws = [torch.from_numpy(synth.det_uniform((co, ci, 3, 3), 980 + k, -0.06, 0.06)) for k, (co, ci) in enumerate(zip(Cos, cin))]
+        bs = [torch.from_numpy(synth.det_uniform((co,), 985 + k, -0.3, 0.3)) if bias else None for k, co in enumerate(Cos)]
+        gys = [torch.from_numpy(synth.det_uniform((N, Cos[-1], h, w), 990 + i, -1.0, 1.0)) for i, (h, w) in enumerate(hws)]
+
+        def run(fn, dtype, dev):
+            x = [t.to(dev, dtype).requires_grad_(need_x) for t in xs]
+            w = [t.to(dev, dtype).requires_grad_(True) for t in ws]
+            b = [t.to(dev, dtype).requires_grad_(True) if t is not None else None for t in bs]
+            ys = fn(x, w, b)
+            torch.autograd.backward(ys, [g.to(dev, dtype) for g in gys])
+            return ys, [t.grad for t in x] if need_x else [], [t.grad for t in w], [t.grad for t in b if t is not None]
+
+        def chain(x, w, b):
+            ys = ops.conv3x3_chain(x, list(zip(w, b)), relus)
+            assert type(ys[0].grad_fn).__name__.startswith("_Conv3x3Chain")
+            return ys
+
+        def separate(x, w, b):
+            for wk, bk, r in zip(w, b, relus):
+                x = ops.conv3x3_levels(x, wk, bk, r)
+            return x
+
+        def ref(x, w, b):
+            for wk, bk, r in zip(w, b, relus):
+                x = [F.relu(F.conv2d(t, wk, bk, 1, 1)) if r else F.conv2d(t, wk, bk, 1, 1) for t in x]
+            return x
+
+        yc, dxc, dwc, dbc = run(chain, torch.float32, DEV)
+        ys, dxs, dws, dbs = run(separate, torch.float32, DEV)
+        for a, b_ in zip(yc, ys):
+            assert torch.equal(a, b_)
+        for a, b_ in zip(dxc + dwc + dbc, dxs + dws + dbs):
+            assert float((a - b_).abs().max()) <= 2e-5 * (float(b_.abs().max()) + 1e-30)   # same arithmetic, different fma contraction
+        yr, dxr, dwr, dbr = run(ref, torch.float64, "cpu")
+        for a, b_ in zip(yc, yr):
+            assert float((a.detach().cpu().double() - b_.detach()).abs().max()) <= 1e-4 * float(b_.detach().abs().max())
+        for a, b_ in zip(dxc + dwc + dbc, dxr + dwr + dbr):
+            ok, msg = cm.kink_robust_close(a, b_, tol=2e-4)
+            assert ok, msg
+    finally:
+        ops.conv3x3_backend(*prev)
+
+
 # ------------------------------------------------------------------------------------------- student conv epilogues
 @pytest.mark.parametrize("N,C,H,W,res,relu,bias_grad", [(2, 8, 6, 8, True, True, False), (1, 5, 3, 5, False, True, True),
                                                         (3, 16, 7, 4, True, False, True), (2, 4, 5, 5, False, False, False)])
