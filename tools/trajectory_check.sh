@@ -12,7 +12,8 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); l=d['losses']
 print('%-52s %6.1f ms/step  '%('$name',d['ms_per_step'])+'  '.join('%s %.6f'%(k,l[k]) for k in ('loss_cls','loss_box_reg','loss_cls.tea','loss_box_reg.tea','loss_distill','total_loss')))" >> $out
 }
-EXTRA="" run "single head pass, F(4x4,3x3), 16-bit masks (shipped)" LGD_X=0
+EXTRA="" run "shipped: single head pass, adjoint backward, chains" LGD_X=0
+EXTRA="" run "LGD_CONV_CHAIN=0 (every conv its own autograd node)" LGD_CONV_CHAIN=0
 EXTRA="--head-passes 2" run "two head passes (reference order)" LGD_X=0
 EXTRA="" run "LGD_WINO=0 (library convolutions)" LGD_WINO=0
 cat $out
