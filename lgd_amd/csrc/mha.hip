@@ -24,6 +24,7 @@ struct GemmProb {
     long long sa_m, sa_k, sb_n, sb_k, sc_m, sc_n;
     float alpha;
     int tile0, tiles_n;
+    int vec;   // both operands qualify for the branch-free 16-byte fetch (gemm_fetch_vec)
 };
 struct GemmArgs { GemmProb p[kMaxProb]; int np, ntiles; };
 
@@ -74,16 +75,31 @@ __device__ __forceinline__ void gemm_stage(float* lds, const float4& v, bool k_c
     else { lds[kk * kLd + r + 0] = v.x; lds[kk * kLd + r + 1] = v.y; lds[kk * kLd + r + 2] = v.z; lds[kk * kLd + r + 3] = v.w; }
 }
 
-__global__ __launch_bounds__(256) void gemm_batch_kernel(GemmArgs a) {
-    __shared__ float sA[2][kBK * kLd];
-    __shared__ float sB[2][kBK * kLd];
-    const int tile = blockIdx.x;
-    int pi = 0;
-    #pragma unroll
-    for (int i = 1; i < kMaxProb; ++i) pi += (i < a.np && tile >= a.p[i].tile0) ? 1 : 0;
-    const GemmProb& p = a.p[pi];
-    const int t = tile - p.tile0;
-    const int m0 = (t / p.tiles_n) * kBM, n0 = (t % p.tiles_n) * kBN;
+// Vectorised operand fetch without control flow: every access is an aligned 16-byte load at an address clamped into the operand,
+// elements beyond M / N / K are zeroed by a select.  Straight-line loads let the compiler COUNT the waits (s_waitcnt vmcnt(n)), which
+// is what keeps the loads of chunk c+2 in flight while chunk c+1 is staged (the branchy form below forces vmcnt(0) at every join).
+// Needs the operand's contiguous extent and its other stride to be multiples of 4 elements and a 16-byte aligned base (p.vec).
+__device__ __forceinline__ float4 gemm_fetch_vec(const float* base, long long s_row, long long s_k, int row0, int nrows, int k0, int K, int tid,
+                                                 int& r, int& kk, bool& ok) {
+    const float* p;
+    if (s_k == 1) {            // k-contiguous: 4 threads per row
+        r = tid >> 2; kk = (tid & 3) * 4;
+        ok = row0 + r < nrows && k0 + kk < K;
+        p = base + (long long)min(row0 + r, nrows - 1) * s_row + min(k0 + kk, K - 4);
+    } else {                   // row-contiguous: 16 threads per k
+        kk = tid >> 4; r = (tid & 15) * 4;
+        ok = k0 + kk < K && row0 + r < nrows;
+        p = base + (long long)min(k0 + kk, K - 1) * s_k + min(row0 + r, nrows - 4);
+    }
+    return *reinterpret_cast<const float4*>(p);   // the caller zeroes it where !ok -- at STAGING time, so that nothing waits on the load here
+}
+
+// Software pipeline over the k-chunks, prefetch distance TWO: while chunk c is multiplied out of LDS buffer c&1, chunk c+1 sits in one
+// register set (staged into the other LDS buffer after the MFMAs) and the loads of chunk c+2 are issued into the other set.  These
+// GEMMs have 10^2 rows -- a handful of workgroups, each a serial chain of K/64 chunks -- so a launch costs (chunks x exposed latency):
+// with distance one (round 1) every chunk exposed a full memory latency, 5.5 us per chunk (89 us for K = 1024).
+template <bool VEC>
+__device__ __forceinline__ void gemm_tile(const GemmProb& p, int m0, int n0, float (*sA)[kBK * kLd], float (*sB)[kBK * kLd]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, kq = lane >> 4;
     const bool a_kc = p.sa_k == 1, b_kc = p.sb_k == 1;
@@ -93,47 +109,61 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmArgs a) {
     #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = {0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
-    constexpr int NS = kBK / 16;  // 16-deep sub-chunks per thread: NS 16-byte loads per operand in flight
+    constexpr int NS = kBK / 16;  // 16-deep sub-chunks per thread: NS 16-byte loads per operand and chunk
     int ra, ka, rb, kb;
-    float4 va[NS], vb[NS];
-    #pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        va[u] = gemm_fetch(p.A, sa_row, sa_kk, m0, p.M, 16 * u, p.K, tid, ra, ka);
-        vb[u] = gemm_fetch(p.B, sb_row, sb_kk, n0, p.N, 16 * u, p.K, tid, rb, kb);
-    }
-    #pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        gemm_stage(sA[0] + 16 * u * kLd, va[u], a_kc, ra, ka);
-        gemm_stage(sB[0] + 16 * u * kLd, vb[u], b_kc, rb, kb);
-    }
-    __syncthreads();
     const int nchunk = (p.K + kBK - 1) / kBK;
-    for (int c = 0; c < nchunk; ++c) {
-        const int cur = c & 1;
-        if (c + 1 < nchunk) {  // next chunk's global loads fly while this chunk is multiplied
-            #pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                va[u] = gemm_fetch(p.A, sa_row, sa_kk, m0, p.M, (c + 1) * kBK + 16 * u, p.K, tid, ra, ka);
-                vb[u] = gemm_fetch(p.B, sb_row, sb_kk, n0, p.N, (c + 1) * kBK + 16 * u, p.K, tid, rb, kb);
+    auto load = [&](float4* va, float4* vb, unsigned& okm, int c) {
+        c = min(c, nchunk - 1);   // past the end: re-read the last chunk (never staged) rather than branch
+        okm = 0u;
+        #pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if constexpr (VEC) {
+                bool oa, ob;
+                va[u] = gemm_fetch_vec(p.A, sa_row, sa_kk, m0, p.M, c * kBK + 16 * u, p.K, tid, ra, ka, oa);
+                vb[u] = gemm_fetch_vec(p.B, sb_row, sb_kk, n0, p.N, c * kBK + 16 * u, p.K, tid, rb, kb, ob);
+                okm |= (oa ? 1u : 0u) << (2 * u) | (ob ? 2u : 0u) << (2 * u);
+            } else {
+                va[u] = gemm_fetch(p.A, sa_row, sa_kk, m0, p.M, c * kBK + 16 * u, p.K, tid, ra, ka);
+                vb[u] = gemm_fetch(p.B, sb_row, sb_kk, n0, p.N, c * kBK + 16 * u, p.K, tid, rb, kb);
             }
         }
+    };
+    auto stage = [&](int buf, const float4* va, const float4* vb, unsigned okm) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        #pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            gemm_stage(sA[buf] + 16 * u * kLd, (!VEC || ((okm >> (2 * u)) & 1u)) ? va[u] : z, a_kc, ra, ka);
+            gemm_stage(sB[buf] + 16 * u * kLd, (!VEC || ((okm >> (2 * u)) & 2u)) ? vb[u] : z, b_kc, rb, kb);
+        }
+    };
+    auto mma = [&](int buf) {
         #pragma unroll
         for (int ks = 0; ks < kBK; ks += 4) {
-            const float av = sA[cur][(ks + kq) * kLd + wave * 16 + r];
+            const float av = sA[buf][(ks + kq) * kLd + wave * 16 + r];
             asum += av;
             #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float bv = sB[cur][(ks + kq) * kLd + j * 16 + r];
+                const float bv = sB[buf][(ks + kq) * kLd + j * 16 + r];
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
             }
         }
-        if (c + 1 < nchunk) {
-            #pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                gemm_stage(sA[cur ^ 1] + 16 * u * kLd, va[u], a_kc, ra, ka);
-                gemm_stage(sB[cur ^ 1] + 16 * u * kLd, vb[u], b_kc, rb, kb);
-            }
-        }
+    };
+    float4 va0[NS], vb0[NS], va1[NS], vb1[NS];
+    unsigned ok0, ok1;
+    load(va0, vb0, ok0, 0);
+    load(va1, vb1, ok1, 1);
+    stage(0, va0, vb0, ok0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; c += 2) {
+        load(va0, vb0, ok0, c + 2);
+        mma(0);
+        if (c + 1 >= nchunk) break;
+        stage(1, va1, vb1, ok1);
+        __syncthreads();
+        load(va1, vb1, ok1, c + 3);
+        mma(1);
+        if (c + 2 >= nchunk) break;
+        stage(0, va0, vb0, ok0);
         __syncthreads();
     }
     #pragma unroll
@@ -153,6 +183,20 @@ __global__ __launch_bounds__(256) void gemm_batch_kernel(GemmArgs a) {
         const int m = m0 + wave * 16 + r;
         if (kq == 0 && m < p.M) p.rowsum[m] = p.alpha * asum;
     }
+}
+
+__global__ __launch_bounds__(256) void gemm_batch_kernel(GemmArgs a) {
+    __shared__ float sA[2][kBK * kLd];
+    __shared__ float sB[2][kBK * kLd];
+    const int tile = blockIdx.x;
+    int pi = 0;
+    #pragma unroll
+    for (int i = 1; i < kMaxProb; ++i) pi += (i < a.np && tile >= a.p[i].tile0) ? 1 : 0;
+    const GemmProb& p = a.p[pi];
+    const int t = tile - p.tile0;
+    const int m0 = (t / p.tiles_n) * kBM, n0 = (t % p.tiles_n) * kBN;
+    if (p.vec) gemm_tile<true>(p, m0, n0, sA, sB);
+    else gemm_tile<false>(p, m0, n0, sA, sB);
 }
 
 // ------------------------------------------------------------------------------------------- attention core
@@ -362,6 +406,11 @@ int lgd_gemm_batch(const lgd_gemm_problem* probs_host, int np, void* stream) {
         p.sa_m = s.sa_m; p.sa_k = s.sa_k; p.sb_n = s.sb_n; p.sb_k = s.sb_k; p.sc_m = s.sc_m; p.sc_n = s.sc_n;
         p.alpha = s.alpha;
         if (!((s.sa_m == 1 || s.sa_k == 1) && (s.sb_n == 1 || s.sb_k == 1))) return LGD_EINVAL;  // one contiguous axis each
+        auto vec_ok = [](const float* base, long long s_row, long long s_k, int nrows, int K) {
+            if ((reinterpret_cast<size_t>(base) & 15) != 0) return false;
+            return s_k == 1 ? (K % 4 == 0 && K >= 4 && s_row % 4 == 0) : (nrows % 4 == 0 && nrows >= 4 && s_k % 4 == 0);
+        };
+        p.vec = (vec_ok(s.A, s.sa_m, s.sa_k, s.M, s.K) && vec_ok(s.B, s.sb_n, s.sb_k, s.N, s.K)) ? 1 : 0;
         p.tile0 = tile; p.tiles_n = (s.N + lgd::kBN - 1) / lgd::kBN;
         tile += ((s.M + lgd::kBM - 1) / lgd::kBM) * p.tiles_n;
     }
