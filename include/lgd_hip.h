@@ -280,6 +280,15 @@ int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host
 int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const uint16_t* relu_bits,
                    const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM, void* stream);
 int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host, void* stream);
+/* Filter transforms of tile = 4 (the host's `U = kron(G,G) @ weight` of the 16-frequency form, done here for the 36-frequency one):
+ *   lgd_wino_filter_fwd: U[f][co][ci] = (G (scale[co] . g) G^T)[f] at U + f*u_plane + co*Ci + ci, and the same values transposed in
+ *     (co, ci) at Ut + f*ut_plane + ci*ut_ld + co (the operand of dV = U^T dM); u_plane / ut_plane / ut_ld let several filters stack
+ *     their slabs along C_out in one buffer (lgd_amd/ops.py::_Conv3x3K).  w: (Co, Ci, 3, 3) contiguous; scale: per-output-channel
+ *     factor of a frozen affine that follows the convolution (detectron2 FrozenBatchNorm2d) or NULL.
+ *   lgd_wino_filter_bwd: dw[co][ci] = scale[co] . G^T dU[:, co, ci] G, dU read at dU + f*du_plane + co*Ci + ci. */
+int lgd_wino_filter_fwd(const float* w, const float* scale, int Co, int Ci, float* U, long long u_plane, float* Ut, long long ut_ld,
+                        long long ut_plane, void* stream);
+int lgd_wino_filter_bwd(const float* dU, long long du_plane, const float* scale, int Co, int Ci, float* dw, void* stream);
 /* lgd_wino_in_t followed by lgd_wino_out_t of the convolution that PRODUCED these maps, in one kernel (tile = 4): the backward link of a
  * conv -> [ReLU] -> conv chain whose intermediate maps have no other consumer (the head towers, the adapter: distillator.py:107-109,
  * sequential_convs.py:10-12).  dV: frequency-domain input gradient of the later conv; relu_bits: the earlier conv's mask table (NULL: no

@@ -862,6 +862,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     else wino4_in_t_body<false, FUSE>(a, l, lds);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Filter transforms of F(4x4,3x3): U = G (s . g) G^T for every (C_out, C_in) pair, written twice -- U [36][Co][Ci] for the forward
+// product and U^T [36][Ci][Co] for dV = U^T dM -- and the adjoint dg = s . G^T dU G.  s = the frozen per-output-channel scale of a
+// FrozenBN that follows the convolution (NULL: none): folding it here costs nothing, where the host-side form paid a scale kernel, a
+// GEMM against kron(G,G), a transposing copy and, backward, another GEMM and another scale kernel per convolution and step.
+//   G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+__device__ __forceinline__ void g6(float a, float b, float c, float* o) {   // G [a b c]^T
+    const float s = (a + c) * (1.f / 6.f), t = b * (1.f / 6.f), u = a * (1.f / 24.f) + c * (1.f / 6.f), v = b * (1.f / 12.f);
+    o[0] = a * 0.25f; o[1] = -s - t; o[2] = t - s; o[3] = u + v; o[4] = u - v; o[5] = c;
+}
+__device__ __forceinline__ void g6t(const float* m, float* o) {            // G^T m, m[6] -> o[3]
+    const float p = m[1] + m[2], q = m[2] - m[1], r = m[3] + m[4], d = m[3] - m[4];
+    o[0] = m[0] * 0.25f - p * (1.f / 6.f) + r * (1.f / 24.f);
+    o[1] = q * (1.f / 6.f) + d * (1.f / 12.f);
+    o[2] = (r - p) * (1.f / 6.f) + m[5];
+}
+
+struct FilterArgs {
+    const float* w; const float* scale; const float* dU;
+    float* U; float* Ut; float* dw;
+    long long u_plane, ut_plane, ut_ld;
+    int Co, Ci;
+};
+
+// 16 x 16 (co, ci) pairs per workgroup; U rows are written straight (ci fastest), U^T through an LDS tile (co fastest)
+__global__ __launch_bounds__(256) void wino4_filter_fwd_kernel(FilterArgs a) {
+    __shared__ float tile[36][16][17];
+    const int cl = threadIdx.x & 15, ol = threadIdx.x >> 4;
+    const int ci = blockIdx.x * 16 + cl, co = blockIdx.y * 16 + ol;
+    const bool on = ci < a.Ci && co < a.Co;
+    float u[6][6];
+    {
+        float g[9];
+        const float sc = (on && a.scale) ? a.scale[co] : 1.f;
+        #pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = on ? a.w[((size_t)co * a.Ci + ci) * 9 + i] * sc : 0.f;
+        float r[6][3];
+        #pragma unroll
+        for (int j = 0; j < 3; ++j) {   // columns: G g
+            float o[6];
+            g6(g[j], g[3 + j], g[6 + j], o);
+            #pragma unroll
+            for (int i = 0; i < 6; ++i) r[i][j] = o[i];
+        }
+        #pragma unroll
+        for (int i = 0; i < 6; ++i) g6(r[i][0], r[i][1], r[i][2], u[i]);   // rows: (G g) G^T
+    }
+    #pragma unroll
+    for (int f = 0; f < 36; ++f) {
+        const float v = u[f / 6][f % 6];
+        if (on) a.U[(size_t)f * a.u_plane + (size_t)co * a.Ci + ci] = v;
+        tile[f][ol][cl] = v;
+    }
+    __syncthreads();
+    const int co2 = blockIdx.y * 16 + cl, ci2 = blockIdx.x * 16 + ol;   // transposed roles: co fastest
+    if (co2 < a.Co && ci2 < a.Ci) {
+        #pragma unroll
+        for (int f = 0; f < 36; ++f) a.Ut[(size_t)f * a.ut_plane + (size_t)ci2 * a.ut_ld + co2] = tile[f][cl][ol];
+    }
+}
+
+__global__ __launch_bounds__(256) void wino4_filter_bwd_kernel(FilterArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.Co * a.Ci) return;
+    const int co = (int)(idx / a.Ci);
+    float m[6][6];
+    #pragma unroll
+    for (int f = 0; f < 36; ++f) m[f / 6][f % 6] = a.dU[(size_t)f * a.u_plane + idx];
+    float r[3][6];
+    #pragma unroll
+    for (int b = 0; b < 6; ++b) {   // columns: G^T dU
+        const float col[6] = {m[0][b], m[1][b], m[2][b], m[3][b], m[4][b], m[5][b]};
+        float o[3];
+        g6t(col, o);
+        r[0][b] = o[0]; r[1][b] = o[1]; r[2][b] = o[2];
+    }
+    const float sc = a.scale ? a.scale[co] : 1.f;
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float o[3];
+        g6t(r[i], o);                // rows: (G^T dU) G
+        #pragma unroll
+        for (int j = 0; j < 3; ++j) a.dw[idx * 9 + 3 * i + j] = o[j] * sc;
+    }
+}
+
 static long long level_tiles(int N, int H, int W, int tile) {
     if (tile == 4) return (((long long)N * ((H + 3) / 4) * ((W + 3) / 4)) + 3) & ~3LL;
     const long long t = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
@@ -995,6 +1081,24 @@ int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, i
     }
     a.buf_in = dV;
     LGD_LAUNCH("wino_in_t_kernel", lgd::wino4_in_t_kernel<false>, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a);
+    return lgd::check_launch();
+}
+
+int lgd_wino_filter_fwd(const float* w, const float* scale, int Co, int Ci, float* U, long long u_plane, float* Ut, long long ut_ld,
+                        long long ut_plane, void* stream) {
+    if (!w || !U || !Ut || Co < 1 || Ci < 1 || u_plane < (long long)Co * Ci || ut_ld < Co || ut_plane < (long long)Ci * ut_ld) return LGD_EINVAL;
+    lgd::FilterArgs a{};
+    a.w = w; a.scale = scale; a.U = U; a.Ut = Ut; a.u_plane = u_plane; a.ut_plane = ut_plane; a.ut_ld = ut_ld; a.Co = Co; a.Ci = Ci;
+    LGD_LAUNCH("wino_filter_kernel", lgd::wino4_filter_fwd_kernel, dim3((Ci + 15) / 16, (Co + 15) / 16), dim3(256), 0, (hipStream_t)stream, a);
+    return lgd::check_launch();
+}
+
+int lgd_wino_filter_bwd(const float* dU, long long du_plane, const float* scale, int Co, int Ci, float* dw, void* stream) {
+    if (!dU || !dw || Co < 1 || Ci < 1 || du_plane < (long long)Co * Ci) return LGD_EINVAL;
+    lgd::FilterArgs a{};
+    a.dU = dU; a.scale = scale; a.dw = dw; a.u_plane = du_plane; a.Co = Co; a.Ci = Ci;
+    const long long n = (long long)Co * Ci;
+    LGD_LAUNCH("wino_filter_bwd_kernel", lgd::wino4_filter_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 

@@ -760,6 +760,37 @@ def _freq_buf(nf, C, T, device):
     return torch.empty((C, nf, T), dtype=torch.float32, device=device).permute(1, 0, 2)
 
 
+def _wino4_filters(lib, ws, scales, Ci, dev):
+    """U (36, sum Co, Ci) and U^T (36, Ci, sum Co) of K filters stacked along C_out, one lgd_wino_filter_fwd launch per filter
+    (the frozen per-channel scale of a FrozenBN that follows the conv is folded in on the way: no scaled copy of the weights)."""
+    Cos = [w.shape[0] for w in ws]
+    Ct = sum(Cos)
+    U = torch.empty((36, Ct, Ci), dtype=torch.float32, device=dev)
+    Ut = torch.empty((36, Ci, Ct), dtype=torch.float32, device=dev)
+    c0 = 0
+    for w, sc, Co in zip(ws, scales, Cos):
+        hip.check(lib.lgd_wino_filter_fwd(hip.ptr(w), hip.ptr(sc) if sc is not None else None, Co, Ci,
+                                          ctypes.c_void_p(U.data_ptr() + 4 * c0 * Ci), Ct * Ci,
+                                          ctypes.c_void_p(Ut.data_ptr() + 4 * c0), Ct, Ci * Ct, hip.stream_ptr()), "lgd_wino_filter_fwd")
+        c0 += Co
+    return U, Ut
+
+
+def _wino4_filter_grads(lib, dU, scales, Cos, need, Ci):
+    """dw_k = scale_k . G^T dU_k G for the filters that need it; dU (36, sum Co, Ci) from the weight-gradient GEMM."""
+    Ct = sum(Cos)
+    out, c0 = [], 0
+    for sc, Co, nd in zip(scales, Cos, need):
+        dw = None
+        if nd:
+            dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=dU.device)
+            hip.check(lib.lgd_wino_filter_bwd(ctypes.c_void_p(dU.data_ptr() + 4 * c0 * Ci), Ct * Ci, hip.ptr(sc) if sc is not None else None,
+                                              Co, Ci, hip.ptr(dw), hip.stream_ptr()), "lgd_wino_filter_bwd")
+        out.append(dw)
+        c0 += Co
+    return out
+
+
 class _Conv3x3K(torch.autograd.Function):
     """K filters nn.Conv2d(Ci, Co_k, 3, stride 1, padding 1) [+ ReLU] applied to the SAME L maps (the pyramid levels; K = 1: one
     conv, K = 2: e.g. the first convs of the cls / bbox towers, which read the same features) in the minimal-filtering form
@@ -768,11 +799,15 @@ class _Conv3x3K(torch.autograd.Function):
     tiles of all levels.  The input is transformed ONCE for all K filters (their U are stacked along C_out: one GEMM), and the
     backward sums their input gradients inside the dV GEMM (K = sum Co_k) -- one adjoint input transform, no gradient-accumulation
     pass.  Forward, input gradient and weight gradient all run at 1/4 (tile 4) or 4/9 (tile 2) of the direct multiplies.
-    apply(K, relu, tile, w_1, b_1, ..., w_K, b_K, x_1, ..., x_L) -> K * L maps, filter-major."""
+    apply(K, relu, tile, scales, w_1, b_1, ..., w_K, b_K, x_1, ..., x_L) -> K * L maps, filter-major; scales: None or one per-output-
+    channel factor (a buffer, no gradient) per filter, applied to the filter inside its transform (tile 4)."""
 
     @staticmethod
-    def forward(ctx, K, relu, tile, *args):
+    def forward(ctx, K, relu, tile, scales, *args):
         ws, bs, xs = list(args[0:2 * K:2]), list(args[1:2 * K:2]), list(args[2 * K:])
+        scales = list(scales) if scales is not None else [None] * K
+        if tile != 4 and any(sc is not None for sc in scales):
+            raise hip.LgdHipError("a per-channel filter scale needs tile = 4 (fold it into the weights for tile 2)")
         hip.require_gpu(*ws, *xs)
         if K > 1 and tile != 4:
             raise hip.LgdHipError("several filters on one input need tile = 4")
@@ -787,8 +822,10 @@ class _Conv3x3K(torch.autograd.Function):
         nf = (tile + 2) ** 2
         hw = hip.int_array([d for x in xs for d in x.shape[2:]])
         T = lib.lgd_wino_tiles(hw, L, N, tile)
-        wcat = ws[0].view(Ct * Ci, 9) if K == 1 else torch.cat([w.view(-1, 9) for w in ws])
-        U = torch.mm(_wino_gg(dev, tile), wcat.t()).view(nf, Ct, Ci)
+        if tile == 4:
+            U, Ut = _wino4_filters(lib, ws, scales, Ci, dev)
+        else:
+            U, Ut = torch.mm(_wino_gg(dev, tile), ws[0].view(Ct * Ci, 9).t()).view(nf, Ct, Ci), None
         V = _freq_buf(nf, Ci, T, dev)
         hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
@@ -806,9 +843,10 @@ class _Conv3x3K(torch.autograd.Function):
                                        hip.ptr_array(yk), hip.ptr(bits[c0]) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
             ys += yk
             c0 += Cos[k]
-        need_w = any(ctx.needs_input_grad[3:3 + 2 * K:2])
+        need_w = any(ctx.needs_input_grad[4:4 + 2 * K:2])
         # the backward needs the transformed filters (tile 4: dV = U^T dM; tile 2: the rotation is a frequency permutation of U)
-        ctx.save_for_backward(U, V if need_w else None, bits, *(ys if (relu and bits is None) else []))
+        ctx.save_for_backward(Ut if tile == 4 else U, V if need_w else None, bits, *(ys if (relu and bits is None) else []))
+        ctx.scales = scales
         ctx.meta = (K, L, N, Ci, Cos, hw, T, bool(relu), [b is not None for b in bs], [tuple(x.shape[2:]) for x in xs], tile, px, fb)
         return tuple(ys)
 
@@ -823,9 +861,9 @@ class _Conv3x3K(torch.autograd.Function):
         # an output nothing downstream used arrives as None
         dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
                for i, g in enumerate(dys)]
-        need_ws = list(ctx.needs_input_grad[3:3 + 2 * K:2])
-        need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[4:4 + 2 * K:2])]
-        need_w, need_x = any(need_ws), any(ctx.needs_input_grad[3 + 2 * K:])
+        need_ws = list(ctx.needs_input_grad[4:4 + 2 * K:2])
+        need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[5:5 + 2 * K:2])]
+        need_w, need_x = any(need_ws), any(ctx.needs_input_grad[4 + 2 * K:])
         dws, dbs = [None] * K, [None] * K
         dxs = [None] * L
         dM = None
@@ -842,7 +880,7 @@ class _Conv3x3K(torch.autograd.Function):
                 c0 += Cos[k]
             if need_x:
                 _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
-                dV = _timed_bmm("wino_gemm_dx", U.transpose(1, 2).contiguous(), dM, out=_freq_buf(nf, Ci, T, dev))
+                dV = _timed_bmm("wino_gemm_dx", U, dM, out=_freq_buf(nf, Ci, T, dev))   # U holds U^T (36, Ci, sum Co) for tile 4
                 dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
                 hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), hip.stream_ptr()), "lgd_wino_in_t")
                 del dV
@@ -870,11 +908,10 @@ class _Conv3x3K(torch.autograd.Function):
                           "lgd_wino_out_t")
         if need_w:
             dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
-            dw = torch.mm(_wino_gg(dev, tile).t(), dU.view(nf, Ct * Ci)).t().reshape(Ct, Ci, 3, 3)
-            c0 = 0
-            for k in range(K):
-                dws[k] = dw[c0:c0 + Cos[k]] if need_ws[k] else None
-                c0 += Cos[k]
+            if tile == 4:
+                dws = _wino4_filter_grads(lib, dU, ctx.scales, Cos, need_ws, Ci)
+            else:
+                dws[0] = torch.mm(_wino_gg(dev, tile).t(), dU.view(nf, Ct * Ci)).t().reshape(Ct, Ci, 3, 3)
         if any(need_bs):
             if dM is not None:
                 # A's row of the interpolation point 1 is all ones: that frequency of dM = A g A^T is the tile's gradient sum
@@ -885,7 +922,7 @@ class _Conv3x3K(torch.autograd.Function):
             for k in range(K):
                 dbs[k] = db[c0:c0 + Cos[k]] if need_bs[k] else None
                 c0 += Cos[k]
-        return (None, None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
+        return (None, None, None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
 
 
 class _Conv3x3Chain(torch.autograd.Function):
@@ -916,7 +953,7 @@ class _Conv3x3Chain(torch.autograd.Function):
         saved, cur = [], xs
         for k in range(K):
             Co, Ci = ws[k].shape[0], ws[k].shape[1]
-            U = torch.mm(_wino_gg(dev, tile), ws[k].view(Co * Ci, 9).t()).view(nf, Co, Ci)
+            U, Ut = _wino4_filters(lib, [ws[k]], [None], Ci, dev)
             V = _freq_buf(nf, Ci, T, dev)
             hip.check(lib.lgd_wino_in(hip.ptr_array(cur), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
             _count_bytes("wino_in_kernel", (px + fb) * Ci)
@@ -927,7 +964,7 @@ class _Conv3x3Chain(torch.autograd.Function):
             hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Co, tile, 0, int(relus[k]),
                                        hip.ptr_array(cur), hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
             del M
-            saved += [U, V if need_ws[k] else None, bits]
+            saved += [Ut, V if need_ws[k] else None, bits]
         ctx.save_for_backward(*saved)
         ctx.meta = (K, L, N, hw, T, shapes, [b is not None for b in bs], px, fb)
         return tuple(cur)
@@ -943,7 +980,7 @@ class _Conv3x3Chain(torch.autograd.Function):
         need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[3:3 + 2 * K:2])]
         need_x = any(ctx.needs_input_grad[2 + 2 * K:])
         dws, dbs, dxs = [None] * K, [None] * K, [None] * L
-        Co = saved[3 * (K - 1)].shape[1]
+        Co = saved[3 * (K - 1)].shape[2]
         dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Co) + shapes[i], dtype=torch.float32, device=dev) for i, g in enumerate(dys)]
         bits = saved[3 * (K - 1) + 2]
         dM = _freq_buf(nf, Co, T, dev)
@@ -951,16 +988,16 @@ class _Conv3x3Chain(torch.autograd.Function):
         hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), None, hip.ptr(bits) if bits is not None else None, hw, L, N, Co, tile, hip.ptr(dM),
                                      hip.stream_ptr()), "lgd_wino_out_t")
         for k in range(K - 1, -1, -1):
-            U, V = saved[3 * k], saved[3 * k + 1]
-            Co, Ci = U.shape[1], U.shape[2]
+            Ut, V = saved[3 * k], saved[3 * k + 1]
+            Ci, Co = Ut.shape[1], Ut.shape[2]
             if need_ws[k]:
                 dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
-                dws[k] = torch.mm(_wino_gg(dev, tile).t(), dU.view(nf, Co * Ci)).t().reshape(Co, Ci, 3, 3)
+                dws[k] = _wino4_filter_grads(lib, dU, [None], [Co], [True], Ci)[0]
             if need_bs[k]:
                 dbs[k] = dM[tile + 3].sum(1)   # A's row of the interpolation point 1 is all ones: the tile's gradient sum
             if k == 0 and not need_x:
                 break
-            dV = _timed_bmm("wino_gemm_dx", U.transpose(1, 2).contiguous(), dM, out=_freq_buf(nf, Ci, T, dev))
+            dV = _timed_bmm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
             del dM
             if k > 0:   # the link to conv k-1: dM_{k-1} = A (in_t(dV) . relu mask) A^T without the map in between
                 pb = saved[3 * (k - 1) + 2]
@@ -980,8 +1017,8 @@ class _Conv3x3:
     """single-filter form of _Conv3x3K with the historical argument order: apply(w, b, relu, tile, *xs)."""
 
     @staticmethod
-    def apply(w, b, relu, tile, *xs):
-        return _Conv3x3K.apply(1, bool(relu), tile, w, b, *xs)
+    def apply(w, b, relu, tile, *xs, scale=None):
+        return _Conv3x3K.apply(1, bool(relu), tile, None if scale is None else (scale,), w, b, *xs)
 
 
 def enable_tuned_gemms(path=None):
@@ -1035,12 +1072,17 @@ def _wino_ok(xs, w):
             and (len(xs) > 1 or w.shape[0] >= _WINO_MIN_CH))
 
 
-def conv3x3_levels(xs, w, b=None, relu=False):
+def conv3x3_levels(xs, w, b=None, relu=False, scale=None):
     """one 3x3 / stride 1 / padding 1 filter [+ ReLU] over a list of maps (the FPN levels): a single Winograd pass over
-    the concatenated tiles.  Tiny problems stay on the library's direct kernels."""
+    the concatenated tiles.  Tiny problems stay on the library's direct kernels.  scale: per-output-channel factor on the filter
+    (the frozen affine of a FrozenBN after the conv), folded into the filter transform on the Winograd path."""
     xs = list(xs)
     if _wino_ok(xs, w):
-        return list(_Conv3x3.apply(w, b, bool(relu), _WINO_TILE, *xs))
+        if scale is not None and _WINO_TILE != 4:
+            w, scale = w * scale.view(-1, 1, 1, 1), None
+        return list(_Conv3x3.apply(w, b, bool(relu), _WINO_TILE, *xs, scale=scale))
+    if scale is not None:
+        w = w * scale.view(-1, 1, 1, 1)
     ys = [F.conv2d(x, w, b, 1, 1) for x in xs]
     return [F.relu_(y) for y in ys] if relu else ys
 
@@ -1050,7 +1092,7 @@ def conv3x3_shared_input(xs, filters, relu=False):
     stacked GEMM, one adjoint input transform for the summed input gradient (see _Conv3x3K).  Returns one list of maps per filter."""
     xs = list(xs)
     if len(filters) > 1 and _WINO_TILE == 4 and all(_wino_ok(xs, w) for w, _ in filters):
-        ys = _Conv3x3K.apply(len(filters), bool(relu), 4, *[t for wb in filters for t in wb], *xs)
+        ys = _Conv3x3K.apply(len(filters), bool(relu), 4, None, *[t for wb in filters for t in wb], *xs)
         return [list(ys[k * len(xs):(k + 1) * len(xs)]) for k in range(len(filters))]
     return [conv3x3_levels(xs, w, b, relu) for w, b in filters]
 
@@ -1067,9 +1109,9 @@ def conv3x3_chain(xs, filters, relus):
     return xs
 
 
-def conv3x3(x, w, b=None, relu=False):
+def conv3x3(x, w, b=None, relu=False, scale=None):
     """single-map form of conv3x3_levels."""
-    return conv3x3_levels([x], w, b, relu)[0]
+    return conv3x3_levels([x], w, b, relu, scale)[0]
 
 
 class Conv3x3(torch.nn.Conv2d):

@@ -62,6 +62,10 @@ class ConvBN(nn.Conv2d):
             if self._pointwise_s2 and not subsampled:
                 x = self.subsample2(x)
             return ops.pointwise_conv_bn(x, self.weight, scale, shift, residual, relu)
+        if self.weight.requires_grad and self._plain3x3 and residual is None:
+            # trainable 3x3 / stride 1: the scale is folded inside the Winograd filter transform (no scaled copy of the weights, and the
+            # backward returns the gradient of the RAW filter); bias + ReLU ride in the output transform
+            return ops.conv3x3(x, self.weight, shift, relu=relu, scale=scale)
         if self.weight.requires_grad:
             w = self.weight * scale.view(-1, 1, 1, 1)
         else:  # frozen (FREEZE_AT prefix, or the backbone-freeze phase): the folded filter is reused until the weight is written

