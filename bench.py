@@ -137,6 +137,12 @@ def gpu_lgd_only(args, n_boxes, ctx, steps=10):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: native libraries write banners to the C stdout (RCCL prints its version block at
+    # communicator init and libc flushes it at exit, i.e. AFTER the record), so fd 1 is pointed at stderr for the whole run and the
+    # record goes to a duplicate of the original stdout
+    sys.stdout.flush()
+    record_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,7 +296,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.boxes, ctx)
-        print(json.dumps(out), flush=True)
+        record_out.write(json.dumps(out) + "\n")
+        record_out.flush()
     if world > 1 or force_ddp:
         dist.barrier()
         dist.destroy_process_group()
