@@ -32,6 +32,13 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// neighbour lane's value across the whole wave in ONE VALU op (DPP wave_shr:1 / wave_shl:1) instead of an LDS ds_bpermute:
+// shr1: lane i <- lane i-1 (lane 0 reads 0); shl1: lane i <- lane i+1 (lane 63 reads 0)
+__device__ __forceinline__ float wave_shr1(float v) { return dpp_f32<0x138>(v); }
+__device__ __forceinline__ float wave_shl1(float v) { return dpp_f32<0x130>(v); }
+__device__ __forceinline__ unsigned wave_shr1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned wave_shl1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+
 // Sum over the 64 lanes of a wave; result is wave-uniform. Fixed order => deterministic.
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]

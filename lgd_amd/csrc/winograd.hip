@@ -395,7 +395,7 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
         mc[0] = up ? pb[uu - TW] : 0u;
         mc[2] = dn ? pb[uu + TW] : 0u;
         #pragma unroll
-        for (int k = 0; k < 3; ++k) { ml[k] = __shfl_up(mc[k], 1); mr[k] = __shfl_down(mc[k], 1); }
+        for (int k = 0; k < 3; ++k) { ml[k] = wave_shr1(mc[k]); mr[k] = wave_shl1(mc[k]); }
         if (lane == 0 && tx != 0) {
             ml[1] = pb[uu - 1]; ml[0] = up ? pb[uu - TW - 1] : 0u; ml[2] = dn ? pb[uu + TW - 1] : 0u;
         }
@@ -422,8 +422,9 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
                 const unsigned nib = mc[f] >> (4 * r);
                 m.x = (nib & 1u) ? m.x : 0.f; m.y = (nib & 2u) ? m.y : 0.f; m.z = (nib & 4u) ? m.z : 0.f; m.w = (nib & 8u) ? m.w : 0.f;
             }
-            // halo columns = the neighbour lanes' edge values (same image row unless first / last tile of the row)
-            float e0 = __shfl_up(m.w, 1), e5 = __shfl_down(m.x, 1);
+            // halo columns = the neighbour lanes' edge values (same image row unless first / last tile of the row): one DPP move each
+            // (measured equal to ds_bpermute shuffles, 136.1 vs 136.4 us: the kernel is bound by its 36-plane store scatter, not by issue)
+            float e0 = wave_shr1(m.w), e5 = wave_shl1(m.x);
             if (lane == 0 && tx != 0) {
                 e0 = yok ? row[x0] : 0.f;
                 if constexpr (MASK == 1) { if (yok) e0 = pm[ro + x0] > 0.f ? e0 : 0.f; }
