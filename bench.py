@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--phase", default="distill", choices=["distill", "nondistill", "frozen"],
                     help="training phase to time: distill = steady state (distill on, backbone training; 150k of the "
                          "180k iterations), nondistill = iterations 20k-30k, frozen = first 20k iterations")
+    ap.add_argument("--host-batch", action="store_true",
+                    help="hand the batch over as pinned HOST tensors and copy it inside every step (the PCIe-inclusive rate noted in "
+                         "DESIGN.md); default: images and annotations resident in HBM when the timed region starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
     ap.add_argument("--head-passes", type=int, default=1, choices=[1, 2],
@@ -175,7 +178,10 @@ def main():
     it0 = {"distill": max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS),
            "nondistill": d.PRE_FREEZE_STUDENT_BACKBONE_ITERS, "frozen": 0}[args.phase]
     Bg = args.batch_per_gpu
-    data = synthetic_batch(Bg, args.height, args.width, args.boxes, seed=1000 + rank, pin=True)
+    if args.host_batch:
+        data = synthetic_batch(Bg, args.height, args.width, args.boxes, seed=1000 + rank, pin=True)
+    else:
+        data = synthetic_batch(Bg, args.height, args.width, args.boxes, seed=1000 + rank, device=dev)
     ctx = bool(d.TEACHER.ADD_CONTEXT_BOX)
 
     def sync():
@@ -281,7 +287,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if not args.host_batch else "synthetic (pinned host batch, copied inside the step)",
             "config": {"workload": "%s%s R-%d FPN + LGD, %d img/GPU, %dx%d (padded %dx%d), "
                                    "%d GT boxes/img, ctx box %s, phase=%s (fwd+bwd+clip+2xSGD)"
                                    % ("BASELINE configs[1]: " if default_cfg and Bg == 8 else "", arch, cfg.MODEL.RESNETS.DEPTH, Bg,

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import hip, ops
 from .registry import CUSTOMIZED_DETECTORS_REGISTRY
 
 
@@ -190,8 +190,7 @@ class DynamicTeacher(nn.Module):
         painted = ops.render_paint(geom, proj, skip_last=self.add_context_box)
         conv = self.local_inst_proj_2D
         if self.add_context_box:
-            last = torch.tensor([o - 1 for o in _offsets(geom.counts)[1:]], dtype=torch.int64).to(attn_out.device,
-                                                                                                non_blocking=True)
+            last = hip.to_device([o - 1 for o in _offsets(geom.counts)[1:]], torch.int64, attn_out.device)
             ctx = ops.linear(attn_out[:, last], self.global_ctx_proj_1D.weight, self.global_ctx_proj_1D.bias)  # (L,B,C)
             return ops.bias_ctx_relu(conv.levels(painted), ctx)
         return conv.levels(painted, relu=True)

@@ -145,6 +145,43 @@ def ptr_array(tensors):
     return arr
 
 
+class _PinnedRing:
+    """Small host -> device uploads (per-image offsets, index lists: a few dozen bytes, several per step) through a ring of PINNED
+    staging slots: `torch.tensor(list).to(device)` reads pageable memory, which the runtime copies synchronously with the host and
+    only after the stream has drained -- every such call let the GPU run dry for 0.2-0.7 ms (tools/gap_profile.sh).  A slot is reused
+    after SLOTS further uploads (hundreds of steps later), long after its copy has executed."""
+    SLOTS, SLOT_BYTES = 1024, 1024
+
+    def __init__(self):
+        self.buf = torch.empty(self.SLOTS * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
+        self.i = 0
+
+    def upload(self, t, device):
+        n = t.numel() * t.element_size()
+        if n == 0 or n > self.SLOT_BYTES:
+            return t.to(device, non_blocking=True)
+        o = self.i * self.SLOT_BYTES
+        self.i = (self.i + 1) % self.SLOTS
+        slot = self.buf[o:o + n].view(t.dtype).view(t.shape)
+        slot.copy_(t)
+        return slot.to(device, non_blocking=True)
+
+
+_ring = None
+
+
+def to_device(values, dtype, device):
+    """device tensor of a short Python list / nested list, uploaded without blocking the host or draining the stream."""
+    global _ring
+    t = torch.tensor(values, dtype=dtype)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return t.to(device)
+    if _ring is None:
+        _ring = _PinnedRing()
+    return _ring.upload(t, device)
+
+
 def int_array(vals):
     return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
 

@@ -36,7 +36,7 @@ class BoxGeometry:
         off = [0]
         for c in self.counts:
             off.append(off[-1] + c)
-        self.img_off = torch.tensor(off, dtype=torch.int32).to(boxes.device, non_blocking=True)
+        self.img_off = hip.to_device(off, torch.int32, boxes.device)
         self._hw = hip.int_array([v for hw in self.level_hw for v in hw])
         n_ints = lib.lgd_geom_ints(self.L, self.B, self.T, self.max_n)
         self.geom = torch.empty(n_ints, dtype=torch.int32, device=boxes.device)
@@ -51,7 +51,7 @@ class BoxGeometry:
         o = lib.lgd_geom_rects_off(self.L, self.B, self.T, self.max_n)
         padded = self.geom[o:o + self.L * self.B * self.max_n * 4].view(self.L, self.B * self.max_n, 4)
         rows = [b * self.max_n + j for b, n in enumerate(self.counts) for j in range(n)]
-        return padded[:, torch.tensor(rows, dtype=torch.int64, device=padded.device)]
+        return padded[:, hip.to_device(rows, torch.int64, padded.device)]
 
     def bands(self):
         """list[L][B] of python lists of row breakpoints."""
@@ -198,7 +198,7 @@ def _offsets(counts):
 def segment_ids(counts, device):
     """(T,) int64 image index of every box row; built on the host (counts are host-known)."""
     ids = [b for b, n in enumerate(counts) for _ in range(n)]
-    return torch.tensor(ids, dtype=torch.int64).to(device, non_blocking=True)
+    return hip.to_device(ids, torch.int64, device)
 
 
 def _levels_meta(maps):
@@ -474,7 +474,7 @@ def mha_blockdiag(q_in, kv_in, counts, in_w, in_b, out_w, out_b, heads, img_off=
     q_in (Lq,T,E), kv_in (Lk,T,E) with Lq == Lk or one of them 1 (operand shared by all levels) -> (max(Lq,Lk),T,E).
     In/out projections: fp32 MFMA GEMM kernel; softmax(QK^T)V: one wave per (image, head)."""
     if img_off is None:
-        img_off = torch.tensor(_offsets(counts), dtype=torch.int32).to(q_in.device, non_blocking=True)
+        img_off = hip.to_device(_offsets(counts), torch.int32, q_in.device)
     return _MhaBlockDiag.apply(q_in, kv_in, in_w, in_b, out_w, out_b, img_off, int(heads))
 
 
@@ -622,7 +622,7 @@ def box_descriptors(boxes_in, classes, in_counts, out_counts, img_h, img_w, num_
     hip.require_gpu(boxes_in)
     dev = boxes_in.device
     B, T = len(out_counts), int(sum(out_counts))
-    offs = torch.tensor([_offsets(in_counts), _offsets(out_counts)], dtype=torch.int32).to(dev, non_blocking=True)
+    offs = hip.to_device([_offsets(in_counts), _offsets(out_counts)], torch.int32, dev)
     boxes_in = hip.dense_f32(boxes_in.reshape(-1, 4)) if boxes_in.numel() else torch.zeros((1, 4), device=dev)
     classes = classes.to(torch.int32).contiguous() if classes.numel() else torch.zeros((1,), dtype=torch.int32, device=dev)
     desc = torch.empty((T, 4 + num_classes), dtype=torch.float32, device=dev)
@@ -1138,7 +1138,7 @@ def anchor_match(anchors, gt_boxes, gt_classes, counts, iou_lo, iou_hi, num_clas
     B, R, T = len(counts), anchors.shape[0], int(sum(counts))
     dev = anchors.device
     if img_off is None:
-        img_off = torch.tensor(_offsets(counts), dtype=torch.int32).to(dev, non_blocking=True)
+        img_off = hip.to_device(_offsets(counts), torch.int32, dev)
     labels = torch.empty((B, R), dtype=torch.int64, device=dev)
     matched = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
     if T:
@@ -1161,7 +1161,7 @@ def fcos_targets(shifts, strides, sizes_of_interest, gt_boxes, gt_classes, count
     pts = hip.dense_f32(torch.cat(list(shifts), 0))
     L, R, B, T = len(shifts), pts.shape[0], len(counts), int(sum(counts))
     if img_off is None:
-        img_off = torch.tensor(_offsets(counts), dtype=torch.int32).to(dev, non_blocking=True)
+        img_off = hip.to_device(_offsets(counts), torch.int32, dev)
     locs = hip.int_array([s.shape[0] for s in shifts])
     fa = lambda v: (ctypes.c_float * len(v))(*[float(x) for x in v])  # noqa: E731
     lo, hi = fa([s[0] for s in sizes_of_interest]), fa([s[1] for s in sizes_of_interest])

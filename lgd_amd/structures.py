@@ -14,7 +14,7 @@ class Boxes:
         return self.tensor.device
 
     def to(self, device):
-        return Boxes(self.tensor.to(device))
+        return Boxes(self.tensor.to(device, non_blocking=True))   # a no-wait copy when the loader pinned the annotation
 
     def __len__(self):
         return self.tensor.shape[0]
@@ -51,7 +51,7 @@ class Instances:
     def to(self, device):
         out = Instances(self._image_size)
         for k, v in self._fields.items():
-            out.set(k, v.to(device) if hasattr(v, "to") else v)
+            out.set(k, (v.to(device, non_blocking=True) if torch.is_tensor(v) else v.to(device)) if hasattr(v, "to") else v)
         return out
 
     def __len__(self):
