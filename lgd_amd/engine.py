@@ -219,7 +219,8 @@ class Trainer:
     def step(self, data, iteration=None):
         it = self.iteration if iteration is None else iteration
         self.set_phase(it)
-        self.model.train()
+        if not self.model.training:   # nn.Module.train() walks the whole module tree: once, not per step
+            self.model.train()
         loss_dict = self.model(data)
         losses = sum(loss_dict.values())
         ok = torch.isfinite(losses.detach())  # the reference asserts this every iteration (train.py:194); here: no host sync

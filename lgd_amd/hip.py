@@ -117,8 +117,14 @@ def load():
     return lib
 
 
+_HAS_GPU = None
+
+
 def require_gpu(*tensors):
-    if not torch.cuda.is_available():
+    global _HAS_GPU
+    if _HAS_GPU is None:   # asked once: torch.cuda.is_available() costs microseconds per call and every op passes through here
+        _HAS_GPU = torch.cuda.is_available()
+    if not _HAS_GPU:
         raise LgdHipError("LGD HIP kernels need a ROCm GPU (gfx950); no device is visible and there is no CPU fallback")
     for t in tensors:
         if not t.is_cuda:
@@ -132,7 +138,9 @@ def check(rc, what):
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """the current HIP stream of the current device as a void* (the raw getter: torch.cuda.current_stream() builds a Stream object
+    and resolves the device index in Python, ~9 us per call x ~300 calls per step)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def ptr(t):
