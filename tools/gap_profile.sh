@@ -25,6 +25,13 @@ for g, _, _ in gaps:
     hist.setdefault(b, [0, 0]); hist[b][0] += 1; hist[b][1] += max(g, 0)
 for b in ("<2us", "<5us", "<20us", "<100us", ">=100us"):
     if b in hist: print("  gaps %-7s n=%5d  total %.2f ms" % (b, hist[b][0], hist[b][1] / 1e6))
+pairs = {}
+for g, a, b in gaps:
+    if g >= 5000:
+        k = (short(a)[:40], short(b)[:40]); pairs.setdefault(k, [0, 0]); pairs[k][0] += 1; pairs[k][1] += g
+print("gap time by (kernel before the gap, kernel after it), gaps >= 5 us:")
+for (a, b), (n_, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:18]:
+    print("  %7.2f ms  n=%4d  %-40s -> %s" % (t / 1e6, n_, a, b))
 print("largest gaps:")
 for g, a, b in sorted(gaps, reverse=True)[:25]:
     print("  %8.1f us  after %-70s before %s" % (g / 1e3, short(a), short(b)))
