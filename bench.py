@@ -17,6 +17,7 @@ instrumentation inside that region); then a SECOND pass of K steps with a HIP ev
 Extra objects on the JSON line (task statement section 4):
   roofline      -- dominant hand-written HIP kernel of the step (HBM bound): algorithmic bytes per launch / mean launch time
   roofline_mfma -- the Winograd channel GEMMs (library, fp32 MFMA): FLOP per launch / mean launch time vs the 157.3 TF peak
+  roofline_lgd_forward -- the north star's aggregate "LGD distill forward": gn_pool + box_paint + in_moments, 4 pyramids of bytes
   cpu_baseline  -- the CPU oracle (oracle/lgd_oracle.py, kind "port") timed on the host cores, rank 0, N=1 only, with
                    `gpu_same_path`: the product's SAME sub-path (teacher + adapter + distill loss, fwd+bwd) timed on the GPU
 """
@@ -264,6 +265,14 @@ def main():
                                                 "max_us": round(v["max_us"], 2), "GBps": round(v.get("GBps", 0.0), 1),
                                                 "launches_per_step": v["launches"] / args.steps}
                                             for n, v in kernels.items() if not n.startswith("wino_gemm")}}
+        # the north star's aggregate: the LGD distill forward = mask pooling (fused with GN + ReLU) + rendering paint + distill moments,
+        # one launch each per step, 4 P of algorithmic bytes together
+        lgd_fwd = None
+        names = ("gn_pool_kernel", "box_paint_kernel", "in_moments_kernel")
+        if all(n in kernels for n in names):
+            us = sum(kernels[n]["avg_us"] for n in names)
+            lgd_fwd = {"bound": "hbm", "kernels": list(names), "alg_bytes": 4 * P, "us": us, "achieved": 4 * P / us / 1e3, "peak": HBM_PEAK_GBPS,
+                       "unit": "GB/s", "frac": 4 * P / us / 1e3 / HBM_PEAK_GBPS}
         gemms = {n: v for n, v in kernels.items() if n.startswith("wino_gemm")}
         if gemms:
             tot_ms = sum(v["total_ms"] for v in gemms.values())
@@ -298,7 +307,7 @@ def main():
             "hbm_peak_alloc_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,
             "head_pass": "single (student + teacher pyramids in one pass)" if getattr(model, "fused_head_pass", False) else "two passes",
-            "roofline": roofline, "roofline_mfma": roofline_mfma,
+            "roofline": roofline, "roofline_mfma": roofline_mfma, "roofline_lgd_forward": lgd_fwd,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.boxes, ctx)
