@@ -1,5 +1,7 @@
 """GPU parity of the PRODUCT modules (lgd_amd.DynamicTeacher / BaseDistillator.distill / meta-archs) against
 the reference golden vectors and the CPU oracle.  Bar: 1e-4 relative (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -516,3 +518,44 @@ def test_trainer_two_ranks_rccl():
         assert p.exitcode == 0
     assert res[0][1] and res[1][1]
     assert res[0][2] == res[1][2]
+
+
+def test_small_uploads_through_the_pinned_ring():
+    """hip.to_device: short host lists reach the device intact through the ring of pinned staging slots, also after the ring has
+    wrapped several times (a slot is rewritten only long after its copy has executed)."""
+    from lgd_amd import hip
+    got, want = [], []
+    for i in range(3 * 1024 + 7):
+        vals = [i, i + 1, 2 * i, -i]
+        want.append(vals)
+        got.append(hip.to_device(vals, torch.int32 if i % 2 else torch.int64, DEV))
+        if i % 256 == 255:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert g.tolist() == w
+    big = list(range(1000))   # larger than a slot: plain copy
+    assert hip.to_device(big, torch.int64, DEV).tolist() == big
+    assert hip.to_device([[1, 2], [3, 4]], torch.int32, DEV).tolist() == [[1, 2], [3, 4]]
+
+
+def test_bench_stdout_is_one_json_record():
+    """the driver contract: `python bench.py ...` prints exactly ONE line on stdout, the JSON record -- also when RCCL is initialised
+    (its version banner goes to the C stdout and would otherwise follow the record)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, LGD_FORCE_DDP="1", MASTER_PORT="29577")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--config", os.path.join(root, "configs", "lgd_retinanet_r50.yaml"), "--batch-per-gpu", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "roofline_mfma", "roofline_lgd_forward"):
+        assert k in rec, k
+    assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
+    assert rec["config"]["workload"] and "model" not in rec["config"]
