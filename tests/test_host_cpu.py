@@ -398,3 +398,51 @@ def test_winograd_matrices_define_the_convolution(tile):
     dM = AT.t() @ gy @ AT
     assert abs(float(dM[1, 1] - gy.sum())) < 1e-12
     assert 1 * n + 1 == tile + 3  # ... which ops._Conv3x3.backward indexes as dM[tile + 3]
+
+
+def test_winograd_adjoint_input_transform_as_a_gather():
+    """The identity lgd_wino_in_t is built on (winograd.hip: wino4_in_t): the adjoint of the F(4x4,3x3) input transform -- overlap-add
+    of the 6x6 windows Z_t = B G_t B^T at stride 4 -- equals, per 4x4 block, a GATHER of the tile's own 36 values, 6 values of each edge
+    neighbour (frequency row / column 0 or 5 only, because B's first row is [4 0 0 0 0 0] and its last [0 0 0 0 0 1]) and 1 of each corner."""
+    BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                   [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+    B = BT.T
+    assert list(B[0]) == [4, 0, 0, 0, 0, 0] and list(B[5]) == [0, 0, 0, 0, 0, 1]
+    rng = np.random.default_rng(0)
+    TH, TW, H, W = 3, 4, 11, 14
+    G = rng.standard_normal((TH, TW, 6, 6))
+    dx = np.zeros((4 * TH + 2, 4 * TW + 2))
+    for ty in range(TH):
+        for tx in range(TW):
+            dx[4 * ty:4 * ty + 6, 4 * tx:4 * tx + 6] += B @ G[ty, tx] @ B.T     # window (ty, tx) starts at pixel (4 ty - 1, 4 tx - 1)
+    ref = dx[1:1 + H, 1:1 + W]
+
+    def mid(g):   # rows 1..4 of B g (the kernel's b6mid)
+        return np.array([4 * (g[2] - g[1]) + 2 * (g[4] - g[3]) + 4 * g[5], -5 * g[0] - 4 * (g[1] + g[2]) - (g[3] + g[4]),
+                         (g[1] - g[2]) + 2 * (g[3] - g[4]) - 5 * g[5], g[0] + g[1] + g[2] + g[3] + g[4]])
+    out = np.zeros((4 * TH, 4 * TW))
+    for ty in range(TH):
+        for tx in range(TW):
+            g = G[ty, tx]
+            up, dn, lf, rt = ty > 0, ty < TH - 1, tx > 0, tx < TW - 1
+            t = np.stack([mid(g[:, b]) for b in range(6)], 1)             # (4, 6): block rows x frequency columns
+            if up:
+                t[0] += G[ty - 1, tx][5]                                   # the upper tile's window row 5 = its frequency row 5
+            if dn:
+                t[3] += 4 * G[ty + 1, tx][0]                               # the lower tile's window row 0 = 4 x its frequency row 0
+            tl = mid(G[ty, tx - 1][:, 5]) if lf else np.zeros(4)
+            tr = mid(G[ty, tx + 1][:, 0]) if rt else np.zeros(4)
+            if up and lf:
+                tl[0] += G[ty - 1, tx - 1][5, 5]
+            if dn and lf:
+                tl[3] += 4 * G[ty + 1, tx - 1][0, 5]
+            if up and rt:
+                tr[0] += G[ty - 1, tx + 1][5, 0]
+            if dn and rt:
+                tr[3] += 4 * G[ty + 1, tx + 1][0, 0]
+            for r in range(4):
+                y = mid(t[r])
+                y[0] += tl[r]
+                y[3] += 4 * tr[r]
+                out[4 * ty + r, 4 * tx:4 * tx + 4] = y
+    assert np.abs(out[:H, :W] - ref).max() < 1e-12
