@@ -404,6 +404,7 @@ def test_winograd_adjoint_input_transform_as_a_gather():
     """The identity lgd_wino_in_t is built on (winograd.hip: wino4_in_t): the adjoint of the F(4x4,3x3) input transform -- overlap-add
     of the 6x6 windows Z_t = B G_t B^T at stride 4 -- equals, per 4x4 block, a GATHER of the tile's own 36 values, 6 values of each edge
     neighbour (frequency row / column 0 or 5 only, because B's first row is [4 0 0 0 0 0] and its last [0 0 0 0 0 1]) and 1 of each corner."""
+    import numpy as np
     BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
                    [0, 4, 0, -5, 0, 1]], dtype=np.float64)
     B = BT.T
