@@ -362,6 +362,27 @@ int lgd_dcn_im2col(const float* x, const float* offset, const float* mask, int N
 int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const float* dcol, int N, int C, int H, int W,
                    int stride, int pad, int dilation, float* dx, float* doffset, float* dmask, void* stream);
 
+/* ------------------------------------------------------------------ gradient clipping + SGD of both optimizers, one launch
+ * [ref: train.py:200-204 stu_optimizer.step() / tea_optimizer.step(); utils/build.py:494-529 torch.optim.SGD(momentum, weight
+ *  decay) wrapped by detectron2's per-parameter gradient clipping, CLIP_TYPE "value"]
+ * For every tensor of the table (device memory, n_tensors entries):
+ *     g <- clamp(g, -clip_value, clip_value);  buf <- mu * buf + (g + wd * p);  p <- p - lr * buf
+ * (torch.optim.SGD's update with dampening 0, nesterov off; a zero-initialised buf reproduces its first step exactly).
+ * blk_off (device, n_tensors + 1 int32): workgroup b works on tensor i with blk_off[i] <= b < blk_off[i+1], on elements
+ * [(b - blk_off[i]) * lgd_sgd_chunk_elems(), ...); n_blocks = blk_off[n_tensors].  clip_value = +inf: no clipping.
+ */
+typedef struct lgd_sgd_tensor {
+    float* p;          /* parameter */
+    float* g;          /* its gradient (the clipped value is written back) */
+    float* m;          /* momentum buffer */
+    int64_t n;         /* elements */
+    float lr, wd, mu;  /* learning rate, weight decay, momentum of the optimizer that owns the tensor */
+    int32_t reserved;
+} lgd_sgd_tensor;
+int lgd_sgd_chunk_elems(void);
+int lgd_sgd_clip_step(const lgd_sgd_tensor* table, const int32_t* blk_off, int n_tensors, int n_blocks, float clip_value,
+                      void* stream);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench.py)
  * When enabled every kernel launch of this library is bracketed by a HIP event pair recorded on
  * the launch stream.  lgd_timing_collect waits for the recorded events, sums the elapsed time per

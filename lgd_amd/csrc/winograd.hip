@@ -333,7 +333,12 @@ __device__ __forceinline__ void a6(const float* g, float* r) {
 }
 
 // The nf = 36 values of the workgroup's 256 tiles go through LDS so that every frequency plane is written / read as ONE
-// 1 KB run (float4 per lane) instead of 256 B per wave; level tile counts are padded to a multiple of 4 with zero tiles.
+// 1 KB run (float4 per lane) instead of 256 B per wave; level tile counts are padded with zero tiles to a multiple of
+// kTilePad = 16, so that every level, every frequency plane and every workgroup's runs start on a 64-byte boundary:
+// runs that are only 16-byte aligned cost the write-heavy transforms 15 % (tools/lab/wino4_lab.hip, plane stride 8404 vs
+// 8400 / 8416 / 8448 floats: 100 vs 85 / 84 / 85 us; 128-byte or 1 KB alignment buys nothing more).  With a pad of 4 the
+// 2-image-per-GPU shapes (2,860 tiles) had every plane misaligned.
+constexpr int kTilePad = 16;
 __device__ __forceinline__ void stage_store36(const float* lds, float* dst, size_t plane, long long t0, long long tend) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     #pragma unroll
@@ -372,7 +377,7 @@ __device__ __forceinline__ void stage_store12(const float* lds, float* dst, size
 template <bool VEC, bool DUAL, int MASK>
 __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
-    const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
+    const long long units = (long long)a.N * TH * TW, padded = (units + kTilePad - 1) & ~(long long)(kTilePad - 1);
     const long long t0 = (long long)(blockIdx.x - a.blk_off[l]) * 256;
     const long long u = t0 + threadIdx.x;
     const bool on = u < units;
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(WinoArgs a) {
 template <bool VEC, bool STAGE>
 __device__ __forceinline__ void wino4_out_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
-    const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
+    const long long units = (long long)a.N * TH * TW, padded = (units + kTilePad - 1) & ~(long long)(kTilePad - 1);
     const long long t0 = (long long)(blockIdx.x - a.blk_off[l]) * 256;
     const long long u = t0 + threadIdx.x;
     const int c = blockIdx.y;
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(256) void wino4_out_kernel(WinoArgs a) {
 template <bool VEC>
 __device__ __forceinline__ void wino4_out_t_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
-    const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
+    const long long units = (long long)a.N * TH * TW, padded = (units + kTilePad - 1) & ~(long long)(kTilePad - 1);
     const long long t0 = (long long)(blockIdx.x - a.blk_off[l]) * 256;
     const long long u = t0 + threadIdx.x;
     const bool on = u < units;
@@ -779,7 +784,7 @@ __device__ __forceinline__ void wino4_in_t_phase(const float* m, size_t plane, i
 template <bool VEC, bool FUSE>
 __device__ __forceinline__ void wino4_in_t_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
-    const long long units = (long long)a.N * TH * TW, padded = (units + 3) & ~3LL;
+    const long long units = (long long)a.N * TH * TW, padded = (units + kTilePad - 1) & ~(long long)(kTilePad - 1);
     const long long t0 = (long long)(blockIdx.x - a.blk_off[l]) * 256;
     const long long u = t0 + threadIdx.x;
     const bool on = u < units;
@@ -950,7 +955,7 @@ __global__ __launch_bounds__(256) void wino4_filter_bwd_kernel(FilterArgs a) {
 }
 
 static long long level_tiles(int N, int H, int W, int tile) {
-    if (tile == 4) return (((long long)N * ((H + 3) / 4) * ((W + 3) / 4)) + 3) & ~3LL;
+    if (tile == 4) return (((long long)N * ((H + 3) / 4) * ((W + 3) / 4)) + kTilePad - 1) & ~(long long)(kTilePad - 1);
     const long long t = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
     return t + (t & 1);
 }

@@ -177,9 +177,14 @@ class Trainer:
         self.iteration = 0
         self._log_acc, self._log_n = None, 0
         self._finite = None  # device-side AND of isfinite(total loss) over the steps since the last check
+        self._fused_sgd = None
         if self.device.type == "cuda":
-            from . import ops
+            from . import ops, optim
             self.tuned_gemms = ops.enable_tuned_gemms()  # opt-in here (not an import side effect): lookup-only solution table
+            # clip + both SGD updates as one HIP launch (csrc/optim.hip); other optimizers / clip types: torch's multi-tensor path
+            if os.environ.get("LGD_FUSED_SGD", "1") != "0" and optim.supported([self.stu_optimizer, self.tea_optimizer], self.clip):
+                self._fused_sgd = optim.FusedClipSGD([self.stu_optimizer, self.tea_optimizer],
+                                                     self.clip.CLIP_VALUE if self.clip.ENABLED else None)
         else:
             self.tuned_gemms = False
 
@@ -225,13 +230,18 @@ class Trainer:
         losses = sum(loss_dict.values())
         ok = torch.isfinite(losses.detach())  # the reference asserts this every iteration (train.py:194); here: no host sync
         self._finite = ok if self._finite is None else self._finite & ok
-        self.stu_optimizer.zero_grad(set_to_none=True)
-        self.tea_optimizer.zero_grad(set_to_none=True)
-        losses.backward()  # DDP: bucketed RCCL all-reduce over xGMI overlaps with this
-        if self.clip.ENABLED:
-            self._clip()
-        self.stu_optimizer.step()
-        self.tea_optimizer.step()
+        if self._fused_sgd is not None:
+            self._fused_sgd.zero_grad()
+            losses.backward()  # DDP: bucketed RCCL all-reduce over xGMI overlaps with this
+            self._fused_sgd.step()   # clip + stu_optimizer.step() + tea_optimizer.step(): one launch
+        else:
+            self.stu_optimizer.zero_grad(set_to_none=True)
+            self.tea_optimizer.zero_grad(set_to_none=True)
+            losses.backward()
+            if self.clip.ENABLED:
+                self._clip()
+            self.stu_optimizer.step()
+            self.tea_optimizer.step()
         self.stu_scheduler.step()
         self.tea_scheduler.step()
         # device-side running sums; no host sync here

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -76,6 +76,8 @@ SIGNATURES = {
     "lgd_box_reg_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
     "lgd_dcn_im2col": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_dcn_col2im": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_sgd_chunk_elems": (c_i, []),
+    "lgd_sgd_clip_step": (c_i, [c_fp, c_fp, c_i, c_i, c_f, c_fp]),
     "lgd_timing_enable": (c_i, [c_i]),
     "lgd_timing_collect": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_i]),
     "lgd_timing_collect_ex": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_fp, c_fp, c_i]),

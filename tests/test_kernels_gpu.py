@@ -1107,3 +1107,76 @@ def test_pointwise_conv_bn_fwd_bwd(N, Ci, Co, H, W, relu, res):
     got = ops.pointwise_conv_bn(ConvBN.subsample2(xs), w.detach(), scale, shift, None, relu)
     want = F.conv2d(xs.double(), w.detach().double(), stride=2) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
     assert cm.rel_err(got, F.relu(want) if relu else want) < FTOL
+
+
+def test_fused_clip_sgd_matches_torch():
+    """csrc/optim.hip (clip by value + SGD momentum / weight decay of two optimizers, one launch) against torch's own
+    clamp_ + torch.optim.SGD(foreach) over four steps [ref: train.py:200-204, utils/build.py:494-529]: odd sizes (vector tail),
+    a multi-chunk tensor, a gradient that is an unaligned view into a flat bucket (scalar path), a parameter without a
+    gradient (skipped, as SGD does), a changing learning rate, state picked up from / visible to torch (state_dict)."""
+    from types import SimpleNamespace
+    from lgd_amd import optim
+    torch.manual_seed(3)
+    sizes = [(1,), (3,), (255,), (64, 3, 7, 7), (4097,), (256, 256, 3, 3), (720,), (5,)]
+
+    def make():
+        torch.manual_seed(4)
+        ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in sizes]
+        a = torch.optim.SGD(ps[:5], 0.02, momentum=0.9, weight_decay=1e-4, foreach=True)
+        b = torch.optim.SGD(ps[5:], 0.05, momentum=0.8, weight_decay=1e-3, foreach=True)
+        return ps, a, b
+    ps0, a0, b0 = make()
+    ps1, a1, b1 = make()
+    clip = SimpleNamespace(ENABLED=True, CLIP_TYPE="value", CLIP_VALUE=0.5, NORM_TYPE=2.0)
+    assert optim.supported([a1, b1], clip)
+    assert not optim.supported([a1, b1], SimpleNamespace(ENABLED=True, CLIP_TYPE="norm", CLIP_VALUE=0.5, NORM_TYPE=2.0))
+    assert not optim.supported([torch.optim.AdamW(ps1[:1], 1e-3)], clip)
+    fused = optim.FusedClipSGD([a1, b1], clip.CLIP_VALUE)
+    bucket = torch.zeros(sizes[2][0] + 9, device=DEV)
+    exact = True
+    for step in range(4):
+        torch.manual_seed(10 + step)
+        gs = [torch.randn(s, device=DEV) * (3.0 if i % 2 else 0.3) for i, s in enumerate(sizes)]
+        for o in (a0, a1):
+            o.param_groups[0]["lr"] = 0.02 * (1 + step)
+        for i, (p0, p1) in enumerate(zip(ps0, ps1)):
+            if i == 7 and step < 2:      # no gradient in the first two steps: no update, no momentum buffer
+                p0.grad = p1.grad = None
+                continue
+            p0.grad = gs[i].clone()
+            if i == 2:                   # 4-byte aligned view (the DDP bucket-view case)
+                bucket[1:1 + gs[i].numel()] = gs[i]
+                p1.grad = bucket[1:1 + gs[i].numel()].view(sizes[i])
+                assert p1.grad.data_ptr() % 16 != 0
+            else:
+                p1.grad = gs[i].clone()
+        g0 = [p.grad for p in ps0 if p.grad is not None]
+        torch._foreach_clamp_min_(g0, -0.5)
+        torch._foreach_clamp_max_(g0, 0.5)
+        a0.step(); b0.step()
+        fused.step()
+        for i, (p0, p1) in enumerate(zip(ps0, ps1)):
+            assert torch.allclose(p0, p1, rtol=1e-6, atol=1e-7), (step, i)
+            exact &= bool(torch.equal(p0, p1))
+            if p0.grad is not None:
+                assert torch.equal(p0.grad, p1.grad), (step, i)       # the clipped gradient is written back
+                o0, o1 = (a0, a1) if i < 5 else (b0, b1)
+                assert torch.allclose(o0.state[p0]["momentum_buffer"], o1.state[p1]["momentum_buffer"], rtol=1e-6, atol=1e-7)
+        assert (7 in [i for i, p in enumerate(ps1) if p in b1.state and "momentum_buffer" in b1.state[p]]) == (step >= 2)
+        if step == 1:   # the state lives in the torch optimizers: a load_state_dict round trip is picked up by the fused step
+            sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b1.state_dict()["state"][0].items()}
+            b1.load_state_dict(b1.state_dict())
+            assert torch.equal(b1.state[ps1[5]]["momentum_buffer"], sd["momentum_buffer"])
+    print("fused clip+SGD vs torch: bit-identical parameters after 4 steps: %s" % exact)
+    # clipping off = +inf
+    ps2, a2, b2 = make()
+    ps3, a3, b3 = make()
+    f2 = optim.FusedClipSGD([a3, b3], None)
+    for p2, p3 in zip(ps2, ps3):
+        g = torch.randn_like(p2) * 5
+        p2.grad, p3.grad = g.clone(), g.clone()
+    a2.step(); b2.step(); f2.step()
+    for p2, p3 in zip(ps2, ps3):
+        assert torch.allclose(p2, p3, rtol=1e-6, atol=1e-7)
+    f2.zero_grad()
+    assert all(p.grad is None for p in ps3)

@@ -559,3 +559,44 @@ def test_bench_stdout_is_one_json_record():
         assert k in rec, k
     assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
     assert rec["config"]["workload"] and "model" not in rec["config"]
+
+
+def test_trainer_fused_sgd_equals_torch_optimizers(monkeypatch):
+    """Trainer.step with the one-launch clip + SGD (csrc/optim.hip, the default) against the same trainer on torch's
+    clamp_ / SGD(foreach) path (LGD_FUSED_SGD=0) from the same weights, three steps across both phase switches
+    [ref: train.py:191-207]; the checkpoint payload keeps the reference's optimizer layout either way."""
+    import copy
+    from lgd_amd import config
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    base = build_model(cfg)
+    twin = copy.deepcopy(base)
+    data = synthetic_batch(2, 256, 320, 5, seed=6)
+    its = (0, 25000, 40000)
+    fused = Trainer(cfg, base, distributed=False)
+    assert fused._fused_sgd is not None
+    monkeypatch.setenv("LGD_FUSED_SGD", "0")
+    plain = Trainer(cfg, twin, distributed=False)
+    assert plain._fused_sgd is None
+    for it in its:
+        fused.step(data, it)
+        plain.step(data, it)
+    worst = 0.0
+    for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
+        worst = max(worst, float((a - b).abs().max() / (a.abs().max() + 1e-12)))
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
+    print("fused clip+SGD trainer vs torch optimizers: worst relative parameter difference %.2e" % worst)
+    sa, sb = fused.state_dict(), plain.state_dict()
+    for k in ("stu_optimizer", "tea_optimizer"):
+        assert len(sa[k]["param_groups"]) == len(sb[k]["param_groups"])
+        assert sorted(sa[k]["state"].keys()) == sorted(sb[k]["state"].keys())
+    # resume: the fused step picks the loaded momentum buffers up
+    fused.load_state_dict(sb)
+    fused.step(data, 40000)
+    plain.step(data, 40000)
+    for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n

@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void wino4_in(const float* __restrict__ x, flo
 }
 
 // staged variants on the [c][f][t] layout: NT threads per block, PH phases of 36/PH planes each (LDS = 36/PH * NT * 4 B)
-template <int NT, int PH, int G = 0, bool SWAP = false>
-__global__ __launch_bounds__(NT) void wino4_in_staged(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W) {
+template <int NT, int PH, int G = 0, bool SWAP = false, bool PLAIN = false>
+__global__ __launch_bounds__(NT) void wino4_in_staged(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W, long long TS = 0) {
     const int TH = H / 4, TW = W / 4;
     const long long T = (long long)N * TH * TW;
     const int c = SWAP ? blockIdx.x : blockIdx.y;
@@ -160,8 +160,9 @@ __global__ __launch_bounds__(NT) void wino4_in_staged(const float* __restrict__ 
         #pragma unroll
         for (int i = 0; i < 6; ++i) r[i][j] = w[i];
     }
-    float* dst = V + (size_t)c * 36 * T + t0;
-    constexpr int NW = NT / 64, RUN4 = NT / 4;  // float4 per plane run
+    if (TS == 0) TS = T;  // plane stride in floats (TS > T: runs aligned to 128 B / 1 KB)
+    float* dst = V + (size_t)c * 36 * TS + t0;
+    constexpr int RUN4 = NT / 4;  // float4 per plane run
     #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
         if (ph) __syncthreads();
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(NT) void wino4_in_staged(const float* __restrict__ 
             const float4 v = *reinterpret_cast<const float4*>(&lds[f * NT + q4 * 4]);
             if (t0 + q4 * 4 + 3 < T) {
                 vf4 q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
-                __builtin_nontemporal_store(q, reinterpret_cast<vf4*>(dst + (size_t)(ph * NPL + f) * T + q4 * 4));
+                if (PLAIN) *reinterpret_cast<vf4*>(dst + (size_t)(ph * NPL + f) * TS + q4 * 4) = q;
+                else __builtin_nontemporal_store(q, reinterpret_cast<vf4*>(dst + (size_t)(ph * NPL + f) * TS + q4 * 4));
             }
         }
     }
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(NT) void wino4_in_staged(const float* __restrict__ 
 
 int main() {
     const int N = 8, C = 256, H = 100, W = 168;
-    const size_t nx = (size_t)N * C * H * W, T = (size_t)N * (H / 4) * (W / 4), nv = 36 * (size_t)C * T;
+    const size_t nx = (size_t)N * C * H * W, T = (size_t)N * (H / 4) * (W / 4), nv = 36 * (size_t)C * (T + 256);
     const int NB = 3;
     std::vector<float*> X(NB), Vb(NB);
     for (int i = 0; i < NB; ++i) { CK(hipMalloc(&X[i], nx * 4)); CK(hipMemset(X[i], 1, nx * 4)); CK(hipMalloc(&Vb[i], nv * 4)); }
@@ -214,6 +216,10 @@ int main() {
 #define STG(NT, PH, G) run("staged NT=" #NT " PH=" #PH " XCD runs G=" #G, [&](float* x, float* v) { const unsigned nb = (unsigned)((T + NT - 1) / NT); wino4_in_staged<NT, PH, G><<<dim3((nb + 8 * G - 1) / (8 * G) * (8 * G), C), NT>>>(x, v, N, C, H, W); })
     run("staged NT=256 PH=1 channel-fastest dispatch", [&](float* x, float* v) { wino4_in_staged<256, 1, 0, true><<<dim3(C, (unsigned)((T + 255) / 256)), 256>>>(x, v, N, C, H, W); });
     run("staged NT=256 PH=3 channel-fastest dispatch", [&](float* x, float* v) { wino4_in_staged<256, 3, 0, true><<<dim3(C, (unsigned)((T + 255) / 256)), 256>>>(x, v, N, C, H, W); });
+#define STS(TSV, PL) run("staged NT=256 PH=3 plane stride " #TSV " plain=" #PL, [&](float* x, float* v) { wino4_in_staged<256, 3, 0, false, PL><<<dim3((unsigned)((T + 255) / 256), C), 256>>>(x, v, N, C, H, W, TSV); })
+    // run alignment: T = 8400 -> runs 16 B aligned; 8416 -> 128 B; 8448 -> 1 KB; 8512 -> 256 B; 8404 -> 16 B (control)
+    STS(8400, false); STS(8404, false); STS(8416, false); STS(8448, false); STS(8512, false); STS(8400, true); STS(8416, true); STS(8448, true);
+    STS(8400, false); STS(8416, false);
     run("C two tiles/thread float2", [&](float* x, float* v) { wino4_in<2><<<dim3((unsigned)((T / 2 + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
     return 0;
 }
