@@ -594,8 +594,9 @@ def test_trainer_fused_sgd_equals_torch_optimizers(monkeypatch):
     for k in ("stu_optimizer", "tea_optimizer"):
         assert len(sa[k]["param_groups"]) == len(sb[k]["param_groups"])
         assert sorted(sa[k]["state"].keys()) == sorted(sb[k]["state"].keys())
-    # resume: the fused step picks the loaded momentum buffers up
-    fused.load_state_dict(sb)
+    # resume: the fused step picks the loaded momentum buffers up (a copy: Optimizer.load_state_dict keeps the tensors it is
+    # handed when dtype and device already match, and `sb` holds plain's LIVE buffers)
+    fused.load_state_dict(copy.deepcopy(sb))
     fused.step(data, 40000)
     plain.step(data, 40000)
     for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
