@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--host-batch", action="store_true",
                     help="hand the batch over as pinned HOST tensors and copy it inside every step (the PCIe-inclusive rate noted in "
                          "DESIGN.md); default: images and annotations resident in HBM when the timed region starts")
+    ap.add_argument("--graph-backbone", action="store_true",
+                    help="replay the student's backbone + FPN forward / backward as hipGraphs (lgd_amd/graphs.py; for the 2 img/GPU configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
     ap.add_argument("--head-passes", type=int, default=1, choices=[1, 2],
@@ -174,7 +176,8 @@ def main():
     torch.manual_seed(0)
     model = build_model(cfg)
     model.fused_head_pass = args.head_passes == 1
-    trainer = Trainer(cfg, model, device=dev, distributed=True if force_ddp else None)
+    trainer = Trainer(cfg, model, device=dev, distributed=True if force_ddp else None,
+                      graph_backbone=True if args.graph_backbone else None)
     d = cfg.MODEL.DISTILLATOR
     it0 = {"distill": max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS),
            "nondistill": d.PRE_FREEZE_STUDENT_BACKBONE_ITERS, "frozen": 0}[args.phase]
@@ -306,6 +309,7 @@ def main():
             "gemm_solution_table_loaded": bool(trainer.tuned_gemms), "conv3x3": "winograd F(%dx%d,3x3)" % (ops._WINO_TILE, ops._WINO_TILE) if ops._WINO_ON else "library",
             "hbm_peak_alloc_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,
+            "graph_backbone": bool(trainer.graph_backbone), "fused_clip_sgd": trainer._fused_sgd is not None,
             "head_pass": "single (student + teacher pyramids in one pass)" if getattr(model, "fused_head_pass", False) else "two passes",
             "roofline": roofline, "roofline_mfma": roofline_mfma, "roofline_lgd_forward": lgd_fwd,
         }

@@ -158,7 +158,7 @@ def freeze_static_unused(model):
 class Trainer:
     """Owns model (+DDP), optimizers, schedulers and the per-iteration phase logic of do_train."""
 
-    def __init__(self, cfg, model, distributed=None, device=None):
+    def __init__(self, cfg, model, distributed=None, device=None, graph_backbone=None):
         self.cfg = cfg
         self.d = cfg.MODEL.DISTILLATOR
         self.max_iter = cfg.SOLVER.MAX_ITER
@@ -187,6 +187,14 @@ class Trainer:
                                                      self.clip.CLIP_VALUE if self.clip.ENABLED else None)
         else:
             self.tuned_gemms = False
+        # hipGraph replay of the student's backbone + FPN forward / backward (lgd_amd/graphs.py): opt-in, pays at 2 images per GPU
+        if graph_backbone is None:
+            graph_backbone = os.environ.get("LGD_GRAPH_BACKBONE", "0") == "1"
+        self.graph_backbone = bool(graph_backbone) and self.device.type == "cuda"
+        if self.graph_backbone:
+            from .graphs import GraphedBackbone
+            s = self.raw_model.student
+            s._graphed_backbone = GraphedBackbone(s.raw_backbone, s.fpn)
 
     # ---- phases ----------------------------------------------------------------------------
     def _set_backbone_frozen(self, frozen):
@@ -313,6 +321,9 @@ class Trainer:
 
     def load_state_dict(self, sd):
         self.raw_model.load_state_dict(sd["model"])
+        g = getattr(self.raw_model.student, "_graphed_backbone", None)
+        if g is not None:
+            g.reset()  # frozen weights / FrozenBN buffers feed caches the captured kernels read
         self.stu_optimizer.load_state_dict(optimizer_state_from_reference(sd["stu_optimizer"], self.stu_optimizer))
         self.tea_optimizer.load_state_dict(optimizer_state_from_reference(sd["tea_optimizer"], self.tea_optimizer))
         self.stu_scheduler.load_state_dict(sd["stu_scheduler"])

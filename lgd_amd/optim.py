@@ -141,3 +141,5 @@ class FusedClipSGD:
         base = dev.data_ptr()
         hip.check(lib.lgd_sgd_clip_step(ctypes.c_void_p(base), ctypes.c_void_p(base + 48 * k), k, n_blocks,
                                         ctypes.c_float(self.clip_value), hip.stream_ptr()), "lgd_sgd_clip_step")
+        for o in self.optimizers:
+            o._opt_called = True   # what the LR schedulers' "scheduler.step() before optimizer.step()" check looks at

@@ -601,3 +601,49 @@ def test_trainer_fused_sgd_equals_torch_optimizers(monkeypatch):
     plain.step(data, 40000)
     for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
+
+
+@pytest.mark.timeout(900)
+def test_graphed_backbone_equals_eager():
+    """lgd_amd/graphs.py: the student's backbone + FPN forward / backward replayed as hipGraphs (opt-in, for the 2 img/GPU
+    configs) must train exactly like the eager path: same parameters after steps across the backbone-freeze phase switch
+    (new requires_grad pattern -> new capture), a second image shape (new capture) and back (cached graph replayed);
+    load_state_dict drops the graphs (frozen weights / FrozenBN buffers feed caches the captured kernels read)."""
+    import copy
+    from lgd_amd import config
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    base = build_model(cfg)
+    twin = copy.deepcopy(base)
+    eager = Trainer(cfg, base, distributed=False, graph_backbone=False)
+    graphed = Trainer(cfg, twin, distributed=False, graph_backbone=True)
+    g = twin.student._graphed_backbone
+    assert getattr(base.student, "_graphed_backbone", None) is None
+    a_data, b_data = synthetic_batch(2, 256, 320, 5, seed=6), synthetic_batch(2, 224, 352, 3, seed=7)
+    plan = [(0, a_data, 1), (1, a_data, 1), (25000, a_data, 2), (25001, b_data, 3), (25002, a_data, 3), (40000, a_data, 3)]
+    for it, data, captures in plan:
+        le = eager.step(data, it)
+        lg = graphed.step(data, it)
+        assert g.captures == captures, (it, g.captures)
+        for k in le:
+            assert torch.allclose(le[k], lg[k], rtol=2e-4, atol=1e-6), (it, k, float(le[k]), float(lg[k]))
+    worst = 0.0
+    for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
+        worst = max(worst, float((a - b).abs().max() / (a.abs().max() + 1e-12)))
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
+    print("graphed backbone vs eager: worst relative parameter difference %.2e after %d steps, %d captures" % (worst, len(plan), g.captures))
+    # eval mode falls back to the eager forward; a checkpoint load drops the graphs
+    twin.eval()
+    with torch.no_grad():
+        twin(a_data)
+    twin.train()
+    graphed.load_state_dict(copy.deepcopy(eager.state_dict()))
+    graphed.step(a_data, 40000)
+    eager.step(a_data, 40000)
+    assert g.captures == 4
+    for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
