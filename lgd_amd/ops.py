@@ -1114,6 +1114,18 @@ def conv3x3(x, w, b=None, relu=False, scale=None):
     return conv3x3_levels([x], w, b, relu, scale)[0]
 
 
+def conv3x3_stride2(x, w, b=None):
+    """3x3 / stride 2 / padding 1 convolution (the FPN's extra levels p6 / p7 [d2-memory: LastLevelP6P7]).  Output pixel (i, j) of the
+    strided convolution is output pixel (2i, 2j) of the stride-1 one, and F(4x4,3x3) spends 36 / 16 = 2.25 multiplies per stride-1
+    output pixel against 9 / 4 = 2.25 per input pixel for the direct strided form: the same GEMM work, so where the Winograd path
+    applies (p6 over res5: 2048 -> 256 channels) the convolution runs as the stride-1 Winograd convolution + every other output,
+    forward, input and weight gradient on the tuned channel GEMMs.  The library's strided implicit-GEMM kernels cost 2.1 ms/step at
+    config 2 (forward, two split weight-gradient passes and NCHW <-> NHWC transposes of the 2048-channel map)."""
+    if _wino_ok([x], w):
+        return conv3x3(x, w, b)[:, :, ::2, ::2]
+    return F.conv2d(x, w, b, 2, 1)
+
+
 class Conv3x3(torch.nn.Conv2d):
     """nn.Conv2d(cin, cout, 3, 1, 1) with the same parameters / state_dict keys; `levels` applies it to a pyramid."""
 

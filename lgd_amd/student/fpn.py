@@ -20,8 +20,8 @@ class LastLevelP6P7(nn.Module):
             nn.init.constant_(m.bias, 0)
 
     def forward(self, c5):
-        p6 = self.p6(c5)
-        return [p6, self.p7(F.relu(p6))]
+        p6 = ops.conv3x3_stride2(c5, self.p6.weight, self.p6.bias)
+        return [p6, ops.conv3x3_stride2(F.relu(p6), self.p7.weight, self.p7.bias)]
 
 
 class FPN(nn.Module):

@@ -1180,3 +1180,33 @@ def test_fused_clip_sgd_matches_torch():
         assert torch.allclose(p2, p3, rtol=1e-6, atol=1e-7)
     f2.zero_grad()
     assert all(p.grad is None for p in ps3)
+
+
+@pytest.mark.parametrize("hw", [(25, 42), (26, 41), (13, 21)])
+def test_conv3x3_stride2_matches_strided_conv(hw):
+    """ops.conv3x3_stride2 (the FPN's p6 / p7 [d2-memory: LastLevelP6P7]): on the Winograd path = stride-1 F(4x4,3x3) convolution +
+    every other output; against F.conv2d(stride=2, padding=1) in fp64 -- values, input / weight / bias gradients -- for odd and even
+    map sizes; the small map takes the library's strided kernel (same check)."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    N, Ci, Co = 8, 192, 128
+    h, w_ = hw
+    x = torch.from_numpy(synth.det_uniform((N, Ci, h, w_), 971, -2.0, 2.0))
+    w = torch.from_numpy(synth.det_uniform((Co, Ci, 3, 3), 972, -0.1, 0.1))
+    b = torch.from_numpy(synth.det_uniform((Co,), 973, -0.5, 0.5))
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, 2, 1)
+    gy = torch.from_numpy(synth.det_uniform(tuple(yr.shape), 974, -1.0, 1.0))
+    yr.backward(gy.double())
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv3x3_stride2(xg, wg, bg)
+    assert tuple(y.shape) == tuple(yr.shape)
+    wino = ops._wino_ok([xg], wg)
+    assert wino == (N * ((h + 1) // 2) * ((w_ + 1) // 2) >= ops._WINO_MIN_TILES)
+    y.backward(gy.to(DEV))
+    scale = lambda t: float(t.detach().abs().max()) + 1e-30
+    tol = 5e-5
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) <= tol * scale(yr)
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= tol * scale(xr.grad)
+    assert float((wg.grad.cpu().double() - wr.grad).abs().max()) <= tol * scale(wr.grad)
+    assert float((bg.grad.cpu().double() - br.grad).abs().max()) <= tol * scale(br.grad)

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT) void wino4_in_staged(const float* __restrict__ 
 
 int main() {
     const int N = 8, C = 256, H = 100, W = 168;
-    const size_t nx = (size_t)N * C * H * W, T = (size_t)N * (H / 4) * (W / 4), nv = 36 * (size_t)C * (T + 256);
+    const size_t nx = (size_t)N * C * H * W, T = (size_t)N * (H / 4) * (W / 4), nv = 36 * (size_t)C * 16640;   // room for the plane-stride experiments (TS up to 16640 floats)
     const int NB = 3;
     std::vector<float*> X(NB), Vb(NB);
     for (int i = 0; i < NB; ++i) { CK(hipMalloc(&X[i], nx * 4)); CK(hipMemset(X[i], 1, nx * 4)); CK(hipMalloc(&Vb[i], nv * 4)); }
@@ -220,6 +220,8 @@ int main() {
     // run alignment: T = 8400 -> runs 16 B aligned; 8416 -> 128 B; 8448 -> 1 KB; 8512 -> 256 B; 8404 -> 16 B (control)
     STS(8400, false); STS(8404, false); STS(8416, false); STS(8448, false); STS(8512, false); STS(8400, true); STS(8416, true); STS(8448, true);
     STS(8400, false); STS(8416, false);
+    // plane stride vs the HBM channel interleave: 34 / 36 / 40 / 48 / 64 / 65 KB planes
+    STS(8704, false); STS(9216, false); STS(10240, false); STS(12288, false); STS(16384, false); STS(16640, false); STS(8400, false);
     run("C two tiles/thread float2", [&](float* x, float* v) { wino4_in<2><<<dim3((unsigned)((T / 2 + 255) / 256), C), 256>>>(x, v, N, C, H, W); });
     return 0;
 }
