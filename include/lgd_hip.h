@@ -317,10 +317,15 @@ int lgd_fcos_targets(const float* shifts, const int32_t* level_locs_host, const 
  * [ref: the detectron2 BottleneckBlock of the reference's student: conv -> FrozenBN (a per-channel
  *  affine, folded into the conv weights + bias) [-> += shortcut] -> relu]
  * lgd_bias_act_fwd : out = x + bias[c] (+ residual) [then ReLU]; x, residual, out: (N, C, HW) fp32; bias / residual may be NULL
+ *   relu_bits (may be NULL): the linear bitmap [out > 0] -- element e is bit e % 32 of word e / 32, lgd_relu_bits_words(N*C*HW)
+ *   uint32 words -- so that the backward reads 1 bit per element instead of the 4-byte output
+ * lgd_relu_bits_bwd: dx = dy where the bitmap says the forward output was > 0, else 0 (2 map transfers instead of 3)
  * lgd_relu_mask_bwd: dx = dy where the saved forward output y > 0, else 0 (total elements)
  */
+size_t lgd_relu_bits_words(long long total);
 int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, int N, int C, int HW, int relu, float* out,
-                     void* stream);
+                     uint32_t* relu_bits, void* stream);
+int lgd_relu_bits_bwd(const uint32_t* relu_bits, const float* dy, long long total, float* dx, void* stream);
 int lgd_relu_mask_bwd(const float* y, const float* dy, long long total, float* dx, void* stream);
 
 /* ------------------------------------------------------------------ anchor <-> ground-truth matching of the student loss

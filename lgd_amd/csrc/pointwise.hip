@@ -12,6 +12,7 @@ struct BiasActArgs {
     const float* bias;   // [C] or null
     const float* res;    // (N, C, HW) residual or null
     float* out;
+    uint32_t* bits;      // null, or the linear bitmap [out > 0]: element e <-> bit e % 32 of word e / 32 (the backward's ReLU mask)
     long long total;     // N*C*HW
     int C, HW, relu;
 };
@@ -19,21 +20,53 @@ struct BiasActArgs {
 template <int VW>
 __global__ __launch_bounds__(256) void bias_act_kernel(BiasActArgs a) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * VW;
-    if (i >= a.total) return;
-    const int c = (int)((i / a.HW) % a.C);  // VW divides HW: the VW elements share a plane
-    const float b = a.bias ? a.bias[c] : 0.f;
-    Vec<VW> v = vload<VW>(a.x + i);
-    if (a.res) {
-        const Vec<VW> r = vload<VW>(a.res + i);
-        #pragma unroll
-        for (int k = 0; k < VW; ++k) v.v[k] += r.v[k];
-    }
+    const bool on = i < a.total;
+    Vec<VW> v;
     #pragma unroll
-    for (int k = 0; k < VW; ++k) {
-        v.v[k] += b;
-        if (a.relu) v.v[k] = fmaxf(v.v[k], 0.f);
+    for (int k = 0; k < VW; ++k) v.v[k] = 0.f;
+    if (on) {
+        const int c = (int)((i / a.HW) % a.C);  // VW divides HW: the VW elements share a plane
+        const float b = a.bias ? a.bias[c] : 0.f;
+        v = vload<VW>(a.x + i);
+        if (a.res) {
+            const Vec<VW> r = vload<VW>(a.res + i);
+            #pragma unroll
+            for (int k = 0; k < VW; ++k) v.v[k] += r.v[k];
+        }
+        #pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            v.v[k] += b;
+            if (a.relu) v.v[k] = fmaxf(v.v[k], 0.f);
+        }
+        vstore<VW>(a.out + i, v);
     }
-    vstore<VW>(a.out + i, v);
+    if (a.bits) {   // wave-uniform: the backward reads 1 bit instead of the 4-byte output
+        if constexpr (VW == 4) {   // a nibble per lane, eight lanes to a word (i of lane 8j is a multiple of 32)
+            unsigned w = 0u;
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) w |= (v.v[k] > 0.f ? 1u : 0u) << k;
+            w <<= (threadIdx.x & 7) * 4;
+            w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
+            if ((threadIdx.x & 7) == 0 && on) a.bits[i >> 5] = w;
+        } else {                   // a bit per lane: the wave's ballot is two words (i of lane 0 is a multiple of 64)
+            const unsigned long long m = __ballot(v.v[0] > 0.f);
+            if ((threadIdx.x & 63) == 0 && on) { a.bits[i >> 5] = (uint32_t)m; a.bits[(i >> 5) + 1] = (uint32_t)(m >> 32); }
+        }
+    }
+}
+
+// dx = dy where the forward output was > 0, from the bitmap bias_act wrote: 2 map transfers instead of 3
+template <int VW>
+__global__ __launch_bounds__(256) void relu_bits_kernel(const uint32_t* __restrict__ bits, const float* __restrict__ dy,
+                                                        float* __restrict__ dx, long long total) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * VW;
+    if (i >= total) return;
+    const unsigned w = bits[i >> 5] >> (unsigned)(i & 31);
+    const Vec<VW> g = vload<VW>(dy + i);
+    Vec<VW> r;
+    #pragma unroll
+    for (int k = 0; k < VW; ++k) r.v[k] = ((w >> k) & 1u) ? g.v[k] : 0.f;
+    vstore<VW>(dx + i, r);
 }
 
 template <int VW>
@@ -52,16 +85,30 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
 
 extern "C" {
 
+size_t lgd_relu_bits_words(long long total) { return total < 1 ? 0 : (size_t)((total + 63) / 64) * 2; }
+
 int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, int N, int C, int HW, int relu, float* out,
-                     void* stream) {
+                     uint32_t* relu_bits, void* stream) {
     if (!x || !out || N < 1 || C < 1 || HW < 1) return LGD_EINVAL;
-    lgd::BiasActArgs a{x, bias, residual, out, (long long)N * C * HW, C, HW, relu ? 1 : 0};
+    lgd::BiasActArgs a{x, bias, residual, out, relu_bits, (long long)N * C * HW, C, HW, relu ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const bool al = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)(residual ? residual : x)) & 15) == 0;
     if (HW % 4 == 0 && al) {
         LGD_LAUNCH("bias_act_kernel", lgd::bias_act_kernel<4>, dim3((unsigned)((a.total / 4 + 255) / 256)), dim3(256), 0, st, a);
     } else {
         LGD_LAUNCH("bias_act_kernel", lgd::bias_act_kernel<1>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
+    }
+    return lgd::check_launch();
+}
+
+int lgd_relu_bits_bwd(const uint32_t* relu_bits, const float* dy, long long total, float* dx, void* stream) {
+    if (!relu_bits || !dy || !dx || total < 1) return LGD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+    if (total % 4 == 0 && al) {
+        LGD_LAUNCH("relu_bits_kernel", lgd::relu_bits_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, relu_bits, dy, dx, total);
+    } else {
+        LGD_LAUNCH("relu_bits_kernel", lgd::relu_bits_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, relu_bits, dy, dx, total);
     }
     return lgd::check_launch();
 }

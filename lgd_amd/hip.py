@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -68,7 +68,9 @@ SIGNATURES = {
     "lgd_wino_filter_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp]),
     "lgd_wino_filter_bwd": (c_i, [c_fp, ctypes.c_longlong, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_in_t_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
-    "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_relu_bits_words": (c_sz, [ctypes.c_longlong]),
+    "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_relu_bits_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_relu_mask_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_anchor_match": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_box_reg_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),

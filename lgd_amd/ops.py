@@ -1250,35 +1250,43 @@ def deform_conv3x3(x, offset, mask, weight, bias=None, stride=1, padding=1, dila
 
 
 # ------------------------------------------------------------------------------------------------ student conv epilogues
+def _relu_bits(lib, numel, device):
+    """workspace of the 1-bit ReLU mask bias_act writes (element e = bit e % 32 of word e // 32)."""
+    return torch.empty(int(lib.lgd_relu_bits_words(int(numel))), dtype=torch.int32, device=device)
+
+
 class _BiasAct(torch.autograd.Function):
-    """relu(x + bias[c] (+ residual)) in one pass; backward = the ReLU mask of the saved output on the incoming gradient
-    (shared by x and the residual), bias gradient only if the bias is a parameter (FrozenBN shifts are buffers)."""
+    """relu(x + bias[c] (+ residual)) in one pass; backward = the ReLU mask on the incoming gradient (shared by x and the
+    residual) from the 1-bit-per-element bitmap the forward wrote (2 map transfers instead of 3, and the output is not kept
+    alive for the mask), bias gradient only if the bias is a parameter (FrozenBN shifts are buffers)."""
 
     @staticmethod
     def forward(ctx, x, bias, residual, relu):
         hip.require_gpu(x)
+        lib = hip.load()
         x = hip.dense_f32(x)
         bias = hip.dense_f32(bias) if bias is not None else None
         residual = hip.dense_f32(residual) if residual is not None else None
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         out = torch.empty_like(x)
-        hip.check(hip.load().lgd_bias_act_fwd(hip.ptr(x), hip.ptr(bias) if bias is not None else None,
-                                              hip.ptr(residual) if residual is not None else None, N, C, HW, int(relu),
-                                              hip.ptr(out), hip.stream_ptr()), "lgd_bias_act_fwd")
+        bits = _relu_bits(lib, x.numel(), x.device) if relu and any(ctx.needs_input_grad) else None
+        hip.check(lib.lgd_bias_act_fwd(hip.ptr(x), hip.ptr(bias) if bias is not None else None,
+                                       hip.ptr(residual) if residual is not None else None, N, C, HW, int(relu),
+                                       hip.ptr(out), hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_bias_act_fwd")
         ctx.relu = bool(relu)
         if relu:
-            ctx.save_for_backward(out)
+            ctx.save_for_backward(bits)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         dy = hip.dense_f32(dy)
         if ctx.relu:
-            (out,) = ctx.saved_tensors
+            (bits,) = ctx.saved_tensors
             dz = torch.empty_like(dy)
-            hip.check(hip.load().lgd_relu_mask_bwd(hip.ptr(out), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
-                      "lgd_relu_mask_bwd")
+            hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
+                      "lgd_relu_bits_bwd")
         else:
             dz = dy
         db = dz.sum((0, 2, 3)) if ctx.needs_input_grad[1] else None
@@ -1294,7 +1302,7 @@ class _PointwiseConvBN(torch.autograd.Function):
     """1x1 / stride 1 convolution with a folded frozen per-channel affine, as ONE autograd node:
         out = relu?( conv(x, w * scale[:, None, None, None]) + shift[c] (+ residual) )
     [d2-memory: conv -> FrozenBN (-> += shortcut) -> relu of the bottleneck blocks, SURVEY.md appendix A].  The filter fold, the
-    library GEMM, the bias / residual / ReLU epilogue kernel and, backward, the ReLU mask kernel, the input-gradient GEMM and the
+    library GEMM, the bias / residual / ReLU epilogue kernel (which also writes the 1-bit ReLU mask) and, backward, the mask kernel, the input-gradient GEMM and the
     weight gradient as per-image NT GEMMs on the NCHW maps run under a single node -- three autograd nodes and their host
     bookkeeping less per convolution than fold * conv1x1 * bias_act, which is what bounds the step at 2 images per GPU."""
 
@@ -1308,20 +1316,22 @@ class _PointwiseConvBN(torch.autograd.Function):
         residual = hip.dense_f32(residual) if residual is not None else None
         N, C = y.shape[0], y.shape[1]
         out = torch.empty_like(y)
+        bits = _relu_bits(lib, y.numel(), y.device) if relu and any(ctx.needs_input_grad) else None
         hip.check(lib.lgd_bias_act_fwd(hip.ptr(y), hip.ptr(shift), hip.ptr(residual) if residual is not None else None, N, C,
-                                       y.numel() // (N * C), int(relu), hip.ptr(out), hip.stream_ptr()), "lgd_bias_act_fwd")
+                                       y.numel() // (N * C), int(relu), hip.ptr(out), hip.ptr(bits) if bits is not None else None,
+                                       hip.stream_ptr()), "lgd_bias_act_fwd")
         ctx.relu = bool(relu)
-        ctx.save_for_backward(x, wf, scale, out if relu else None)
+        ctx.save_for_backward(x, wf, scale, bits)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, wf, scale, out = ctx.saved_tensors
+        x, wf, scale, bits = ctx.saved_tensors
         dy = hip.dense_f32(dy)
         if ctx.relu:
             dz = torch.empty_like(dy)
-            hip.check(hip.load().lgd_relu_mask_bwd(hip.ptr(out), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
-                      "lgd_relu_mask_bwd")
+            hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
+                      "lgd_relu_bits_bwd")
         else:
             dz = dy
         dx = dw = None

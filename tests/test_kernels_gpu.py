@@ -806,9 +806,12 @@ def test_conv3x3_chain(N, Ci, Cos, hws, relus, bias, need_x):
 
 # ------------------------------------------------------------------------------------------- student conv epilogues
 @pytest.mark.parametrize("N,C,H,W,res,relu,bias_grad", [(2, 8, 6, 8, True, True, False), (1, 5, 3, 5, False, True, True),
-                                                        (3, 16, 7, 4, True, False, True), (2, 4, 5, 5, False, False, False)])
+                                                        (3, 16, 7, 4, True, False, True), (2, 4, 5, 5, False, False, False),
+                                                        (2, 64, 50, 84, True, True, False), (3, 7, 33, 37, True, True, True),
+                                                        (1, 3, 9, 20, False, True, False)])
 def test_bias_act_fwd_bwd(N, C, H, W, res, relu, bias_grad):
-    """relu(x + bias[c] + residual) in one pass == the three torch ops (bit-exact: same fp32 additions in the same order)."""
+    """relu(x + bias[c] + residual) in one pass == the three torch ops (bit-exact: same fp32 additions in the same order); the
+    backward takes the ReLU mask from the 1-bit-per-element bitmap the forward wrote (float4 and scalar layouts, partial words)."""
     import torch.nn.functional as F
     from lgd_amd import ops
     x = torch.from_numpy(synth.det_uniform((N, C, H, W), 921, -1.0, 1.0)).to(DEV).requires_grad_(True)
