@@ -323,6 +323,9 @@ int lgd_fcos_targets(const float* shifts, const int32_t* level_locs_host, const 
  * lgd_relu_mask_bwd: dx = dy where the saved forward output y > 0, else 0 (total elements)
  */
 size_t lgd_relu_bits_words(long long total);
+/* frozen stem epilogue [d2-memory: BasicStem -- conv1 -> FrozenBN -> relu -> max_pool2d(3, stride 2, padding 1)]:
+ * out (N, C, (H-1)/2+1, (W-1)/2+1) = max_pool2d(relu(y + bias[c]), 3, 2, 1) of the conv output y (N, C, H, W) in one pass. Forward only. */
+int lgd_stem_bias_relu_maxpool(const float* y, const float* bias, int N, int C, int H, int W, float* out, void* stream);
 int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, int N, int C, int HW, int relu, float* out,
                      uint32_t* relu_bits, void* stream);
 int lgd_relu_bits_bwd(const uint32_t* relu_bits, const float* dy, long long total, float* dx, void* stream);

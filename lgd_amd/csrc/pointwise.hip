@@ -126,3 +126,85 @@ int lgd_relu_mask_bwd(const float* y, const float* dy, long long total, float* d
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Frozen stem epilogue: out = max_pool2d(relu(y + bias[c]), 3, stride 2, padding 1) of the 7x7 / stride-2 stem convolution's output y
+// [d2-memory: BasicStem.forward -- conv1 -> FrozenBN -> relu_ -> max_pool2d(kernel 3, stride 2, padding 1); SURVEY.md appendix A].
+// relu and the bias add are monotonic, so max(relu(v + b)) = relu(max(v) + b): one pass reads the conv output once (through the
+// caches for the overlapping windows) and writes the quarter-size map.  torch: bias / ReLU pass (2 maps) + pooling kernel (1.25
+// maps at 1.7 TB/s): 0.2 + 0.4 ms per step at config 2 for a map that is 550 MB.  Forward only: the stem is frozen (FREEZE_AT >= 1).
+namespace lgd {
+
+__global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict__ y, const float* __restrict__ bias, float* __restrict__ out,
+                                                        int C, int H, int W, int Ho, int Wo, long long total) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int ox = (int)(o % Wo), oy = (int)((o / Wo) % Ho);
+    const long long plane = o / ((long long)Wo * Ho);            // n * C + c
+    const float* p = y + plane * H * W;
+    const int x0 = 2 * ox - 1, y0 = 2 * oy - 1;
+    float m = -INFINITY;                                          // the padding never wins: the window always holds (2 oy, 2 ox)
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int yy = y0 + i;
+        if (yy < 0 || yy >= H) continue;
+        const float* row = p + (size_t)yy * W;
+        #pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int xx = x0 + j;
+            if (xx >= 0 && xx < W) m = fmaxf(m, row[xx]);   // plain loads: neighbouring windows re-read these lines from the caches
+        }
+    }
+    out[o] = fmaxf(m + bias[(int)(plane % C)], 0.f);
+}
+
+// W % 4 == 0: a thread produces TWO horizontally adjacent outputs from one aligned float4 per input row (columns 4k .. 4k+3) and the
+// column 4k-1 from its left neighbour lane (a DPP shift; the wave's first lane loads it): fully coalesced 16-byte loads instead of
+// nine stride-2 dword loads per output (measured 319 -> 170 us on the 8 x 64 x 400 x 672 stem map; torch: ~600 us for the two passes).
+__global__ __launch_bounds__(256) void stem_pool_pair_kernel(const float* __restrict__ y, const float* __restrict__ bias, float* __restrict__ out,
+                                                             int C, int H, int W, int Ho, int Wo, long long total_pairs) {
+    const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool on = u < total_pairs;
+    const long long uu = on ? u : total_pairs - 1;
+    const int WP = Wo >> 1;
+    const int k = (int)(uu % WP), oy = (int)((uu / WP) % Ho);
+    const long long plane = uu / ((long long)WP * Ho);
+    const float* p = y + plane * H * W;
+    const int lane = threadIdx.x & 63;
+    float m0 = -INFINITY, m1 = -INFINITY;
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int yy = 2 * oy - 1 + i;
+        const bool yok = yy >= 0 && yy < H;
+        const float* row = p + (size_t)(yok ? yy : 0) * W + 4 * k;
+        float4 v = *reinterpret_cast<const float4*>(row);
+        float left = wave_shr1(v.w);                       // column 4k-1 = the previous pair's last column (same row unless k == 0)
+        if (lane == 0 && k > 0) left = row[-1];
+        if (k == 0) left = -INFINITY;
+        if (yok) {
+            m0 = fmaxf(m0, fmaxf(fmaxf(left, v.x), v.y));   // output 2k  : columns 4k-1, 4k, 4k+1
+            m1 = fmaxf(m1, fmaxf(fmaxf(v.y, v.z), v.w));    // output 2k+1: columns 4k+1, 4k+2, 4k+3
+        }
+    }
+    if (!on) return;
+    const float b = bias[(int)(plane % C)];
+    float2 r = make_float2(fmaxf(m0 + b, 0.f), fmaxf(m1 + b, 0.f));
+    *reinterpret_cast<float2*>(out + (plane * Ho + oy) * (long long)Wo + 2 * k) = r;
+}
+
+}  // namespace lgd
+
+extern "C" int lgd_stem_bias_relu_maxpool(const float* y, const float* bias, int N, int C, int H, int W, float* out, void* stream) {
+    if (!y || !bias || !out || N < 1 || C < 1 || H < 1 || W < 1) return LGD_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;         // floor((H + 2 - 3) / 2) + 1
+    const long long total = (long long)N * C * Ho * Wo;
+    if (W % 4 == 0 && (((uintptr_t)y | (uintptr_t)out) & 15) == 0) {   // Wo = W / 2 is even, rows of y / out stay 16- / 8-byte aligned
+        const long long pairs = total / 2;
+        LGD_LAUNCH("stem_pool_kernel", lgd::stem_pool_pair_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
+                   (hipStream_t)stream, y, bias, out, C, H, W, Ho, Wo, pairs);
+        return lgd::check_launch();
+    }
+    LGD_LAUNCH("stem_pool_kernel", lgd::stem_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+               y, bias, out, C, H, W, Ho, Wo, total);
+    return lgd::check_launch();
+}

@@ -1298,6 +1298,17 @@ def bias_act(x, bias=None, residual=None, relu=True):
     return _BiasAct.apply(x, bias, residual, bool(relu))
 
 
+def stem_bias_relu_maxpool(y, bias):
+    """max_pool2d(relu(y + bias[c]), 3, 2, 1) of the frozen stem convolution's output in one pass (no autograd: the stem is frozen)."""
+    hip.require_gpu(y, bias)
+    y, bias = hip.dense_f32(y.detach()), hip.dense_f32(bias.detach())
+    N, C, H, W = y.shape
+    out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=y.device)
+    hip.check(hip.load().lgd_stem_bias_relu_maxpool(hip.ptr(y), hip.ptr(bias), N, C, H, W, hip.ptr(out), hip.stream_ptr()),
+              "lgd_stem_bias_relu_maxpool")
+    return out
+
+
 class _PointwiseConvBN(torch.autograd.Function):
     """1x1 / stride 1 convolution with a folded frozen per-channel affine, as ONE autograd node:
         out = relu?( conv(x, w * scale[:, None, None, None]) + shift[c] (+ residual) )

@@ -137,6 +137,18 @@ class Stem(nn.Module):
         self.conv1 = ConvBN(cin, cout, 7, 2, 3)
 
     def forward(self, x):
+        c = self.conv1
+        if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and (x.requires_grad or c.weight.requires_grad)):
+            # frozen stem (FREEZE_AT >= 1, the reference's configs): conv with the folded filter, then bias + ReLU + 3x3/2 max-pool
+            # in ONE pass over the 550 MB conv output (ops.stem_bias_relu_maxpool) instead of an epilogue pass and a pooling pass
+            scale, shift = c.norm.scale_shift()
+            key = (id(c.weight), c.weight._version, id(scale))
+            if getattr(c, "_fold_key", None) != key:
+                with torch.no_grad():
+                    c._fold = c.weight * scale.view(-1, 1, 1, 1)
+                c._fold_key = key
+            with torch.no_grad():
+                return ops.stem_bias_relu_maxpool(F.conv2d(x, c._fold, None, c.stride, c.padding), shift)
         return F.max_pool2d(self.conv1(x, relu=True), 3, 2, 1)
 
 

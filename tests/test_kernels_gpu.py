@@ -1213,3 +1213,35 @@ def test_conv3x3_stride2_matches_strided_conv(hw):
     assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= tol * scale(xr.grad)
     assert float((wg.grad.cpu().double() - wr.grad).abs().max()) <= tol * scale(wr.grad)
     assert float((bg.grad.cpu().double() - br.grad).abs().max()) <= tol * scale(br.grad)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 400, 672), (1, 5, 7, 9), (3, 4, 8, 6), (1, 2, 1, 1), (1, 3, 6, 8), (2, 2, 5, 12), (1, 1, 3, 260)])
+def test_stem_bias_relu_maxpool(N, C, H, W):
+    """ops.stem_bias_relu_maxpool (frozen stem epilogue [d2-memory: BasicStem: FrozenBN shift -> relu -> max_pool2d(3, 2, 1)]) ==
+    the three torch ops, bit for bit (bias add and ReLU are monotonic, so they commute with the max); and the ResNet stem that uses it
+    == the unfused stem."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    y = torch.from_numpy(synth.det_uniform((N, C, H, W), 981, -3.0, 3.0)).to(DEV)
+    b = torch.from_numpy(synth.det_uniform((C,), 982, -1.0, 1.0)).to(DEV)
+    got = ops.stem_bias_relu_maxpool(y, b)
+    ref = F.max_pool2d(F.relu(y + b.view(1, -1, 1, 1)), 3, 2, 1)
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref)
+
+
+def test_resnet_stem_fused_equals_unfused():
+    from lgd_amd.student.resnet import Stem
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    stem = Stem(3, 64).to(DEV)
+    stem.conv1.norm.weight.uniform_(0.5, 1.5); stem.conv1.norm.bias.uniform_(-0.5, 0.5)
+    stem.conv1.norm.running_mean.uniform_(-0.2, 0.2); stem.conv1.norm.running_var.uniform_(0.5, 1.5)
+    for p in stem.parameters():
+        p.requires_grad = False
+    x = torch.randn(2, 3, 96, 160, device=DEV)
+    with torch.no_grad():
+        fused = stem(x)
+        unfused = F.max_pool2d(stem.conv1(x, relu=True), 3, 2, 1)
+    assert fused.shape == unfused.shape
+    assert torch.allclose(fused, unfused, rtol=1e-5, atol=1e-6)
