@@ -1356,6 +1356,60 @@ class _PointwiseConvBN(torch.autograd.Function):
         return dx, dw, None, None, (dz if ctx.needs_input_grad[4] else None), None
 
 
+class _PointwiseConvBNSkip(torch.autograd.Function):
+    """conv1 of an identity-shortcut bottleneck block together with the shortcut itself:
+        out, skip = relu(conv1x1(x, w * scale) + shift), x
+    [d2-memory: BottleneckBlock.forward -- out = conv1(x) ...; out += shortcut (= x); SURVEY.md appendix A].  `skip` goes into conv3's
+    residual add, so BOTH gradients of x arrive at this node, and the input-gradient GEMM accumulates onto the shortcut's gradient
+    (beta = 1: dx = W^T dz + d_skip) instead of autograd adding the two maps in a separate pass over the block's input-size map
+    (3 map transfers; measured per block at config 2, tools/skip_accum_probe.py: res3 350 -> 200 us, res4 255 -> 208 us)."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, shift):
+        hip.require_gpu(x, w)
+        lib = hip.load()
+        x = hip.dense_f32(x)
+        wf = w * scale.view(-1, 1, 1, 1)
+        y = F.conv2d(x, wf)
+        N, C = y.shape[0], y.shape[1]
+        out = torch.empty_like(y)
+        bits = _relu_bits(lib, y.numel(), y.device) if any(ctx.needs_input_grad) else None
+        hip.check(lib.lgd_bias_act_fwd(hip.ptr(y), hip.ptr(shift), None, N, C, y.numel() // (N * C), 1, hip.ptr(out),
+                                       hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_bias_act_fwd")
+        ctx.save_for_backward(x, wf, scale, bits)
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, wf, scale, bits = ctx.saved_tensors
+        N, Ci, Co = x.shape[0], x.shape[1], wf.shape[0]
+        dx = dw = None
+        dz = None
+        if dy is not None:
+            dy = hip.dense_f32(dy)
+            dz = torch.empty_like(dy)
+            hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
+                      "lgd_relu_bits_bwd")
+        if ctx.needs_input_grad[0]:
+            if dz is None:
+                dx = dskip
+            elif dskip is None:
+                dx = torch.ops.aten.convolution_backward(dz, x, wf, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+            else:   # W^T dz accumulated onto the shortcut's gradient inside the GEMM (out of place: dskip may be shared)
+                dx = torch.baddbmm(hip.dense_f32(dskip).view(N, Ci, -1), wf.view(Co, Ci).t().unsqueeze(0).expand(N, Ci, Co),
+                                   dz.view(N, Co, -1)).view_as(x)
+        if ctx.needs_input_grad[1] and dz is not None:
+            dw = torch.bmm(dz.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2)).sum(0)
+            dw = (dw * scale.view(-1, 1)).view(Co, Ci, 1, 1)
+        return dx, dw, None, None
+
+
+def pointwise_conv_bn_skip(x, w, scale, shift):
+    """(relu(conv1x1(x, w * scale) + shift), x): conv1 + identity shortcut of a bottleneck block as one node (see above)."""
+    return _PointwiseConvBNSkip.apply(x, w, scale, shift)
+
+
 def pointwise_conv_bn(x, w, scale, shift, residual=None, relu=True):
     """relu?(conv1x1(x, w * scale) + shift (+ residual)); scale / shift are the frozen affine of the FrozenBN that follows."""
     return _PointwiseConvBN.apply(x, w, scale, shift, residual, bool(relu))

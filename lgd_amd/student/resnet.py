@@ -94,6 +94,13 @@ class Bottleneck(nn.Module):
         shared = self.conv1._pointwise_s2 and self.shortcut is not None and self.shortcut._pointwise_s2
         if shared:  # conv1 and the projection shortcut read the same every-other-pixel view of x: take it once
             x = ConvBN.subsample2(x)
+        if (self.shortcut is None and self.conv1._pointwise and x.is_cuda and x.dtype == torch.float32
+                and torch.is_grad_enabled() and x.requires_grad):
+            # identity block: conv1 and the shortcut as one node, so that conv1's input-gradient GEMM accumulates onto the
+            # shortcut's gradient instead of a separate add pass (ops._PointwiseConvBNSkip)
+            scale, shift = self.conv1.norm.scale_shift()
+            out, sc = ops.pointwise_conv_bn_skip(x, self.conv1.weight, scale, shift)
+            return self.conv3(self.conv2(out, relu=True), relu=True, residual=sc)
         out = self.conv1(x, relu=True, subsampled=shared)
         out = self.conv2(out, relu=True)
         sc = self.shortcut(x, subsampled=shared) if self.shortcut is not None else x

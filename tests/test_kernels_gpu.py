@@ -1245,3 +1245,63 @@ def test_resnet_stem_fused_equals_unfused():
         unfused = F.max_pool2d(stem.conv1(x, relu=True), 3, 2, 1)
     assert fused.shape == unfused.shape
     assert torch.allclose(fused, unfused, rtol=1e-5, atol=1e-6)
+
+
+def test_identity_bottleneck_skip_node_vs_fp64():
+    """An identity-shortcut Bottleneck on the GPU (conv1 + shortcut as ops._PointwiseConvBNSkip: the input-gradient GEMM accumulates
+    onto the shortcut's gradient, beta = 1) against the same block in fp64 on the CPU [d2-memory: BottleneckBlock.forward]: output,
+    input gradient (the sum of the two paths) and the three filter gradients; also with only the skip path / only the conv path
+    receiving a gradient."""
+    import copy
+    from lgd_amd import ops
+    from lgd_amd.student.resnet import Bottleneck
+    torch.manual_seed(11)
+    blk = Bottleneck(256, 256, 64, 1)
+    for m in (blk.conv1, blk.conv2, blk.conv3):
+        m.norm.weight.uniform_(0.5, 1.5); m.norm.bias.uniform_(-0.3, 0.3)
+        m.norm.running_mean.uniform_(-0.2, 0.2); m.norm.running_var.uniform_(0.5, 1.5)
+    ref = copy.deepcopy(blk).double()
+    blk = blk.to(DEV)
+    x = torch.from_numpy(synth.det_uniform((2, 256, 24, 36), 1501, -1.0, 1.0))
+    gy = torch.from_numpy(synth.det_uniform((2, 256, 24, 36), 1502, -1.0, 1.0))
+    xg = x.to(DEV).requires_grad_(True)
+    y = blk(xg)
+    names = [type(n).__name__ for n in _graph_nodes(y.grad_fn)]
+    assert any("PointwiseConvBNSkip" in n for n in names), names
+    y.backward(gy.to(DEV))
+    import torch.nn.functional as F
+
+    def cbn(c, t, pad=0):   # conv -> FrozenBN, plain torch in fp64 (the product modules have no CPU path)
+        scale = c.norm.weight * (c.norm.running_var + c.norm.eps).rsqrt()
+        shift = c.norm.bias - c.norm.running_mean * scale
+        return F.conv2d(t, c.weight, None, 1, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    xr = x.double().requires_grad_(True)
+    yr = F.relu(cbn(ref.conv3, F.relu(cbn(ref.conv2, F.relu(cbn(ref.conv1, xr)), 1))) + xr)
+    yr.backward(gy.double())
+    assert cm.rel_err(y, yr) < 5e-5
+    assert cm.rel_err(xg.grad, xr.grad) < 1e-4
+    for a, b in zip(blk.parameters(), ref.parameters()):
+        assert cm.rel_err(a.grad, b.grad) < 1e-4
+    # partial gradients through the node itself
+    w, scale, shift = blk.conv1.weight.detach(), *blk.conv1.norm.scale_shift()
+    x2 = x.to(DEV).requires_grad_(True)
+    out, skip = ops.pointwise_conv_bn_skip(x2, w, scale, shift)
+    g = torch.from_numpy(synth.det_uniform(tuple(skip.shape), 1503, -1.0, 1.0)).to(DEV)
+    (gx,) = torch.autograd.grad(skip, x2, g, retain_graph=True)
+    assert torch.equal(gx, g)
+    go = torch.from_numpy(synth.det_uniform(tuple(out.shape), 1504, -1.0, 1.0)).to(DEV)
+    (gx2,) = torch.autograd.grad(out, x2, go)
+    x3 = x.to(DEV).requires_grad_(True)
+    (gx3,) = torch.autograd.grad(ops.pointwise_conv_bn(x3, w, scale, shift, None, True), x3, go)
+    assert cm.rel_err(gx2, gx3) < 1e-6
+
+
+def _graph_nodes(fn, seen=None):
+    seen = set() if seen is None else seen
+    if fn is None or fn in seen:
+        return []
+    seen.add(fn)
+    out = [fn]
+    for nxt, _ in fn.next_functions:
+        out += _graph_nodes(nxt, seen)
+    return out
