@@ -1343,6 +1343,7 @@ class _PointwiseConvBN(torch.autograd.Function):
             dz = torch.empty_like(dy)
             hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
                       "lgd_relu_bits_bwd")
+            dz._lgd_exclusive = True   # fresh; after the GEMMs below its only reader is whoever receives the residual gradient
         else:
             dz = dy
         dx = dw = None
@@ -1396,9 +1397,16 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
             elif dskip is None:
                 dx = torch.ops.aten.convolution_backward(dz, x, wf, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-            else:   # W^T dz accumulated onto the shortcut's gradient inside the GEMM (out of place: dskip may be shared)
-                dx = torch.baddbmm(hip.dense_f32(dskip).view(N, Ci, -1), wf.view(Co, Ci).t().unsqueeze(0).expand(N, Ci, Co),
-                                   dz.view(N, Co, -1)).view_as(x)
+            else:
+                # W^T dz accumulated onto the shortcut's gradient inside the GEMM.  In place when the incoming tensor is the fresh,
+                # otherwise unreferenced ReLU-masked gradient that conv3's node (_PointwiseConvBN.backward) produced for its
+                # residual input and tagged as such; any other tensor (a sum autograd built, a caller's buffer) is left untouched:
+                # torch.baddbmm out of place = a copy of it + the same GEMM (measured: the copy costs what the add pass did).
+                acc = hip.dense_f32(dskip)
+                own = getattr(dskip, "_lgd_exclusive", False) and acc is dskip
+                a3 = acc.view(N, Ci, -1)
+                dx = torch.baddbmm(a3, wf.view(Co, Ci).t().unsqueeze(0).expand(N, Ci, Co), dz.view(N, Co, -1),
+                                   **({"out": a3} if own else {})).view_as(x)
         if ctx.needs_input_grad[1] and dz is not None:
             dw = torch.bmm(dz.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2)).sum(0)
             dw = (dw * scale.view(-1, 1)).view(Co, Ci, 1, 1)

@@ -1282,6 +1282,28 @@ def test_identity_bottleneck_skip_node_vs_fp64():
     assert cm.rel_err(xg.grad, xr.grad) < 1e-4
     for a, b in zip(blk.parameters(), ref.parameters()):
         assert cm.rel_err(a.grad, b.grad) < 1e-4
+    # the in-place accumulation must be taken (the residual gradient of conv3's node is tagged) and must not touch foreign tensors
+    from lgd_amd import ops as _ops
+    calls = []
+    orig = torch.baddbmm
+
+    def spy(inp, b1, b2, **kw):
+        calls.append("out" in kw)
+        return orig(inp, b1, b2, **kw)
+    torch.baddbmm = spy
+    try:
+        x4 = x.to(DEV).requires_grad_(True)
+        blk(x4).backward(gy.to(DEV))
+        assert calls == [True], calls
+        calls.clear()
+        x5 = x.to(DEV).requires_grad_(True)
+        o5, s5 = _ops.pointwise_conv_bn_skip(x5, blk.conv1.weight.detach(), *blk.conv1.norm.scale_shift())
+        gs = torch.from_numpy(synth.det_uniform(tuple(s5.shape), 1505, -1.0, 1.0)).to(DEV)
+        keep = gs.clone()
+        torch.autograd.backward([o5, s5], [torch.ones_like(o5), gs])
+        assert calls == [False] and torch.equal(gs, keep)   # a caller's gradient buffer is not accumulated into
+    finally:
+        torch.baddbmm = orig
     # partial gradients through the node itself
     w, scale, shift = blk.conv1.weight.detach(), *blk.conv1.norm.scale_shift()
     x2 = x.to(DEV).requires_grad_(True)
