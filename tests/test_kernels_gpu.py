@@ -1327,3 +1327,45 @@ def _graph_nodes(fn, seen=None):
     for nxt, _ in fn.next_functions:
         out += _graph_nodes(nxt, seen)
     return out
+
+
+def test_fpn_topdown_vs_fp64_definition():
+    """student/fpn.py on the GPU (lateral 1x1 convs as ops.conv1x1 GEMMs, bias + top-down sum fused in ops.bias_act, 3x3 output
+    convs on the Winograd / library path, p6 / p7 through ops.conv3x3_stride2) against the FPN definition in fp64
+    [d2-memory: FPN.forward + LastLevelP6P7, SURVEY.md appendix A]: the five maps and every parameter's gradient."""
+    import copy
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from lgd_amd.student.fpn import FPN, LastLevelP6P7
+    torch.manual_seed(21)
+    chans = (128, 256, 512)
+    fpn = FPN(nn.Sequential(), ("res3", "res4", "res5"), chans, 64, LastLevelP6P7(chans[-1], 64, "res5"))
+    ref = copy.deepcopy(fpn).double()
+    fpn = fpn.to(DEV)
+    sizes = ((64, 96), (32, 48), (16, 24))
+    feats = {k: torch.from_numpy(synth.det_uniform((2, c, h, w), 1600 + i, -1.0, 1.0))
+             for i, (k, c, (h, w)) in enumerate(zip(("res3", "res4", "res5"), chans, sizes))}
+    fg = {k: v.to(DEV).requires_grad_(True) for k, v in feats.items()}
+    out = fpn(fg)
+    assert list(out.keys()) == ["p3", "p4", "p5", "p6", "p7"]
+    fr = {k: v.double().requires_grad_(True) for k, v in feats.items()}
+    prev, res = None, []
+    for k, idx in (("res5", 5), ("res4", 4), ("res3", 3)):
+        lat = getattr(ref, "fpn_lateral%d" % idx)
+        o = getattr(ref, "fpn_output%d" % idx)
+        t = F.conv2d(fr[k], lat.weight, lat.bias)
+        if prev is not None:
+            t = t + F.interpolate(prev, scale_factor=2.0, mode="nearest")
+        prev = t
+        res.insert(0, F.conv2d(t, o.weight, o.bias, 1, 1))
+    p6 = F.conv2d(fr["res5"], ref.top_block.p6.weight, ref.top_block.p6.bias, 2, 1)
+    res += [p6, F.conv2d(F.relu(p6), ref.top_block.p7.weight, ref.top_block.p7.bias, 2, 1)]
+    gs = [torch.from_numpy(synth.det_uniform(tuple(r.shape), 1650 + i, -1.0, 1.0)) for i, r in enumerate(res)]
+    torch.autograd.backward(res, [g.double() for g in gs])
+    torch.autograd.backward(list(out.values()), [g.to(DEV) for g in gs])
+    for (k, a), b in zip(out.items(), res):
+        assert cm.rel_err(a, b) < 5e-5, k
+    for k in feats:
+        assert cm.rel_err(fg[k].grad, fr[k].grad) < 1e-4, k
+    for (n, a), (_, b) in zip(fpn.named_parameters(), ref.named_parameters()):
+        assert cm.rel_err(a.grad, b.grad) < 1e-4, n
