@@ -328,6 +328,9 @@ size_t lgd_relu_bits_words(long long total);
 int lgd_stem_bias_relu_maxpool(const float* y, const float* bias, int N, int C, int H, int W, float* out, void* stream);
 int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, int N, int C, int HW, int relu, float* out,
                      uint32_t* relu_bits, void* stream);
+/* weight gradient of a pointwise convolution from per-image partial products: out[o][i] = scale[o] * sum_n part[n][o][i]
+ * (scale may be NULL); part (N, Co, Ci), out (Co, Ci). */
+int lgd_sum_batch_scale(const float* part, const float* scale, int N, int Co, int Ci, float* out, void* stream);
 int lgd_relu_bits_bwd(const uint32_t* relu_bits, const float* dy, long long total, float* dx, void* stream);
 int lgd_relu_mask_bwd(const float* y, const float* dy, long long total, float* dx, void* stream);
 

@@ -208,3 +208,26 @@ extern "C" int lgd_stem_bias_relu_maxpool(const float* y, const float* bias, int
                y, bias, out, C, H, W, Ho, Wo, total);
     return lgd::check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a pointwise convolution from its per-image partial products: out[o][i] = scale[o] * sum_n part[n][o][i]
+// (part = bmm(dz (N, Co, HW), x^T (N, HW, Ci)); scale = the frozen per-channel factor of the FrozenBN folded into the filter, or
+// null).  torch: a reduce launch + a scale launch per convolution (52 - 200 tiny launches per step).
+namespace lgd {
+__global__ __launch_bounds__(256) void sum_batch_scale_kernel(const float* __restrict__ part, const float* __restrict__ scale,
+                                                              float* __restrict__ out, int N, int Co, int Ci) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x, per = (long long)Co * Ci;
+    if (i >= per) return;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += part[(long long)n * per + i];
+    out[i] = scale ? s * scale[(int)(i / Ci)] : s;
+}
+}  // namespace lgd
+
+extern "C" int lgd_sum_batch_scale(const float* part, const float* scale, int N, int Co, int Ci, float* out, void* stream) {
+    if (!part || !out || N < 1 || Co < 1 || Ci < 1) return LGD_EINVAL;
+    const long long per = (long long)Co * Ci;
+    LGD_LAUNCH("sum_batch_scale_kernel", lgd::sum_batch_scale_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0,
+               (hipStream_t)stream, part, scale, out, N, Co, Ci);
+    return lgd::check_launch();
+}

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -71,6 +71,7 @@ SIGNATURES = {
     "lgd_relu_bits_words": (c_sz, [ctypes.c_longlong]),
     "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_stem_bias_relu_maxpool": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_sum_batch_scale": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_relu_bits_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_relu_mask_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_anchor_match": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),

@@ -1298,6 +1298,17 @@ def bias_act(x, bias=None, residual=None, relu=True):
     return _BiasAct.apply(x, bias, residual, bool(relu))
 
 
+def _pointwise_dw(dz, x, scale=None):
+    """dW (Co, Ci, 1, 1) = scale[o] * sum_n dz[n] (Co x HW) @ x[n]^T (HW x Ci): per-image NT GEMMs on the NCHW maps (one batched
+    launch), then batch sum + frozen scale in one small kernel."""
+    N, Co, Ci = dz.shape[0], dz.shape[1], x.shape[1]
+    part = torch.bmm(dz.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2))
+    dw = torch.empty((Co, Ci, 1, 1), dtype=torch.float32, device=dz.device)
+    hip.check(hip.load().lgd_sum_batch_scale(hip.ptr(part), hip.ptr(scale) if scale is not None else None, N, Co, Ci, hip.ptr(dw),
+                                             hip.stream_ptr()), "lgd_sum_batch_scale")
+    return dw
+
+
 def stem_bias_relu_maxpool(y, bias):
     """max_pool2d(relu(y + bias[c]), 3, 2, 1) of the frozen stem convolution's output in one pass (no autograd: the stem is frozen)."""
     hip.require_gpu(y, bias)
@@ -1318,11 +1329,12 @@ class _PointwiseConvBN(torch.autograd.Function):
     bookkeeping less per convolution than fold * conv1x1 * bias_act, which is what bounds the step at 2 images per GPU."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, shift, residual, relu):
+    def forward(ctx, x, w, scale, shift, residual, relu, wf=None):
         hip.require_gpu(x, w)
         lib = hip.load()
         x = hip.dense_f32(x)
-        wf = w * scale.view(-1, 1, 1, 1)
+        if wf is None:   # wf given: the folded filter of a FROZEN convolution, cached by the caller until the weight is written
+            wf = w * scale.view(-1, 1, 1, 1)
         y = F.conv2d(x, wf)
         residual = hip.dense_f32(residual) if residual is not None else None
         N, C = y.shape[0], y.shape[1]
@@ -1352,9 +1364,8 @@ class _PointwiseConvBN(torch.autograd.Function):
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             N, Ci, Co = x.shape[0], x.shape[1], wf.shape[0]
-            dw = torch.bmm(dz.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2)).sum(0)
-            dw = (dw * scale.view(-1, 1)).view(Co, Ci, 1, 1)
-        return dx, dw, None, None, (dz if ctx.needs_input_grad[4] else None), None
+            dw = _pointwise_dw(dz, x, scale)
+        return dx, dw, None, None, (dz if ctx.needs_input_grad[4] else None), None, None
 
 
 class _PointwiseConvBNSkip(torch.autograd.Function):
@@ -1408,8 +1419,7 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
                 dx = torch.baddbmm(a3, wf.view(Co, Ci).t().unsqueeze(0).expand(N, Ci, Co), dz.view(N, Co, -1),
                                    **({"out": a3} if own else {})).view_as(x)
         if ctx.needs_input_grad[1] and dz is not None:
-            dw = torch.bmm(dz.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2)).sum(0)
-            dw = (dw * scale.view(-1, 1)).view(Co, Ci, 1, 1)
+            dw = _pointwise_dw(dz, x, scale)
         return dx, dw, None, None
 
 
@@ -1418,9 +1428,10 @@ def pointwise_conv_bn_skip(x, w, scale, shift):
     return _PointwiseConvBNSkip.apply(x, w, scale, shift)
 
 
-def pointwise_conv_bn(x, w, scale, shift, residual=None, relu=True):
-    """relu?(conv1x1(x, w * scale) + shift (+ residual)); scale / shift are the frozen affine of the FrozenBN that follows."""
-    return _PointwiseConvBN.apply(x, w, scale, shift, residual, bool(relu))
+def pointwise_conv_bn(x, w, scale, shift, residual=None, relu=True, wf=None):
+    """relu?(conv1x1(x, w * scale) + shift (+ residual)); scale / shift are the frozen affine of the FrozenBN that follows;
+    wf: the pre-folded filter w * scale of a frozen convolution (skips the fold launch)."""
+    return _PointwiseConvBN.apply(x, w, scale, shift, residual, bool(relu), wf)
 
 
 class _Conv1x1(torch.autograd.Function):
@@ -1444,7 +1455,7 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             N, Ci = x.shape[0], x.shape[1]
             Co = w.shape[0]
-            dw = torch.bmm(dy.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2)).sum(0).view(Co, Ci, 1, 1)
+            dw = _pointwise_dw(dy, x)
         return dx, dw
 
 

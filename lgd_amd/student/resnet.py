@@ -50,6 +50,15 @@ class ConvBN(nn.Conv2d):
         # whose weight gradient transposes both operands to NHWC first (4.5 ms/step at config 2)
         self._pointwise_s2 = (k == 1 and stride == 2 and padding == 0 and groups == 1)
 
+    def _frozen_fold(self, scale):
+        """weight * scale of a frozen convolution, computed once and reused until the weight (or the FrozenBN) is written."""
+        key = (id(self.weight), self.weight._version, id(scale))
+        if getattr(self, "_fold_key", None) != key:
+            with torch.no_grad():
+                self._fold = self.weight * scale.view(-1, 1, 1, 1)
+            self._fold_key = key
+        return self._fold
+
     @staticmethod
     def subsample2(x):
         return x[:, :, ::2, ::2].contiguous()
@@ -61,7 +70,8 @@ class ConvBN(nn.Conv2d):
         if self._pointwise or self._pointwise_s2:  # fold + GEMM + epilogue (and their backward) as one autograd node
             if self._pointwise_s2 and not subsampled:
                 x = self.subsample2(x)
-            return ops.pointwise_conv_bn(x, self.weight, scale, shift, residual, relu)
+            return ops.pointwise_conv_bn(x, self.weight, scale, shift, residual, relu,
+                                         None if self.weight.requires_grad else self._frozen_fold(scale))
         if self.weight.requires_grad and self._plain3x3 and residual is None:
             # trainable 3x3 / stride 1: the scale is folded inside the Winograd filter transform (no scaled copy of the weights, and the
             # backward returns the gradient of the RAW filter); bias + ReLU ride in the output transform
@@ -69,12 +79,7 @@ class ConvBN(nn.Conv2d):
         if self.weight.requires_grad:
             w = self.weight * scale.view(-1, 1, 1, 1)
         else:  # frozen (FREEZE_AT prefix, or the backbone-freeze phase): the folded filter is reused until the weight is written
-            key = (id(self.weight), self.weight._version, id(scale))
-            if getattr(self, "_fold_key", None) != key:
-                with torch.no_grad():
-                    self._fold = self.weight * scale.view(-1, 1, 1, 1)
-                self._fold_key = key
-            w = self._fold
+            w = self._frozen_fold(scale)
         if self._plain3x3 and residual is None:  # 3x3 / stride 1: Winograd transforms + GEMMs (bias + ReLU fused in the output transform)
             return ops.conv3x3(x, w, shift, relu=relu)
         y = F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
@@ -149,13 +154,8 @@ class Stem(nn.Module):
             # frozen stem (FREEZE_AT >= 1, the reference's configs): conv with the folded filter, then bias + ReLU + 3x3/2 max-pool
             # in ONE pass over the 550 MB conv output (ops.stem_bias_relu_maxpool) instead of an epilogue pass and a pooling pass
             scale, shift = c.norm.scale_shift()
-            key = (id(c.weight), c.weight._version, id(scale))
-            if getattr(c, "_fold_key", None) != key:
-                with torch.no_grad():
-                    c._fold = c.weight * scale.view(-1, 1, 1, 1)
-                c._fold_key = key
             with torch.no_grad():
-                return ops.stem_bias_relu_maxpool(F.conv2d(x, c._fold, None, c.stride, c.padding), shift)
+                return ops.stem_bias_relu_maxpool(F.conv2d(x, c._frozen_fold(scale), None, c.stride, c.padding), shift)
         return F.max_pool2d(self.conv1(x, relu=True), 3, 2, 1)
 
 
