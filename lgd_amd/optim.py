@@ -58,6 +58,7 @@ class FusedClipSGD:
         self._state_ids = None     # Optimizer.load_state_dict installs a new state dict: the cached buffers are then stale
         self._grp = np.array([k * 4096 + gi for k, gi in self.owner], dtype=np.int64)
         self.chunk = None
+        self._checked_idx = None
         rec = 48 * n + 4 * (n + 1)
         self._slot_bytes = (rec + 255) // 256 * 256
         self._pinned = None
@@ -99,10 +100,12 @@ class FusedClipSGD:
         if not idx:
             return
         hip.require_gpu(grads[idx[0]])
-        for i in idx:
-            g = grads[i]
-            if g.dtype != torch.float32 or not g.is_contiguous() or g.is_sparse:
-                raise hip.LgdHipError("fused SGD needs dense contiguous fp32 gradients")
+        if idx != self._checked_idx:   # layout checks once per set of parameters that receive gradients (autograd hands out the
+            for i in idx:              # same kind of tensor every step; the checks cost ~0.12 ms of the ~0.4 ms this call takes)
+                g = grads[i]
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.is_sparse:
+                    raise hip.LgdHipError("fused SGD needs dense contiguous fp32 gradients")
+            self._checked_idx = idx
         self._buffers(idx)
         ii = np.asarray(idx, dtype=np.int64)
         k = len(idx)
@@ -117,8 +120,10 @@ class FusedClipSGD:
         raw = host.numpy()
         tab = raw[:48 * k].view(_TENSOR_DT)
         blk = raw[48 * k:48 * k + 4 * (k + 1)].view(np.int32)
-        tab["p"] = np.fromiter((self.params[i].data_ptr() for i in idx), dtype=np.uint64, count=k)
-        tab["g"] = np.fromiter((grads[i].data_ptr() for i in idx), dtype=np.uint64, count=k)
+        ptr_of = torch.Tensor.data_ptr
+        params = self.params
+        tab["p"] = np.fromiter(map(ptr_of, [params[i] for i in idx]), dtype=np.uint64, count=k)
+        tab["g"] = np.fromiter(map(ptr_of, [grads[i] for i in idx]), dtype=np.uint64, count=k)
         tab["m"] = self._m_ptr[ii]
         tab["n"] = self._numel[ii]
         hyper = {}
