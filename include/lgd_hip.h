@@ -273,13 +273,19 @@ int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* la
  *   lgd_wino_out writes it (with relu = 1); lgd_wino_in / lgd_wino_out_t take it INSTEAD of relu_ref_host as the gradient mask:
  *   1 bit per pixel instead of re-reading the 4-byte forward output, and the forward output need not be kept for the backward. */
 size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N, int tile);
+/* pre_bias (tile = 4 only, may be NULL): the maps are PRE-activations of a conv -> per-channel bias -> ReLU whose output feeds this
+ *   convolution and nothing else (conv1 -> FrozenBN -> ReLU -> conv2 of a bottleneck block): lgd_wino_in transforms
+ *   relu(x + pre_bias[c]) -- the epilogue pass of the producing convolution is folded into this load -- and writes the activation
+ *   mask per tile to pre_bits ([C][T] uint16, may be NULL when no backward follows); lgd_wino_in_t takes pre_bits and returns the
+ *   gradient of the RAW maps (zero where the activation was <= 0).  Not combined with dM / relu_ref_host / relu_bits. */
 int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, const uint16_t* relu_bits, const int32_t* level_hw_host,
-                int L, int N, int C, int tile, int flip, float* V, float* dM, void* stream);
+                int L, int N, int C, int tile, int flip, float* V, float* dM, const float* pre_bias, uint16_t* pre_bits, void* stream);
 int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host, int L, int N, int C, int tile, int flip,
                  int relu, float* const* y_host, uint16_t* relu_bits, void* stream);
 int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const uint16_t* relu_bits,
                    const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM, void* stream);
-int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host, void* stream);
+int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host,
+                  const uint16_t* pre_bits, void* stream);
 /* Filter transforms of tile = 4 (the host's `U = kron(G,G) @ weight` of the 16-frequency form, done here for the 36-frequency one):
  *   lgd_wino_filter_fwd: U[f][co][ci] = (G (scale[co] . g) G^T)[f] at U + f*u_plane + co*Ci + ci, and the same values transposed in
  *     (co, ci) at Ut + f*ut_plane + ci*ut_ld + co (the operand of dV = U^T dM); u_plane / ut_plane / ut_ld let several filters stack

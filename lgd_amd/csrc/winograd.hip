@@ -374,7 +374,10 @@ __device__ __forceinline__ void stage_store12(const float* lds, float* dst, size
 
 // MASK: 0 = none; 1 = zero the gradient where the forward output y (mask_ref) is <= 0; 2 = the same mask from the 16-bit
 // per-tile table the forward output transform wrote (1 bit per pixel instead of re-reading the 4-byte output).
-template <bool VEC, bool DUAL, int MASK>
+// PRE: the maps are PRE-activations -- the transform reads relu(x + bias[c]) (the bias + ReLU epilogue of the producing 1x1 convolution
+// folded into this load: conv1 -> FrozenBN -> ReLU -> conv2 of a bottleneck block) and writes the tile's 16-bit
+// activation mask (bit 4*i+j = its own 4x4 block's pixel (i, j) > 0) for the adjoint transform of the backward (wino4_in_t).
+template <bool VEC, bool DUAL, int MASK, bool PRE = false>
 __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
     const long long units = (long long)a.N * TH * TW, padded = (units + kTilePad - 1) & ~(long long)(kTilePad - 1);
@@ -390,6 +393,7 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
     const float* pm = MASK == 1 ? a.mask_ref[l] + img : nullptr;
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const int lane = threadIdx.x & 63;
+    const float prb = PRE ? a.bias[c] : 0.f;
     // MASK == 2: this tile's, the upper and the lower tile's masks (rows -1 / 0..3 / 4 of the window), and the same three of
     // the left and right neighbour tiles (columns -1 and 4) from the neighbour lanes; only the wave's end lanes load them
     unsigned mc[3] = {0u, 0u, 0u}, ml[3] = {0u, 0u, 0u}, mr[3] = {0u, 0u, 0u};
@@ -427,6 +431,9 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
                 const unsigned nib = mc[f] >> (4 * r);
                 m.x = (nib & 1u) ? m.x : 0.f; m.y = (nib & 2u) ? m.y : 0.f; m.z = (nib & 4u) ? m.z : 0.f; m.w = (nib & 8u) ? m.w : 0.f;
             }
+            if constexpr (PRE) {   // rows beyond the map stay the zero padding (of the ACTIVATION)
+                if (yok) { m.x = fmaxf(m.x + prb, 0.f); m.y = fmaxf(m.y + prb, 0.f); m.z = fmaxf(m.z + prb, 0.f); m.w = fmaxf(m.w + prb, 0.f); }
+            }
             // halo columns = the neighbour lanes' edge values (same image row unless first / last tile of the row): one DPP move each
             // (measured equal to ds_bpermute shuffles, 136.1 vs 136.4 us: the kernel is bound by its 36-plane store scatter, not by issue)
             float e0 = wave_shr1(m.w), e5 = wave_shl1(m.x);
@@ -434,11 +441,13 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
                 e0 = yok ? row[x0] : 0.f;
                 if constexpr (MASK == 1) { if (yok) e0 = pm[ro + x0] > 0.f ? e0 : 0.f; }
                 if constexpr (MASK == 2) e0 = ((ml[f] >> (4 * r + 3)) & 1u) ? e0 : 0.f;
+                if constexpr (PRE) { if (yok) e0 = fmaxf(e0 + prb, 0.f); }
             }
             if ((lane == 63 || u + 1 >= units) && tx != TW - 1) {
                 e5 = yok ? row[x0 + 5] : 0.f;
                 if constexpr (MASK == 1) { if (yok) e5 = pm[ro + x0 + 5] > 0.f ? e5 : 0.f; }
                 if constexpr (MASK == 2) e5 = ((mr[f] >> (4 * r)) & 1u) ? e5 : 0.f;
+                if constexpr (PRE) { if (yok) e5 = fmaxf(e5 + prb, 0.f); }
             }
             if (tx == 0) e0 = 0.f;
             if (tx == TW - 1) e5 = 0.f;
@@ -455,12 +464,23 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
                     const int cc = j == 0 ? 3 : (j == 5 ? 0 : j - 1);
                     e = ((w16 >> (4 * r + cc)) & 1u) ? e : 0.f;
                 }
+                if constexpr (PRE) { if (ok) e = fmaxf(e + prb, 0.f); }
                 d[i][j] = e;
             }
         }
     }
     const size_t base = (size_t)c * a.cs + (size_t)a.tile_off[l] + t0;
     const long long tend = padded - t0;  // tiles of this workgroup that exist (incl. zero pad tiles), relative to t0
+    if constexpr (PRE) {
+        if (a.bits_out && on) {   // the tile's own 4x4 block = window rows / columns 1..4 (pixels beyond the map are 0 -> bit 0)
+            unsigned bits = 0u;
+            #pragma unroll
+            for (int i = 0; i < 4; ++i)
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) bits |= (d[i + 1][j + 1] > 0.f ? 1u : 0u) << (4 * i + j);
+            a.bits_out[(size_t)c * plane + (size_t)a.tile_off[l] + u] = (unsigned short)bits;
+        }
+    }
     {
         float r[6][6];
         #pragma unroll
@@ -514,12 +534,12 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
     }
 }
 
-template <bool DUAL, int MASK>
+template <bool DUAL, int MASK, bool PRE = false>
 __global__ __launch_bounds__(256) void wino4_in_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[12 * 256];
     const int l = wino_level(a);
-    if (a.pair[l]) wino4_in_body<true, DUAL, MASK>(a, l, lds);
-    else wino4_in_body<false, DUAL, MASK>(a, l, lds);
+    if (a.pair[l]) wino4_in_body<true, DUAL, MASK, PRE>(a, l, lds);
+    else wino4_in_body<false, DUAL, MASK, PRE>(a, l, lds);
 }
 
 template <bool VEC, bool STAGE>
@@ -805,12 +825,16 @@ __device__ __forceinline__ void wino4_in_t_body(const WinoArgs& a, int l, float*
     if constexpr (!FUSE) {
         if (!on) return;
         float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
+        // optional: the activation mask the PRE input transform wrote (the maps were pre-activations: dx is the gradient of the RAW map)
+        const unsigned mb = a.bits_in ? a.bits_in[(size_t)c * plane + (size_t)a.tile_off[l] + u] : 0xffffu;
         #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float y[4];
             b6mid(t[r], y);         // rows: window columns 1..4 of (B G) B^T
             y[0] += tl[r];          // the left tile's window column 5 (B[5][5] = 1)
             y[3] += 4.f * tr[r];    // the right tile's window column 0 (B[0][0] = 4)
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = ((mb >> (4 * r + j)) & 1u) ? y[j] : 0.f;
             if (oy + r >= H) continue;
             float* row = p + (size_t)(oy + r) * W + ox;
             if constexpr (VEC) {
@@ -1002,12 +1026,14 @@ size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N, int tile) {
 }
 
 int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, const uint16_t* relu_bits, const int32_t* level_hw_host,
-                int L, int N, int C, int tile, int flip, float* V, float* dM, void* stream) {
+                int L, int N, int C, int tile, int flip, float* V, float* dM, const float* pre_bias, uint16_t* pre_bits, void* stream) {
     lgd::WinoArgs a;
     unsigned blocks;
     if (!x_host || !V || lgd::wino_fill(a, level_hw_host, L, N, C, flip, 0, tile, &blocks) != LGD_OK) return LGD_EINVAL;
     if (relu_bits && (relu_ref_host || tile != 4)) return LGD_EINVAL;
+    if ((pre_bias || pre_bits) && (!pre_bias || tile != 4 || dM || relu_bits || relu_ref_host)) return LGD_EINVAL;
     a.bits_in = relu_bits;
+    a.bias = pre_bias; a.bits_out = pre_bits;
     for (int l = 0; l < L; ++l) {
         if (!x_host[l] || (relu_ref_host && !relu_ref_host[l])) return LGD_EINVAL;
         a.maps_in[l] = x_host[l];
@@ -1017,7 +1043,9 @@ int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, c
     const dim3 grid(blocks, C), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool mask = relu_ref_host != nullptr;
-    if (tile == 4) {
+    if (tile == 4 && pre_bias) {
+        LGD_LAUNCH("wino_in_kernel", (lgd::wino4_in_kernel<false, 0, true>), grid, block, 0, st, a);
+    } else if (tile == 4) {
         if (dM) {
             if (relu_bits) { LGD_LAUNCH("wino_in_dual_kernel", (lgd::wino4_in_kernel<true, 2>), grid, block, 0, st, a); }
             else if (mask) { LGD_LAUNCH("wino_in_dual_kernel", (lgd::wino4_in_kernel<true, 1>), grid, block, 0, st, a); }
@@ -1077,10 +1105,12 @@ int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_hos
     return lgd::check_launch();
 }
 
-int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host, void* stream) {
+int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host,
+                  const uint16_t* pre_bits, void* stream) {
     lgd::WinoArgs a;
     unsigned blocks;
     if (!dV || !dx_host || tile != 4 || lgd::wino_fill(a, level_hw_host, L, N, C, 0, 0, tile, &blocks) != LGD_OK) return LGD_EINVAL;
+    a.bits_in = pre_bits;
     for (int l = 0; l < L; ++l) {
         if (!dx_host[l]) return LGD_EINVAL;
         a.maps_out[l] = dx_host[l];

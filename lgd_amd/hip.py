@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -61,10 +61,10 @@ SIGNATURES = {
     "lgd_focal_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
     "lgd_focal_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
     "lgd_wino_tiles": (c_sz, [c_fp, c_i, c_i, c_i]),
-    "lgd_wino_in": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_wino_in": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_out": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_wino_out_t": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
-    "lgd_wino_in_t": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_wino_in_t": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_wino_filter_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp]),
     "lgd_wino_filter_bwd": (c_i, [c_fp, ctypes.c_longlong, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_in_t_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),

@@ -799,12 +799,17 @@ class _Conv3x3K(torch.autograd.Function):
     tiles of all levels.  The input is transformed ONCE for all K filters (their U are stacked along C_out: one GEMM), and the
     backward sums their input gradients inside the dV GEMM (K = sum Co_k) -- one adjoint input transform, no gradient-accumulation
     pass.  Forward, input gradient and weight gradient all run at 1/4 (tile 4) or 4/9 (tile 2) of the direct multiplies.
-    apply(K, relu, tile, scales, w_1, b_1, ..., w_K, b_K, x_1, ..., x_L) -> K * L maps, filter-major; scales: None or one per-output-
-    channel factor (a buffer, no gradient) per filter, applied to the filter inside its transform (tile 4)."""
+    apply(K, relu, tile, scales, pre, w_1, b_1, ..., w_K, b_K, x_1, ..., x_L) -> K * L maps, filter-major; scales: None or one per-output-
+    channel factor (a buffer, no gradient) per filter, applied to the filter inside its transform (tile 4); pre: None, or a per-INPUT-
+    channel bias (a buffer): the maps are then pre-activations and the convolution runs on relu(x + pre[c]) -- the bias + ReLU epilogue
+    of the producing 1x1 convolution folded into the input transform, its backward mask into the adjoint transform (tile 4), so the
+    gradient returned for x is the gradient of the RAW map."""
 
     @staticmethod
-    def forward(ctx, K, relu, tile, scales, *args):
+    def forward(ctx, K, relu, tile, scales, pre, *args):
         ws, bs, xs = list(args[0:2 * K:2]), list(args[1:2 * K:2]), list(args[2 * K:])
+        if pre is not None and tile != 4:
+            raise hip.LgdHipError("a folded pre-activation needs tile = 4")
         scales = list(scales) if scales is not None else [None] * K
         if tile != 4 and any(sc is not None for sc in scales):
             raise hip.LgdHipError("a per-channel filter scale needs tile = 4 (fold it into the weights for tile 2)")
@@ -827,7 +832,12 @@ class _Conv3x3K(torch.autograd.Function):
         else:
             U, Ut = torch.mm(_wino_gg(dev, tile), ws[0].view(Ct * Ci, 9).t()).view(nf, Ct, Ci), None
         V = _freq_buf(nf, Ci, T, dev)
-        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
+        pre = hip.dense_f32(pre) if pre is not None else None
+        pre_bits = (torch.empty((Ci, T), dtype=torch.int16, device=dev)
+                    if pre is not None and any(ctx.needs_input_grad[5 + 2 * K:]) else None)
+        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None,
+                                  hip.ptr(pre) if pre is not None else None, hip.ptr(pre_bits) if pre_bits is not None else None,
+                                  hip.stream_ptr()), "lgd_wino_in")
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
         fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
         _count_bytes("wino_in_kernel", (px + fb) * Ci)
@@ -843,16 +853,16 @@ class _Conv3x3K(torch.autograd.Function):
                                        hip.ptr_array(yk), hip.ptr(bits[c0]) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
             ys += yk
             c0 += Cos[k]
-        need_w = any(ctx.needs_input_grad[4:4 + 2 * K:2])
+        need_w = any(ctx.needs_input_grad[5:5 + 2 * K:2])
         # the backward needs the transformed filters (tile 4: dV = U^T dM; tile 2: the rotation is a frequency permutation of U)
-        ctx.save_for_backward(Ut if tile == 4 else U, V if need_w else None, bits, *(ys if (relu and bits is None) else []))
+        ctx.save_for_backward(Ut if tile == 4 else U, V if need_w else None, bits, pre_bits, *(ys if (relu and bits is None) else []))
         ctx.scales = scales
         ctx.meta = (K, L, N, Ci, Cos, hw, T, bool(relu), [b is not None for b in bs], [tuple(x.shape[2:]) for x in xs], tile, px, fb)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
-        U, V, bits, *yref = ctx.saved_tensors
+        U, V, bits, pre_bits, *yref = ctx.saved_tensors
         K, L, N, Ci, Cos, hw, T, relu, has_bias, shapes, tile, px, fb = ctx.meta
         Ct = sum(Cos)
         lib = hip.load()
@@ -861,9 +871,9 @@ class _Conv3x3K(torch.autograd.Function):
         # an output nothing downstream used arrives as None
         dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
                for i, g in enumerate(dys)]
-        need_ws = list(ctx.needs_input_grad[4:4 + 2 * K:2])
-        need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[5:5 + 2 * K:2])]
-        need_w, need_x = any(need_ws), any(ctx.needs_input_grad[4 + 2 * K:])
+        need_ws = list(ctx.needs_input_grad[5:5 + 2 * K:2])
+        need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[6:6 + 2 * K:2])]
+        need_w, need_x = any(need_ws), any(ctx.needs_input_grad[5 + 2 * K:])
         dws, dbs = [None] * K, [None] * K
         dxs = [None] * L
         dM = None
@@ -882,7 +892,8 @@ class _Conv3x3K(torch.autograd.Function):
                 _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
                 dV = _timed_bmm("wino_gemm_dx", U, dM, out=_freq_buf(nf, Ci, T, dev))   # U holds U^T (36, Ci, sum Co) for tile 4
                 dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-                hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), hip.stream_ptr()), "lgd_wino_in_t")
+                hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs),
+                                            hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in_t")
                 del dV
         elif tile == 2 and (need_x or need_w):
             Co = Cos[0]
@@ -895,7 +906,7 @@ class _Conv3x3K(torch.autograd.Function):
                 _count_bytes("wino_out_kernel", (px + fb) * Ci)
                 Vd = _freq_buf(nf, Co, T, dev)
                 hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, None, hw, L, N, Co, tile, 1, hip.ptr(Vd),
-                                          hip.ptr(dM) if need_w else None, hip.stream_ptr()), "lgd_wino_in")
+                                          hip.ptr(dM) if need_w else None, None, None, hip.stream_ptr()), "lgd_wino_in")
                 Md = _timed_bmm("wino_gemm_dx", U.transpose(1, 2), Vd, out=_freq_buf(nf, Ci, T, dev))
                 del Vd
                 dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
@@ -922,7 +933,7 @@ class _Conv3x3K(torch.autograd.Function):
             for k in range(K):
                 dbs[k] = db[c0:c0 + Cos[k]] if need_bs[k] else None
                 c0 += Cos[k]
-        return (None, None, None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
+        return (None, None, None, None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
 
 
 class _Conv3x3Chain(torch.autograd.Function):
@@ -955,7 +966,8 @@ class _Conv3x3Chain(torch.autograd.Function):
             Co, Ci = ws[k].shape[0], ws[k].shape[1]
             U, Ut = _wino4_filters(lib, [ws[k]], [None], Ci, dev)
             V = _freq_buf(nf, Ci, T, dev)
-            hip.check(lib.lgd_wino_in(hip.ptr_array(cur), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, hip.stream_ptr()), "lgd_wino_in")
+            hip.check(lib.lgd_wino_in(hip.ptr_array(cur), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, None, None, hip.stream_ptr()),
+                      "lgd_wino_in")
             _count_bytes("wino_in_kernel", (px + fb) * Ci)
             M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
             bits = torch.empty((Co, T), dtype=torch.int16, device=dev) if relus[k] else None
@@ -1008,7 +1020,7 @@ class _Conv3x3Chain(torch.autograd.Function):
             else:
                 _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
                 dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-                hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), hip.stream_ptr()), "lgd_wino_in_t")
+                hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), None, hip.stream_ptr()), "lgd_wino_in_t")
             del dV
         return (None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
 
@@ -1017,8 +1029,8 @@ class _Conv3x3:
     """single-filter form of _Conv3x3K with the historical argument order: apply(w, b, relu, tile, *xs)."""
 
     @staticmethod
-    def apply(w, b, relu, tile, *xs, scale=None):
-        return _Conv3x3K.apply(1, bool(relu), tile, None if scale is None else (scale,), w, b, *xs)
+    def apply(w, b, relu, tile, *xs, scale=None, pre=None):
+        return _Conv3x3K.apply(1, bool(relu), tile, None if scale is None else (scale,), pre, w, b, *xs)
 
 
 def enable_tuned_gemms(path=None):
@@ -1072,15 +1084,21 @@ def _wino_ok(xs, w):
             and (len(xs) > 1 or w.shape[0] >= _WINO_MIN_CH))
 
 
-def conv3x3_levels(xs, w, b=None, relu=False, scale=None):
+def conv3x3_levels(xs, w, b=None, relu=False, scale=None, pre=None):
     """one 3x3 / stride 1 / padding 1 filter [+ ReLU] over a list of maps (the FPN levels): a single Winograd pass over
     the concatenated tiles.  Tiny problems stay on the library's direct kernels.  scale: per-output-channel factor on the filter
-    (the frozen affine of a FrozenBN after the conv), folded into the filter transform on the Winograd path."""
+    (the frozen affine of a FrozenBN after the conv), folded into the filter transform on the Winograd path.  pre: per-input-channel
+    bias of a bias + ReLU that precedes the convolution (the maps are its pre-activations), folded into the input transform on the
+    F(4x4,3x3) path (see _Conv3x3K); elsewhere applied as its own pass."""
     xs = list(xs)
     if _wino_ok(xs, w):
+        if pre is not None and _WINO_TILE != 4:
+            xs, pre = [bias_act(x, pre, None, True) for x in xs], None
         if scale is not None and _WINO_TILE != 4:
             w, scale = w * scale.view(-1, 1, 1, 1), None
-        return list(_Conv3x3.apply(w, b, bool(relu), _WINO_TILE, *xs, scale=scale))
+        return list(_Conv3x3.apply(w, b, bool(relu), _WINO_TILE, *xs, scale=scale, pre=pre))
+    if pre is not None:
+        xs = [bias_act(x, pre, None, True) for x in xs]
     if scale is not None:
         w = w * scale.view(-1, 1, 1, 1)
     ys = [F.conv2d(x, w, b, 1, 1) for x in xs]
@@ -1092,7 +1110,7 @@ def conv3x3_shared_input(xs, filters, relu=False):
     stacked GEMM, one adjoint input transform for the summed input gradient (see _Conv3x3K).  Returns one list of maps per filter."""
     xs = list(xs)
     if len(filters) > 1 and _WINO_TILE == 4 and all(_wino_ok(xs, w) for w, _ in filters):
-        ys = _Conv3x3K.apply(len(filters), bool(relu), 4, None, *[t for wb in filters for t in wb], *xs)
+        ys = _Conv3x3K.apply(len(filters), bool(relu), 4, None, None, *[t for wb in filters for t in wb], *xs)
         return [list(ys[k * len(xs):(k + 1) * len(xs)]) for k in range(len(filters))]
     return [conv3x3_levels(xs, w, b, relu) for w, b in filters]
 
@@ -1109,9 +1127,17 @@ def conv3x3_chain(xs, filters, relus):
     return xs
 
 
-def conv3x3(x, w, b=None, relu=False, scale=None):
+def conv3x3(x, w, b=None, relu=False, scale=None, pre=None):
     """single-map form of conv3x3_levels."""
-    return conv3x3_levels([x], w, b, relu, scale)[0]
+    return conv3x3_levels([x], w, b, relu, scale, pre)[0]
+
+
+def conv3x3_folds_pre(N, C, H, W, Cout, device, dtype=torch.float32):
+    """True if conv3x3 on a (N, C, H, W) map would take the F(4x4,3x3) path, i.e. can fold a preceding bias + ReLU into its input
+    transform: the producer may then hand over its raw output (student/resnet.py::Bottleneck)."""
+    tiles = N * ((H + 1) // 2) * ((W + 1) // 2)
+    return (_WINO_ON and _WINO_TILE == 4 and device.type == "cuda" and dtype == torch.float32 and tiles >= _WINO_MIN_TILES
+            and C >= _WINO_MIN_CH and Cout >= _WINO_MIN_CH)
 
 
 def conv3x3_stride2(x, w, b=None):
@@ -1336,6 +1362,10 @@ class _PointwiseConvBN(torch.autograd.Function):
         if wf is None:   # wf given: the folded filter of a FROZEN convolution, cached by the caller until the weight is written
             wf = w * scale.view(-1, 1, 1, 1)
         y = F.conv2d(x, wf)
+        if shift is None and residual is None and not relu:   # raw output: the consumer folds the bias + ReLU into its own load
+            ctx.relu = False
+            ctx.save_for_backward(x, wf, scale, None)
+            return y
         residual = hip.dense_f32(residual) if residual is not None else None
         N, C = y.shape[0], y.shape[1]
         out = torch.empty_like(y)
@@ -1377,12 +1407,16 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
     (3 map transfers; measured per block at config 2, tools/skip_accum_probe.py: res3 350 -> 200 us, res4 255 -> 208 us)."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, shift):
+    def forward(ctx, x, w, scale, shift, raw=False):
         hip.require_gpu(x, w)
         lib = hip.load()
         x = hip.dense_f32(x)
         wf = w * scale.view(-1, 1, 1, 1)
         y = F.conv2d(x, wf)
+        ctx.raw = bool(raw)
+        if raw:   # the 3x3 convolution that follows folds + shift and the ReLU into its input transform (and the mask into its adjoint)
+            ctx.save_for_backward(x, wf, scale, None)
+            return y, x.view_as(x)
         N, C = y.shape[0], y.shape[1]
         out = torch.empty_like(y)
         bits = _relu_bits(lib, y.numel(), y.device) if any(ctx.needs_input_grad) else None
@@ -1397,7 +1431,9 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
         N, Ci, Co = x.shape[0], x.shape[1], wf.shape[0]
         dx = dw = None
         dz = None
-        if dy is not None:
+        if dy is not None and ctx.raw:
+            dz = hip.dense_f32(dy)
+        elif dy is not None:
             dy = hip.dense_f32(dy)
             dz = torch.empty_like(dy)
             hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
@@ -1420,12 +1456,13 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
                                    **({"out": a3} if own else {})).view_as(x)
         if ctx.needs_input_grad[1] and dz is not None:
             dw = _pointwise_dw(dz, x, scale)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def pointwise_conv_bn_skip(x, w, scale, shift):
-    """(relu(conv1x1(x, w * scale) + shift), x): conv1 + identity shortcut of a bottleneck block as one node (see above)."""
-    return _PointwiseConvBNSkip.apply(x, w, scale, shift)
+def pointwise_conv_bn_skip(x, w, scale, shift, raw=False):
+    """(relu(conv1x1(x, w * scale) + shift), x): conv1 + identity shortcut of a bottleneck block as one node (see above);
+    raw: (conv1x1(x, w * scale), x) -- bias and ReLU are left to the consumer (conv3x3(..., pre=shift))."""
+    return _PointwiseConvBNSkip.apply(x, w, scale, shift, bool(raw))
 
 
 def pointwise_conv_bn(x, w, scale, shift, residual=None, relu=True, wf=None):

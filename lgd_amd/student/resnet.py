@@ -63,25 +63,26 @@ class ConvBN(nn.Conv2d):
     def subsample2(x):
         return x[:, :, ::2, ::2].contiguous()
 
-    def forward(self, x, relu=False, residual=None, subsampled=False):
+    def forward(self, x, relu=False, residual=None, subsampled=False, raw=False, pre=None):
         """conv -> FrozenBN [-> += residual] [-> ReLU]: the affine is folded into the filter; bias, residual and ReLU are ONE
-        pass over the conv output (ops.bias_act) instead of three."""
+        pass over the conv output (ops.bias_act) instead of three.  raw (1x1 only): return the scaled convolution alone -- the 3x3
+        convolution that consumes it applies this layer's shift + ReLU inside its input transform (its `pre` = this shift)."""
         scale, shift = self.norm.scale_shift()
         if self._pointwise or self._pointwise_s2:  # fold + GEMM + epilogue (and their backward) as one autograd node
             if self._pointwise_s2 and not subsampled:
                 x = self.subsample2(x)
-            return ops.pointwise_conv_bn(x, self.weight, scale, shift, residual, relu,
+            return ops.pointwise_conv_bn(x, self.weight, scale, None if raw else shift, residual, relu and not raw,
                                          None if self.weight.requires_grad else self._frozen_fold(scale))
         if self.weight.requires_grad and self._plain3x3 and residual is None:
             # trainable 3x3 / stride 1: the scale is folded inside the Winograd filter transform (no scaled copy of the weights, and the
             # backward returns the gradient of the RAW filter); bias + ReLU ride in the output transform
-            return ops.conv3x3(x, self.weight, shift, relu=relu, scale=scale)
+            return ops.conv3x3(x, self.weight, shift, relu=relu, scale=scale, pre=pre)
         if self.weight.requires_grad:
             w = self.weight * scale.view(-1, 1, 1, 1)
         else:  # frozen (FREEZE_AT prefix, or the backbone-freeze phase): the folded filter is reused until the weight is written
             w = self._frozen_fold(scale)
         if self._plain3x3 and residual is None:  # 3x3 / stride 1: Winograd transforms + GEMMs (bias + ReLU fused in the output transform)
-            return ops.conv3x3(x, w, shift, relu=relu)
+            return ops.conv3x3(x, w, shift, relu=relu, pre=pre)
         y = F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
         return ops.bias_act(y, shift, residual, relu)
 
@@ -99,15 +100,21 @@ class Bottleneck(nn.Module):
         shared = self.conv1._pointwise_s2 and self.shortcut is not None and self.shortcut._pointwise_s2
         if shared:  # conv1 and the projection shortcut read the same every-other-pixel view of x: take it once
             x = ConvBN.subsample2(x)
+        # conv1's FrozenBN shift + ReLU folded into conv2's Winograd input transform (and the mask into its adjoint): conv1 hands
+        # over its raw GEMM output, no epilogue pass over the mid-size map in either direction
+        s1 = 2 if (self.conv1._pointwise_s2 and not shared) else 1
+        fold = self.conv2._plain3x3 and ops.conv3x3_folds_pre(x.shape[0], self.conv1.out_channels, (x.shape[2] + s1 - 1) // s1,
+                                                              (x.shape[3] + s1 - 1) // s1, self.conv2.out_channels, x.device, x.dtype)
+        pre = self.conv1.norm.scale_shift()[1] if fold else None
         if (self.shortcut is None and self.conv1._pointwise and x.is_cuda and x.dtype == torch.float32
                 and torch.is_grad_enabled() and x.requires_grad):
             # identity block: conv1 and the shortcut as one node, so that conv1's input-gradient GEMM accumulates onto the
             # shortcut's gradient instead of a separate add pass (ops._PointwiseConvBNSkip)
             scale, shift = self.conv1.norm.scale_shift()
-            out, sc = ops.pointwise_conv_bn_skip(x, self.conv1.weight, scale, shift)
-            return self.conv3(self.conv2(out, relu=True), relu=True, residual=sc)
-        out = self.conv1(x, relu=True, subsampled=shared)
-        out = self.conv2(out, relu=True)
+            out, sc = ops.pointwise_conv_bn_skip(x, self.conv1.weight, scale, shift, raw=fold)
+            return self.conv3(self.conv2(out, relu=True, pre=pre), relu=True, residual=sc)
+        out = self.conv1(x, relu=True, subsampled=shared, raw=fold)
+        out = self.conv2(out, relu=True, pre=pre)
         sc = self.shortcut(x, subsampled=shared) if self.shortcut is not None else x
         return self.conv3(out, relu=True, residual=sc)
 

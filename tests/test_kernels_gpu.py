@@ -1369,3 +1369,92 @@ def test_fpn_topdown_vs_fp64_definition():
         assert cm.rel_err(fg[k].grad, fr[k].grad) < 1e-4, k
     for (n, a), (_, b) in zip(fpn.named_parameters(), ref.named_parameters()):
         assert cm.rel_err(a.grad, b.grad) < 1e-4, n
+
+
+@pytest.mark.parametrize("hws", [((40, 56),), ((21, 30), (9, 13)), ((8, 8), (7, 5), (4, 4))])
+def test_conv3x3_folded_preactivation(hws):
+    """conv3x3(x, w, b, relu, scale, pre=p) on the F(4x4,3x3) path == conv(relu(x + p[c])) in fp64: the bias + ReLU of the producing
+    1x1 convolution folded into the input transform (float4 and scalar loads, partial tiles, several levels), its mask into the
+    adjoint input transform: values, the gradient of the RAW input, filter / bias gradients."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=4)
+    try:
+        N, Ci, Co = 3, 64, 96
+        xs = [torch.from_numpy(synth.det_uniform((N, Ci, h, w), 1701 + i, -2.0, 2.0)) for i, (h, w) in enumerate(hws)]
+        w = torch.from_numpy(synth.det_uniform((Co, Ci, 3, 3), 1702, -0.1, 0.1))
+        b = torch.from_numpy(synth.det_uniform((Co,), 1703, -0.5, 0.5))
+        sc = torch.from_numpy(synth.det_uniform((Co,), 1704, 0.5, 1.5))
+        p = torch.from_numpy(synth.det_uniform((Ci,), 1705, -0.7, 0.7))
+        gys = [torch.from_numpy(synth.det_uniform((N, Co, h, w_), 1750 + i, -1.0, 1.0)) for i, (h, w_) in enumerate(hws)]
+        xr = [x.double().requires_grad_(True) for x in xs]
+        wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+        yr = [F.relu(F.conv2d(F.relu(x + p.double().view(1, -1, 1, 1)), wr * sc.double().view(-1, 1, 1, 1), br, 1, 1)) for x in xr]
+        torch.autograd.backward(yr, [g.double() for g in gys])
+        xg = [x.to(DEV).requires_grad_(True) for x in xs]
+        wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        ys = ops.conv3x3_levels(xg, wg, bg, relu=True, scale=sc.to(DEV), pre=p.to(DEV))
+        assert type(ys[0].grad_fn).__name__.startswith("_Conv3x3K")
+        torch.autograd.backward(ys, [g.to(DEV) for g in gys])
+        scale = lambda t: float(t.detach().abs().max()) + 1e-30
+        for y, r in zip(ys, yr):
+            assert float((y.detach().cpu().double() - r.detach()).abs().max()) <= 5e-5 * scale(r)
+        gscale = max(scale(x.grad) for x in xr)
+        for x, r in zip(xg, xr):
+            d = (x.grad.cpu().double() - r.grad).abs()
+            # a unit whose second-layer pre-activation is within rounding of 0 may flip; the first-layer mask (x + p > 0) is exact
+            assert float((d > 5e-5 * gscale).double().mean()) < 1e-3
+            assert torch.equal(x.grad.cpu() == 0, (r.grad == 0)) or float(((x.grad.cpu() == 0) != (r.grad == 0)).double().mean()) < 1e-3
+        assert float((wg.grad.cpu().double() - wr.grad).abs().max()) <= 1e-4 * scale(wr.grad)
+        assert float((bg.grad.cpu().double() - br.grad).abs().max()) <= 1e-4 * scale(br.grad)
+        # forward only (frozen convolution under no_grad): no mask table, same values
+        with torch.no_grad():
+            y0 = ops.conv3x3_levels([x.to(DEV) for x in xs], w.to(DEV), b.to(DEV), relu=True, scale=sc.to(DEV), pre=p.to(DEV))
+        for a, r in zip(y0, ys):
+            assert torch.equal(a, r.detach())
+    finally:
+        ops.conv3x3_backend(*prev)
+
+
+@pytest.mark.parametrize("stride,wino", [(1, True), (1, False), (2, True), (2, False)])
+def test_bottleneck_blocks_vs_fp64(stride, wino):
+    """student/resnet.py::Bottleneck on the GPU -- identity block (conv1 + shortcut node, beta = 1 accumulation) and projection block
+    (stride 2 in the 1x1 convs, shared subsampled input), with conv1's shift + ReLU folded into conv2's Winograd input transform
+    (wino) or on the library path (not wino) -- against the block in fp64 [d2-memory: BottleneckBlock, STRIDE_IN_1X1]."""
+    import copy
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    from lgd_amd.student.resnet import Bottleneck
+    prev = ops.conv3x3_backend(winograd=wino, min_tiles=0, tile=4)
+    try:
+        torch.manual_seed(13 + stride)
+        cin, cout, mid = (256, 256, 64) if stride == 1 else (128, 256, 64)
+        blk = Bottleneck(cin, cout, mid, stride)
+        convs = [blk.conv1, blk.conv2, blk.conv3] + ([blk.shortcut] if blk.shortcut is not None else [])
+        for m in convs:
+            m.norm.weight.uniform_(0.5, 1.5); m.norm.bias.uniform_(-0.3, 0.3)
+            m.norm.running_mean.uniform_(-0.2, 0.2); m.norm.running_var.uniform_(0.5, 1.5)
+        ref = copy.deepcopy(blk).double()
+        blk = blk.to(DEV)
+        x = torch.from_numpy(synth.det_uniform((2, cin, 26, 36), 1801, -1.0, 1.0))
+        xg = x.to(DEV).requires_grad_(True)
+        y = blk(xg)
+        gy = torch.from_numpy(synth.det_uniform(tuple(y.shape), 1802, -1.0, 1.0))
+        y.backward(gy.to(DEV))
+
+        def cbn(c, t, s=1, pad=0):
+            scale = c.norm.weight * (c.norm.running_var + c.norm.eps).rsqrt()
+            shift = c.norm.bias - c.norm.running_mean * scale
+            return F.conv2d(t, c.weight, None, s, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        xr = x.double().requires_grad_(True)
+        o = F.relu(cbn(ref.conv1, xr, stride))
+        o = cbn(ref.conv3, F.relu(cbn(ref.conv2, o, 1, 1)))
+        yr = F.relu(o + (cbn(ref.shortcut, xr, stride) if ref.shortcut is not None else xr))
+        yr.backward(gy.double())
+        assert cm.rel_err(y, yr) < 5e-5
+        gs = float(xr.grad.abs().max())
+        assert float(((xg.grad.cpu().double() - xr.grad).abs() > 1e-4 * gs).double().mean()) < 1e-3   # ReLU-kink flips only
+        for (n, a), (_, b) in zip(blk.named_parameters(), ref.named_parameters()):
+            assert cm.rel_err(a.grad, b.grad) < 2e-4, n
+    finally:
+        ops.conv3x3_backend(*prev)

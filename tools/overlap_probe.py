@@ -45,7 +45,7 @@ for maps in (5, 10):
         hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, len(lv), N, C, 4, 0, 0, hip.ptr_array(dxs), None, ctypes.c_void_p(stream.cuda_stream)), "out")
 
     def k_dual(stream):
-        hip.check(lib.lgd_wino_in(hip.ptr_array(dys), None, hip.ptr(bits), hw, len(lv), N, C, 4, 0, hip.ptr(Vd), hip.ptr(dM), ctypes.c_void_p(stream.cuda_stream)), "in")
+        hip.check(lib.lgd_wino_in(hip.ptr_array(dys), None, hip.ptr(bits), hw, len(lv), N, C, 4, 0, hip.ptr(Vd), hip.ptr(dM), None, None, ctypes.c_void_p(stream.cuda_stream)), "in")
 
     def g_dw():
         return torch.bmm(dM, V.transpose(1, 2))
