@@ -15,5 +15,6 @@ print('%-52s %6.1f ms/step  '%('$name',d['ms_per_step'])+'  '.join('%s %.6f'%(k,
 EXTRA="" run "shipped: single head pass, adjoint backward, chains" LGD_X=0
 EXTRA="" run "LGD_CONV_CHAIN=0 (every conv its own autograd node)" LGD_CONV_CHAIN=0
 EXTRA="--head-passes 2" run "two head passes (reference order)" LGD_X=0
+EXTRA="" run "LGD_FUSED_SGD=0 (torch clamp_ + SGD foreach)" LGD_FUSED_SGD=0
 EXTRA="" run "LGD_WINO=0 (library convolutions)" LGD_WINO=0
 cat $out
