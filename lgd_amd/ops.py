@@ -1055,7 +1055,9 @@ def enable_tuned_gemms(path=None):
 
 _TUNED_GEMM = False  # set by enable_tuned_gemms(); Trainer / bench.py opt in, importing this module changes nothing
 _WINO_TILE = int(os.environ.get("LGD_WINO_TILE", "4"))  # output tile of the minimal-filtering form: 4 -> F(4x4,3x3), 2 -> F(2x2,3x3)
-_WINO_MIN_TILES = int(os.environ.get("LGD_WINO_MIN_TILES", "2000"))
+# smallest problem (2x2-output tiles over all maps of the call) that takes the Winograd path; measured at config 4 (R-101, 2 img/GPU,
+# whose res5 3x3 convolutions have 546): 2000 -> 35.7, 500 -> 35.1, 100 -> 35.3 ms/step in one call
+_WINO_MIN_TILES = int(os.environ.get("LGD_WINO_MIN_TILES", "500"))
 _WINO_MIN_CH = int(os.environ.get("LGD_WINO_MIN_CH", "64"))
 _WINO_ON = os.environ.get("LGD_WINO", "1") != "0"
 _CHAIN_ON = os.environ.get("LGD_CONV_CHAIN", "1") != "0"  # 0: every conv of a chain as its own autograd node (A/B measurements)

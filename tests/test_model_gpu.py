@@ -180,7 +180,7 @@ _FC_KEYS = _RN_KEYS | {"loss_centerness", "loss_centerness.tea"}
 
 @pytest.fixture
 def conv_backend(request):
-    """'winograd': winograd.hip forced onto the small test problems (production threshold: 2000 tiles); 'library': LGD_WINO=0."""
+    """'winograd': winograd.hip forced onto the small test problems (production threshold: 500 tiles); 'library': LGD_WINO=0."""
     from lgd_amd import ops
     prev = ops.conv3x3_backend(winograd=(request.param == "winograd"), min_tiles=0)
     yield request.param
