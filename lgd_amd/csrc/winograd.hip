@@ -413,58 +413,112 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
         }
     }
     float d[6][6];
-    #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int y = y0 + i;
-        const bool yok = y >= 0 && y < H;
-        const size_t ro = (size_t)(yok ? y : 0) * W;
-        const float* row = p + ro;
-        // window row i lives in tile-row r of family f (0: upper tile, 1: this tile, 2: lower tile)
-        const int f = i == 0 ? 0 : (i == 5 ? 2 : 1), r = i == 0 ? 3 : (i == 5 ? 0 : i - 1);
-        if constexpr (VEC) {
-            float4 m = yok ? *reinterpret_cast<const float4*>(row + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (VEC) {
+        // Phase 1: EVERY load of the 6x6 window is issued before anything consumes one -- six aligned float4 rows (+ the ReLU reference
+        // rows for MASK == 1) and, on the wave's end lanes, the two halo columns.  Written as one loop (load, mask / activate, DPP
+        // halo exchange per row) the compiler put a wait behind each row's load: 6 (plain) to 18 (PRE) exposed HBM latencies per
+        // workgroup instead of one (the PRE variant measured 13-17 % slower than the plain one for 36 extra VALU operations).
+        float4 m[6], km[6];
+        float hl[6], hr[6], kl[6], kr[6];
+        const bool needL = lane == 0 && tx != 0, needR = (lane == 63 || u + 1 >= units) && tx != TW - 1;
+        #pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int y = y0 + i;
+            const bool yok = y >= 0 && y < H;
+            const size_t ro = (size_t)(yok ? y : 0) * W;
+            m[i] = yok ? *reinterpret_cast<const float4*>(p + ro + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (MASK == 1) km[i] = yok ? *reinterpret_cast<const float4*>(pm + ro + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (needL) {
+            #pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int y = y0 + i;
+                const bool yok = y >= 0 && y < H;
+                const size_t ro = (size_t)(yok ? y : 0) * W;
+                hl[i] = yok ? p[ro + x0] : 0.f;
+                if constexpr (MASK == 1) kl[i] = yok ? pm[ro + x0] : 0.f;
+            }
+        }
+        if (needR) {
+            #pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int y = y0 + i;
+                const bool yok = y >= 0 && y < H;
+                const size_t ro = (size_t)(yok ? y : 0) * W;
+                hr[i] = yok ? p[ro + x0 + 5] : 0.f;
+                if constexpr (MASK == 1) kr[i] = yok ? pm[ro + x0 + 5] : 0.f;
+            }
+        }
+        // Phase 2: masks / folded activation, halo exchange, window assembly
+        #pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int y = y0 + i;
+            const bool yok = y >= 0 && y < H;
+            // window row i lives in tile-row r of family f (0: upper tile, 1: this tile, 2: lower tile)
+            const int f = i == 0 ? 0 : (i == 5 ? 2 : 1), r = i == 0 ? 3 : (i == 5 ? 0 : i - 1);
+            float4 v = m[i];
             if constexpr (MASK == 1) {
-                const float4 k = yok ? *reinterpret_cast<const float4*>(pm + ro + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
-                m.x = k.x > 0.f ? m.x : 0.f; m.y = k.y > 0.f ? m.y : 0.f; m.z = k.z > 0.f ? m.z : 0.f; m.w = k.w > 0.f ? m.w : 0.f;
+                v.x = km[i].x > 0.f ? v.x : 0.f; v.y = km[i].y > 0.f ? v.y : 0.f; v.z = km[i].z > 0.f ? v.z : 0.f; v.w = km[i].w > 0.f ? v.w : 0.f;
             }
             if constexpr (MASK == 2) {
                 const unsigned nib = mc[f] >> (4 * r);
-                m.x = (nib & 1u) ? m.x : 0.f; m.y = (nib & 2u) ? m.y : 0.f; m.z = (nib & 4u) ? m.z : 0.f; m.w = (nib & 8u) ? m.w : 0.f;
+                v.x = (nib & 1u) ? v.x : 0.f; v.y = (nib & 2u) ? v.y : 0.f; v.z = (nib & 4u) ? v.z : 0.f; v.w = (nib & 8u) ? v.w : 0.f;
             }
-            if constexpr (PRE) {   // rows beyond the map stay the zero padding (of the ACTIVATION)
-                if (yok) { m.x = fmaxf(m.x + prb, 0.f); m.y = fmaxf(m.y + prb, 0.f); m.z = fmaxf(m.z + prb, 0.f); m.w = fmaxf(m.w + prb, 0.f); }
-            }
+            // PRE: rows beyond the map stay the zero padding of the ACTIVATION: relu(0 + -inf) = 0, no branch
+            const float pbv = PRE ? (yok ? prb : -INFINITY) : 0.f;
+            if constexpr (PRE) { v.x = fmaxf(v.x + pbv, 0.f); v.y = fmaxf(v.y + pbv, 0.f); v.z = fmaxf(v.z + pbv, 0.f); v.w = fmaxf(v.w + pbv, 0.f); }
             // halo columns = the neighbour lanes' edge values (same image row unless first / last tile of the row): one DPP move each
-            // (measured equal to ds_bpermute shuffles, 136.1 vs 136.4 us: the kernel is bound by its 36-plane store scatter, not by issue)
-            float e0 = wave_shr1(m.w), e5 = wave_shl1(m.x);
-            if (lane == 0 && tx != 0) {
-                e0 = yok ? row[x0] : 0.f;
-                if constexpr (MASK == 1) { if (yok) e0 = pm[ro + x0] > 0.f ? e0 : 0.f; }
+            // (measured equal to ds_bpermute shuffles, 136.1 vs 136.4 us)
+            float e0 = wave_shr1(v.w), e5 = wave_shl1(v.x);
+            if (needL) {
+                e0 = hl[i];
+                if constexpr (MASK == 1) e0 = kl[i] > 0.f ? e0 : 0.f;
                 if constexpr (MASK == 2) e0 = ((ml[f] >> (4 * r + 3)) & 1u) ? e0 : 0.f;
-                if constexpr (PRE) { if (yok) e0 = fmaxf(e0 + prb, 0.f); }
+                if constexpr (PRE) e0 = fmaxf(e0 + pbv, 0.f);
             }
-            if ((lane == 63 || u + 1 >= units) && tx != TW - 1) {
-                e5 = yok ? row[x0 + 5] : 0.f;
-                if constexpr (MASK == 1) { if (yok) e5 = pm[ro + x0 + 5] > 0.f ? e5 : 0.f; }
+            if (needR) {
+                e5 = hr[i];
+                if constexpr (MASK == 1) e5 = kr[i] > 0.f ? e5 : 0.f;
                 if constexpr (MASK == 2) e5 = ((mr[f] >> (4 * r)) & 1u) ? e5 : 0.f;
-                if constexpr (PRE) { if (yok) e5 = fmaxf(e5 + prb, 0.f); }
+                if constexpr (PRE) e5 = fmaxf(e5 + pbv, 0.f);
             }
             if (tx == 0) e0 = 0.f;
             if (tx == TW - 1) e5 = 0.f;
-            d[i][0] = e0; d[i][1] = m.x; d[i][2] = m.y; d[i][3] = m.z; d[i][4] = m.w; d[i][5] = e5;
-        } else {
+            d[i][0] = e0; d[i][1] = v.x; d[i][2] = v.y; d[i][3] = v.z; d[i][4] = v.w; d[i][5] = e5;
+        }
+    } else {
+        // W % 4 != 0 (res5 / p5 / p7 at 800x1344): 36 dword loads, all issued before the first is consumed (same reason as above)
+        float kk[6][6];
+        #pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int y = y0 + i;
+            const bool yok = y >= 0 && y < H;
+            const size_t ro = (size_t)(yok ? y : 0) * W;
             #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int x = x0 + j;
                 const bool ok = yok && x >= 0 && x < W;
-                float e = ok ? row[x] : 0.f;
-                if constexpr (MASK == 1) { if (ok) e = pm[ro + x] > 0.f ? e : 0.f; }
+                d[i][j] = ok ? p[ro + x] : 0.f;
+                if constexpr (MASK == 1) kk[i][j] = ok ? pm[ro + x] : 0.f;
+            }
+        }
+        #pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int y = y0 + i;
+            const bool yok = y >= 0 && y < H;
+            const int f = i == 0 ? 0 : (i == 5 ? 2 : 1), r = i == 0 ? 3 : (i == 5 ? 0 : i - 1);
+            #pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int x = x0 + j;
+                const bool ok = yok && x >= 0 && x < W;
+                float e = d[i][j];
+                if constexpr (MASK == 1) e = kk[i][j] > 0.f ? e : 0.f;
                 if constexpr (MASK == 2) {
                     const unsigned w16 = j == 0 ? ml[f] : (j == 5 ? mr[f] : mc[f]);
                     const int cc = j == 0 ? 3 : (j == 5 ? 0 : j - 1);
                     e = ((w16 >> (4 * r + cc)) & 1u) ? e : 0.f;
                 }
-                if constexpr (PRE) { if (ok) e = fmaxf(e + prb, 0.f); }
+                if constexpr (PRE) e = fmaxf(e + (ok ? prb : -INFINITY), 0.f);
                 d[i][j] = e;
             }
         }
@@ -640,28 +694,43 @@ __device__ __forceinline__ void wino4_out_t_body(const WinoArgs& a, int l, float
     const float* p = a.maps_in[l] + img;
     const float* pm = a.mask_ref[l] ? a.mask_ref[l] + img : nullptr;
     const unsigned mb = a.bits_in ? a.bits_in[(size_t)c * plane + (size_t)a.tile_off[l] + uu] : 0xffffu;
-    float g[4][4];
+    // all loads of the 4x4 block first, then the masks: with load + (runtime-optional) reference load + mask per row in one loop the
+    // compiler waited for each row before issuing the next (four exposed HBM latencies per workgroup instead of one)
+    float g[4][4], kref[4][4];
     #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int y = 4 * ty + i;
         const bool yok = y < H;
         const size_t ro = (size_t)(yok ? y : 0) * W + 4 * tx;
         if constexpr (VEC) {
-            float4 m = yok ? ldg_stream4(p + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pm) {
-                const float4 k = yok ? *reinterpret_cast<const float4*>(pm + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
-                m.x = k.x > 0.f ? m.x : 0.f; m.y = k.y > 0.f ? m.y : 0.f; m.z = k.z > 0.f ? m.z : 0.f; m.w = k.w > 0.f ? m.w : 0.f;
-            }
+            const float4 m = yok ? ldg_stream4(p + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
             g[i][0] = m.x; g[i][1] = m.y; g[i][2] = m.z; g[i][3] = m.w;
         } else {
             #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = yok && 4 * tx + j < W;
-                float e = ok ? p[ro + j] : 0.f;
-                if (ok && pm) e = pm[ro + j] > 0.f ? e : 0.f;
-                g[i][j] = e;
+            for (int j = 0; j < 4; ++j) g[i][j] = (yok && 4 * tx + j < W) ? p[ro + j] : 0.f;
+        }
+    }
+    if (pm) {
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = 4 * ty + i;
+            const bool yok = y < H;
+            const size_t ro = (size_t)(yok ? y : 0) * W + 4 * tx;
+            if constexpr (VEC) {
+                const float4 k = yok ? *reinterpret_cast<const float4*>(pm + ro) : make_float4(0.f, 0.f, 0.f, 0.f);
+                kref[i][0] = k.x; kref[i][1] = k.y; kref[i][2] = k.z; kref[i][3] = k.w;
+            } else {
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) kref[i][j] = (yok && 4 * tx + j < W) ? pm[ro + j] : 0.f;
             }
         }
+        #pragma unroll
+        for (int i = 0; i < 4; ++i)
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) g[i][j] = kref[i][j] > 0.f ? g[i][j] : 0.f;
+    }
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) {
         const unsigned nib = mb >> (4 * i);
         #pragma unroll
         for (int j = 0; j < 4; ++j) g[i][j] = ((nib >> j) & 1u) ? g[i][j] : 0.f;

@@ -11,5 +11,5 @@ done
 F=$(ls /tmp/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1)
 W=$(ls /tmp/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
 mkdir -p $R/gpurun_out
-python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r02_bench_pmc_fetch_write.csv $R/gpurun_out/r02_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing (BASELINE configs[1], B=8 800x1333; round 2 launch mix: single head pass, 16-bit ReLU masks)"
+python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r02_bench_pmc_fetch_write.csv $R/gpurun_out/r02_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing (BASELINE configs[1], B=8 800x1333; end of round 2 launch mix)"
 cat $R/gpurun_out/r02_bench_pmc_fetch_write.csv

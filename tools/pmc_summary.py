@@ -53,7 +53,17 @@ TIMER_NAMES = {
 
 def short(name):
     n = name.replace("lgd::", "")
-    return TIMER_NAMES.get(n, [re.sub(r"<.*$", "", n)])
+    if n in TIMER_NAMES:
+        return TIMER_NAMES[n]
+    m = re.match(r"wino4_in_kernel<(true|false), \d(, (true|false))?>$", n)      # <DUAL, MASK[, PRE]>
+    if m:
+        return ["wino_in_dual_kernel" if m.group(1) == "true" else "wino_in_kernel"]
+    m = re.match(r"wino4_in_t_kernel<(true|false)>$", n)                            # <FUSE>
+    if m:
+        return ["wino_in_t_out_t_kernel" if m.group(1) == "true" else "wino_in_t_kernel"]
+    base = re.sub(r"<.*$", "", n)
+    return [{"stem_pool_pair_kernel": "stem_pool_kernel", "wino4_filter_fwd_kernel": "wino_filter_kernel",
+             "wino4_filter_bwd_kernel": "wino_filter_bwd_kernel", "relu_bits_kernel": "relu_bits_kernel"}.get(base, base)]
 
 
 def traffic_json(summary_csv, out_json, note):
