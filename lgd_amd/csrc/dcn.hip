@@ -66,11 +66,18 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(DcnArgs a) {
 }
 
 // thread per (n, tap, pixel) and channel slice (blockIdx.y): loops over the slice's channels; dx by atomic scatter, d offset /
-// d mask summed in registers (one atomic per slice when the channels are split to fill the GPU on the small stages)
+// d mask summed in registers (one atomic per slice when the channels are split to fill the GPU on the small stages).
+// The kernel is bound by the L2's float-atomic rate (~210 G lane-atomics/s: four per channel and sample).  Neighbouring lanes are
+// neighbouring output pixels of one tap, and with smooth offsets lane L+1's top-left cell IS lane L's top-right cell: in that case
+// lane L hands its two right-column contributions to lane L+1 (one DPP shift each), which adds them to its own left-column ones
+// before the atomic -- two atomics per lane instead of four wherever the sampling grid is locally regular, any offsets stay exact
+// (the hand-over happens only where the two cells coincide).
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
     const int HoWo = a.Ho * a.Wo;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)a.N * 9 * HoWo) return;
+    const long long total = (long long)a.N * 9 * HoWo;
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i0 < total;
+    const long long i = live ? i0 : total - 1;      // no early exit: the lanes exchange values below
     const int pix = (int)(i % HoWo), k = (int)((i / HoWo) % 9), n = (int)(i / ((long long)HoWo * 9));
     const int ho = pix / a.Wo, wo = pix % a.Wo, ky = k / 3, kx = k % 3;
     const float* off = a.offset + (size_t)n * 18 * HoWo + pix;
@@ -78,30 +85,47 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
     const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + off[(size_t)(2 * k) * HoWo];
     const float pxx = (float)(wo * a.stride - a.pad + kx * a.dil) + off[(size_t)(2 * k + 1) * HoWo];
     const Bilin b = bilin_setup(py, pxx, a.H, a.W);
+    const bool in = live && b.in;
+    const float wy0 = 1.f - b.wy1, wx0 = 1.f - b.wx1;
+    const bool y0ok = in && b.y0 >= 0 && b.y0 < a.H, y1ok = in && b.y0 + 1 >= 0 && b.y0 + 1 < a.H;
+    const bool x0ok = b.x0 >= 0 && b.x0 < a.W, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < a.W;
+    const bool ok00 = y0ok && x0ok, ok01 = y0ok && x1ok, ok10 = y1ok && x0ok, ok11 = y1ok && x1ok;
+    const long long o00 = (long long)b.y0 * a.W + b.x0;          // may be negative where the sample hangs over the border
+    // lane L+1 takes over lane L's right column iff it samples the same image, the same rows and the column one to the right
+    const int lane = threadIdx.x & 63;
+    const unsigned ln = wave_shr1((unsigned)n), ly = wave_shr1((unsigned)b.y0), lx = wave_shr1((unsigned)b.x0), lin = wave_shr1(in ? 1u : 0u);
+    const bool takeL = lane > 0 && in && lin && ln == (unsigned)n && ly == (unsigned)b.y0 && lx + 1u == (unsigned)b.x0;
+    // (its own statement: inside `lane < 63 && ...` the shift would run with lane 63 masked off, and lane 62 would read 0 from it)
+    const unsigned rtake = wave_shl1(takeL ? 1u : 0u);
+    const bool giveR = (lane < 63) & (rtake != 0u);
     float gy = 0.f, gx = 0.f, gm = 0.f;
-    if (b.in) {
-        const float wy0 = 1.f - b.wy1, wx0 = 1.f - b.wx1;
-        const bool y0ok = b.y0 >= 0 && b.y0 < a.H, y1ok = b.y0 + 1 >= 0 && b.y0 + 1 < a.H;
-        const bool x0ok = b.x0 >= 0 && b.x0 < a.W, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < a.W;
-        const size_t o00 = (size_t)b.y0 * a.W + b.x0;
-        const int c0 = blockIdx.y * a.cchunk, c1 = min(a.C, c0 + a.cchunk);
-        for (int c = c0; c < c1; ++c) {
-            const size_t plane = ((size_t)n * a.C + c) * a.H * a.W;
-            const float* p = a.x + plane;
-            float* dp = a.dx + plane;
-            const float g = a.dcol[(((size_t)n * a.C + c) * 9 + k) * HoWo + pix];
-            const float v00 = (y0ok && x0ok) ? p[o00] : 0.f, v01 = (y0ok && x1ok) ? p[o00 + 1] : 0.f;
-            const float v10 = (y1ok && x0ok) ? p[o00 + a.W] : 0.f, v11 = (y1ok && x1ok) ? p[o00 + a.W + 1] : 0.f;
-            const float gmk = g * m;
-            if (y0ok && x0ok) unsafeAtomicAdd(dp + o00, gmk * wy0 * wx0);
-            if (y0ok && x1ok) unsafeAtomicAdd(dp + o00 + 1, gmk * wy0 * b.wx1);
-            if (y1ok && x0ok) unsafeAtomicAdd(dp + o00 + a.W, gmk * b.wy1 * wx0);
-            if (y1ok && x1ok) unsafeAtomicAdd(dp + o00 + a.W + 1, gmk * b.wy1 * b.wx1);
-            gy += gmk * (wx0 * (v10 - v00) + b.wx1 * (v11 - v01));
-            gx += gmk * (wy0 * (v01 - v00) + b.wy1 * (v11 - v10));
-            gm += g * (wy0 * (wx0 * v00 + b.wx1 * v01) + b.wy1 * (wx0 * v10 + b.wx1 * v11));
+    const int c0 = blockIdx.y * a.cchunk, c1 = min(a.C, c0 + a.cchunk);
+    for (int c = c0; c < c1; ++c) {                                // wave-uniform trip count: every lane runs the exchange
+        const size_t plane = ((size_t)n * a.C + c) * a.H * a.W;
+        const float* p = a.x + plane;
+        float* dp = a.dx + plane;
+        const float g = in ? a.dcol[(((size_t)n * a.C + c) * 9 + k) * HoWo + pix] : 0.f;
+        const float v00 = ok00 ? p[o00] : 0.f, v01 = ok01 ? p[o00 + 1] : 0.f;
+        const float v10 = ok10 ? p[o00 + a.W] : 0.f, v11 = ok11 ? p[o00 + a.W + 1] : 0.f;
+        const float gmk = g * m;
+        float a00 = ok00 ? gmk * wy0 * wx0 : 0.f, a01 = ok01 ? gmk * wy0 * b.wx1 : 0.f;
+        float a10 = ok10 ? gmk * b.wy1 * wx0 : 0.f, a11 = ok11 ? gmk * b.wy1 * b.wx1 : 0.f;
+        // the left neighbour's right column = my left column's cells (valid iff mine are).  Selects, not a branch, and the shifts as
+        // statements of their own: a DPP move that ends up under a lane mask reads 0 from the masked-off source lanes
+        const float r01 = wave_shr1(a01), r11 = wave_shr1(a11);
+        a00 += takeL ? r01 : 0.f;
+        a10 += takeL ? r11 : 0.f;
+        if (ok00) unsafeAtomicAdd(dp + o00, a00);
+        if (ok10) unsafeAtomicAdd(dp + o00 + a.W, a10);
+        if (!giveR) {
+            if (ok01) unsafeAtomicAdd(dp + o00 + 1, a01);
+            if (ok11) unsafeAtomicAdd(dp + o00 + a.W + 1, a11);
         }
+        gy += gmk * (wx0 * (v10 - v00) + b.wx1 * (v11 - v01));
+        gx += gmk * (wy0 * (v01 - v00) + b.wy1 * (v11 - v10));
+        gm += g * (wy0 * (wx0 * v00 + b.wx1 * v01) + b.wy1 * (wx0 * v10 + b.wx1 * v11));
     }
+    if (!live) return;
     float* oy = a.doffset + ((size_t)n * 18 + 2 * k) * HoWo + pix;
     float* om = a.dmask ? a.dmask + ((size_t)n * 9 + k) * HoWo + pix : nullptr;
     if (gridDim.y == 1) {

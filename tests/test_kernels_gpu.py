@@ -1458,3 +1458,27 @@ def test_bottleneck_blocks_vs_fp64(stride, wino):
             assert cm.rel_err(a.grad, b.grad) < 2e-4, n
     finally:
         ops.conv3x3_backend(*prev)
+
+
+@pytest.mark.parametrize("scale", [0.0, 0.1, 0.3, 0.6, 2.0])
+def test_deform_conv3x3_dx_neighbour_lane_merge(scale):
+    """dcn_col2im hands a lane's right-column contributions to its right neighbour lane wherever the two samples' cells coincide
+    (half the atomics on locally regular sampling grids): dx / d offset / d mask against the per-tap restatement for offsets from
+    exactly zero (every lane merges) over small (some lanes merge, the case a wrong lane mask breaks) to large (none do)."""
+    from lgd_amd import ops
+    torch.manual_seed(int(scale * 10))
+    N, C, O, H, W = 2, 6, 5, 9, 11
+    x = torch.randn(N, C, H, W, device=DEV, requires_grad=True)
+    off = (torch.randn(N, 18, H, W, device=DEV) * scale).requires_grad_(True)
+    m = torch.rand(N, 9, H, W, device=DEV, requires_grad=True)
+    w = torch.randn(O, C, 3, 3, device=DEV, requires_grad=True)
+    gy = torch.randn(N, O, H, W, device=DEV)
+    ops.deform_conv3x3(x, off, m, w, None, 1, 1, 1).backward(gy)
+    got = [t.grad.clone() for t in (x, off, m)]
+    for t in (x, off, m, w):
+        t.grad = None
+    SO.modulated_deform_conv2d(x, off, m, w, None, 1, 1, 1).backward(gy)
+    for g, t, name in zip(got, (x, off, m), ("x", "offset", "mask")):
+        if name == "offset" and scale == 0.0:
+            continue   # integer sampling positions sit on the kink of the bilinear interpolation: one-sided derivatives differ
+        assert float((g - t.grad).abs().max()) <= 2e-4 * float(t.grad.abs().max()) + 1e-6, name
