@@ -1241,7 +1241,9 @@ class _DeformConv(torch.autograd.Function):
         col = torch.empty((N, C * 9, Ho * Wo), dtype=torch.float32, device=x.device)
         hip.check(lib.lgd_dcn_im2col(hip.ptr(x), hip.ptr(offset), hip.ptr(mask) if mask is not None else None, N, C, H, W,
                                      stride, padding, dilation, hip.ptr(col), hip.stream_ptr()), "lgd_dcn_im2col")
-        out = torch.matmul(weight.view(O, C * 9), col).view(N, O, Ho, Wo)
+        # batched GEMM with the filter as a stride-0 batch: torch.matmul(2-D, 3-D) folds the batch by transposing + copying the whole
+        # column matrix (and the result back): 135 strided copies = 8 of config 5's 58 ms of kernels per step (rocprofv3)
+        out = torch.bmm(weight.view(1, O, C * 9).expand(N, O, C * 9), col).view(N, O, Ho, Wo)
         if bias is not None:
             out = out + bias.view(1, -1, 1, 1)
         ctx.save_for_backward(x, offset, mask, weight, col)
@@ -1258,7 +1260,7 @@ class _DeformConv(torch.autograd.Function):
         dy = hip.dense_f32(dy).view(N, O, -1)
         dx = doff = dmask = dw = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
-            dcol = torch.matmul(weight.view(O, C * 9).t(), dy)
+            dcol = torch.bmm(weight.view(1, O, C * 9).transpose(1, 2).expand(N, C * 9, O), dy)
             dx = torch.empty_like(x)
             doff = torch.empty_like(offset)
             dmask = torch.empty_like(mask) if mask is not None else None

@@ -144,10 +144,11 @@ class DeformBottleneck(Bottleneck):
             offset, mask = om, torch.ones_like(om[:, :9])
         c2 = self.conv2
         scale, shift = c2.norm.scale_shift()
-        out = modulated_deform_conv2d(out, offset, mask, c2.weight * scale.view(-1, 1, 1, 1), shift, c2.stride[0],
+        out = modulated_deform_conv2d(out, offset, mask, c2.weight * scale.view(-1, 1, 1, 1), None, c2.stride[0],
                                       c2.padding[0], c2.dilation[0])
+        out = ops.bias_act(out, shift, None, True) if out.is_cuda else F.relu_(out + shift.view(1, -1, 1, 1))   # one pass
         sc = self.shortcut(x, subsampled=shared) if self.shortcut is not None else x
-        return self.conv3(F.relu_(out), relu=True, residual=sc)
+        return self.conv3(out, relu=True, residual=sc)
 
 
 class Stem(nn.Module):
