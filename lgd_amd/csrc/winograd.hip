@@ -50,6 +50,15 @@ __device__ __forceinline__ int wino_level(const WinoArgs& a) {
     return __builtin_amdgcn_readfirstlane(l);
 }
 
+// (tx, ty, n) of tile u of a level in 32-bit arithmetic (a level has < 2^31 tiles: wino_fill checks).  The long long form
+// `u % TW, (u / TW) % TH, u / (TW * TH)` compiles to four software 64-bit divisions, ~600 of the ~2000 instructions of a transform
+// kernel and all of them in front of its first load; the transforms turned out to be as much VALU-issue- as HBM-bound
+// (1160 VALU instructions per tile = 87 us of pure issue for the 110 us pyramid launch).
+__device__ __forceinline__ void tile_coords(long long u, int TW, int TH, int& tx, int& ty, int& n) {
+    const unsigned v = (unsigned)u, r = v / (unsigned)TW, q = r / (unsigned)TH;
+    tx = (int)(v - r * (unsigned)TW); ty = (int)(r - q * (unsigned)TH); n = (int)q;
+}
+
 // G g G^T of the rotated filter is the frequency permutation 0<->3 (rows 1,2 of G are symmetric under the flip)
 __device__ __forceinline__ int freq(int i, int j, int flip) {
     const int pi = (i == 0 || i == 3) ? 3 - i : i, pj = (j == 0 || j == 3) ? 3 - j : j;
@@ -387,7 +396,8 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
     const long long uu = on ? u : units - 1;
     const int c = blockIdx.y;
     const size_t plane = (size_t)a.T;
-    const int tx = (int)(uu % TW), ty = (int)((uu / TW) % TH), n = (int)(uu / ((long long)TW * TH));
+    int tx, ty, n;
+    tile_coords(uu, TW, TH, tx, ty, n);
     const size_t img = ((size_t)n * a.C + c) * H * W;
     const float* p = a.maps_in[l] + img;
     const float* pm = MASK == 1 ? a.mask_ref[l] + img : nullptr;
@@ -632,7 +642,8 @@ __device__ __forceinline__ void wino4_out_body(const WinoArgs& a, int l, float* 
             #pragma unroll
             for (int j = 0; j < 6; ++j) mm[i][j] = __builtin_nontemporal_load(m + (size_t)(6 * i + j) * plane + threadIdx.x);
     }
-    const int tx = (int)(u % TW), ty = (int)((u / TW) % TH), n = (int)(u / ((long long)TW * TH));
+    int tx, ty, n;
+    tile_coords(u, TW, TH, tx, ty, n);
     float r[4][6];
     #pragma unroll
     for (int j = 0; j < 6; ++j) {  // columns: A^T m
@@ -689,7 +700,8 @@ __device__ __forceinline__ void wino4_out_t_body(const WinoArgs& a, int l, float
     const long long uu = on ? u : units - 1;
     const int c = blockIdx.y;
     const size_t plane = (size_t)a.T;
-    const int tx = (int)(uu % TW), ty = (int)((uu / TW) % TH), n = (int)(uu / ((long long)TW * TH));
+    int tx, ty, n;
+    tile_coords(uu, TW, TH, tx, ty, n);
     const size_t img = ((size_t)n * a.C + c) * H * W;
     const float* p = a.maps_in[l] + img;
     const float* pm = a.mask_ref[l] ? a.mask_ref[l] + img : nullptr;
@@ -880,7 +892,8 @@ __device__ __forceinline__ void wino4_in_t_body(const WinoArgs& a, int l, float*
     const long long uu = on ? u : units - 1;
     const int c = blockIdx.y;
     const size_t plane = (size_t)a.T;
-    const int tx = (int)(uu % TW), ty = (int)((uu / TW) % TH), n = (int)(uu / ((long long)TW * TH));
+    int tx, ty, n;
+    tile_coords(uu, TW, TH, tx, ty, n);
     const bool hasL = on && tx > 0, hasR = on && tx < TW - 1, hasU = on && ty > 0, hasD = on && ty < TH - 1;
     const float* m = a.buf_in + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0;
     // t[r][b]: window row r+1 (= block row r) of B G per frequency column b, incl. the vertical neighbours' rows;
@@ -1073,6 +1086,7 @@ static int wino_fill(WinoArgs& a, const int32_t* level_hw, int L, int N, int C, 
         a.tile_off[l] = off;
         a.blk_off[l] = blk;
         const long long units = (long long)N * a.TH[l] * ((tile == 2 && a.pair[l]) ? a.TW[l] / 2 : a.TW[l]);
+        if (units >= (1LL << 31) - 256) return LGD_EINVAL;   // the kernels index a level's tiles in 32 bits
         blk += (unsigned)((units + 1 + 255) / 256);  // +1: the thread that writes the zero pad tile (tile 2)
         off += level_tiles(N, H, W, tile);
     }
