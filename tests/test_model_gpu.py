@@ -647,3 +647,42 @@ def test_graphed_backbone_equals_eager():
     assert g.captures == 4
     for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("yaml_name", ["lgd_retinanet_r50.yaml", "lgd_fcos_r50.yaml"])   # (R-101-DCNv2 passes too: 3.5 min of library conv search)
+def test_full_size_step_shipped_path_vs_library_convolutions(monkeypatch, yaml_name):
+    """Two training steps of the distillator meta-arch (BASELINE configs 2 / 3) at the BASELINE image size (2 x 800 x 1333, 10 boxes; every 3x3 convolution of the
+    backbone, FPN, head and teacher is above the Winograd threshold) on the shipped path -- F(4x4,3x3) transforms with the folded
+    pre-activations, conv1 + shortcut nodes with beta = 1 accumulation, FPN laterals as GEMMs, fused stem epilogue, one-launch clip +
+    SGD -- against the same model on the library's convolutions and torch's optimizers: same losses (the loss of step 2 goes through
+    every gradient and the parameter update) [ref: train.py:184-207]."""
+    import copy
+    from lgd_amd import config, ops
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", yaml_name), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    base = build_model(cfg)
+    twin = copy.deepcopy(base)
+    data = synthetic_batch(2, 800, 1333, 10, seed=3)
+    d = cfg.MODEL.DISTILLATOR
+    it0 = max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS)
+    prev = ops.conv3x3_backend(winograd=True, tile=4)
+    try:
+        a = Trainer(cfg, base, distributed=False)
+        assert a._fused_sgd is not None
+        la = [{k: float(v) for k, v in a.step(data, it0 + i).items()} for i in range(2)]
+        ops.conv3x3_backend(winograd=False)
+        monkeypatch.setenv("LGD_FUSED_SGD", "0")
+        b = Trainer(cfg, twin, distributed=False)
+        assert b._fused_sgd is None
+        lb = [{k: float(v) for k, v in b.step(data, it0 + i).items()} for i in range(2)]
+    finally:
+        ops.conv3x3_backend(*prev)
+    for i in range(2):
+        for k in la[i]:
+            assert abs(la[i][k] - lb[i][k]) <= 2e-4 * abs(lb[i][k]) + 1e-6, (i, k, la[i][k], lb[i][k])
+    print("full-size step, shipped vs library path: step-2 losses", la[1], lb[1])
