@@ -240,66 +240,57 @@ int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* la
                        const int32_t* level_hw_host, int L, int N, int A, int K, float alpha, float gamma,
                        const float* grad_loss, float* const* grad_logits_host, void* stream);
 
-/* ------------------------------------------------------------------ K8: 3x3 convolutions (Winograd F(2x2,3x3) data transforms)
+/* ------------------------------------------------------------------ K8: 3x3 convolutions (Winograd data transforms)
  * Replaces the data movement of nn.Conv2d(C, C', 3, padding=1) on the path: dynamic_teacher.py:57,61,67-73
  * (student_proj_2D, local_inst_proj_2D, refinement_module), models/adapters/sequential_convs.py:10-12 and the
  * student head re-run on the teacher features (distillator.py:107-109).  Each of these modules applies ONE filter
- * to every pyramid level, so the tiles of all L levels are concatenated: T = lgd_wino_tiles(level_hw, L, N) =
- * sum_l even(N * ceil(H_l/2) * ceil(W_l/2)) (a level with an odd tile count is followed by one all-zero pad tile).
- * The 16 per-frequency channel products M[f] = U[f] (C' x C) @ V[f] (C x T) between the transforms are plain library
- * GEMMs issued by the host (hipBLASLt); U = G g G^T is built by the host from the nn.Conv2d weight.
- * V, M, dM are [C][nf][T] fp32 (nf = 16 frequencies for tile = 2), tile index fastest: the GEMM of frequency f sees a
- * (C x T) matrix with leading dimension nf*T and batch stride T.  x_host / y_host / dy_host: host arrays of L device pointers
- * to (N, C, H_l, W_l) maps.
- *   lgd_wino_in   : V  = B^T d B  of the 4x4 input window of every tile (stride 2, zero halo 1); if dM != NULL also
- *                   dM = A g A^T of the window's 2x2 centre (the two backward operands in one pass over dy)
- *   lgd_wino_out  : y  = A^T m A + bias (bias may be NULL) [then ReLU if relu], 2x2 outputs per tile, clipped to H x W
- *   lgd_wino_out_t: dM = A dy A^T alone, the adjoint of lgd_wino_out (weight gradient: dU[f] = dM[f] @ V[f]^T)
- *   lgd_wino_in_t : dx = the adjoint of lgd_wino_in (tile = 4 only): overlap-add of B dV B^T over the 6x6 windows, written as a
- *                   gather per 4x4 block (deterministic, no atomics).  With it the backward pass of a convolution expands dy ONCE:
- *                   dM = out_t(dy), dV[f] = U[f]^T @ dM[f], dx = in_t(dV), dU[f] = dM[f] @ V[f]^T -- the autograd of the forward
- *                   pipeline itself, 2.25 maps of frequency-buffer writes less than the rotated-filter form below.
- * relu_ref_host (may be NULL): the forward outputs y_l of a conv evaluated with relu = 1; the incoming gradient is
- *   zeroed where y_l <= 0 while it is read (the ReLU backward costs no pass of its own).
- * tile = 2 computes the input gradient as the same pipeline run on dy with the filter rotated by 180 degrees and transposed in (C', C).
- * tile = 2: F(2x2,3x3) as described (16 frequencies, windows 4x4 at stride 2); the rotation is the frequency
- *   permutation (0<->3 on both axes), applied by the transforms when flip = 1, so the host reuses U and only
- *   transposes it: dx = out(U[f]^T @ in(dy, flip=1), flip=1).
- * tile = 4: F(4x4,3x3): 36 frequencies (buffers [C][36][T]), windows 6x6 at stride 4, 4x4 outputs per tile,
- *   T = sum_l (N * ceil(H_l/4) * ceil(W_l/4) rounded up to a multiple of 4 with zero tiles); flip must be 0 -- the host transforms the rotated filter.
- *   0.56x the GEMM work and ~0.65x the transform traffic of tile = 2; fp32 rounding ~1e-5 of the output scale per
- *   convolution instead of ~6e-7.
- * relu_bits (tile = 4 only, may be NULL): [C][T] uint16, one entry per tile: bit 4*i+j set <=> output (i,j) of the tile is > 0.
- *   lgd_wino_out writes it (with relu = 1); lgd_wino_in / lgd_wino_out_t take it INSTEAD of relu_ref_host as the gradient mask:
- *   1 bit per pixel instead of re-reading the 4-byte forward output, and the forward output need not be kept for the backward. */
-size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N, int tile);
-/* pre_bias (tile = 4 only, may be NULL): the maps are PRE-activations of a conv -> per-channel bias -> ReLU whose output feeds this
+ * to every pyramid level, so the tiles of all L levels are concatenated: T = lgd_wino_tiles(level_hw, L, N, tile) =
+ * sum_l pad16(N * ceil(H_l/tile) * ceil(W_l/tile)) (every level is followed by all-zero pad tiles up to a multiple of 16).
+ * tile = 4: F(4x4,3x3), nf = 36 frequencies, windows 6x6 at stride 4 (2.25 multiplies per output pixel, fp32 rounding ~1e-5 of the
+ *   output scale per convolution); tile = 6: F(6x6,3x3), nf = 64, windows 8x8 at stride 6 (1.78 multiplies, ~1.8e-5).
+ * The nf per-frequency channel products M[f] = U[f] (C' x C) @ V[f] (C x T) between the transforms are plain library
+ * GEMMs issued by the host (rocBLAS / hipBLASLt); U = G g G^T comes from lgd_wino_filter_fwd.
+ * V, M, dM, dV are [C][nf][T] fp32, tile index fastest: the GEMM of frequency f sees a (C x T) matrix with leading dimension nf*T
+ * and batch stride T.  x_host / y_host / dy_host / dx_host: host arrays of L device pointers to (N, C, H_l, W_l) maps.
+ *   lgd_wino_in   : V  = B^T d B  of the (tile+2)^2 input window of every tile (stride tile, zero halo 1)
+ *   lgd_wino_out  : y  = A^T m A + bias (bias may be NULL) [then ReLU if relu], tile x tile outputs per tile, clipped to H x W
+ *   lgd_wino_out_t: dM = A (dy . mask) A^T, the adjoint of lgd_wino_out: the ONE expansion of dy the backward needs
+ *                   (dU[f] = dM[f] @ V[f]^T, dV[f] = U[f]^T @ dM[f])
+ *   lgd_wino_in_t : dx = the adjoint of lgd_wino_in: overlap-add of B dV B^T over the windows, written as a gather per
+ *                   tile x tile block (deterministic, no atomics)
+ * Mask tables (relu_bits / pre_bits, may be NULL): [C][T] entries of lgd_wino_mask_bytes(tile) bytes (uint16 for tile 4, uint64 for
+ *   tile 6), bit tile*i+j set <=> pixel (i,j) of the tile's own block is > 0.  lgd_wino_out writes relu_bits (with relu = 1);
+ *   lgd_wino_out_t / lgd_wino_in_t_out_t take it as the gradient mask: 1 bit per pixel instead of re-reading the 4-byte forward
+ *   output, and the forward output need not be kept for the backward.
+ * pre_bias (may be NULL): the maps are PRE-activations of a conv -> per-channel bias -> ReLU whose output feeds this
  *   convolution and nothing else (conv1 -> FrozenBN -> ReLU -> conv2 of a bottleneck block): lgd_wino_in transforms
  *   relu(x + pre_bias[c]) -- the epilogue pass of the producing convolution is folded into this load -- and writes the activation
- *   mask per tile to pre_bits ([C][T] uint16, may be NULL when no backward follows); lgd_wino_in_t takes pre_bits and returns the
- *   gradient of the RAW maps (zero where the activation was <= 0).  Not combined with dM / relu_ref_host / relu_bits. */
-int lgd_wino_in(const float* const* x_host, const float* const* relu_ref_host, const uint16_t* relu_bits, const int32_t* level_hw_host,
-                int L, int N, int C, int tile, int flip, float* V, float* dM, const float* pre_bias, uint16_t* pre_bits, void* stream);
-int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host, int L, int N, int C, int tile, int flip,
-                 int relu, float* const* y_host, uint16_t* relu_bits, void* stream);
-int lgd_wino_out_t(const float* const* dy_host, const float* const* relu_ref_host, const uint16_t* relu_bits,
-                   const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM, void* stream);
+ *   mask per tile to pre_bits (may be NULL when no backward follows); lgd_wino_in_t takes pre_bits and returns the
+ *   gradient of the RAW maps (zero where the activation was <= 0). */
+size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N, int tile);
+size_t lgd_wino_mask_bytes(int tile);
+int lgd_wino_in(const float* const* x_host, const int32_t* level_hw_host, int L, int N, int C, int tile, float* V,
+                const float* pre_bias, void* pre_bits, void* stream);
+int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host, int L, int N, int C, int tile,
+                 int relu, float* const* y_host, void* relu_bits, void* stream);
+int lgd_wino_out_t(const float* const* dy_host, const void* relu_bits, const int32_t* level_hw_host, int L, int N, int C, int tile,
+                   float* dM, void* stream);
 int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host,
-                  const uint16_t* pre_bits, void* stream);
-/* Filter transforms of tile = 4 (the host's `U = kron(G,G) @ weight` of the 16-frequency form, done here for the 36-frequency one):
+                  const void* pre_bits, void* stream);
+/* Filter transforms:
  *   lgd_wino_filter_fwd: U[f][co][ci] = (G (scale[co] . g) G^T)[f] at U + f*u_plane + co*Ci + ci, and the same values transposed in
  *     (co, ci) at Ut + f*ut_plane + ci*ut_ld + co (the operand of dV = U^T dM); u_plane / ut_plane / ut_ld let several filters stack
  *     their slabs along C_out in one buffer (lgd_amd/ops.py::_Conv3x3K).  w: (Co, Ci, 3, 3) contiguous; scale: per-output-channel
  *     factor of a frozen affine that follows the convolution (detectron2 FrozenBatchNorm2d) or NULL.
  *   lgd_wino_filter_bwd: dw[co][ci] = scale[co] . G^T dU[:, co, ci] G, dU read at dU + f*du_plane + co*Ci + ci. */
-int lgd_wino_filter_fwd(const float* w, const float* scale, int Co, int Ci, float* U, long long u_plane, float* Ut, long long ut_ld,
-                        long long ut_plane, void* stream);
-int lgd_wino_filter_bwd(const float* dU, long long du_plane, const float* scale, int Co, int Ci, float* dw, void* stream);
-/* lgd_wino_in_t followed by lgd_wino_out_t of the convolution that PRODUCED these maps, in one kernel (tile = 4): the backward link of a
+int lgd_wino_filter_fwd(const float* w, const float* scale, int Co, int Ci, int tile, float* U, long long u_plane, float* Ut,
+                        long long ut_ld, long long ut_plane, void* stream);
+int lgd_wino_filter_bwd(const float* dU, long long du_plane, const float* scale, int Co, int Ci, int tile, float* dw, void* stream);
+/* lgd_wino_in_t followed by lgd_wino_out_t of the convolution that PRODUCED these maps, in one kernel: the backward link of a
  * conv -> [ReLU] -> conv chain whose intermediate maps have no other consumer (the head towers, the adapter: distillator.py:107-109,
  * sequential_convs.py:10-12).  dV: frequency-domain input gradient of the later conv; relu_bits: the earlier conv's mask table (NULL: no
- * ReLU between them); dM: A (dx . mask) A^T of the earlier conv, same [C][36][T] layout.  The gradient map dx is never materialised. */
-int lgd_wino_in_t_out_t(const float* dV, const uint16_t* relu_bits, const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM,
+ * ReLU between them); dM: A (dx . mask) A^T of the earlier conv, same [C][nf][T] layout.  The gradient map dx is never materialised. */
+int lgd_wino_in_t_out_t(const float* dV, const void* relu_bits, const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM,
                         void* stream);
 
 /* ------------------------------------------------------------------ FCOS ground-truth assignment

@@ -132,11 +132,11 @@ def load_checkpoint(path, model, trainer=None, resume=False):
     c2 = bool(data.get("matching_heuristics", False)) or data.get("__author__") == "Caffe2"
     rep = load_model_state(model, data["model"], c2_backbone=c2)
     if resume and trainer is not None and "stu_optimizer" in data:
-        from .engine import optimizer_state_from_reference
+        from .engine import load_scheduler_state, optimizer_state_from_reference
         trainer.stu_optimizer.load_state_dict(optimizer_state_from_reference(data["stu_optimizer"], trainer.stu_optimizer))
         trainer.tea_optimizer.load_state_dict(optimizer_state_from_reference(data["tea_optimizer"], trainer.tea_optimizer))
-        trainer.stu_scheduler.load_state_dict(data["stu_scheduler"])
-        trainer.tea_scheduler.load_state_dict(data["tea_scheduler"])
+        load_scheduler_state(trainer.stu_scheduler, data["stu_scheduler"])
+        load_scheduler_state(trainer.tea_scheduler, data["tea_scheduler"])
         trainer.iteration = data.get("iteration", -1) + 1
         rep.iteration = trainer.iteration
     return rep

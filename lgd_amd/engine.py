@@ -69,6 +69,21 @@ def build_distillator_lr_scheduler(solver, optimizer, max_iter=None):
     raise ValueError("Unknown LR sheduler: {}".format(name))
 
 
+def load_scheduler_state(scheduler, state):
+    """restore a LambdaLR of build_distillator_lr_scheduler from its own state_dict OR from the state of the reference's
+    detectron2 WarmupMultiStepLR / WarmupCosineLR (`milestones, gamma, warmup_*, base_lrs, last_epoch, _step_count, _last_lr`:
+    no `lr_lambdas`, which LambdaLR.load_state_dict pops unconditionally; and `_last_lr` / `base_lrs` hold one entry per
+    parameter, utils/build.py:494-512).  The schedule itself is a pure function of the iteration, so only the position is
+    taken and the learning rates are recomputed for this optimizer's groups."""
+    last = int(state["last_epoch"])
+    scheduler.last_epoch = last
+    scheduler._step_count = int(state.get("_step_count", last + 1))
+    lrs = [base * lmbda(last) for base, lmbda in zip(scheduler.base_lrs, scheduler.lr_lambdas)]
+    for g, lr in zip(scheduler.optimizer.param_groups, lrs):
+        g["lr"] = lr
+    scheduler._last_lr = lrs
+
+
 def _unwrap(model):
     return model.module if isinstance(model, DistributedDataParallel) else model
 
@@ -232,7 +247,9 @@ class Trainer:
     def step(self, data, iteration=None):
         it = self.iteration if iteration is None else iteration
         self.set_phase(it)
-        if not self.model.training:   # nn.Module.train() walks the whole module tree: once, not per step
+        # nn.Module.train() walks the whole module tree: once, not per step.  Both flags: an evaluation in the middle of training
+        # (the reference runs do_test inside the loop) calls raw_model.eval(), which leaves a DDP wrapper's own flag at True
+        if not (self.model.training and self.raw_model.training):
             self.model.train()
         loss_dict = self.model(data)
         losses = sum(loss_dict.values())
@@ -326,6 +343,6 @@ class Trainer:
             g.reset()  # frozen weights / FrozenBN buffers feed caches the captured kernels read
         self.stu_optimizer.load_state_dict(optimizer_state_from_reference(sd["stu_optimizer"], self.stu_optimizer))
         self.tea_optimizer.load_state_dict(optimizer_state_from_reference(sd["tea_optimizer"], self.tea_optimizer))
-        self.stu_scheduler.load_state_dict(sd["stu_scheduler"])
-        self.tea_scheduler.load_state_dict(sd["tea_scheduler"])
+        load_scheduler_state(self.stu_scheduler, sd["stu_scheduler"])
+        load_scheduler_state(self.tea_scheduler, sd["tea_scheduler"])
         self.iteration = sd.get("iteration", -1) + 1

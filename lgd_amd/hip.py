@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -61,12 +61,13 @@ SIGNATURES = {
     "lgd_focal_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
     "lgd_focal_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
     "lgd_wino_tiles": (c_sz, [c_fp, c_i, c_i, c_i]),
-    "lgd_wino_in": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
-    "lgd_wino_out": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
-    "lgd_wino_out_t": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_wino_mask_bytes": (c_sz, [c_i]),
+    "lgd_wino_in": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_wino_out": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_wino_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_in_t": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
-    "lgd_wino_filter_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp]),
-    "lgd_wino_filter_bwd": (c_i, [c_fp, ctypes.c_longlong, c_fp, c_i, c_i, c_fp, c_fp]),
+    "lgd_wino_filter_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp]),
+    "lgd_wino_filter_bwd": (c_i, [c_fp, ctypes.c_longlong, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_in_t_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_relu_bits_words": (c_sz, [ctypes.c_longlong]),
     "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
@@ -162,23 +163,36 @@ def ptr_array(tensors):
 class _PinnedRing:
     """Small host -> device uploads (per-image offsets, index lists: a few dozen bytes, several per step) through a ring of PINNED
     staging slots: `torch.tensor(list).to(device)` reads pageable memory, which the runtime copies synchronously with the host and
-    only after the stream has drained -- every such call let the GPU run dry for 0.2-0.7 ms (tools/gap_profile.sh).  A slot is reused
-    after SLOTS further uploads (hundreds of steps later), long after its copy has executed."""
-    SLOTS, SLOT_BYTES = 1024, 1024
+    only after the stream has drained -- every such call let the GPU run dry for 0.2-0.7 ms (tools/gap_profile.sh).  The ring is cut
+    into SEGMENTS of slots; the last upload of a segment records an event on its stream and the first upload of the ring's next pass
+    over that segment waits for it -- a slot is never rewritten before the copy that read it has executed (in practice the event is
+    hundreds of steps old and the wait is a flag test)."""
+    SLOTS, SLOT_BYTES, SEGMENT = 1024, 1024, 128
 
     def __init__(self):
         self.buf = torch.empty(self.SLOTS * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
         self.i = 0
+        self.events = [None] * (self.SLOTS // self.SEGMENT)
+        self.waits = 0   # how many segment re-entries found an event to wait for (tests)
 
     def upload(self, t, device):
         n = t.numel() * t.element_size()
         if n == 0 or n > self.SLOT_BYTES:
             return t.to(device, non_blocking=True)
+        seg, first = divmod(self.i, self.SEGMENT)
+        if first == 0 and self.events[seg] is not None:
+            self.events[seg].synchronize()
+            self.waits += 1
         o = self.i * self.SLOT_BYTES
-        self.i = (self.i + 1) % self.SLOTS
         slot = self.buf[o:o + n].view(t.dtype).view(t.shape)
         slot.copy_(t)
-        return slot.to(device, non_blocking=True)
+        out = slot.to(device, non_blocking=True)
+        if first == self.SEGMENT - 1:
+            if self.events[seg] is None:
+                self.events[seg] = torch.cuda.Event()
+            self.events[seg].record()   # the current stream: the one the copy above was issued on
+        self.i = (self.i + 1) % self.SLOTS
+        return out
 
 
 _ring = None

@@ -739,19 +739,13 @@ def label_planes(labels, level_hw, A):
 
 
 # ------------------------------------------------------------------------------------------------ K8: 3x3 convolutions
-_WINO_GG = {}
-_WINO_G = {2: [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
-           4: [[1 / 4, 0.0, 0.0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
-               [1 / 24, -1 / 12, 1 / 6], [0.0, 0.0, 1.0]]}
-
-
-def _wino_gg(device, tile):
-    """(F, 9) Kronecker form of U = G g G^T: U[a*n+b] = sum_ij G[a,i] G[b,j] g[i,j]; F = 16 (tile 2) or 36 (tile 4)."""
-    key = (str(device), tile)
-    if key not in _WINO_GG:
-        G = torch.tensor(_WINO_G[tile], dtype=torch.float64)
-        _WINO_GG[key] = torch.kron(G, G).to(torch.float32).contiguous().to(device)
-    return _WINO_GG[key]
+# G of F(tile x tile, 3x3) (tests/test_host_cpu.py::test_winograd_matrices_define_the_convolution holds the kernels' matrices to the
+# definition; the device code carries its own copies in csrc/winograd.hip / winograd6.hip)
+_WINO_G = {4: [[1 / 4, 0.0, 0.0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+               [1 / 24, -1 / 12, 1 / 6], [0.0, 0.0, 1.0]],
+           6: [[1.0, 0.0, 0.0], [-2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9], [1 / 90, 1 / 45, 2 / 45], [1 / 90, -1 / 45, 2 / 45],
+               [32 / 45, 16 / 45, 8 / 45], [32 / 45, -16 / 45, 8 / 45], [0.0, 0.0, 1.0]]}
+_WINO_MASK_DTYPE = {4: torch.int16, 6: torch.int64}   # per-tile activation masks: 16 bits per 4x4 tile, 36 of 64 bits per 6x6 tile
 
 
 def _freq_buf(nf, C, T, device):
@@ -760,24 +754,25 @@ def _freq_buf(nf, C, T, device):
     return torch.empty((C, nf, T), dtype=torch.float32, device=device).permute(1, 0, 2)
 
 
-def _wino4_filters(lib, ws, scales, Ci, dev):
-    """U (36, sum Co, Ci) and U^T (36, Ci, sum Co) of K filters stacked along C_out, one lgd_wino_filter_fwd launch per filter
+def _wino_filters(lib, ws, scales, Ci, dev, tile):
+    """U (nf, sum Co, Ci) and U^T (nf, Ci, sum Co) of K filters stacked along C_out, one lgd_wino_filter_fwd launch per filter
     (the frozen per-channel scale of a FrozenBN that follows the conv is folded in on the way: no scaled copy of the weights)."""
     Cos = [w.shape[0] for w in ws]
     Ct = sum(Cos)
-    U = torch.empty((36, Ct, Ci), dtype=torch.float32, device=dev)
-    Ut = torch.empty((36, Ci, Ct), dtype=torch.float32, device=dev)
+    nf = (tile + 2) ** 2
+    U = torch.empty((nf, Ct, Ci), dtype=torch.float32, device=dev)
+    Ut = torch.empty((nf, Ci, Ct), dtype=torch.float32, device=dev)
     c0 = 0
     for w, sc, Co in zip(ws, scales, Cos):
-        hip.check(lib.lgd_wino_filter_fwd(hip.ptr(w), hip.ptr(sc) if sc is not None else None, Co, Ci,
+        hip.check(lib.lgd_wino_filter_fwd(hip.ptr(w), hip.ptr(sc) if sc is not None else None, Co, Ci, tile,
                                           ctypes.c_void_p(U.data_ptr() + 4 * c0 * Ci), Ct * Ci,
                                           ctypes.c_void_p(Ut.data_ptr() + 4 * c0), Ct, Ci * Ct, hip.stream_ptr()), "lgd_wino_filter_fwd")
         c0 += Co
     return U, Ut
 
 
-def _wino4_filter_grads(lib, dU, scales, Cos, need, Ci):
-    """dw_k = scale_k . G^T dU_k G for the filters that need it; dU (36, sum Co, Ci) from the weight-gradient GEMM."""
+def _wino_filter_grads(lib, dU, scales, Cos, need, Ci, tile):
+    """dw_k = scale_k . G^T dU_k G for the filters that need it; dU (nf, sum Co, Ci) from the weight-gradient GEMM."""
     Ct = sum(Cos)
     out, c0 = [], 0
     for sc, Co, nd in zip(scales, Cos, need):
@@ -785,7 +780,7 @@ def _wino4_filter_grads(lib, dU, scales, Cos, need, Ci):
         if nd:
             dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=dU.device)
             hip.check(lib.lgd_wino_filter_bwd(ctypes.c_void_p(dU.data_ptr() + 4 * c0 * Ci), Ct * Ci, hip.ptr(sc) if sc is not None else None,
-                                              Co, Ci, hip.ptr(dw), hip.stream_ptr()), "lgd_wino_filter_bwd")
+                                              Co, Ci, tile, hip.ptr(dw), hip.stream_ptr()), "lgd_wino_filter_bwd")
         out.append(dw)
         c0 += Co
     return out
@@ -794,28 +789,26 @@ def _wino4_filter_grads(lib, dU, scales, Cos, need, Ci):
 class _Conv3x3K(torch.autograd.Function):
     """K filters nn.Conv2d(Ci, Co_k, 3, stride 1, padding 1) [+ ReLU] applied to the SAME L maps (the pyramid levels; K = 1: one
     conv, K = 2: e.g. the first convs of the cls / bbox towers, which read the same features) in the minimal-filtering form
-    F(tile x tile, 3x3), tile = 4 (default) or 2: HIP data transforms (lgd_wino_in / lgd_wino_out / lgd_wino_out_t /
-    lgd_wino_in_t) around per-frequency channel GEMMs (hipBLASLt / rocBLAS fp32 MFMA through torch.bmm) over the concatenated
-    tiles of all levels.  The input is transformed ONCE for all K filters (their U are stacked along C_out: one GEMM), and the
-    backward sums their input gradients inside the dV GEMM (K = sum Co_k) -- one adjoint input transform, no gradient-accumulation
-    pass.  Forward, input gradient and weight gradient all run at 1/4 (tile 4) or 4/9 (tile 2) of the direct multiplies.
+    F(tile x tile, 3x3), tile = 6 or 4: HIP data transforms (lgd_wino_in / lgd_wino_out / lgd_wino_out_t / lgd_wino_in_t) around
+    per-frequency channel GEMMs (hipBLASLt / rocBLAS fp32 MFMA through torch.bmm) over the concatenated tiles of all levels.  The
+    input is transformed ONCE for all K filters (their U are stacked along C_out: one GEMM), and the backward sums their input
+    gradients inside the dV GEMM (K = sum Co_k) -- one adjoint input transform, no gradient-accumulation pass.  Forward, input
+    gradient and weight gradient all run at 64/324 (tile 6) or 1/4 (tile 4) of the direct multiplies.  The backward is the autograd of
+    the pipeline itself: dy is expanded ONCE (dM = A dy A^T), dV[f] = U[f]^T dM[f] comes back through the adjoint of the input
+    transform, the weight gradient is dU[f] = dM[f] V[f]^T.
     apply(K, relu, tile, scales, pre, w_1, b_1, ..., w_K, b_K, x_1, ..., x_L) -> K * L maps, filter-major; scales: None or one per-output-
-    channel factor (a buffer, no gradient) per filter, applied to the filter inside its transform (tile 4); pre: None, or a per-INPUT-
+    channel factor (a buffer, no gradient) per filter, applied to the filter inside its transform; pre: None, or a per-INPUT-
     channel bias (a buffer): the maps are then pre-activations and the convolution runs on relu(x + pre[c]) -- the bias + ReLU epilogue
-    of the producing 1x1 convolution folded into the input transform, its backward mask into the adjoint transform (tile 4), so the
+    of the producing 1x1 convolution folded into the input transform, its backward mask into the adjoint transform, so the
     gradient returned for x is the gradient of the RAW map."""
 
     @staticmethod
     def forward(ctx, K, relu, tile, scales, pre, *args):
         ws, bs, xs = list(args[0:2 * K:2]), list(args[1:2 * K:2]), list(args[2 * K:])
-        if pre is not None and tile != 4:
-            raise hip.LgdHipError("a folded pre-activation needs tile = 4")
+        if tile not in _WINO_MASK_DTYPE:
+            raise hip.LgdHipError("Winograd output tile must be 4 or 6")
         scales = list(scales) if scales is not None else [None] * K
-        if tile != 4 and any(sc is not None for sc in scales):
-            raise hip.LgdHipError("a per-channel filter scale needs tile = 4 (fold it into the weights for tile 2)")
         hip.require_gpu(*ws, *xs)
-        if K > 1 and tile != 4:
-            raise hip.LgdHipError("several filters on one input need tile = 4")
         lib = hip.load()
         ws = [hip.dense_f32(w) for w in ws]
         xs = [hip.dense_f32(x) for x in xs]
@@ -825,49 +818,47 @@ class _Conv3x3K(torch.autograd.Function):
         Ct = sum(Cos)
         dev = ws[0].device
         nf = (tile + 2) ** 2
+        mdt, mb = _WINO_MASK_DTYPE[tile], _WINO_MASK_DTYPE[tile].itemsize
         hw = hip.int_array([d for x in xs for d in x.shape[2:]])
         T = lib.lgd_wino_tiles(hw, L, N, tile)
-        if tile == 4:
-            U, Ut = _wino4_filters(lib, ws, scales, Ci, dev)
-        else:
-            U, Ut = torch.mm(_wino_gg(dev, tile), ws[0].view(Ct * Ci, 9).t()).view(nf, Ct, Ci), None
+        U, Ut = _wino_filters(lib, ws, scales, Ci, dev, tile)
         V = _freq_buf(nf, Ci, T, dev)
         pre = hip.dense_f32(pre) if pre is not None else None
-        pre_bits = (torch.empty((Ci, T), dtype=torch.int16, device=dev)
+        pre_bits = (torch.empty((Ci, T), dtype=mdt, device=dev)
                     if pre is not None and any(ctx.needs_input_grad[5 + 2 * K:]) else None)
-        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None,
+        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), hw, L, N, Ci, tile, hip.ptr(V),
                                   hip.ptr(pre) if pre is not None else None, hip.ptr(pre_bits) if pre_bits is not None else None,
                                   hip.stream_ptr()), "lgd_wino_in")
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
         fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
         _count_bytes("wino_in_kernel", (px + fb) * Ci)
         M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
-        # ReLU mask for the backward: 16 bits per 4x4 output tile written by the output transform (tile 4), so the backward reads
-        # 1 bit instead of 4 bytes per pixel and the forward output is not kept alive; tile 2 keeps the output itself
-        bits = torch.empty((Ct, T), dtype=torch.int16, device=dev) if (relu and tile == 4) else None
+        # ReLU mask for the backward: one bit per pixel, a table entry per tile, written by the output transform, so the backward
+        # reads 1 bit instead of 4 bytes per pixel and the forward output is not kept alive
+        bits = torch.empty((Ct, T), dtype=mdt, device=dev) if relu else None
         ys, c0 = [], 0
         for k in range(K):   # one output transform per filter: its channels are a contiguous slab of M ([C][nf][T])
             yk = [torch.empty((N, Cos[k]) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
-            _count_bytes("wino_out_kernel", (px + fb + (2 * T if bits is not None else 0)) * Cos[k])
-            hip.check(lib.lgd_wino_out(hip.ptr(M[:, c0]), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Cos[k], tile, 0, int(relu),
+            _count_bytes("wino_out_kernel", (px + fb + (mb * T if bits is not None else 0)) * Cos[k])
+            hip.check(lib.lgd_wino_out(hip.ptr(M[:, c0]), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Cos[k], tile, int(relu),
                                        hip.ptr_array(yk), hip.ptr(bits[c0]) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
             ys += yk
             c0 += Cos[k]
         need_w = any(ctx.needs_input_grad[5:5 + 2 * K:2])
-        # the backward needs the transformed filters (tile 4: dV = U^T dM; tile 2: the rotation is a frequency permutation of U)
-        ctx.save_for_backward(Ut if tile == 4 else U, V if need_w else None, bits, pre_bits, *(ys if (relu and bits is None) else []))
+        ctx.save_for_backward(Ut, V if need_w else None, bits, pre_bits)   # the backward needs U^T (dV = U^T dM)
         ctx.scales = scales
-        ctx.meta = (K, L, N, Ci, Cos, hw, T, bool(relu), [b is not None for b in bs], [tuple(x.shape[2:]) for x in xs], tile, px, fb)
+        ctx.meta = (K, L, N, Ci, Cos, hw, T, [b is not None for b in bs], [tuple(x.shape[2:]) for x in xs], tile, px, fb)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
-        U, V, bits, pre_bits, *yref = ctx.saved_tensors
-        K, L, N, Ci, Cos, hw, T, relu, has_bias, shapes, tile, px, fb = ctx.meta
+        Ut, V, bits, pre_bits = ctx.saved_tensors
+        K, L, N, Ci, Cos, hw, T, has_bias, shapes, tile, px, fb = ctx.meta
         Ct = sum(Cos)
         lib = hip.load()
-        dev = U.device
+        dev = Ut.device
         nf = (tile + 2) ** 2
+        mb = _WINO_MASK_DTYPE[tile].itemsize
         # an output nothing downstream used arrives as None
         dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
                for i, g in enumerate(dys)]
@@ -876,59 +867,29 @@ class _Conv3x3K(torch.autograd.Function):
         need_w, need_x = any(need_ws), any(ctx.needs_input_grad[5 + 2 * K:])
         dws, dbs = [None] * K, [None] * K
         dxs = [None] * L
-        dM = None
-        if tile == 4 and (need_x or need_w or any(need_bs)):
-            # the autograd of the forward pipeline itself: dy is expanded ONCE (dM = A dy A^T); the input gradient is
-            # dV[f] = U[f]^T dM[f] brought back by the adjoint of the input transform, the weight gradient dU[f] = dM[f] V[f]^T
-            dM = _freq_buf(nf, Ct, T, dev)
-            c0 = 0
-            for k in range(K):
-                gk = dys[k * L:(k + 1) * L]
-                _count_bytes("wino_out_t_kernel", (px + fb + (2 * T if bits is not None else 0)) * Cos[k])
-                hip.check(lib.lgd_wino_out_t(hip.ptr_array(gk), None, hip.ptr(bits[c0]) if bits is not None else None, hw, L, N, Cos[k], tile,
-                                             hip.ptr(dM[:, c0]), hip.stream_ptr()), "lgd_wino_out_t")
-                c0 += Cos[k]
-            if need_x:
-                _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
-                dV = _timed_bmm("wino_gemm_dx", U, dM, out=_freq_buf(nf, Ci, T, dev))   # U holds U^T (36, Ci, sum Co) for tile 4
-                dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-                hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs),
-                                            hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in_t")
-                del dV
-        elif tile == 2 and (need_x or need_w):
-            Co = Cos[0]
-            ref = hip.ptr_array(yref) if relu else None
-            pdy = px * Co * (2 if relu else 1)   # dy + the forward output as the ReLU mask
-            dM = _freq_buf(nf, Co, T, dev) if need_w else None
-            if need_x:
-                # the same pipeline on dy with the rotated, transposed filter (a frequency permutation of U: flip = 1)
-                _count_bytes("wino_in_dual_kernel" if need_w else "wino_in_kernel", pdy + fb * Co * (2 if need_w else 1))
-                _count_bytes("wino_out_kernel", (px + fb) * Ci)
-                Vd = _freq_buf(nf, Co, T, dev)
-                hip.check(lib.lgd_wino_in(hip.ptr_array(dys), ref, None, hw, L, N, Co, tile, 1, hip.ptr(Vd),
-                                          hip.ptr(dM) if need_w else None, None, None, hip.stream_ptr()), "lgd_wino_in")
-                Md = _timed_bmm("wino_gemm_dx", U.transpose(1, 2), Vd, out=_freq_buf(nf, Ci, T, dev))
-                del Vd
-                dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-                hip.check(lib.lgd_wino_out(hip.ptr(Md), None, hw, L, N, Ci, tile, 1, 0, hip.ptr_array(dxs), None, hip.stream_ptr()),
-                          "lgd_wino_out")
-                del Md
-            else:
-                _count_bytes("wino_out_t_kernel", pdy + fb * Co)
-                hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), ref, None, hw, L, N, Co, tile, hip.ptr(dM), hip.stream_ptr()),
-                          "lgd_wino_out_t")
+        if not (need_x or need_w or any(need_bs)):
+            return (None, None, None, None, None, *[None] * (2 * K), *dxs)
+        dM = _freq_buf(nf, Ct, T, dev)
+        c0 = 0
+        for k in range(K):
+            gk = dys[k * L:(k + 1) * L]
+            _count_bytes("wino_out_t_kernel", (px + fb + (mb * T if bits is not None else 0)) * Cos[k])
+            hip.check(lib.lgd_wino_out_t(hip.ptr_array(gk), hip.ptr(bits[c0]) if bits is not None else None, hw, L, N, Cos[k], tile,
+                                         hip.ptr(dM[:, c0]), hip.stream_ptr()), "lgd_wino_out_t")
+            c0 += Cos[k]
+        if need_x:
+            _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
+            dV = _timed_bmm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
+            dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
+            hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs),
+                                        hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in_t")
+            del dV
         if need_w:
             dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
-            if tile == 4:
-                dws = _wino4_filter_grads(lib, dU, ctx.scales, Cos, need_ws, Ci)
-            else:
-                dws[0] = torch.mm(_wino_gg(dev, tile).t(), dU.view(nf, Ct * Ci)).t().reshape(Ct, Ci, 3, 3)
+            dws = _wino_filter_grads(lib, dU, ctx.scales, Cos, need_ws, Ci, tile)
         if any(need_bs):
-            if dM is not None:
-                # A's row of the interpolation point 1 is all ones: that frequency of dM = A g A^T is the tile's gradient sum
-                db = dM[tile + 3].sum(1)
-            else:  # tile 2, bias gradient alone
-                db = sum((g * (y > 0) if relu else g).sum((0, 2, 3)) for g, y in zip(dys, yref if relu else dys))
+            # A's row of the interpolation point 1 is all ones: that frequency of dM = A g A^T is the tile's gradient sum
+            db = dM[tile + 3].sum(1)
             c0 = 0
             for k in range(K):
                 dbs[k] = db[c0:c0 + Cos[k]] if need_bs[k] else None
@@ -939,17 +900,18 @@ class _Conv3x3K(torch.autograd.Function):
 class _Conv3x3Chain(torch.autograd.Function):
     """K convolutions 3x3 / stride 1 / padding 1 in SEQUENCE over the same L maps, conv k [+ ReLU if relus[k]] feeding conv k+1 and
     nothing else (the head towers after their first conv incl. the score conv, the adapter: distillator.py:107-109 ->
-    retinanet.py:36-43, sequential_convs.py:10-12).  The forward is the per-conv F(4x4,3x3) pipeline of _Conv3x3K.  The backward keeps
+    retinanet.py:36-43, sequential_convs.py:10-12).  The forward is the per-conv Winograd pipeline of _Conv3x3K.  The backward keeps
     the gradient in the FREQUENCY domain across a link: dV_k = U_k^T dM_k goes through ONE kernel (lgd_wino_in_t_out_t: adjoint input
-    transform, ReLU mask of conv k-1, A . A^T) into dM_{k-1}; the intermediate gradient maps are neither written nor re-read (4.5
-    instead of 6.5 map transfers per link).  apply(K, relus, w_1, b_1, ..., w_K, b_K, x_1, ..., x_L) -> the L maps of the last conv."""
+    transform, ReLU mask of conv k-1, A . A^T) into dM_{k-1}; the intermediate gradient maps are neither written nor re-read.
+    apply(K, relus, tile, w_1, b_1, ..., w_K, b_K, x_1, ..., x_L) -> the L maps of the last conv."""
 
     @staticmethod
-    def forward(ctx, K, relus, *args):
+    def forward(ctx, K, relus, tile, *args):
         ws, bs, xs = list(args[0:2 * K:2]), list(args[1:2 * K:2]), list(args[2 * K:])
         hip.require_gpu(*ws, *xs)
         lib = hip.load()
-        tile, nf = 4, 36
+        nf = (tile + 2) ** 2
+        mdt, mb = _WINO_MASK_DTYPE[tile], _WINO_MASK_DTYPE[tile].itemsize
         ws = [hip.dense_f32(w) for w in ws]
         xs = [hip.dense_f32(x) for x in xs]
         bs = [hip.dense_f32(b) if b is not None else None for b in bs]
@@ -960,51 +922,51 @@ class _Conv3x3Chain(torch.autograd.Function):
         T = lib.lgd_wino_tiles(hw, L, N, tile)
         px = 4 * N * sum(h * w_ for h, w_ in shapes)   # bytes of one channel of the maps
         fb = 4 * nf * T                                # bytes of one channel of a frequency buffer
-        need_ws = list(ctx.needs_input_grad[2:2 + 2 * K:2])
+        need_ws = list(ctx.needs_input_grad[3:3 + 2 * K:2])
         saved, cur = [], xs
         for k in range(K):
             Co, Ci = ws[k].shape[0], ws[k].shape[1]
-            U, Ut = _wino4_filters(lib, [ws[k]], [None], Ci, dev)
+            U, Ut = _wino_filters(lib, [ws[k]], [None], Ci, dev, tile)
             V = _freq_buf(nf, Ci, T, dev)
-            hip.check(lib.lgd_wino_in(hip.ptr_array(cur), None, None, hw, L, N, Ci, tile, 0, hip.ptr(V), None, None, None, hip.stream_ptr()),
-                      "lgd_wino_in")
+            hip.check(lib.lgd_wino_in(hip.ptr_array(cur), hw, L, N, Ci, tile, hip.ptr(V), None, None, hip.stream_ptr()), "lgd_wino_in")
             _count_bytes("wino_in_kernel", (px + fb) * Ci)
             M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
-            bits = torch.empty((Co, T), dtype=torch.int16, device=dev) if relus[k] else None
+            bits = torch.empty((Co, T), dtype=mdt, device=dev) if relus[k] else None
             cur = [torch.empty((N, Co) + s, dtype=torch.float32, device=dev) for s in shapes]
-            _count_bytes("wino_out_kernel", (px + fb + (2 * T if bits is not None else 0)) * Co)
-            hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Co, tile, 0, int(relus[k]),
+            _count_bytes("wino_out_kernel", (px + fb + (mb * T if bits is not None else 0)) * Co)
+            hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Co, tile, int(relus[k]),
                                        hip.ptr_array(cur), hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
             del M
             saved += [Ut, V if need_ws[k] else None, bits]
         ctx.save_for_backward(*saved)
-        ctx.meta = (K, L, N, hw, T, shapes, [b is not None for b in bs], px, fb)
+        ctx.meta = (K, L, N, hw, T, shapes, [b is not None for b in bs], px, fb, tile)
         return tuple(cur)
 
     @staticmethod
     def backward(ctx, *dys):
         saved = ctx.saved_tensors
-        K, L, N, hw, T, shapes, has_bias, px, fb = ctx.meta
+        K, L, N, hw, T, shapes, has_bias, px, fb, tile = ctx.meta
         lib = hip.load()
-        tile, nf = 4, 36
+        nf = (tile + 2) ** 2
+        mb = _WINO_MASK_DTYPE[tile].itemsize
         dev = saved[0].device
-        need_ws = list(ctx.needs_input_grad[2:2 + 2 * K:2])
-        need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[3:3 + 2 * K:2])]
-        need_x = any(ctx.needs_input_grad[2 + 2 * K:])
+        need_ws = list(ctx.needs_input_grad[3:3 + 2 * K:2])
+        need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[4:4 + 2 * K:2])]
+        need_x = any(ctx.needs_input_grad[3 + 2 * K:])
         dws, dbs, dxs = [None] * K, [None] * K, [None] * L
         Co = saved[3 * (K - 1)].shape[2]
         dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Co) + shapes[i], dtype=torch.float32, device=dev) for i, g in enumerate(dys)]
         bits = saved[3 * (K - 1) + 2]
         dM = _freq_buf(nf, Co, T, dev)
-        _count_bytes("wino_out_t_kernel", (px + fb + (2 * T if bits is not None else 0)) * Co)
-        hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), None, hip.ptr(bits) if bits is not None else None, hw, L, N, Co, tile, hip.ptr(dM),
+        _count_bytes("wino_out_t_kernel", (px + fb + (mb * T if bits is not None else 0)) * Co)
+        hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), hip.ptr(bits) if bits is not None else None, hw, L, N, Co, tile, hip.ptr(dM),
                                      hip.stream_ptr()), "lgd_wino_out_t")
         for k in range(K - 1, -1, -1):
             Ut, V = saved[3 * k], saved[3 * k + 1]
             Ci, Co = Ut.shape[1], Ut.shape[2]
             if need_ws[k]:
                 dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
-                dws[k] = _wino4_filter_grads(lib, dU, [None], [Co], [True], Ci)[0]
+                dws[k] = _wino_filter_grads(lib, dU, [None], [Co], [True], Ci, tile)[0]
             if need_bs[k]:
                 dbs[k] = dM[tile + 3].sum(1)   # A's row of the interpolation point 1 is all ones: the tile's gradient sum
             if k == 0 and not need_x:
@@ -1014,7 +976,7 @@ class _Conv3x3Chain(torch.autograd.Function):
             if k > 0:   # the link to conv k-1: dM_{k-1} = A (in_t(dV) . relu mask) A^T without the map in between
                 pb = saved[3 * (k - 1) + 2]
                 dM = _freq_buf(nf, Ci, T, dev)
-                _count_bytes("wino_in_t_out_t_kernel", (2 * fb + (2 * T if pb is not None else 0)) * Ci)
+                _count_bytes("wino_in_t_out_t_kernel", (2 * fb + (mb * T if pb is not None else 0)) * Ci)
                 hip.check(lib.lgd_wino_in_t_out_t(hip.ptr(dV), hip.ptr(pb) if pb is not None else None, hw, L, N, Ci, tile, hip.ptr(dM),
                                                   hip.stream_ptr()), "lgd_wino_in_t_out_t")
             else:
@@ -1022,7 +984,7 @@ class _Conv3x3Chain(torch.autograd.Function):
                 dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
                 hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), None, hip.stream_ptr()), "lgd_wino_in_t")
             del dV
-        return (None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
+        return (None, None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
 
 
 class _Conv3x3:
@@ -1054,18 +1016,19 @@ def enable_tuned_gemms(path=None):
 
 
 _TUNED_GEMM = False  # set by enable_tuned_gemms(); Trainer / bench.py opt in, importing this module changes nothing
-_WINO_TILE = int(os.environ.get("LGD_WINO_TILE", "4"))  # output tile of the minimal-filtering form: 4 -> F(4x4,3x3), 2 -> F(2x2,3x3)
-# smallest problem (2x2-output tiles over all maps of the call) that takes the Winograd path; measured at config 4 (R-101, 2 img/GPU,
+# output tile of the minimal-filtering form: 6 -> F(6x6,3x3) (64 frequencies, 1.78 multiplies per output pixel), 4 -> F(4x4,3x3) (36, 2.25)
+_WINO_TILE = int(os.environ.get("LGD_WINO_TILE", "4"))
+# smallest problem (2x2-pixel blocks over all maps of the call) that takes the Winograd path; measured at config 4 (R-101, 2 img/GPU,
 # whose res5 3x3 convolutions have 546): 2000 -> 35.7, 500 -> 35.1, 100 -> 35.3 ms/step in one call
-_WINO_MIN_TILES = int(os.environ.get("LGD_WINO_MIN_TILES", "500"))
-_WINO_MIN_CH = int(os.environ.get("LGD_WINO_MIN_CH", "64"))
-_WINO_ON = os.environ.get("LGD_WINO", "1") != "0"
-_CHAIN_ON = os.environ.get("LGD_CONV_CHAIN", "1") != "0"  # 0: every conv of a chain as its own autograd node (A/B measurements)
+_WINO_MIN_TILES = 500
+_WINO_MIN_CH = 64
+_WINO_ON = True
 
 
 def conv3x3_backend(winograd=None, min_tiles=None, tile=None):
-    """run-time form of the LGD_WINO / LGD_WINO_MIN_TILES / LGD_WINO_TILE debug switches (tests force the Winograd kernels
-    onto small problems, or the library convolutions onto large ones); returns the previous (winograd, min_tiles, tile)."""
+    """which implementation the 3x3 convolutions take: tests force the Winograd kernels onto problems below the production
+    threshold (min_tiles = 0), or the library's convolutions onto large ones (winograd = False) to compare the two; tile selects
+    F(6x6,3x3) or F(4x4,3x3).  Returns the previous (winograd, min_tiles, tile)."""
     global _WINO_ON, _WINO_MIN_TILES, _WINO_TILE
     prev = (_WINO_ON, _WINO_MIN_TILES, _WINO_TILE)
     if winograd is not None:
@@ -1073,8 +1036,8 @@ def conv3x3_backend(winograd=None, min_tiles=None, tile=None):
     if min_tiles is not None:
         _WINO_MIN_TILES = int(min_tiles)
     if tile is not None:
-        if int(tile) not in (2, 4):
-            raise ValueError("tile must be 2 or 4")
+        if int(tile) not in _WINO_MASK_DTYPE:
+            raise ValueError("tile must be 4 or 6")
         _WINO_TILE = int(tile)
     return prev
 
@@ -1091,13 +1054,9 @@ def conv3x3_levels(xs, w, b=None, relu=False, scale=None, pre=None):
     the concatenated tiles.  Tiny problems stay on the library's direct kernels.  scale: per-output-channel factor on the filter
     (the frozen affine of a FrozenBN after the conv), folded into the filter transform on the Winograd path.  pre: per-input-channel
     bias of a bias + ReLU that precedes the convolution (the maps are its pre-activations), folded into the input transform on the
-    F(4x4,3x3) path (see _Conv3x3K); elsewhere applied as its own pass."""
+    Winograd path (see _Conv3x3K); elsewhere applied as its own pass."""
     xs = list(xs)
     if _wino_ok(xs, w):
-        if pre is not None and _WINO_TILE != 4:
-            xs, pre = [bias_act(x, pre, None, True) for x in xs], None
-        if scale is not None and _WINO_TILE != 4:
-            w, scale = w * scale.view(-1, 1, 1, 1), None
         return list(_Conv3x3.apply(w, b, bool(relu), _WINO_TILE, *xs, scale=scale, pre=pre))
     if pre is not None:
         xs = [bias_act(x, pre, None, True) for x in xs]
@@ -1111,19 +1070,20 @@ def conv3x3_shared_input(xs, filters, relu=False):
     """several 3x3 / stride 1 / padding 1 filters [(w, b), ...] [+ ReLU] on the SAME list of maps: one input transform, one
     stacked GEMM, one adjoint input transform for the summed input gradient (see _Conv3x3K).  Returns one list of maps per filter."""
     xs = list(xs)
-    if len(filters) > 1 and _WINO_TILE == 4 and all(_wino_ok(xs, w) for w, _ in filters):
-        ys = _Conv3x3K.apply(len(filters), bool(relu), 4, None, None, *[t for wb in filters for t in wb], *xs)
+    if len(filters) > 1 and all(_wino_ok(xs, w) for w, _ in filters):
+        ys = _Conv3x3K.apply(len(filters), bool(relu), _WINO_TILE, None, None, *[t for wb in filters for t in wb], *xs)
         return [list(ys[k * len(xs):(k + 1) * len(xs)]) for k in range(len(filters))]
     return [conv3x3_levels(xs, w, b, relu) for w, b in filters]
 
 
-def conv3x3_chain(xs, filters, relus):
+def conv3x3_chain(xs, filters, relus, fused_links=True):
     """filters [(w, b), ...] applied in sequence to a list of maps, ReLU after conv k where relus[k]; the maps between two convs have no
-    other consumer, so the backward crosses each link in the frequency domain (see _Conv3x3Chain)."""
+    other consumer, so the backward crosses each link in the frequency domain (see _Conv3x3Chain).  fused_links = False: every conv
+    as its own autograd node (what the chain is tested against)."""
     xs = list(xs)
     relus = tuple(bool(r) for r in relus)
-    if _CHAIN_ON and len(filters) > 1 and _WINO_TILE == 4 and all(_wino_ok(xs, w) and w.shape[1] >= _WINO_MIN_CH for w, _ in filters):
-        return list(_Conv3x3Chain.apply(len(filters), relus, *[t for wb in filters for t in wb], *xs))
+    if fused_links and len(filters) > 1 and all(_wino_ok(xs, w) and w.shape[1] >= _WINO_MIN_CH for w, _ in filters):
+        return list(_Conv3x3Chain.apply(len(filters), relus, _WINO_TILE, *[t for wb in filters for t in wb], *xs))
     for (w, b), r in zip(filters, relus):
         xs = conv3x3_levels(xs, w, b, r)
     return xs
@@ -1135,17 +1095,17 @@ def conv3x3(x, w, b=None, relu=False, scale=None, pre=None):
 
 
 def conv3x3_folds_pre(N, C, H, W, Cout, device, dtype=torch.float32):
-    """True if conv3x3 on a (N, C, H, W) map would take the F(4x4,3x3) path, i.e. can fold a preceding bias + ReLU into its input
+    """True if conv3x3 on a (N, C, H, W) map would take the Winograd path, i.e. can fold a preceding bias + ReLU into its input
     transform: the producer may then hand over its raw output (student/resnet.py::Bottleneck)."""
     tiles = N * ((H + 1) // 2) * ((W + 1) // 2)
-    return (_WINO_ON and _WINO_TILE == 4 and device.type == "cuda" and dtype == torch.float32 and tiles >= _WINO_MIN_TILES
+    return (_WINO_ON and device.type == "cuda" and dtype == torch.float32 and tiles >= _WINO_MIN_TILES
             and C >= _WINO_MIN_CH and Cout >= _WINO_MIN_CH)
 
 
 def conv3x3_stride2(x, w, b=None):
     """3x3 / stride 2 / padding 1 convolution (the FPN's extra levels p6 / p7 [d2-memory: LastLevelP6P7]).  Output pixel (i, j) of the
-    strided convolution is output pixel (2i, 2j) of the stride-1 one, and F(4x4,3x3) spends 36 / 16 = 2.25 multiplies per stride-1
-    output pixel against 9 / 4 = 2.25 per input pixel for the direct strided form: the same GEMM work, so where the Winograd path
+    strided convolution is output pixel (2i, 2j) of the stride-1 one, and F(4x4,3x3) spends 36 / 16 = 2.25 (F(6x6,3x3): 1.78) multiplies
+    per stride-1 output pixel against 9 / 4 = 2.25 per input pixel for the direct strided form: the same GEMM work or less, so where the Winograd path
     applies (p6 over res5: 2048 -> 256 channels) the convolution runs as the stride-1 Winograd convolution + every other output,
     forward, input and weight gradient on the tuned channel GEMMs.  The library's strided implicit-GEMM kernels cost 2.1 ms/step at
     config 2 (forward, two split weight-gradient passes and NCHW <-> NHWC transposes of the 2048-channel map)."""

@@ -146,5 +146,8 @@ class FusedClipSGD:
         base = dev.data_ptr()
         hip.check(lib.lgd_sgd_clip_step(ctypes.c_void_p(base), ctypes.c_void_p(base + 48 * k), k, n_blocks,
                                         ctypes.c_float(self.clip_value), hip.stream_ptr()), "lgd_sgd_clip_step")
+        # the kernel wrote p, g and the momentum buffers through raw pointers: tell autograd's version counters, which the fold
+        # caches (ConvBN._frozen_fold, FrozenBatchNorm2d.scale_shift) key on and the saved-tensor check reads
+        torch.autograd.graph.increment_version([params[i] for i in idx] + [grads[i] for i in idx] + [self._m_ref[i] for i in idx])
         for o in self.optimizers:
             o._opt_called = True   # what the LR schedulers' "scheduler.step() before optimizer.step()" check looks at

@@ -122,11 +122,15 @@ class FCOSCT(nn.Module):
         self.score_threshold, self.topk_candidates = f.SCORE_THRESH_TEST, f.TOPK_CANDIDATES_TEST
         self.nms_threshold, self.max_detections_per_image = f.NMS_THRESH_TEST, cfg.TEST.DETECTIONS_PER_IMAGE
         self.shift_offset = cfg.MODEL.SHIFT_GENERATOR.OFFSET
+        # registration order = the reference's (thirdparty_heads/fcos.py:93-97 backbone, head; customized_detectors/fcos.py:23-27
+        # then fpn alias, raw_backbone): named_parameters() runs FPN -> head -> bottom-up ResNet, the index order of the reference's
+        # one-group-per-parameter optimizer state
         self.backbone = build_resnet_fpn(cfg)
-        self.fpn = self.backbone  # [ref: customized_detectors/fcos.py:23-27]
-        self.raw_backbone = self.fpn.bottom_up
-        self.fpn.bottom_up = nn.Sequential()
+        raw_backbone = self.backbone.bottom_up
+        self.backbone.bottom_up = nn.Sequential()
         self.head = FCOSHead(cfg)
+        self.fpn = self.backbone  # [ref: customized_detectors/fcos.py:23-27]
+        self.raw_backbone = raw_backbone
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), persistent=False)
         self._shift_cache = {}

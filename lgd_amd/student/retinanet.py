@@ -178,16 +178,20 @@ class RetinaNetCT(nn.Module):
         self.test_score_thresh, self.test_topk = rc.SCORE_THRESH_TEST, rc.TOPK_CANDIDATES_TEST
         self.test_nms_thresh, self.max_detections = rc.NMS_THRESH_TEST, cfg.TEST.DETECTIONS_PER_IMAGE
         self.vis_period = cfg.VIS_PERIOD
-        # separate fpn and backbone exactly like the reference (retinanet.py:29-34)
+        # separate fpn and backbone exactly like the reference (retinanet.py:29-34).  Registration ORDER is the reference's too:
+        # detectron2's RetinaNet registers `backbone` (the FPN) and `head`; RetinaNetCT then adds the alias `fpn` and, last,
+        # `raw_backbone` -- so named_parameters() runs FPN -> head -> bottom-up ResNet, the order in which the reference's
+        # optimizers index their one-group-per-parameter state (utils/build.py:494-512); checkpoints map by that index.
         self.backbone = build_resnet_fpn(cfg)
-        self.fpn = self.backbone
-        self.raw_backbone = self.fpn.bottom_up
-        self.fpn.bottom_up = nn.Sequential()
+        raw_backbone = self.backbone.bottom_up
+        self.backbone.bottom_up = nn.Sequential()
         strides = [8, 16, 32, 64, 128][:len(self.head_in_features)]
         self.anchor_generator = AnchorGenerator(cfg.MODEL.ANCHOR_GENERATOR.SIZES, cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS,
-                                                strides, cfg.MODEL.ANCHOR_GENERATOR.OFFSET)
+                                                strides, cfg.MODEL.ANCHOR_GENERATOR.OFFSET)   # buffers only: no place in the order
         self.head = RetinaNetHead(cfg.MODEL.FPN.OUT_CHANNELS, self.num_classes, self.anchor_generator.num_cell_anchors[0],
                                   rc.NUM_CONVS, rc.PRIOR_PROB)
+        self.fpn = self.backbone
+        self.raw_backbone = raw_backbone
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), persistent=False)
         # EMA of the positive-anchor count; a device tensor so that no step needs a host sync

@@ -162,6 +162,23 @@ def test_optimizer_layout_matches_reference_and_round_trips():
                 seen.add(id(p))
                 want_stu.append(p)
     assert [id(p) for p in tr.stu_optimizer.param_groups[0]["params"]] == [id(p) for p in want_stu]
+    # ... and that order is the REFERENCE's, written out: its FCOS registers `backbone` (the FPN, whose bottom_up the CT wrapper
+    # empties) and `head` (thirdparty_heads/fcos.py:93-97; FCOSHead.__init__ :433-512), then the alias `fpn` (skipped by the
+    # memo) and `raw_backbone` (customized_detectors/fcos.py:23-27); the adapter follows (utils/build.py:511).  A reference
+    # checkpoint indexes its one-group-per-parameter optimizer state by exactly this sequence.
+    fpn = ["backbone.%s.%s" % (m_, wb) for m_ in ("fpn_lateral3", "fpn_output3", "fpn_lateral4", "fpn_output4", "fpn_lateral5",
+                                                  "fpn_output5", "top_block.p6", "top_block.p7") for wb in ("weight", "bias")]
+    head = ["head.%s.%d.%s" % (sub, 3 * i + j, wb) for sub in ("cls_subnet", "bbox_subnet") for i in range(4) for j in (0, 1)
+            for wb in ("weight", "bias")]
+    head += ["head.%s.%s" % (m_, wb) for m_ in ("cls_score", "bbox_pred", "centerness") for wb in ("weight", "bias")]
+    head += ["head.scales.%d.scale" % i for i in range(5)]
+    names = {id(p): n for n, p in m.student.named_parameters(remove_duplicate=False) if not n.startswith("fpn.")}
+    got = [names[id(p)] for p in tr.stu_optimizer.param_groups[0]["params"] if id(p) in names]
+    assert got[:len(fpn) + len(head)] == fpn + head
+    rest = got[len(fpn) + len(head):]
+    assert rest[0] == "raw_backbone.res3.0.shortcut.weight" and all(n.startswith("raw_backbone.res") for n in rest)
+    n_adapter = len(list(m.adapter.parameters()))
+    assert [id(p) for p in tr.stu_optimizer.param_groups[0]["params"][-n_adapter:]] == [id(p) for p in m.adapter.parameters()]
     for p in tr.tea_optimizer.param_groups[0]["params"][:3]:  # give some state to carry
         p.grad = torch.ones_like(p)
     tr.tea_optimizer.step()
@@ -174,6 +191,45 @@ def test_optimizer_layout_matches_reference_and_round_trips():
     st = tr2.tea_optimizer.state_dict()
     assert len(st["param_groups"]) == 1 and sorted(st["state"]) == [0, 1, 2]
     assert torch.equal(st["state"][0]["momentum_buffer"], tr.tea_optimizer.state_dict()["state"][0]["momentum_buffer"])
+
+
+def test_resume_from_reference_shaped_optimizer_and_scheduler_state():
+    """a checkpoint as the REFERENCE writes it: one param group per parameter in the reference's named_parameters order
+    (utils/build.py:494-512) and detectron2 WarmupMultiStepLR scheduler states (no `lr_lambdas`, one base_lr per parameter).
+    Momentum buffers must land on the parameter of the same reference index -- checked by NAME with a buffer that encodes it."""
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    cfg = config.setup_cfg(os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", "cpu"])
+    m = build_model(cfg)
+    tr = Trainer(cfg, m, device=torch.device("cpu"), distributed=False)
+    # the reference's own enumeration, restated from utils/build.py:494-512 over the reference's registration order
+    ref_order, memo = [], set()
+    stu = m.student
+    for prefix, mod in (("student.backbone.", stu.backbone), ("student.head.", stu.head), ("student.raw_backbone.", stu.raw_backbone),
+                        ("adapter.", m.adapter)):
+        for n, p in mod.named_parameters():
+            if (p.requires_grad or getattr(p, "_lgd_phase_frozen", False)) and id(p) not in memo:
+                memo.add(id(p))
+                ref_order.append((prefix + n, p))
+    state = {i: {"momentum_buffer": torch.full_like(p, float(i))} for i, (_, p) in enumerate(ref_order)}
+    groups = [{"lr": 0.01, "momentum": 0.9, "dampening": 0, "weight_decay": 1e-4, "nesterov": False, "params": [i]}
+              for i in range(len(ref_order))]
+    d2_sched = {"milestones": [120000, 160000], "gamma": 0.1, "warmup_factor": 0.001, "warmup_iters": 1000, "warmup_method": "linear",
+                "base_lrs": [0.01] * len(ref_order), "last_epoch": 130000, "_step_count": 130001,
+                "_get_lr_called_within_step": False, "_last_lr": [0.001] * len(ref_order)}
+    sd = tr.state_dict()
+    sd["stu_optimizer"] = {"state": state, "param_groups": groups}
+    sd["stu_scheduler"], sd["tea_scheduler"] = dict(d2_sched), dict(d2_sched)
+    sd["iteration"] = 129999
+    tr.load_state_dict(sd)
+    for i, (n, p) in enumerate(ref_order):
+        buf = tr.stu_optimizer.state[p]["momentum_buffer"]
+        assert float(buf.flatten()[0]) == float(i), n
+    assert tr.stu_scheduler.last_epoch == 130000 and tr.iteration == 130000
+    assert abs(tr.stu_optimizer.param_groups[0]["lr"] - 0.001) < 1e-12   # past the first milestone: base_lr * gamma
+    tr.stu_optimizer.step()
+    tr.stu_scheduler.step()
+    assert tr.stu_scheduler.last_epoch == 130001 and abs(tr.stu_scheduler.get_last_lr()[0] - 0.001) < 1e-12
 
 
 def test_reference_checkpoint_loader(tmp_path):
@@ -369,27 +425,29 @@ def test_dcnv2_config_builds():
     assert m.state_dict()["student.raw_backbone.res4.22.conv2_offset.weight"].shape == (27, 256, 3, 3)
 
 
-@pytest.mark.parametrize("tile", [2, 4])
+_WINO_BT = {4: [[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                [0, 4, 0, -5, 0, 1]],
+            6: [[1, 0, -21 / 4, 0, 21 / 4, 0, -1, 0], [0, 1, 1, -17 / 4, -17 / 4, 1, 1, 0], [0, -1, 1, 17 / 4, -17 / 4, -1, 1, 0],
+                [0, .5, .25, -2.5, -1.25, 2, 1, 0], [0, -.5, .25, 2.5, -1.25, -2, 1, 0], [0, 2, 4, -2.5, -5, .5, 1, 0],
+                [0, -2, 4, 2.5, -5, -.5, 1, 0], [0, -1, 0, 21 / 4, 0, -21 / 4, 0, 1]]}
+_WINO_AT = {4: [[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]],
+            6: [[1, 1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, .5, -.5, 0], [0, 1, 1, 4, 4, .25, .25, 0], [0, 1, -1, 8, -8, .125, -.125, 0],
+                [0, 1, 1, 16, 16, 1 / 16, 1 / 16, 0], [0, 1, -1, 32, -32, 1 / 32, -1 / 32, 1]]}
+
+
+@pytest.mark.parametrize("tile", [4, 6])
 def test_winograd_matrices_define_the_convolution(tile):
-    """host side of K8: the filter-transform matrix G the wrapper ships (ops._WINO_G, as kron(G, G)) together with the
-    B^T / A^T the transforms hard-code (restated here) satisfies the minimal-filtering identity
+    """host side of K8: the filter-transform matrix G (ops._WINO_G) together with the B^T / A^T the transforms hard-code (restated
+    here: csrc/winograd.hip bt6 / at6, csrc/winograd6.hip bt8 / at8) satisfies the minimal-filtering identity
     A^T [ (G g G^T) * (B^T d B) ] A == valid 3x3 correlation of the (tile+2)^2 window, in fp64."""
     from lgd_amd import ops
-    if tile == 2:
-        BT = [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]]
-        AT = [[1, 1, 1, 0], [0, 1, -1, -1]]
-    else:
-        BT = [[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
-              [0, 4, 0, -5, 0, 1]]
-        AT = [[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]]
-    BT, AT = torch.tensor(BT, dtype=torch.float64), torch.tensor(AT, dtype=torch.float64)
+    BT, AT = torch.tensor(_WINO_BT[tile], dtype=torch.float64), torch.tensor(_WINO_AT[tile], dtype=torch.float64)
     G = torch.tensor(ops._WINO_G[tile], dtype=torch.float64)
     n = tile + 2
     gen = torch.Generator().manual_seed(3)
     d = torch.randn(n, n, dtype=torch.float64, generator=gen)
     g = torch.randn(3, 3, dtype=torch.float64, generator=gen)
-    U = (torch.kron(G, G) @ g.reshape(9)).reshape(n, n)          # what ops._wino_gg applies to the flattened filter
-    assert torch.allclose(U, G @ g @ G.t(), atol=1e-12)
+    U = G @ g @ G.t()
     y = AT @ (U * (BT @ d @ BT.t())) @ AT.t()
     ref = torch.nn.functional.conv2d(d[None, None], g[None, None])[0, 0]
     assert torch.allclose(y, ref, atol=1e-10)
@@ -397,7 +455,58 @@ def test_winograd_matrices_define_the_convolution(tile):
     gy = torch.randn(tile, tile, dtype=torch.float64, generator=gen)
     dM = AT.t() @ gy @ AT
     assert abs(float(dM[1, 1] - gy.sum())) < 1e-12
-    assert 1 * n + 1 == tile + 3  # ... which ops._Conv3x3.backward indexes as dM[tile + 3]
+    assert 1 * n + 1 == tile + 3  # ... which ops._Conv3x3K.backward indexes as dM[tile + 3]
+    # what the gather form of the adjoint input transform rests on: window row / column 0 depends on frequency 0 only, n-1 on n-1 only
+    assert [float(v) for v in BT[:, 0]] == [float(BT[0, 0])] + [0.0] * (n - 1)
+    assert [float(v) for v in BT[:, n - 1]] == [0.0] * (n - 1) + [1.0]
+
+
+def test_winograd6_adjoint_input_transform_as_a_gather():
+    """The identity lgd_wino_in_t (tile = 6) is built on (winograd6.hip: wino6_in_t_phase / vacc8): the adjoint of the F(6x6,3x3) input
+    transform -- overlap-add of the 8x8 windows Z_t = B G_t B^T at stride 6 -- equals, per 6x6 block, a GATHER of the tile's own 64
+    values, 8 of each edge neighbour and 1 of each corner, evaluated ROW FIRST: every frequency row a goes through the horizontal
+    transform h = (B g_a)[1..6] (+ the left tile's G[a][7], + the right tile's G[a][0]) and is then accumulated with B^T[a][r+1]."""
+    import numpy as np
+    BT = np.array(_WINO_BT[6], dtype=np.float64)
+    B = BT.T
+    rng = np.random.default_rng(0)
+    TH, TW, H, W = 3, 4, 16, 21
+    G = rng.standard_normal((TH, TW, 8, 8))
+    dx = np.zeros((6 * TH + 2, 6 * TW + 2))
+    for ty in range(TH):
+        for tx in range(TW):
+            dx[6 * ty:6 * ty + 8, 6 * tx:6 * tx + 8] += B @ G[ty, tx] @ B.T     # window (ty, tx) starts at pixel (6 ty - 1, 6 tx - 1)
+    ref = dx[1:1 + H, 1:1 + W]
+
+    def mid(g):   # entries 1..6 of B g (the kernel's b8mid)
+        d12, s12, d34, s34, d56, s56 = g[1] - g[2], g[1] + g[2], g[3] - g[4], g[3] + g[4], g[5] - g[6], g[5] + g[6]
+        return np.array([d12 + .5 * d34 + 2 * d56 - g[7], -5.25 * g[0] + s12 + .25 * s34 + 4 * s56,
+                         -4.25 * d12 - 2.5 * (d34 + d56) + 5.25 * g[7], 5.25 * g[0] - 4.25 * s12 - 1.25 * s34 - 5 * s56,
+                         d12 + 2 * d34 + .5 * d56 - 5.25 * g[7], s12 + s34 + s56 - g[0]])
+    for g in rng.standard_normal((3, 8)):
+        assert np.abs(mid(g) - (B @ g)[1:7]).max() < 1e-12
+    C = BT[:, 1:7]   # vacc8's coefficient table: B^T[a][r+1]
+    out = np.zeros((6 * TH, 6 * TW))
+    for ty in range(TH):
+        for tx in range(TW):
+            up, dn, lf, rt = ty > 0, ty < TH - 1, tx > 0, tx < TW - 1
+
+            def hrow(t_y, a):   # horizontal transform of frequency row a of tile (t_y, tx) incl. its left / right neighbours' columns
+                h = mid(G[t_y, tx][a])
+                if lf:
+                    h[0] += G[t_y, tx - 1][a, 7]
+                if rt:
+                    h[5] += G[t_y, tx + 1][a, 0]
+                return h
+            z = np.zeros((6, 6))
+            for a in range(8):
+                z += np.outer(C[a], hrow(ty, a))
+            if dn:
+                z[5] += hrow(ty + 1, 0)   # the lower tile's window row 0 = its frequency row 0
+            if up:
+                z[0] += hrow(ty - 1, 7)   # the upper tile's window row 7 = its frequency row 7
+            out[6 * ty:6 * ty + 6, 6 * tx:6 * tx + 6] = z
+    assert np.abs(out[:H, :W] - ref).max() < 1e-12
 
 
 def test_winograd_adjoint_input_transform_as_a_gather():

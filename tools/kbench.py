@@ -50,7 +50,7 @@ def one(it):
     torch.autograd.grad(pl.sum(), fr)
     zs = ops.bias_ctx_relu(fr, cvec)
     torch.autograd.grad(sum(v.sum() for v in zs), fr)
-    cy = ops._Conv3x3.apply(wconv, bconv, True, ops._WINO_TILE, *fr)  # one 256->256 filter + ReLU over the pyramid: wino_in / wino_out / dual
+    cy = ops._Conv3x3.apply(wconv, bconv, True, ops._WINO_TILE, *fr)  # one 256->256 filter + ReLU over the pyramid: wino_in / wino_out / wino_out_t / wino_in_t
     torch.autograd.grad(sum(v.sum() for v in cy), [wconv] + fr)
     o = ops.mha_blockdiag(q, kv, counts, mh.in_proj_weight, mh.in_proj_bias, mh.out_proj.weight, mh.out_proj.bias, 8, geom.img_off)
     torch.autograd.grad(o.sum(), [q, kv])
@@ -70,9 +70,8 @@ alg = {"in_moments_kernel": 2 * P, "in_mse_bwd_kernel": 3 * P, "box_sum_kernel":
        "gn_pool_kernel": P, "gn_pool_bwd_stats_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
 tl = ops._WINO_TILE
 FB = 4 * (tl + 2) ** 2 * C * sum(B * ((h + tl - 1) // tl) * ((w + tl - 1) // tl) for h, w in level_hw)  # one frequency buffer
-MB = 2 * C * (FB // (4 * (tl + 2) ** 2 * C))  # 16-bit ReLU mask per tile
-alg.update({"wino_in_kernel": P + FB, "wino_out_kernel": P + FB + MB, "wino_in_dual_kernel": P + MB + 2 * FB,
-            "wino_out_t_kernel": P + MB + FB, "wino_in_t_kernel": P + FB})
+MB = ops._WINO_MASK_DTYPE[tl].itemsize * C * (FB // (4 * (tl + 2) ** 2 * C))  # ReLU mask table: one entry per tile
+alg.update({"wino_in_kernel": P + FB, "wino_out_kernel": P + FB + MB, "wino_out_t_kernel": P + MB + FB, "wino_in_t_kernel": P + FB})
 res = {}
 for k, (n, ms, _lo, _hi) in sorted(t.items(), key=lambda kv: -kv[1][1]):
     us = 1e3 * ms / n
