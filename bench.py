@@ -17,6 +17,8 @@ instrumentation inside that region); then a SECOND pass of K steps with a HIP ev
 Extra objects on the JSON line (task statement section 4):
   roofline      -- dominant hand-written HIP kernel of the step (HBM bound): algorithmic bytes per launch / mean launch time
   roofline_mfma -- the Winograd channel GEMMs (library, fp32 MFMA): FLOP per launch / mean launch time vs the 157.3 TF peak
+  roofline_mfma_pointwise -- the student's 1x1 convolutions (library GEMMs: forward, input gradient, weight gradient), same form
+  host_batch    -- the same steps with the batches handed over as pinned HOST tensors and copied inside every step
   roofline_lgd_forward -- the north star's aggregate "LGD distill forward": gn_pool + box_paint + in_moments, 4 pyramids of bytes
   cpu_baseline  -- the CPU oracle (oracle/lgd_oracle.py, kind "port") timed on the host cores, rank 0, N=1 only, with
                    `gpu_same_path`: the product's SAME sub-path (teacher + adapter + distill loss, fwd+bwd) timed on the GPU
@@ -51,8 +53,13 @@ def parse():
                     help="training phase to time: distill = steady state (distill on, backbone training; 150k of the "
                          "180k iterations), nondistill = iterations 20k-30k, frozen = first 20k iterations")
     ap.add_argument("--host-batch", action="store_true",
-                    help="hand the batch over as pinned HOST tensors and copy it inside every step (the PCIe-inclusive rate noted in "
-                         "DESIGN.md); default: images and annotations resident in HBM when the timed region starts")
+                    help="time ONLY the host-batch protocol (pinned HOST tensors copied inside every step, what the reference's step "
+                         "contains: retinanet.py:48) as `value`; default: `value` = batches resident in HBM when the timed region starts "
+                         "(task statement section 4) AND the host-batch rate of the same steps in `host_batch` on the same line")
+    ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
+    ap.add_argument("--multiscale", action="store_true",
+                    help="per-image short side drawn from INPUT.MIN_SIZE_TRAIN (640..800, max 1333: BASELINE config 5, "
+                         "configs/Base-RetinaNet.yaml:26) instead of every image at --height x --width")
     ap.add_argument("--graph-backbone", action="store_true",
                     help="replay the student's backbone + FPN forward / backward as hipGraphs (lgd_amd/graphs.py; for the 2 img/GPU configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,10 +189,19 @@ def main():
     it0 = {"distill": max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS),
            "nondistill": d.PRE_FREEZE_STUDENT_BACKBONE_ITERS, "frozen": 0}[args.phase]
     Bg = args.batch_per_gpu
-    if args.host_batch:
-        data = synthetic_batch(Bg, args.height, args.width, args.boxes, seed=1000 + rank, pin=True)
-    else:
-        data = synthetic_batch(Bg, args.height, args.width, args.boxes, seed=1000 + rank, device=dev)
+    from lgd_amd.data import multiscale_sizes
+    nb = max(1, args.batches)
+
+    def make_batches(**kw):
+        out = []
+        for j in range(nb):
+            seed = 1000 + rank + 7919 * j
+            sizes = (multiscale_sizes(Bg, args.height, args.width, tuple(cfg.INPUT.MIN_SIZE_TRAIN), cfg.INPUT.MAX_SIZE_TRAIN, seed=seed)
+                     if args.multiscale else None)
+            out.append(synthetic_batch(Bg, args.height, args.width, args.boxes, seed=seed, sizes=sizes, **kw))
+        return out
+    host_batches = make_batches(pin=True) if (args.host_batch or world == 1) else None
+    batches = host_batches if args.host_batch else make_batches(device=dev)
     ctx = bool(d.TEACHER.ADD_CONTEXT_BOX)
 
     def sync():
@@ -193,13 +209,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        trainer.step(data, it0 + i)
+    it = [it0]
+
+    def run_steps(n, data_sets):
+        for _ in range(n):
+            trainer.step(data_sets[it[0] % nb], it[0])
+            it[0] += 1
+
+    run_steps(max(args.warmup, nb if args.multiscale else 0), batches)   # multi-scale: every batch shape once (library kernel selection)
     trainer.fetch_metrics()
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        trainer.step(data, it0 + args.warmup + i)
+    run_steps(args.steps, batches)
     sync()
     dt = time.perf_counter() - t0
     metrics = trainer.fetch_metrics()  # raises on non-finite losses
@@ -207,6 +228,16 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # the same steps with the batches handed over as pinned host tensors (N = 1 only; never `value` unless --host-batch)
+    dt_host = None
+    if host_batches is not None and not args.host_batch and world == 1:
+        run_steps(min(2, args.steps), host_batches)
+        sync()
+        t0 = time.perf_counter()
+        run_steps(args.steps, host_batches)
+        sync()
+        dt_host = time.perf_counter() - t0
+        trainer.fetch_metrics()
     # second pass, instrumented: an event pair around every launch of the library and around the Winograd GEMMs
     ktimes, kbytes, kflops, dt_instr = {}, {}, {}, None
     if not args.no_kernel_timing:  # every rank steps (the gradient all-reduce is collective); rank 0 carries the timers
@@ -214,8 +245,7 @@ def main():
             ops.kernel_timer_enable(True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(args.steps):
-            trainer.step(data, it0 + args.warmup + args.steps + i)
+        run_steps(args.steps, batches)
         torch.cuda.synchronize()
         dt_instr = time.perf_counter() - t1
         if rank == 0:
@@ -229,14 +259,17 @@ def main():
     if rank == 0:
         Hp, Wp = (args.height + 31) // 32 * 32, (args.width + 31) // 32 * 32
         from lgd_amd import synth
-        P = Bg * 256 * sum(h * w for h, w in synth.pyramid_shapes(Hp, Wp)) * 4  # one fp32 pyramid, bytes
+        # one fp32 pyramid, bytes: the padded batch tensor's (multi-scale: the mean over the rotated batches, each padded to its own maximum)
+        pads = [((max(x["height"] for x in b) + 31) // 32 * 32, (max(x["width"] for x in b) + 31) // 32 * 32) for b in batches]
+        px_pyr = sum(sum(h * w for h, w in synth.pyramid_shapes(hp, wp)) for hp, wp in pads) / len(pads)
+        P = Bg * 256 * px_pyr * 4
         # algorithmic bytes per launch
         alg = {"in_moments_kernel": 2 * P, "in_mse_bwd_kernel": 3 * P, "box_sum_kernel": P, "box_paint_kernel": P,
                "gn_stats_kernel": P, "gn_apply_kernel": 2 * P, "gn_bwd_stats_kernel": 2 * P, "gn_bwd_apply_kernel": 3 * P,
                "ctx_relu_kernel": 2 * P, "ctx_relu_bwd_kernel": 3 * P,
                "gn_pool_kernel": P, "gn_pool_bwd_stats_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
         # focal loss: logits (N, 9*80, H, W) read once (fwd) / read + written (bwd); int32 label planes (N, 9, H, W) on top
-        Pf = Bg * sum(h * w for h, w in synth.pyramid_shapes(Hp, Wp)) * 9 * 4
+        Pf = Bg * px_pyr * 9 * 4
         alg.update({"focal_fwd_kernel": 80 * Pf + Pf, "focal_bwd_kernel": 2 * 80 * Pf + Pf})
         alg.update({k: v / max(ktimes[k][0], 1) for k, v in kbytes.items() if k in ktimes})  # mean bytes per launch
         kernels = {}
@@ -267,7 +300,7 @@ def main():
                         "all_hip_kernels": {n: {"avg_us": round(v["avg_us"], 2), "min_us": round(v["min_us"], 2),
                                                 "max_us": round(v["max_us"], 2), "GBps": round(v.get("GBps", 0.0), 1),
                                                 "launches_per_step": v["launches"] / args.steps}
-                                            for n, v in kernels.items() if not n.startswith("wino_gemm")}}
+                                            for n, v in kernels.items() if "_gemm" not in n}}
         # the north star's aggregate: the LGD distill forward = mask pooling (fused with GN + ReLU) + rendering paint + distill moments,
         # one launch each per step, 4 P of algorithmic bytes together
         lgd_fwd = None
@@ -276,6 +309,20 @@ def main():
             us = sum(kernels[n]["avg_us"] for n in names)
             lgd_fwd = {"bound": "hbm", "kernels": list(names), "alg_bytes": 4 * P, "us": us, "achieved": 4 * P / us / 1e3, "peak": HBM_PEAK_GBPS,
                        "unit": "GB/s", "frac": 4 * P / us / 1e3 / HBM_PEAK_GBPS}
+        roofline_pw = None
+        pw = {n: v for n, v in kernels.items() if n.startswith("pw_gemm")}
+        if pw:
+            tot_ms = sum(v["total_ms"] for v in pw.values())
+            tot_fl = sum(kflops[n] for n in pw)
+            n_l = sum(v["launches"] for v in pw.values())
+            ach = tot_fl / (1e-3 * tot_ms) / 1e12
+            roofline_pw = {"bound": "mfma", "kernel": "the student's 1x1 convolutions (library GEMMs: forward = MIOpen's GEMM path, input gradient, "
+                           "weight gradient as per-image NT GEMMs)", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "flop_per_launch": tot_fl / n_l,
+                           "avg_launch_us": 1e3 * tot_ms / n_l, "ms_per_step": tot_ms / args.steps,
+                           "by_kind": {n: {"TFLOPs": round(v["TFLOPs"], 1), "avg_us": round(v["avg_us"], 1), "min_us": round(v["min_us"], 1),
+                                           "max_us": round(v["max_us"], 1), "launches_per_step": v["launches"] / args.steps}
+                                       for n, v in pw.items()}}
         gemms = {n: v for n, v in kernels.items() if n.startswith("wino_gemm")}
         if gemms:
             tot_ms = sum(v["total_ms"] for v in gemms.values())
@@ -299,11 +346,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if not args.host_batch else "synthetic (pinned host batch, copied inside the step)",
+            "dtype": "f32",
+            "data": ("synthetic (%d distinct batches rotated; %s)" % (nb, "pinned HOST batches copied inside every step" if args.host_batch
+                                                                      else "device-resident when the timed region starts, no H2D copy inside it")),
+            "host_batch": None if dt_host is None else {
+                "value": Bg * args.steps / dt_host, "unit": "images/sec", "ms_per_step": 1e3 * dt_host / args.steps,
+                "note": "the same %d steps with the batches as pinned host tensors copied inside every step (non-blocking, on the step's "
+                        "stream): what the reference's step contains (retinanet.py:48)" % args.steps},
             "config": {"workload": "%s%s R-%d FPN + LGD, %d img/GPU, %dx%d (padded %dx%d), "
-                                   "%d GT boxes/img, ctx box %s, phase=%s (fwd+bwd+clip+2xSGD)"
-                                   % ("BASELINE configs[1]: " if default_cfg and Bg == 8 else "", arch, cfg.MODEL.RESNETS.DEPTH, Bg,
-                                      args.height, args.width, Hp, Wp, args.boxes, "on" if ctx else "off", args.phase),
+                                   "%d GT boxes/img, ctx box %s, phase=%s (fwd+bwd+clip+2xSGD)%s"
+                                   % ("BASELINE configs[1]: " if default_cfg and Bg == 8 and not args.multiscale else "", arch,
+                                      cfg.MODEL.RESNETS.DEPTH, Bg, args.height, args.width, Hp, Wp, args.boxes, "on" if ctx else "off", args.phase,
+                                      ", multi-scale: short side per image from %s" % (list(cfg.INPUT.MIN_SIZE_TRAIN),) if args.multiscale else ""),
                        "yaml": os.path.relpath(args.config, ROOT), "global_batch": world * Bg, "parallelism": "dp%d" % world},
             "losses": {k: round(v, 6) for k, v in metrics.items()},
             "gemm_solution_table_loaded": bool(trainer.tuned_gemms), "conv3x3": "winograd F(%dx%d,3x3)" % (ops._WINO_TILE, ops._WINO_TILE) if ops._WINO_ON else "library",
@@ -311,7 +365,7 @@ def main():
             "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,
             "graph_backbone": bool(trainer.graph_backbone), "fused_clip_sgd": trainer._fused_sgd is not None,
             "head_pass": "single (student + teacher pyramids in one pass)" if getattr(model, "fused_head_pass", False) else "two passes",
-            "roofline": roofline, "roofline_mfma": roofline_mfma, "roofline_lgd_forward": lgd_fwd,
+            "roofline": roofline, "roofline_mfma": roofline_mfma, "roofline_mfma_pointwise": roofline_pw, "roofline_lgd_forward": lgd_fwd,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.boxes, ctx)

@@ -20,6 +20,20 @@
 // ReLU / activation masks: 36 bits per tile in a uint64 table [C][T], bit 6 i + j = pixel (i, j) of the tile's own block.
 #include "winograd.h"
 
+// minimum waves per SIMD the register allocator is held to, per kernel (lab knobs: tools/wino6_variants.sh measures them)
+#ifndef LGD_W6_IN_WAVES
+#define LGD_W6_IN_WAVES 3
+#endif
+#ifndef LGD_W6_OUT_WAVES
+#define LGD_W6_OUT_WAVES 3
+#endif
+#ifndef LGD_W6_OUTT_WAVES
+#define LGD_W6_OUTT_WAVES 5
+#endif
+#ifndef LGD_W6_INT_WAVES
+#define LGD_W6_INT_WAVES 3
+#endif
+
 namespace lgd {
 
 // B^T d: 8 -> 8
@@ -262,7 +276,7 @@ __device__ __forceinline__ void wino6_in_body(const WinoArgs& a, int l, float* l
 }
 
 template <bool PRE>
-__global__ __launch_bounds__(256) void wino6_in_kernel(WinoArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_IN_WAVES, 8))) void wino6_in_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
     if (a.pair[l]) wino6_in_body<true, PRE>(a, l, lds);
@@ -304,62 +318,65 @@ __device__ __forceinline__ void wino6_out_body(const WinoArgs& a, int l, float* 
     const int c = blockIdx.y;
     const size_t plane = (size_t)a.T;
     const float* m = a.buf_in + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0;
-    float mm[8][8];
+    // columns first, accumulated as the frequency rows arrive (two per LDS phase): r[i][b] = sum_a A^T[i][a] M[a][b] -- 48 accumulators
+    // instead of holding all 64 values and then 48 more (118 -> 5 waves per SIMD worth of registers)
+    float r[6][8];
     #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
         if (ph) __syncthreads();
         stage_load16(m, plane, ph, padded - t0, lds);
         __syncthreads();
         #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-            #pragma unroll
-            for (int j = 0; j < 8; ++j) mm[2 * ph + ii][j] = lds[(8 * ii + j) * 256 + threadIdx.x];
+        for (int b = 0; b < 8; ++b) {
+            const float ga = lds[b * 256 + threadIdx.x], gb = lds[(8 + b) * 256 + threadIdx.x];   // frequency rows 2 ph, 2 ph + 1
+            if (ph == 0) {          // a = 0: [1 0 0 0 0 0];  a = 1: [1 1 1 1 1 1]
+                r[0][b] = ga + gb; r[1][b] = gb; r[2][b] = gb; r[3][b] = gb; r[4][b] = gb; r[5][b] = gb;
+            } else if (ph == 1) {   // a = 2: [1 -1 1 -1 1 -1];  a = 3: [1 2 4 8 16 32]
+                r[0][b] += ga + gb; r[1][b] += 2.f * gb - ga; r[2][b] += ga + 4.f * gb; r[3][b] += 8.f * gb - ga;
+                r[4][b] += ga + 16.f * gb; r[5][b] += 32.f * gb - ga;
+            } else if (ph == 2) {   // a = 4: [1 -2 4 -8 16 -32];  a = 5: [1 1/2 1/4 1/8 1/16 1/32]
+                r[0][b] += ga + gb; r[1][b] += 0.5f * gb - 2.f * ga; r[2][b] += 4.f * ga + 0.25f * gb; r[3][b] += 0.125f * gb - 8.f * ga;
+                r[4][b] += 16.f * ga + 0.0625f * gb; r[5][b] += 0.03125f * gb - 32.f * ga;
+            } else {                // a = 6: [1 -1/2 1/4 -1/8 1/16 -1/32];  a = 7: [0 0 0 0 0 1]
+                r[0][b] += ga; r[1][b] -= 0.5f * ga; r[2][b] += 0.25f * ga; r[3][b] -= 0.125f * ga; r[4][b] += 0.0625f * ga;
+                r[5][b] += gb - 0.03125f * ga;
+            }
+        }
     }
     if (u >= units) return;
     int tx, ty, n;
     tile_coords(u, TW, TH, tx, ty, n);
-    float r[6][8];
-    #pragma unroll
-    for (int j = 0; j < 8; ++j) {  // columns: A^T m
-        const float col[8] = {mm[0][j], mm[1][j], mm[2][j], mm[3][j], mm[4][j], mm[5][j], mm[6][j], mm[7][j]};
-        float w[6];
-        at8(col, w);
-        #pragma unroll
-        for (int i = 0; i < 6; ++i) r[i][j] = w[i];
-    }
     const float b = a.bias ? a.bias[c] : 0.f;
     float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
     const int oy = 6 * ty, ox = 6 * tx;
     const bool odd = tx & 1;
-    float y[6][6];
-    #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        at8(r[i], y[i]);
+    const bool relu = a.relu != 0;
+    Bits36 bits{0u, 0u};
+    for6([&](auto R) {   // row by row: transform, bias / ReLU, mask bits, store
+        constexpr int i = R.value;
+        float y[6];
+        at8(r[i], y);
         #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            y[i][j] += b;
-            if (a.relu) y[i][j] = fmaxf(y[i][j], 0.f);
+            y[j] += b;
+            if (relu) y[j] = fmaxf(y[j], 0.f);
         }
-    }
-    if (a.bits_out) {
-        Bits36 bits{0u, 0u};
-        for36([&](auto I, auto J) { set36<6 * I.value + J.value>(bits, y[I.value][J.value] > 0.f); });
-        store_bits36(a.bits_out, (size_t)c * plane + (size_t)a.tile_off[l] + u, bits);
-    }
-    #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        if (oy + i >= H) continue;
-        float* row = p + (size_t)(oy + i) * W;
-        if constexpr (VEC) {
-            store_row6(row, ox, W, odd, y[i][0], y[i][1], y[i][2], y[i][3], y[i][4], y[i][5]);
-        } else {
-            #pragma unroll
-            for (int j = 0; j < 6; ++j) if (ox + j < W) row[ox + j] = y[i][j];
+        set36<6 * i + 0>(bits, y[0] > 0.f); set36<6 * i + 1>(bits, y[1] > 0.f); set36<6 * i + 2>(bits, y[2] > 0.f);
+        set36<6 * i + 3>(bits, y[3] > 0.f); set36<6 * i + 4>(bits, y[4] > 0.f); set36<6 * i + 5>(bits, y[5] > 0.f);
+        if (oy + i < H) {
+            float* row = p + (size_t)(oy + i) * W;
+            if constexpr (VEC) {
+                store_row6(row, ox, W, odd, y[0], y[1], y[2], y[3], y[4], y[5]);
+            } else {
+                #pragma unroll
+                for (int j = 0; j < 6; ++j) if (ox + j < W) row[ox + j] = y[j];
+            }
         }
-    }
+    });
+    if (a.bits_out) store_bits36(a.bits_out, (size_t)c * plane + (size_t)a.tile_off[l] + u, bits);
 }
 
-__global__ __launch_bounds__(256) void wino6_out_kernel(WinoArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_OUT_WAVES, 8))) void wino6_out_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
     if (a.pair[l]) wino6_out_body<true>(a, l, lds);
@@ -440,7 +457,7 @@ __device__ __forceinline__ void wino6_out_t_body(const WinoArgs& a, int l, float
     expand_block6(g, on, lds, a.buf_out + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0, plane, padded - t0, false);
 }
 
-__global__ __launch_bounds__(256) void wino6_out_t_kernel(WinoArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_OUTT_WAVES, 8))) void wino6_out_t_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
     if (a.pair[l]) wino6_out_t_body<true>(a, l, lds);
@@ -610,7 +627,7 @@ __device__ __forceinline__ void wino6_in_t_body(const WinoArgs& a, int l, float*
 }
 
 template <bool FUSE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void wino6_in_t_kernel(WinoArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_INT_WAVES, 8))) void wino6_in_t_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
     if (a.pair[l]) wino6_in_t_body<true, FUSE>(a, l, lds);

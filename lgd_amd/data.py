@@ -7,16 +7,43 @@ from . import synth
 from .structures import Boxes, Instances
 
 
-def synthetic_batch(B, h=800, w=1333, n_boxes=10, seed=0, table=False, device="cpu", pin=False):
-    gts = synth.synth_gt(B, h, w, n_boxes, seed=seed, table=table)
-    imgs = synth.synth_images(B, h, w, seed=seed + 1)
+def multiscale_sizes(B, h=800, w=1333, min_sizes=(640, 672, 704, 736, 768, 800), max_size=1333, seed=0):
+    """per-image (height, width) of detectron2's ResizeShortestEdge with MIN_SIZE_TRAIN_SAMPLING "choice"
+    [ref: configs/Base-RetinaNet.yaml:26 MIN_SIZE_TRAIN (640,...,800); utils/dataset_mapper.py:257-355; d2-memory]: the short side of
+    every image is drawn from `min_sizes`, the long side follows the aspect ratio of the (h x w) source image and is capped at
+    `max_size` (then the short side shrinks with it).  Deterministic (hash of `seed`)."""
+    u = synth.det_uniform((B,), 50021 + seed, 0.0, 1.0)
     out = []
     for b in range(B):
-        img = torch.from_numpy(imgs[b])
-        boxes = torch.from_numpy(gts[b][0].copy())
-        cls = torch.from_numpy(gts[b][1].copy())
+        s = min_sizes[min(int(u[b] * len(min_sizes)), len(min_sizes) - 1)]
+        scale = s / min(h, w)
+        if max(h, w) * scale > max_size:
+            scale = max_size / max(h, w)
+        out.append((int(h * scale + 0.5), int(w * scale + 0.5)))
+    return out
+
+
+def synthetic_batch(B, h=800, w=1333, n_boxes=10, seed=0, table=False, device="cpu", pin=False, sizes=None):
+    """sizes: optional per-image (height, width) list (multi-scale training: the images of a batch differ in size and the meta-arch
+    pads them to the batch maximum rounded up to 32, detectron2 ImageList.from_tensors); default: every image h x w."""
+    sizes = list(sizes) if sizes is not None else [(h, w)] * B
+    base_gt = base_img = None
+    if any(tuple(sz) == (h, w) for sz in sizes):   # images at the source size: the fixed-size batch's arrays (bit-identical to it)
+        base_gt = synth.synth_gt(B, h, w, n_boxes, seed=seed, table=table)
+        base_img = synth.synth_images(B, h, w, seed=seed + 1)
+    out = []
+    for b in range(B):
+        hb, wb = sizes[b]
+        if (hb, wb) == (h, w):
+            gt, img = base_gt[b], base_img[b]
+        else:
+            gt = synth.synth_gt(1, hb, wb, n_boxes, seed=seed * 131 + b, table=table)[0]
+            img = synth.synth_images(1, hb, wb, seed=(seed + 1) * 977 + b)[0]
+        img = torch.from_numpy(img)
+        boxes = torch.from_numpy(gt[0].copy())
+        cls = torch.from_numpy(gt[1].copy())
         if pin and torch.cuda.is_available():
             img, boxes, cls = img.pin_memory(), boxes.pin_memory(), cls.pin_memory()
-        out.append({"image": img.to(device), "height": h, "width": w,
-                    "instances": Instances((h, w), gt_boxes=Boxes(boxes.to(device)), gt_classes=cls.to(device))})
+        out.append({"image": img.to(device), "height": hb, "width": wb,
+                    "instances": Instances((hb, wb), gt_boxes=Boxes(boxes.to(device)), gt_classes=cls.to(device))})
     return out

@@ -114,3 +114,15 @@ def closed_form_params(shapes, gain=1.0):
             a = gain * (3.0 / fan_in) ** 0.5
             out[name] = det_uniform(shp, name_seed(name), -a, a)
     return out
+
+
+def fcos_head_params(shapes, gain=2.0 ** 0.5):
+    """closed-form parameters for an FCOS head state_dict (thirdparty_heads/fcos.py:433-512 names): conv weights / biases as
+    closed_form_params (gain sqrt(2): the towers keep their signal through four conv + GroupNorm + ReLU layers), GroupNorm weights and
+    the per-level `scales.i.scale` ~ U(0.5, 1.5) (a closed-form U(-0.1, 0.1) 'bias-like' gamma would switch the norm layers off)."""
+    out = closed_form_params(shapes, gain)
+    for name, shp in shapes.items():
+        is_gn_weight = name.endswith(".weight") and len(tuple(shp)) == 1
+        if is_gn_weight or name.endswith(".scale"):
+            out[name] = det_uniform(tuple(shp), name_seed(name), 0.5, 1.5)
+    return out

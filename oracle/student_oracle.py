@@ -190,3 +190,53 @@ def group_norm_relu(x, groups, weight, bias, relu=True, eps=1e-5):
     """nn.GroupNorm(groups, C)(x) [+ ReLU] of the FCOS towers [ref: thirdparty_heads/fcos.py:455-470]."""
     y = F.group_norm(x, groups, weight, bias, eps)
     return F.relu(y) if relu else y
+
+
+def fcos_head_param_shapes(C=256, num_classes=80, num_convs=4, num_levels=5):
+    """state_dict names / shapes of the reference FCOSHead [ref: thirdparty_heads/fcos.py:453-512]: towers of (conv3x3, GroupNorm(32),
+    ReLU) at Sequential indices 3k, 3k+1, 3k+2; cls_score / bbox_pred / centerness convs; one learnable scalar per level."""
+    s = {}
+    for sub in ("cls_subnet", "bbox_subnet"):
+        for k in range(num_convs):
+            s["%s.%d.weight" % (sub, 3 * k)] = (C, C, 3, 3)
+            s["%s.%d.bias" % (sub, 3 * k)] = (C,)
+            s["%s.%d.weight" % (sub, 3 * k + 1)] = (C,)
+            s["%s.%d.bias" % (sub, 3 * k + 1)] = (C,)
+    for name, co in (("cls_score", num_classes), ("bbox_pred", 4), ("centerness", 1)):
+        s[name + ".weight"] = (co, C, 3, 3)
+        s[name + ".bias"] = (co,)
+    for i in range(num_levels):
+        s["scales.%d.scale" % i] = (1,)
+    return s
+
+
+def fcos_head_forward(p, features, strides, num_convs=4, centerness_on_reg=True, norm_reg_targets=True):
+    """FCOSHead.forward [ref: thirdparty_heads/fcos.py:514-546] on a dict of parameters under the reference's state_dict names: per
+    level, cls / bbox towers of conv3x3 -> GroupNorm(32) -> ReLU [:455-470], cls_score on the cls tower, centerness on the bbox tower
+    (CENTERNESS_ON_REG) [:534-538], bbox_pred * scales[level] then ReLU(.) * stride (NORM_REG_TARGETS) or exp(.) [:540-544].
+    Returns (logits, bbox_reg, centerness), lists over levels."""
+    def tower(x, sub):
+        for k in range(num_convs):
+            x = F.conv2d(x, p["%s.%d.weight" % (sub, 3 * k)], p["%s.%d.bias" % (sub, 3 * k)], 1, 1)
+            x = F.relu(F.group_norm(x, 32, p["%s.%d.weight" % (sub, 3 * k + 1)], p["%s.%d.bias" % (sub, 3 * k + 1)], 1e-5))
+        return x
+    logits, regs, ctrs = [], [], []
+    for level, x in enumerate(features):
+        c, b = tower(x, "cls_subnet"), tower(x, "bbox_subnet")
+        logits.append(F.conv2d(c, p["cls_score.weight"], p["cls_score.bias"], 1, 1))
+        ctrs.append(F.conv2d(b if centerness_on_reg else c, p["centerness.weight"], p["centerness.bias"], 1, 1))
+        r = F.conv2d(b, p["bbox_pred.weight"], p["bbox_pred.bias"], 1, 1) * p["scales.%d.scale" % level]
+        regs.append(F.relu(r) * strides[level] if norm_reg_targets else torch.exp(r))
+    return logits, regs, ctrs
+
+
+def fcos_shifts(level_hw, strides, offset=0.5, device="cpu"):
+    """cvpods ShiftGenerator (NUM_SHIFTS = 1) [cvpods-memory, SURVEY.md appendix B]: per level the cell centres
+    (x, y) = (j * s + offset * s, i * s + offset * s), row-major -> list of (H*W, 2)."""
+    out = []
+    for (h, w), s in zip(level_hw, strides):
+        sx = torch.arange(0, w * s, s, dtype=torch.float32, device=device) + offset * s
+        sy = torch.arange(0, h * s, s, dtype=torch.float32, device=device) + offset * s
+        yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+        out.append(torch.stack((xx.reshape(-1), yy.reshape(-1)), 1))
+    return out

@@ -117,3 +117,38 @@ def oracle_grads_on_device(name, device):
     grads = {n: v.grad for n, v in p.items()}
     grads.update({"adapter." + n: v.grad for n, v in pa.items()})
     return {k: feats[k].grad for k in feats}, grads
+
+
+# ---- FCOS fixtures (tests/golden/make_golden.py: run_fcos_gt_case / run_fcos_head_case, generated from the reference's in-tree FCOS)
+FCOS_STRIDES = [8, 16, 32, 64, 128]
+FCOS_SOI = [[-1, 64], [64, 128], [128, 256], [256, 512], [512, float("inf")]]
+FCOS_GT_CASES = {"fcos_gt_small_r15": ("small", 1.5), "fcos_gt_small_r0": ("small", 0.0), "fcos_gt_full_r15": ("full", 1.5)}
+FCOS_HEAD_LEVELS = [(24, 32), (12, 16), (6, 8), (3, 4), (2, 2)]
+
+
+def fcos_gt_inputs(case):
+    """ground truth of the FCOS target-assignment fixtures: `small` = three 512x640 images -- random boxes, nested boxes of equal
+    centre + a duplicate (min-area ties, first index wins), a crowd of 40 overlapping boxes; `full` = two images at the config-3
+    shape 800x1344.  (An image WITHOUT boxes cannot go through the reference: its `gt_positions_area.min(dim=0)` raises on an empty
+    dimension, thirdparty_heads/fcos.py:259.)"""
+    if case == "small":
+        H, W = 512, 640
+        gts = synth.synth_gt(3, H, W, 8, seed=9)
+        nested = np.array([[100.0, 100.0, 420.0, 400.0], [180.0, 175.0, 340.0, 325.0], [180.0, 175.0, 340.0, 325.0]], np.float32)
+        gts[1] = (np.concatenate([gts[1][0], nested]), np.concatenate([gts[1][1], np.array([3, 4, 5], np.int64)]))
+        u = synth.det_uniform((40, 5), 7771, 0.0, 1.0).astype(np.float64)
+        x1, y1 = u[:, 0] * 560, u[:, 1] * 440
+        crowd = np.stack([x1, y1, np.minimum(W - 1.0, x1 + 8 + u[:, 2] * 300), np.minimum(H - 1.0, y1 + 8 + u[:, 3] * 260)], 1)
+        gts[2] = (crowd.astype(np.float32), np.minimum((u[:, 4] * 80).astype(np.int64), 79))
+        return H, W, gts
+    H, W = 800, 1344
+    return H, W, synth.synth_gt(2, H, W, 10, seed=0)
+
+
+def fcos_head_inputs(B=2):
+    """closed-form features and output probes of the `fcos_head` fixture."""
+    feats = [synth.det_uniform((B, 256, h, w), 4100 + i, -1.0, 1.0) for i, (h, w) in enumerate(FCOS_HEAD_LEVELS)]
+    co = {"logits": 80, "reg": 4, "ctr": 1}
+    probes = {kind: [synth.det_uniform((B, co[kind], h, w), 4200 + 10 * i + len(kind), -1.0, 1.0) for i, (h, w) in enumerate(FCOS_HEAD_LEVELS)]
+              for kind in co}
+    return feats, probes

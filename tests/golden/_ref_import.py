@@ -104,3 +104,76 @@ def make_cfg(add_ctx=True, interact="stuGuided", detach_app=False, box_format="x
             ),
         ),
     )
+
+
+def import_reference_fcos():
+    """The reference's in-tree FCOS (models/customized_detectors/thirdparty_heads/fcos.py: `FCOSHead` :433-546, `FCOS.get_ground_truth`
+    :177-284, `FCOS.losses` :105-175) imported with stand-ins for the cvpods / detectron2 names its module header pulls in.
+
+    Stand-ins WITHOUT arithmetic (names only; nothing they compute reaches a fixture):
+      cvpods.layers.ShapeSpec / generalized_batched_nms, cvpods.utils.comm / log_first_n, cvpods.modeling.losses.iou_loss /
+      sigmoid_focal_loss_jit (only `FCOS.losses` calls them -- not run here: their arithmetic stays UNPINNED),
+      detectron2.modeling.build_backbone, detectron2.structures.ImageList / Instances,
+      cvpods.modeling.anchor_generator.ShiftGenerator (FCOSHead.__init__ reads `.num_cell_shifts`: one shift per cell, the
+      configs' NUM_SHIFTS = 1), cvpods.layers.cat (= torch.cat).
+    Stand-ins WITH arithmetic -- public one-line definitions restated from memory, so what they compute is NOT pinned by the fixtures
+    that flow through them (the fixtures pin everything the reference does AROUND them: centre sampling, size ranges, min-area ties,
+    background, centerness):
+      cvpods.modeling.box_regression.Shift2BoxTransform.get_deltas(shifts, boxes) = cat(shifts - boxes[..., :2], boxes[..., 2:] - shifts)
+      detectron2.structures.Boxes.get_centers() = (xy1 + xy2) / 2, .area() = (x2 - x1) * (y2 - y1), indexing."""
+    import torch
+    if "models.customized_detectors.thirdparty_heads.fcos" in sys.modules:
+        return sys.modules["models"]._lgd_ref_fcos
+    import_reference()
+
+    class ShapeSpec:
+        def __init__(self, channels=None, height=None, width=None, stride=None):
+            self.channels, self.height, self.width, self.stride = channels, height, width, stride
+
+    class ShiftGenerator:
+        def __init__(self, cfg, input_shape):
+            self.num_cell_shifts = [1 for _ in input_shape]
+
+    class Shift2BoxTransform:
+        def __init__(self, weights):
+            self.weights = weights
+
+        def get_deltas(self, shifts, boxes):
+            return torch.cat((shifts - boxes[..., :2], boxes[..., 2:] - shifts), dim=-1)
+
+    class Boxes:
+        def __init__(self, tensor):
+            self.tensor = tensor
+
+        def get_centers(self):
+            return (self.tensor[:, :2] + self.tensor[:, 2:]) / 2
+
+        def area(self):
+            b = self.tensor
+            return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+        def __getitem__(self, item):
+            return Boxes(self.tensor[item])
+
+        def __len__(self):
+            return self.tensor.shape[0]
+
+    def _unused(*a, **k):
+        raise RuntimeError("stand-in without arithmetic was called")
+
+    sys.modules["detectron2.modeling"].build_backbone = _unused
+    st = sys.modules["detectron2.structures"]
+    st.ImageList, st.Instances, st.Boxes = object, object, Boxes
+    _mod("cvpods")
+    _mod("cvpods.modeling")
+    _mod("cvpods.modeling.anchor_generator", ShiftGenerator=ShiftGenerator)
+    _mod("cvpods.layers", ShapeSpec=ShapeSpec, cat=torch.cat, generalized_batched_nms=_unused)
+    _mod("cvpods.modeling.box_regression", Shift2BoxTransform=Shift2BoxTransform)
+    _mod("cvpods.modeling.losses", iou_loss=_unused, sigmoid_focal_loss_jit=_unused)
+    _mod("cvpods.utils", comm=types.SimpleNamespace(), log_first_n=_unused)
+    th = _mod("models.customized_detectors.thirdparty_heads")
+    th.__path__ = [REF_ROOT + "/models/customized_detectors/thirdparty_heads"]
+    fc = importlib.import_module("models.customized_detectors.thirdparty_heads.fcos")
+    ns = types.SimpleNamespace(FCOS=fc.FCOS, FCOSHead=fc.FCOSHead, Boxes=Boxes, ShapeSpec=ShapeSpec, Shift2BoxTransform=Shift2BoxTransform)
+    sys.modules["models"]._lgd_ref_fcos = ns
+    return ns

@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
-from _ref_import import import_reference, make_cfg  # noqa: E402
+from _ref_import import import_reference, import_reference_fcos, make_cfg  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))
+import common as cm  # noqa: E402  (tests/common.py: the closed-form inputs the tests regenerate)
 from lgd_amd import synth  # noqa: E402
 from oracle import lgd_oracle as O  # noqa: E402
 
@@ -156,7 +158,7 @@ def run_teacher_case(ref, name, B, H, W, gt, add_ctx, interact, box_format="x1y1
             return
         total.backward()
         for k in keys:
-            g = sample(feats[k].grad)
+            g = sample(feats[k].grad, stride)
             out["gfeat_s_" + k], out["gfeat_sq_" + k] = g["s"], g["sq"]
         for n, prm in list(teacher.named_parameters()) + [("adapter." + n, q) for n, q in d.adapter["distill"].named_parameters()]:
             if prm.grad is None:
@@ -228,6 +230,71 @@ def run_distill_case(ref, name, B, H, W, coef):
     print(name, "saved", {k: float(v) for k, v in out.items() if k.startswith("loss") or k == "in_mse"})
 
 
+def run_fcos_gt_case(fc, name, case, radius):
+    """the REAL FCOS.get_ground_truth [thirdparty_heads/fcos.py:177-284] (through the stand-ins _ref_import documents: the arithmetic of
+    Shift2BoxTransform.get_deltas and Boxes.get_centers / area is restated there, everything else is the reference's)."""
+    if ONLY and name not in ONLY:
+        return
+    from oracle import student_oracle as SO
+    H, W, gts = cm.fcos_gt_inputs(case)
+    level_hw = synth.pyramid_shapes(H, W)
+    shifts = SO.fcos_shifts(level_hw, cm.FCOS_STRIDES)
+    me = types.SimpleNamespace(object_sizes_of_interest=cm.FCOS_SOI, shift2box_transform=fc.Shift2BoxTransform((1.0, 1.0, 1.0, 1.0)),
+                               center_sampling_radius=radius, fpn_strides=cm.FCOS_STRIDES, num_classes=80)
+
+    class T:
+        def __init__(self, b, c):
+            self.gt_boxes, self.gt_classes = fc.Boxes(torch.from_numpy(b.copy())), torch.from_numpy(c.copy())
+
+        def __len__(self):
+            return len(self.gt_boxes)
+    targets = [T(b, c) for b, c in gts]
+    cls, deltas, ctr = fc.FCOS.get_ground_truth(me, [shifts for _ in gts], targets)
+    fg = (cls >= 0) & (cls != 80)
+    out = {"classes": cls.numpy().astype(np.uint8), "fg_deltas": deltas[fg].numpy(), "fg_centerness": ctr[fg].numpy(),
+           "n_fg": np.int64(int(fg.sum()))}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "R=%d" % cls.shape[1], "foreground", int(fg.sum()), "saved")
+
+
+def run_fcos_head_case(fc, name, B):
+    """the REAL FCOSHead [thirdparty_heads/fcos.py:433-546] (pure torch; ShiftGenerator is a name-only stand-in) on closed-form
+    parameters and features: outputs of every level and the gradients of loss = sum_l <out_l, probe_l>."""
+    if ONLY and name not in ONLY:
+        return
+    from oracle import student_oracle as SO
+    NS = types.SimpleNamespace
+    cfg = NS(MODEL=NS(FCOS=NS(NUM_CLASSES=80, NUM_CONVS=4, PRIOR_PROB=0.01, FPN_STRIDES=cm.FCOS_STRIDES, CENTERNESS_ON_REG=True,
+                              NORM_REG_TARGETS=True)))
+    head = fc.FCOSHead(cfg, [fc.ShapeSpec(channels=256) for _ in cm.FCOS_HEAD_LEVELS])
+    shapes = SO.fcos_head_param_shapes()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.fcos_head_params(shapes).items()}
+    missing, unexpected = head.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    head.train()
+    feats_np, probes = cm.fcos_head_inputs(B)
+    feats = [torch.from_numpy(f.copy()).requires_grad_(True) for f in feats_np]
+    logits, regs, ctrs = head(feats)
+    out, total = {}, 0.0
+    for kind, maps in (("logits", logits), ("reg", regs), ("ctr", ctrs)):
+        for i, t in enumerate(maps):
+            s = sample(t, 7)
+            out["%s_s_%d" % (kind, i)], out["%s_sum_%d" % (kind, i)], out["%s_sq_%d" % (kind, i)] = s["s"], s["sum"], s["sq"]
+            if i >= 3:
+                out["%s_full_%d" % (kind, i)] = t.detach().numpy()
+            total = total + (t * torch.from_numpy(probes[kind][i])).sum()
+    out["total"] = np.float64(total.item())
+    total.backward()
+    for i, f in enumerate(feats):
+        g = sample(f.grad, 7)
+        out["gfeat_s_%d" % i], out["gfeat_sq_%d" % i] = g["s"], g["sq"]
+    for n, prm in head.named_parameters():
+        g = sample(prm.grad)
+        out["gw_s_" + n], out["gw_sq_" + n] = g["s"][:64], g["sq"]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "saved", len(out), "arrays; total %.6f" % out["total"])
+
+
 def to_t(gt):
     return [(b, c) for b, c in gt]
 
@@ -241,7 +308,7 @@ def main():
     gt_b = synth.synth_gt(3, 384, 512, 7, seed=9)
     gt_b[1] = (np.zeros((0, 4), np.float32), np.zeros((0,), np.int64))
     gt_b[2] = (gt_b[2][0][:4], gt_b[2][1][:4])
-    run_teacher_case(ref, "c1b_noctx_labelguided_wh", 3, 384, 512, gt_b, False, "labelGuided", box_format="x1y1wh")
+    run_teacher_case(ref, "c1b_noctx_labelguided_wh", 3, 384, 512, gt_b, False, "labelGuided", box_format="x1y1wh", with_grads=True)
     # C1c: ctx=NO stuGuided (the shipped FCOS R-50 configuration), non-square, with grads, coef != 1
     gt_c = synth.synth_gt(2, 320, 480, 6, seed=4)
     run_teacher_case(ref, "c1c_noctx_stuguided", 2, 320, 480, gt_c, False, "stuGuided", with_grads=True, coef=2.5, feat_seed=13)
@@ -250,13 +317,18 @@ def main():
     run_mask_case(ref, "c2_masks_800x1344", 800, 1344, gt2, True)
     # the full BASELINE shape, B=2 800x1344, 10 boxes/img: config 2 (ctx=YES) and config 3 (ctx=NO)
     gt_f = synth.synth_gt(2, 800, 1344, 10, seed=0)
-    run_teacher_case(ref, "c2_full_ctx_800x1344", 2, 800, 1344, gt_f, True, "stuGuided", with_loss=True, feat_seed=17,
+    run_teacher_case(ref, "c2_full_ctx_800x1344", 2, 800, 1344, gt_f, True, "stuGuided", with_grads=True, feat_seed=17,
                      stride=FULL_STRIDE, full_small_levels=False)
-    run_teacher_case(ref, "c3_full_noctx_800x1344", 2, 800, 1344, gt_f, False, "stuGuided", with_loss=True, feat_seed=19,
+    run_teacher_case(ref, "c3_full_noctx_800x1344", 2, 800, 1344, gt_f, False, "stuGuided", with_grads=True, feat_seed=19,
                      stride=FULL_STRIDE, full_small_levels=False)
     # distill alone
     run_distill_case(ref, "distill_c1", 2, 512, 512, coef=1.0)
     run_distill_case(ref, "distill_coef", 2, 256, 320, coef=0.37)
+    # the FCOS code that IS in the reference tree: target assignment and the head
+    fc = import_reference_fcos()
+    for name, (case, radius) in cm.FCOS_GT_CASES.items():
+        run_fcos_gt_case(fc, name, case, radius)
+    run_fcos_head_case(fc, "fcos_head", 2)
 
 
 if __name__ == "__main__":

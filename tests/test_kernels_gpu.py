@@ -1096,6 +1096,28 @@ def test_fcos_targets_bit_exact(radius):
 
 
 # ------------------------------------------------------------------------------------------- student bottleneck: 1x1 conv + FrozenBN (+ residual) + ReLU
+@pytest.mark.parametrize("name", list(cm.FCOS_GT_CASES))
+def test_fcos_targets_match_reference_golden(name):
+    """lgd_fcos_targets against outputs of the reference's OWN FCOS.get_ground_truth [thirdparty_heads/fcos.py:177-284] (fixtures
+    tests/golden/fcos_gt_*.npz, generated from /root/reference by tests/golden/make_golden.py): the class of every location, and for
+    the foreground the ltrb targets bit-identical, centerness to 1 ulp (the kernel evaluates the IEEE value through fp64)."""
+    from lgd_amd import ops
+    case, radius = cm.FCOS_GT_CASES[name]
+    g = cm.golden(name)
+    H, W, gts = cm.fcos_gt_inputs(case)
+    shifts = SO.fcos_shifts(synth.pyramid_shapes(H, W), cm.FCOS_STRIDES, device=DEV)
+    boxes = torch.cat([torch.from_numpy(b) for b, _ in gts]).to(DEV)
+    classes = torch.cat([torch.from_numpy(c) for _, c in gts]).to(DEV)
+    cls, dl, ct = ops.fcos_targets(shifts, cm.FCOS_STRIDES, cm.FCOS_SOI, boxes, classes, [len(b) for b, _ in gts], 80, radius)
+    cls, dl, ct = cls.cpu(), dl.cpu(), ct.cpu()
+    assert np.array_equal(cls.numpy().astype(np.uint8), g["classes"])
+    fg = (cls >= 0) & (cls != 80)
+    assert int(fg.sum()) == int(g["n_fg"])
+    assert np.array_equal(dl[fg].numpy(), g["fg_deltas"])
+    ref_ct = torch.from_numpy(g["fg_centerness"])
+    assert float(((ct[fg] - ref_ct).abs() / ref_ct.clamp(min=1e-30)).max()) <= 1.3e-7
+
+
 @pytest.mark.parametrize("N,Ci,Co,H,W,relu,res", [(2, 64, 256, 20, 28, True, True), (3, 256, 64, 13, 21, True, False),
                                                   (2, 128, 128, 8, 12, False, True), (1, 32, 48, 7, 11, False, False)])
 def test_pointwise_conv_bn_fwd_bwd(N, Ci, Co, H, W, relu, res):

@@ -133,26 +133,21 @@ def test_distill_loss_and_grads_match_reference(run):
     pr = cm.probes({k: tea[k] for k in O.LEVELS})
     total = loss + sum((tea[k] * pr[k].to(DEV)).sum() for k in O.LEVELS)
     assert abs(total.item() - float(g["total_loss"])) < TOL * abs(float(g["total_loss"])) + 1e-6
-    if "gfeat_s_p3" not in g:
-        return  # the full-size cases store the losses only
     total.backward()
     # Model-level gradients and ReLU kinks.  The CPU reference agrees with an fp64 evaluation to 2..4e-6 on every level (no
     # conditioning problem), but a pre-activation within rounding noise of zero takes its backward mask from the summation order
     # of whoever computed it: the ORACLE's own fp32 torch ops, run on this GPU, leave the reference by 1e-3 (p3) / 3..5e-3 (p5) on
     # case c1 and by ~5e-6 on the other levels (tools/diag_grad_chain.py, profiles/r02_diag_*); the HIP path shows the same on
-    # whichever levels ITS rounding flips.  One flipped unit reaches 7x7x256 inputs through the refinement convs (20 % of a
-    # 16x16 level), so no element-wise criterion survives it.  What is asserted instead: the five levels run the same kernels
-    # with the same weights, so a kernel or wiring error shows on every level -- at least two levels must agree with the
-    # reference to 1e-4 (measured 4e-6 .. 1e-5), the flipped ones to 2e-2.  Which levels flip moves with any change of rounding:
-    # p3 / p5 with the host-side filter transform of round 1, p3 / p4 / p5 with the in-kernel one (a level of 64 x 64 x 256 units
-    # per ReLU layer almost surely has one within 1e-7 of zero; p6 / p7 rarely do).  Every kernel's backward is held to 2e-5 on its
-    # own in tests/test_kernels_gpu.py, and chains of convolutions to 1e-4 against fp64 under the kernels' own masks
-    # (test_conv3x3_chain).
+    # whichever levels ITS rounding flips (a level of 64 x 64 x 256 units per ReLU layer almost surely has one within 1e-7 of zero,
+    # the 100 x 168 levels of the full-size cases have dozens).  One flipped unit reaches 7x7x256 inputs through the refinement convs
+    # (20 % of a 16x16 level), so no element-wise criterion survives it.  The HARD assert on the model-level gradients is therefore
+    # test_teacher_gradients_fp64_under_product_masks below (fp64 oracle under the product's own masks: ALL levels and parameters to
+    # 1e-4); here the deviation from the reference's fp32 gradients is printed next to that of torch's own ops on this device and
+    # only bounded at the size a flip can have (2e-2).
     dev_feat, dev_w = cm.oracle_grads_on_device(run["name"], DEV)
-    errs = {k: cm.rel_err(cm.sample(feats[k].grad)[0], g["gfeat_s_" + k]) for k in O.LEVELS}
+    errs = {k: cm.rel_err(cm.sample(feats[k].grad, run["stride"])[0], g["gfeat_s_" + k]) for k in O.LEVELS}
     print("feature-gradient parity vs reference [%s]: %s" % (run["backend"], "; ".join(
-        "%s product %.1e / torch-ops-on-this-GPU %.1e" % (k, errs[k], cm.rel_err(cm.sample(dev_feat[k])[0], g["gfeat_s_" + k])) for k in O.LEVELS)))
-    assert sum(e <= 1e-4 for e in errs.values()) >= 2, errs
+        "%s product %.1e / torch-ops-on-this-GPU %.1e" % (k, errs[k], cm.rel_err(cm.sample(dev_feat[k], run["stride"])[0], g["gfeat_s_" + k])) for k in O.LEVELS)))
     assert all(e <= 2e-2 for e in errs.values()), errs
     named = list(teacher.named_parameters()) + [("adapter." + n, p) for n, p in d.adapter["distill"].named_parameters()]
     worst = (0.0, 0.0, "")
@@ -686,3 +681,264 @@ def test_full_size_step_shipped_path_vs_library_convolutions(monkeypatch, yaml_n
         for k in la[i]:
             assert abs(la[i][k] - lb[i][k]) <= 2e-4 * abs(lb[i][k]) + 1e-6, (i, k, la[i][k], lb[i][k])
     print("full-size step, shipped vs library path: step-2 losses", la[1], lb[1])
+
+
+@pytest.mark.parametrize("tile", [4, 6])
+def test_fcos_head_matches_reference_golden(tile):
+    """the product FCOSHead (lgd_amd/student/fcos.py: shared-input Winograd convolutions, gn_group.hip GroupNorm(32) + ReLU over all
+    maps, per-level scale) against outputs and gradients of the reference's OWN FCOSHead [thirdparty_heads/fcos.py:433-546]
+    (tests/golden/fcos_head.npz, generated from /root/reference): same state_dict names, closed-form parameters and features."""
+    from lgd_amd import config, ops
+    from lgd_amd.student.fcos import FCOSHead
+    from oracle import student_oracle as SO
+    g = cm.golden("fcos_head")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_fcos_r50.yaml"), ["MODEL.DEVICE", DEV])
+    head = FCOSHead(cfg)
+    sd = {k: torch.from_numpy(v) for k, v in synth.fcos_head_params(SO.fcos_head_param_shapes()).items()}
+    missing, unexpected = head.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    head.to(DEV).train()
+    feats_np, probes = cm.fcos_head_inputs()
+    feats = [torch.from_numpy(f).to(DEV).requires_grad_(True) for f in feats_np]
+    prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=tile)
+    try:
+        outs = dict(zip(("logits", "reg", "ctr"), head(feats)))
+        total = 0.0
+        for kind, maps in outs.items():
+            for i, t in enumerate(maps):
+                e = cm.rel_err(t.detach().reshape(-1)[::7], g["%s_s_%d" % (kind, i)])
+                assert e < 1e-4, (kind, i, e)
+                if i >= 3:
+                    assert cm.rel_err(t.detach(), g["%s_full_%d" % (kind, i)]) < 1e-4
+                total = total + (t * torch.from_numpy(probes[kind][i]).to(DEV)).sum()
+        assert abs(float(total.detach()) - float(g["total"])) <= 1e-4 * abs(float(g["total"]))
+        total.backward()
+    finally:
+        ops.conv3x3_backend(*prev)
+    # Gradients against the reference's fp32 run are a DIAGNOSTIC: four GroupNorm(32) + ReLU layers per tower, and a unit within
+    # rounding of zero takes its mask from the summation order -- through the group statistics one flip moves every element of its
+    # group (measured: 4e-3 relative L2 at the 24 x 32 level).  The hard assert is test_fcos_head_gradients_fp64_under_product_masks.
+    worst = 0.0
+    for i, f in enumerate(feats):
+        e = cm.rel_err(f.grad.reshape(-1)[::7], g["gfeat_s_%d" % i])
+        assert e < 2e-2, (i, e)
+        worst = max(worst, e)
+    for n, prm in head.named_parameters():
+        e = cm.rel_err(prm.grad.reshape(-1)[::cm.SAMPLE_STRIDE][:64], g["gw_s_" + n])
+        assert e < 2e-2, (n, e)
+        worst = max(worst, e)
+    print("FCOS head vs reference: worst gradient deviation %.2e (tile %d)" % (worst, tile))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Model-level gradients under PINNED activation masks (VERDICT r02 item 2c).  A pre-activation within fp32 rounding of zero takes its
+# backward mask from the summation order of whoever computed it, so the reference's fp32 gradients (golden) and the product's differ
+# by O(1e-3) on whichever levels have such a unit (test_distill_loss_and_grads_match_reference prints both deviations).  Here the
+# question "are the product's kernels and wiring right?" is asked without that noise: the ORACLE is evaluated in fp64 with every ReLU
+# mask taken from the product's own forward (15 row-LN ReLUs of the label encoder / canoni_proj_1D, student_proj_2D, rendering, the
+# two refinement ReLUs, the two adapter ReLUs, per level) -- then ALL five levels and ALL parameters must agree to 1e-4.
+class _PinnedReluF:
+    """stands in for torch.nn.functional inside oracle/lgd_oracle.py: relu(x) = x * (the product's mask for this site)."""
+
+    def __init__(self, masks):
+        import torch.nn.functional as F
+        self._F, self._masks, self.used, self.flip_frac = F, list(masks), 0, []
+
+    def __getattr__(self, name):
+        return getattr(self._F, name)
+
+    def relu(self, x):
+        m = self._masks[self.used].to(x.device)
+        self.used += 1
+        assert tuple(m.shape) == tuple(x.shape), (self.used, tuple(m.shape), tuple(x.shape))
+        self.flip_frac.append(float(((x.detach() > 0) != m).double().mean()))
+        return x * m.to(x.dtype)
+
+
+def _run_product_capturing_masks(name, coef):
+    """the product DynamicTeacher + adapter + distill loss with every ReLU-bearing op observable: the fused forms whose activation
+    never reaches memory are replaced by their unfused kernels (gn_pool -> gn1 + mask_pool; the adapter's conv chain -> one node per
+    conv, whose forward kernels are the chain's), everything else is the shipped path."""
+    from lgd_amd import ops
+    from lgd_amd.adapters import SequentialConvs
+    from lgd_amd.base_distillator import BaseDistillator
+    from lgd_amd.structures import ImageList
+    B, H, W, ctx, interact, fmt, _, _ = cm.CASES[name]
+    rec = {"ln": [], "proj": None, "render": None, "gn": [], "adapter": []}
+    real = {k: getattr(ops, k) for k in ("row_ln", "gn_relu_mask_pool", "bias_ctx_relu", "gn1", "conv3x3_chain", "conv3x3_levels")}
+    on = lambda ys: [(y.detach() > 0).cpu() for y in ys]  # noqa: E731
+
+    def row_ln(x, relu):
+        y = real["row_ln"](x, relu)
+        if relu:
+            rec["ln"].append((y.detach() > 0).cpu())
+        return y
+
+    def pool(geom, xs):
+        ys = real["gn1"](xs, True)
+        rec["proj"] = on(ys)
+        return ops.mask_pool(geom, ys)
+
+    def ctx_relu(xs, c):
+        ys = real["bias_ctx_relu"](xs, c)
+        rec["render"] = on(ys)
+        return ys
+
+    def gn1(xs, relu):
+        ys = real["gn1"](xs, relu)
+        if relu:
+            rec["gn"].append(on(ys))
+        return ys
+
+    def levels(xs, w, b=None, relu=False, **kw):
+        ys = real["conv3x3_levels"](xs, w, b, relu, **kw)
+        if relu:   # the rendering conv of the configurations without a context box
+            rec["render"] = on(ys)
+        return ys
+
+    def chain(xs, filters, relus):
+        for (w, b), r in zip(filters, relus):
+            xs = real["conv3x3_levels"](xs, w, b, r)
+            if r:
+                rec["adapter"].append(on(xs))
+        return xs
+
+    class D(BaseDistillator):
+        def __init__(self, c):
+            torch.nn.Module.__init__(self)
+            self.coef = c
+            self.adapter = torch.nn.ModuleDict({"distill": SequentialConvs(None)})
+    prev = ops.conv3x3_backend(winograd=True, min_tiles=0)
+    patched = {"row_ln": row_ln, "gn_relu_mask_pool": pool, "bias_ctx_relu": ctx_relu, "gn1": gn1, "conv3x3_chain": chain,
+               "conv3x3_levels": levels}
+    try:
+        for k, f in patched.items():
+            setattr(ops, k, f)
+        teacher = _teacher(name)
+        d = D(coef)
+        d.adapter["distill"].load_state_dict(cm.adapter_params(), strict=True)
+        d.to(DEV)
+        d.distill_flag = 1
+        feats = {k: v.to(DEV).requires_grad_(True) for k, v in cm.case_feats(name).items()}
+        images = ImageList(torch.zeros(B, 3, H, W, device=DEV), [(H, W)] * B)
+        tea, _, _ = teacher((_batched_inputs(cm.case_gt(name), H, W), images, None, feats))
+        loss = d.distill({"stu": feats, "tea": tea}, None, None, None, None)
+        pr = cm.probes({k: tea[k] for k in O.LEVELS})
+        total = loss + sum((tea[k] * pr[k].to(DEV)).sum() for k in O.LEVELS)
+        total.backward()
+    finally:
+        for k, f in real.items():
+            setattr(ops, k, f)
+        ops.conv3x3_backend(*prev)
+    grads = {n: p.grad for n, p in teacher.named_parameters()}
+    grads.update({"adapter." + n: p.grad for n, p in d.adapter["distill"].named_parameters()})
+    return rec, {k: feats[k].grad for k in O.LEVELS}, grads, float(total.detach())
+
+
+@pytest.mark.parametrize("name", list(cm.CASES))
+def test_teacher_gradients_fp64_under_product_masks(name):
+    B, H, W, ctx, interact, fmt, coef, _ = cm.CASES[name]
+    rec, gfeat, gw, total = _run_product_capturing_masks(name, coef)
+    L = len(O.LEVELS)
+    assert len(rec["ln"]) == 15 and len(rec["gn"]) == 2 and len(rec["adapter"]) == 2 and rec["proj"] and rec["render"]
+    # the oracle's ReLU sites in ITS call order (oracle/lgd_oracle.py: label encoder 14, canoni 1, student_proj_2D per level, rendering
+    # per level, refinement level by level (2 ReLUs each), then the adapter level by level (2 ReLUs each))
+    order = rec["ln"] + rec["proj"] + rec["render"]
+    for lv in range(L):
+        order += [rec["gn"][0][lv], rec["gn"][1][lv]]
+    for lv in range(L):
+        order += [rec["adapter"][0][lv], rec["adapter"][1][lv]]
+    pinned = _PinnedReluF(order)
+    p = {k: v.double().requires_grad_(True) for k, v in cm.teacher_params().items()}
+    pa = {k: v.double().requires_grad_(True) for k, v in cm.adapter_params().items()}
+    feats = {k: v.double().requires_grad_(True) for k, v in cm.case_feats(name).items()}
+    real_F = O.F
+    O.F = pinned
+    try:
+        tea, _, _ = O.teacher_forward(p, feats, cm.case_gt(name), (H, W), ctx, interact, False, fmt)
+        loss = O.distill_loss(pa, feats, tea, coef, 1)
+    finally:
+        O.F = real_F
+    assert pinned.used == len(order)
+    assert max(pinned.flip_frac) < 2e-3, pinned.flip_frac   # the masks ARE the oracle's, up to the units within rounding of zero
+    pr = cm.probes(tea)
+    ref_total = loss + sum((tea[k] * pr[k].double()).sum() for k in tea)
+    assert abs(total - float(ref_total.detach())) <= 1e-5 * abs(float(ref_total.detach()))
+    ref_total.backward()
+    errs = {k: cm.rel_err(gfeat[k], feats[k].grad) for k in O.LEVELS}
+    assert all(e <= 1e-4 for e in errs.values()), errs   # ALL five levels (measured ~1e-5)
+    worst = (0.0, "")
+    refs = dict(p)
+    refs.update({"adapter." + n: v for n, v in pa.items()})
+    for n, g in gw.items():
+        r = refs[n].grad
+        if r is None or float(r.abs().max()) < 1e-9:   # never-used parameters; adapter.4.bias in front of an InstanceNorm (analytically 0)
+            assert g is None or float(g.abs().max()) < 1e-6, n
+            continue
+        e = cm.rel_err(g, r)
+        worst = max(worst, (e, n))
+        assert e <= 1e-4, (n, e)
+    print("gradients under pinned masks [%s]: features %s; worst parameter %.1e (%s); flipped units <= %.1e of a site"
+          % (name, " ".join("%s %.1e" % kv for kv in errs.items()), worst[0], worst[1], max(pinned.flip_frac)))
+
+
+@pytest.mark.parametrize("tile", [4, 6])
+def test_fcos_head_gradients_fp64_under_product_masks(tile):
+    """the product FCOSHead's gradients against the oracle head in fp64 evaluated under the PRODUCT's activation masks (8 GroupNorm +
+    ReLU calls over all levels, the ReLU of the regression branch): every feature and parameter gradient to 1e-4."""
+    from lgd_amd import config, ops
+    from lgd_amd.student.fcos import FCOSHead
+    from oracle import student_oracle as SO
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_fcos_r50.yaml"), ["MODEL.DEVICE", DEV])
+    head = FCOSHead(cfg)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fcos_head_params(SO.fcos_head_param_shapes()).items()}, strict=True)
+    head.to(DEV).train()
+    feats_np, probes = cm.fcos_head_inputs()
+    feats = [torch.from_numpy(f).to(DEV).requires_grad_(True) for f in feats_np]
+    L = len(feats)
+    gn_masks = []
+    real_gn = ops.group_norm_relu
+
+    def gn(xs, *a, **k):
+        ys = real_gn(xs, *a, **k)
+        gn_masks.append([(y.detach() > 0).cpu() for y in ys])
+        return ys
+    prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=tile)
+    ops.group_norm_relu = gn
+    try:
+        outs = dict(zip(("logits", "reg", "ctr"), head(feats)))
+        total = sum((t * torch.from_numpy(probes[kind][i]).to(DEV)).sum() for kind, maps in outs.items() for i, t in enumerate(maps))
+        total.backward()
+    finally:
+        ops.group_norm_relu = real_gn
+        ops.conv3x3_backend(*prev)
+    assert len(gn_masks) == 8   # per tower layer: the cls tower's call, then the bbox tower's
+    reg_masks = [(t.detach() > 0).cpu() for t in outs["reg"]]
+    # the oracle's ReLU sites in its call order: per level -- cls tower (4), bbox tower (4), then the regression branch
+    order = []
+    for lv in range(L):
+        order += [gn_masks[2 * k][lv] for k in range(4)] + [gn_masks[2 * k + 1][lv] for k in range(4)] + [reg_masks[lv]]
+    pinned = _PinnedReluF(order)
+    p = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in synth.fcos_head_params(SO.fcos_head_param_shapes()).items()}
+    f64 = [torch.from_numpy(f).double().requires_grad_(True) for f in feats_np]
+    real_F = SO.F
+    SO.F = pinned
+    try:
+        ref = dict(zip(("logits", "reg", "ctr"), SO.fcos_head_forward(p, f64, cm.FCOS_STRIDES)))
+    finally:
+        SO.F = real_F
+    assert pinned.used == len(order) and max(pinned.flip_frac) < 2e-3, pinned.flip_frac
+    rt = sum((t * torch.from_numpy(probes[kind][i]).double()).sum() for kind, maps in ref.items() for i, t in enumerate(maps))
+    assert abs(float(total.detach()) - float(rt.detach())) <= 1e-5 * abs(float(rt.detach()))
+    rt.backward()
+    errs = {"feature level %d" % i: cm.rel_err(a.grad, b.grad) for i, (a, b) in enumerate(zip(feats, f64))}
+    errs.update({n: cm.rel_err(prm.grad, p[n].grad) for n, prm in head.named_parameters()})
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print("FCOS head gradients under pinned masks (tile %d): worst %s; flipped units <= %.1e of a site"
+          % (tile, ", ".join("%s %.1e" % kv for kv in top), max(pinned.flip_frac)))
+    # the per-level `scales.i.scale` are scalars: their gradient is ONE signed sum over the level's regression map (probe in [-1, 1]),
+    # so cancellation carries the fp32 rounding of its terms into the relative error (measured 1.3e-4 at the 12 x 16 level): 5e-4
+    bad = {n: e for n, e in errs.items() if e > (5e-4 if n.endswith(".scale") else 1e-4)}
+    assert not bad, bad

@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 from lgd_amd import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+print("tuned GEMM table:", ops.enable_tuned_gemms())
 dev = "cuda"
 hws = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
 torch.manual_seed(0)
@@ -40,7 +41,7 @@ for name, nb, npyr, Co in (("pyramid 256->256", B, 1, 256), ("both pyramids 256-
     w = (torch.randn(Co, 256, 3, 3, device=dev) * 0.02).requires_grad_(True)
     bb = torch.zeros(Co, device=dev, requires_grad=True)
     gys = [torch.randn(nb, Co, h, w_, device=dev) for _ in range(npyr) for h, w_ in hws]
-    for tile in (4, 6):
+    for tile in [int(t) for t in os.environ.get("LGD_WINO_AB_TILES", "4,6").split(",")]:
         def step():
             ys = ops._Conv3x3.apply(w, bb, True, tile, *xs)
             torch.autograd.backward(ys, gys)
