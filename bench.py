@@ -56,12 +56,14 @@ def parse():
                     help="time ONLY the host-batch protocol (pinned HOST tensors copied inside every step, what the reference's step "
                          "contains: retinanet.py:48) as `value`; default: `value` = batches resident in HBM when the timed region starts "
                          "(task statement section 4) AND the host-batch rate of the same steps in `host_batch` on the same line")
+    ap.add_argument("--wino-tile", type=int, default=None, choices=[4, 6], help="F(4x4,3x3) instead of the default F(6x6,3x3) (A/B runs)")
+    ap.add_argument("--library-convs", action="store_true", help="every 3x3 convolution on the vendor library instead of winograd*.hip (A/B runs)")
+    ap.add_argument("--torch-optimizers", action="store_true", help="torch's multi-tensor clip + SGD instead of the one-launch optim.hip step (A/B runs)")
+    ap.add_argument("--no-host-pass", action="store_true", help="skip the extra pass that measures the host-batch rate (profiling runs)")
     ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--multiscale", action="store_true",
                     help="per-image short side drawn from INPUT.MIN_SIZE_TRAIN (640..800, max 1333: BASELINE config 5, "
                          "configs/Base-RetinaNet.yaml:26) instead of every image at --height x --width")
-    ap.add_argument("--graph-backbone", action="store_true",
-                    help="replay the student's backbone + FPN forward / backward as hipGraphs (lgd_amd/graphs.py; for the 2 img/GPU configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
     ap.add_argument("--head-passes", type=int, default=1, choices=[1, 2],
@@ -178,13 +180,16 @@ def main():
     from lgd_amd.distillator import build_model
     from lgd_amd.engine import Trainer
     hip.load()  # fail loudly if the HIP extension is missing
+    if args.wino_tile is not None:
+        ops.conv3x3_backend(tile=args.wino_tile)
+    if args.library_convs:
+        ops.conv3x3_backend(winograd=False)
 
     cfg = config.setup_cfg(args.config, ["MODEL.DEVICE", "cuda:%d" % local_rank])
     torch.manual_seed(0)
     model = build_model(cfg)
     model.fused_head_pass = args.head_passes == 1
-    trainer = Trainer(cfg, model, device=dev, distributed=True if force_ddp else None,
-                      graph_backbone=True if args.graph_backbone else None)
+    trainer = Trainer(cfg, model, device=dev, distributed=True if force_ddp else None, fused_sgd=not args.torch_optimizers)
     d = cfg.MODEL.DISTILLATOR
     it0 = {"distill": max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS),
            "nondistill": d.PRE_FREEZE_STUDENT_BACKBONE_ITERS, "frozen": 0}[args.phase]
@@ -200,7 +205,7 @@ def main():
                      if args.multiscale else None)
             out.append(synthetic_batch(Bg, args.height, args.width, args.boxes, seed=seed, sizes=sizes, **kw))
         return out
-    host_batches = make_batches(pin=True) if (args.host_batch or world == 1) else None
+    host_batches = make_batches(pin=True) if (args.host_batch or (world == 1 and not args.no_host_pass)) else None
     batches = host_batches if args.host_batch else make_batches(device=dev)
     ctx = bool(d.TEACHER.ADD_CONTEXT_BOX)
 
@@ -230,7 +235,7 @@ def main():
     dt = float(tmax.item())
     # the same steps with the batches handed over as pinned host tensors (N = 1 only; never `value` unless --host-batch)
     dt_host = None
-    if host_batches is not None and not args.host_batch and world == 1:
+    if host_batches is not None and not args.host_batch and world == 1 and not args.no_host_pass:
         run_steps(min(2, args.steps), host_batches)
         sync()
         t0 = time.perf_counter()
@@ -287,13 +292,13 @@ def main():
         roofline = roofline_mfma = None
         if dom:
             traffic = None
-            tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            tf = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
             if os.path.exists(tf) and is_cfg1:  # the counters were collected on configs[1]
                 traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
             k = kernels[dom]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
-                        "traffic_source": "static profile: profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                        "traffic_source": "static profile: profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                           "over this command, not re-measured in this run)" if traffic is not None else None,
                         "alg_bytes_per_launch": alg[dom], "avg_launch_us": k["avg_us"], "min_launch_us": k["min_us"],
                         "max_launch_us": k["max_us"],
@@ -363,7 +368,7 @@ def main():
             "gemm_solution_table_loaded": bool(trainer.tuned_gemms), "conv3x3": "winograd F(%dx%d,3x3)" % (ops._WINO_TILE, ops._WINO_TILE) if ops._WINO_ON else "library",
             "hbm_peak_alloc_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,
-            "graph_backbone": bool(trainer.graph_backbone), "fused_clip_sgd": trainer._fused_sgd is not None,
+            "fused_clip_sgd": trainer._fused_sgd is not None,
             "head_pass": "single (student + teacher pyramids in one pass)" if getattr(model, "fused_head_pass", False) else "two passes",
             "roofline": roofline, "roofline_mfma": roofline_mfma, "roofline_mfma_pointwise": roofline_pw, "roofline_lgd_forward": lgd_fwd,
         }

@@ -16,6 +16,11 @@
 //     wave-wide prefix sum (DPP) parked in wave-private LDS -- no atomics, fixed order (bit-reproducible run to run).
 #include "common.h"
 
+// rows per load group of the band-streaming kernels (two groups in flight per wave and plane)
+#ifndef LGD_BAND_G
+#define LGD_BAND_G 4
+#endif
+
 namespace lgd {
 
 struct BoxArgs {
@@ -124,7 +129,7 @@ struct ScanScratch { double E[64]; float loc[256]; };   // per wave and plane: e
 
 template <int VW, int NP>
 __device__ __forceinline__ void box_sum_scan(const BoxArgs& a, const Plane& p, ScanScratch* sc) {
-    constexpr int G = 4;
+    constexpr int G = LGD_BAND_G;
     const int lane = threadIdx.x & 63;
     const size_t psz = (size_t)p.H * p.W;
     const float* __restrict__ src = a.in[p.l] + ((size_t)p.b * a.C + p.c) * psz;
@@ -263,7 +268,7 @@ static void launch_box_sum(const char* name, const BoxArgs& a, int np, int nblk,
 // per launch); splitting the big planes' rows over four waves is slower here too (66 / 92 us).
 template <int VW, int MODE>
 __device__ __forceinline__ void paint_rows(const BoxArgs& a, const Plane& p) {
-    constexpr int G = 4;
+    constexpr int G = LGD_BAND_G;
     const int lane = threadIdx.x & 63;
     const size_t base = ((size_t)p.b * a.C + p.c) * p.H * p.W;
     const float* __restrict__ src = MODE != 2 ? a.gx[p.l] + base : nullptr;

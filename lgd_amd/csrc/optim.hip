@@ -17,6 +17,12 @@ namespace lgd {
 
 constexpr int kSgdChunk = 4096;  // elements per workgroup: 256 threads x 4 float4
 
+// 4 floats at a 4-byte-aligned address: under DistributedDataParallel(gradient_as_bucket_view=True) a gradient is a view into a flat
+// bucket at the sum of the preceding parameters' sizes (train.py:279-281), i.e. dword- but not 16-byte-aligned as soon as one of them
+// has a size that is not a multiple of 4 (FCOS `scales`, the centerness bias).  gfx950 runs global memory in unaligned access mode, so
+// the accesses stay dwordx4 (the compiler emits them for this type); round 2 sent such tensors down the scalar path.
+typedef float sgd_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
 template <bool VEC>
 __device__ __forceinline__ void sgd_chunk(const lgd_sgd_tensor& t, long long base, float clip) {
     const float lr = t.lr, wd = t.wd, mu = t.mu;
@@ -27,7 +33,11 @@ __device__ __forceinline__ void sgd_chunk(const lgd_sgd_tensor& t, long long bas
         for (int k = 0; k < 4; ++k) {
             const long long i = base + (long long)(k * 256 + threadIdx.x) * 4;
             on[k] = i + 3 < t.n;
-            if (on[k]) { p[k] = *reinterpret_cast<const float4*>(t.p + i); g[k] = ldg_stream4(t.g + i); m[k] = *reinterpret_cast<const float4*>(t.m + i); }
+            if (on[k]) {
+                p[k] = *reinterpret_cast<const float4*>(t.p + i); m[k] = *reinterpret_cast<const float4*>(t.m + i);
+                const sgd_f4u gv = *reinterpret_cast<const sgd_f4u*>(t.g + i);
+                g[k] = make_float4(gv.x, gv.y, gv.z, gv.w);
+            }
         }
         #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -42,11 +52,13 @@ __device__ __forceinline__ void sgd_chunk(const lgd_sgd_tensor& t, long long bas
                 gg[j] = c; mm[j] = b; pp[j] = __builtin_fmaf(-lr, b, pp[j]);
             }
             *reinterpret_cast<float4*>(t.p + i) = p[k];
-            *reinterpret_cast<float4*>(t.g + i) = g[k];
+            sgd_f4u go; go.x = g[k].x; go.y = g[k].y; go.z = g[k].z; go.w = g[k].w;
+            *reinterpret_cast<sgd_f4u*>(t.g + i) = go;
             *reinterpret_cast<float4*>(t.m + i) = m[k];
         }
     }
-    // scalar path: unaligned tensors (views into a flat bucket), and the < 4-element tail of a vector chunk
+    // scalar path: parameters / momentum buffers that are not 16-byte aligned (never torch's own allocations), and the < 4-element
+    // tail of a vector chunk
     const long long end = base + kSgdChunk < t.n ? base + kSgdChunk : t.n;
     long long i0 = base;
     if constexpr (VEC) i0 = end == t.n ? (t.n & ~3LL) : end;   // only the last chunk has a tail
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256) void sgd_clip_kernel(const lgd_sgd_tensor* __r
     const lgd_sgd_tensor t = tab[lo];
     const long long base = (long long)((int)blockIdx.x - blk_off[lo]) * kSgdChunk;
     if (base >= t.n) return;
-    const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.m)) & 15) == 0;
+    const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.m)) & 15) == 0 && (reinterpret_cast<uintptr_t>(t.g) & 3) == 0;
     if (vec) sgd_chunk<true>(t, base, clip);
     else sgd_chunk<false>(t, base, clip);
 }

@@ -283,19 +283,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_IN_W
     else wino6_in_body<false, PRE>(a, l, lds);
 }
 
-// two frequency rows (16 planes x 256 tiles) of M / dV -> LDS as 1 KB runs; `m` = the slab's first tile in plane 0 of the channel
-__device__ __forceinline__ void stage_load16(const float* m, size_t plane, int ph, long long valid, float* lds) {
-    wino_vf4 q[4];
+// two frequency rows (16 planes x 256 tiles) of M / dV as 1 KB runs: issued into registers (slab_issue) and parked in LDS later
+// (slab_park), so that the loads of phase p + 1 are in flight while phase p is consumed -- at 3-4 waves per SIMD (the 6x6 kernels'
+// register budget) a workgroup that waits for its slab, consumes it and only then asks for the next one leaves the memory system idle
+// for a latency per phase; `m` = the slab's first tile in plane 0 of the channel
+struct Slab16 { wino_vf4 q[4]; };
+__device__ __forceinline__ Slab16 slab_issue(const float* m, size_t plane, int ph, long long valid) {
+    Slab16 s;
     #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = k * 256 + threadIdx.x, f = idx >> 6, q4 = idx & 63;
-        q[k].x = q[k].y = q[k].z = q[k].w = 0.f;
-        if (q4 * 4 < valid) q[k] = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(m + (size_t)(16 * ph + f) * plane + q4 * 4));
+        s.q[k].x = s.q[k].y = s.q[k].z = s.q[k].w = 0.f;
+        if (q4 * 4 < valid) s.q[k] = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(m + (size_t)(16 * ph + f) * plane + q4 * 4));
     }
+    return s;
+}
+__device__ __forceinline__ void slab_park(const Slab16& s, float* lds) {
     #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = k * 256 + threadIdx.x, f = idx >> 6, q4 = idx & 63;
-        *reinterpret_cast<float4*>(&lds[f * 256 + q4 * 4]) = make_float4(q[k].x, q[k].y, q[k].z, q[k].w);
+        *reinterpret_cast<float4*>(&lds[f * 256 + q4 * 4]) = make_float4(s.q[k].x, s.q[k].y, s.q[k].z, s.q[k].w);
     }
 }
 
@@ -321,10 +328,12 @@ __device__ __forceinline__ void wino6_out_body(const WinoArgs& a, int l, float* 
     // columns first, accumulated as the frequency rows arrive (two per LDS phase): r[i][b] = sum_a A^T[i][a] M[a][b] -- 48 accumulators
     // instead of holding all 64 values and then 48 more (118 -> 5 waves per SIMD worth of registers)
     float r[6][8];
+    Slab16 cur = slab_issue(m, plane, 0, padded - t0);
     #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
-        if (ph) __syncthreads();
-        stage_load16(m, plane, ph, padded - t0, lds);
+        if (ph) __syncthreads();   // the previous phase's LDS reads are done
+        slab_park(cur, lds);
+        if (ph < 3) cur = slab_issue(m, plane, ph + 1, padded - t0);   // in flight while this phase is consumed
         __syncthreads();
         #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -488,61 +497,73 @@ __device__ __forceinline__ void vacc8(const float (&h)[6], float (&z)[6][6]) {
     }
 }
 
+// what one phase (frequency rows 2 PH, 2 PH + 1) needs from memory: the workgroup's slab and, on the edge waves, the values of
+// neighbour tiles OUTSIDE the slab (the first / last TW + 1 threads' vertical neighbours, thread 0's left and thread 255's right one)
+struct InTLoads { wino_vf4 q[4]; float eL[2], eR[2], eV[8], eVl, eVr; };
+
 template <int PH>
-__device__ __forceinline__ void wino6_in_t_phase(const float* m, size_t plane, int nvalid, float* lds, int TW, bool hasL, bool hasR,
-                                                 bool hasU, bool hasD, float (&z)[6][6]) {
+__device__ __forceinline__ InTLoads wino6_in_t_issue(const float* m, size_t plane, int nvalid, int TW, bool hasL, bool hasR, bool hasU, bool hasD) {
     const int tid = threadIdx.x;
     const float* mp = m + (size_t)(16 * PH) * plane;   // wave-uniform base; everything below is a 32-bit offset from it
     const int ip = (int)plane;                          // 16 planes of one channel: < 2^31 elements for any map that fits the HBM
-    if (PH) __syncthreads();
-    wino_vf4 q[4];
+    InTLoads ld;
     #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = k * 256 + tid, f = idx >> 6, q4 = idx & 63;
-        q[k].x = q[k].y = q[k].z = q[k].w = 0.f;
-        if (q4 * 4 < nvalid) q[k] = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(mp + (f * ip + q4 * 4)));
+        ld.q[k].x = ld.q[k].y = ld.q[k].z = ld.q[k].w = 0.f;
+        if (q4 * 4 < nvalid) ld.q[k] = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(mp + (f * ip + q4 * 4)));
     }
-    // Neighbour tiles outside the workgroup's 256-tile slab: branch-free per lane, only the edge WAVES issue these loads (wave-uniform
-    // test); a lane of such a wave whose neighbour is inside the slab (or does not exist) re-reads its own tile
+    // branch-free per lane, only the edge WAVES issue these loads (wave-uniform test); a lane of such a wave whose neighbour is inside
+    // the slab (or does not exist) re-reads its own tile
     const int wb = tid & ~63, own = min(tid, nvalid - 1);
     auto far = [&](int fl, int d, bool need) -> float {
         const int li = tid + d;
         return mp[fl * ip + ((need && (li < 0 || li >= 256)) ? li : own)];
     };
+    ld.eL[0] = ld.eL[1] = ld.eR[0] = ld.eR[1] = ld.eVl = ld.eVr = 0.f;
+    #pragma unroll
+    for (int b = 0; b < 8; ++b) ld.eV[b] = 0.f;
+    if (wb == 0) { ld.eL[0] = far(7, -1, hasL); ld.eL[1] = far(15, -1, hasL); }
+    if (wb == 192) { ld.eR[0] = far(0, 1, hasR); ld.eR[1] = far(8, 1, hasR); }
+    if constexpr (PH == 0 || PH == 3) {
+        constexpr int vrow = PH == 3 ? 8 : 0;              // frequency row 7 (upper neighbour) lives in planes 8..15 of phase 3
+        const int vd = PH == 3 ? -TW : TW;                 // phase 0: frequency row 0 of the LOWER tile row; phase 3: row 7 of the UPPER one
+        const bool hasV = PH == 3 ? hasU : hasD;
+        if (PH == 3 ? (wb - TW - 1 < 0) : (wb + 63 + TW + 1 >= 256)) {
+            #pragma unroll
+            for (int b = 0; b < 8; ++b) ld.eV[b] = far(vrow + b, vd, hasV);
+            ld.eVl = far(vrow + 7, vd - 1, hasV && hasL);
+            ld.eVr = far(vrow, vd + 1, hasV && hasR);
+        }
+    }
+    return ld;
+}
+
+__device__ __forceinline__ void wino6_in_t_park(const InTLoads& ld, float* lds) {
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = k * 256 + threadIdx.x, f = idx >> 6, q4 = idx & 63;
+        *reinterpret_cast<float4*>(&lds[f * 256 + q4 * 4]) = make_float4(ld.q[k].x, ld.q[k].y, ld.q[k].z, ld.q[k].w);
+    }
+}
+
+template <int PH>
+__device__ __forceinline__ void wino6_in_t_consume(const InTLoads& ld, const float* lds, int TW, bool hasL, bool hasR, bool hasU, bool hasD,
+                                                   float (&z)[6][6]) {
+    const int tid = threadIdx.x;
     // value of local plane fl (global plane 16 PH + fl) of the tile d positions further along the level's tile run
     auto pick = [&](int fl, int d, bool need, float e) -> float {
         const int li = tid + d;
         const float v = lds[fl * 256 + min(max(li, 0), 255)];
         return !need ? 0.f : ((li >= 0 && li < 256) ? v : e);
     };
-    float eL[2] = {0.f, 0.f}, eR[2] = {0.f, 0.f};
-    if (wb == 0) { eL[0] = far(7, -1, hasL); eL[1] = far(15, -1, hasL); }
-    if (wb == 192) { eR[0] = far(0, 1, hasR); eR[1] = far(8, 1, hasR); }
-    constexpr int vrow = PH == 3 ? 8 : 0;              // frequency row 7 (upper neighbour) lives in planes 8..15 of phase 3
-    const int vd = PH == 3 ? -TW : TW;                 // phase 0: frequency row 0 of the LOWER tile row; phase 3: row 7 of the UPPER one
-    const bool hasV = PH == 3 ? hasU : hasD;
-    float eV[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, eVl = 0.f, eVr = 0.f;
-    if constexpr (PH == 0 || PH == 3) {
-        if (PH == 3 ? (wb - TW - 1 < 0) : (wb + 63 + TW + 1 >= 256)) {
-            #pragma unroll
-            for (int b = 0; b < 8; ++b) eV[b] = far(vrow + b, vd, hasV);
-            eVl = far(vrow + 7, vd - 1, hasV && hasL);
-            eVr = far(vrow, vd + 1, hasV && hasR);
-        }
-    }
-    #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = k * 256 + tid, f = idx >> 6, q4 = idx & 63;
-        *reinterpret_cast<float4*>(&lds[f * 256 + q4 * 4]) = make_float4(q[k].x, q[k].y, q[k].z, q[k].w);
-    }
-    __syncthreads();
     {   // frequency row 2 PH
         float g[8], h[6];
         #pragma unroll
         for (int b = 0; b < 8; ++b) g[b] = lds[b * 256 + tid];
         b8mid(g, h);
-        h[0] += pick(7, -1, hasL, eL[0]);    // the left tile's window column 7 = its frequency column 7
-        h[5] += pick(0, 1, hasR, eR[0]);     // the right tile's window column 0 = its frequency column 0
+        h[0] += pick(7, -1, hasL, ld.eL[0]);    // the left tile's window column 7 = its frequency column 7
+        h[5] += pick(0, 1, hasR, ld.eR[0]);     // the right tile's window column 0 = its frequency column 0
         vacc8<2 * PH>(h, z);
     }
     {   // frequency row 2 PH + 1
@@ -550,19 +571,22 @@ __device__ __forceinline__ void wino6_in_t_phase(const float* m, size_t plane, i
         #pragma unroll
         for (int b = 0; b < 8; ++b) g[b] = lds[(8 + b) * 256 + tid];
         b8mid(g, h);
-        h[0] += pick(15, -1, hasL, eL[1]);
-        h[5] += pick(8, 1, hasR, eR[1]);
+        h[0] += pick(15, -1, hasL, ld.eL[1]);
+        h[5] += pick(8, 1, hasR, ld.eR[1]);
         vacc8<2 * PH + 1>(h, z);
     }
     if constexpr (PH == 0 || PH == 3) {
         // PH 0: the lower tile's window row 0 (= its frequency row 0, B^T[0][0] = 1) is this block's row 5;
         // PH 3: the upper tile's window row 7 (= its frequency row 7, B^T[7][7] = 1) is this block's row 0
+        constexpr int vrow = PH == 3 ? 8 : 0;
+        const int vd = PH == 3 ? -TW : TW;
+        const bool hasV = PH == 3 ? hasU : hasD;
         float g[8], h[6];
         #pragma unroll
-        for (int b = 0; b < 8; ++b) g[b] = pick(vrow + b, vd, hasV, eV[b]);
+        for (int b = 0; b < 8; ++b) g[b] = pick(vrow + b, vd, hasV, ld.eV[b]);
         b8mid(g, h);
-        h[0] += pick(vrow + 7, vd - 1, hasV && hasL, eVl);
-        h[5] += pick(vrow, vd + 1, hasV && hasR, eVr);
+        h[0] += pick(vrow + 7, vd - 1, hasV && hasL, ld.eVl);
+        h[5] += pick(vrow, vd + 1, hasV && hasR, ld.eVr);
         #pragma unroll
         for (int j = 0; j < 6; ++j) z[PH == 0 ? 5 : 0][j] += h[j];
     }
@@ -590,10 +614,26 @@ __device__ __forceinline__ void wino6_in_t_body(const WinoArgs& a, int l, float*
         #pragma unroll
         for (int j = 0; j < 6; ++j) z[r][j] = 0.f;
     const int nvalid = (int)min(padded - t0, 256LL);
-    wino6_in_t_phase<0>(m, plane, nvalid, lds, TW, hasL, hasR, hasU, hasD, z);
-    wino6_in_t_phase<1>(m, plane, nvalid, lds, TW, hasL, hasR, hasU, hasD, z);
-    wino6_in_t_phase<2>(m, plane, nvalid, lds, TW, hasL, hasR, hasU, hasD, z);
-    wino6_in_t_phase<3>(m, plane, nvalid, lds, TW, hasL, hasR, hasU, hasD, z);
+    // software pipeline over the four LDS phases: the loads of phase p + 1 are issued before phase p is consumed
+    InTLoads la = wino6_in_t_issue<0>(m, plane, nvalid, TW, hasL, hasR, hasU, hasD);
+    wino6_in_t_park(la, lds);
+    InTLoads lb = wino6_in_t_issue<1>(m, plane, nvalid, TW, hasL, hasR, hasU, hasD);
+    __syncthreads();
+    wino6_in_t_consume<0>(la, lds, TW, hasL, hasR, hasU, hasD, z);
+    __syncthreads();
+    wino6_in_t_park(lb, lds);
+    la = wino6_in_t_issue<2>(m, plane, nvalid, TW, hasL, hasR, hasU, hasD);
+    __syncthreads();
+    wino6_in_t_consume<1>(lb, lds, TW, hasL, hasR, hasU, hasD, z);
+    __syncthreads();
+    wino6_in_t_park(la, lds);
+    lb = wino6_in_t_issue<3>(m, plane, nvalid, TW, hasL, hasR, hasU, hasD);
+    __syncthreads();
+    wino6_in_t_consume<2>(la, lds, TW, hasL, hasR, hasU, hasD, z);
+    __syncthreads();
+    wino6_in_t_park(lb, lds);
+    __syncthreads();
+    wino6_in_t_consume<3>(lb, lds, TW, hasL, hasR, hasU, hasD, z);
     const int oy = 6 * ty, ox = 6 * tx;
     // optional mask: the activation bits the PRE input transform wrote (the maps were pre-activations: dx is the gradient of the RAW
     // map) or, FUSE, the producing convolution's ReLU bits

@@ -173,7 +173,7 @@ def freeze_static_unused(model):
 class Trainer:
     """Owns model (+DDP), optimizers, schedulers and the per-iteration phase logic of do_train."""
 
-    def __init__(self, cfg, model, distributed=None, device=None, graph_backbone=None):
+    def __init__(self, cfg, model, distributed=None, device=None, fused_sgd=True):
         self.cfg = cfg
         self.d = cfg.MODEL.DISTILLATOR
         self.max_iter = cfg.SOLVER.MAX_ITER
@@ -193,23 +193,16 @@ class Trainer:
         self._log_acc, self._log_n = None, 0
         self._finite = None  # device-side AND of isfinite(total loss) over the steps since the last check
         self._fused_sgd = None
+        self.fused_sgd_enabled = fused_sgd   # False: torch's multi-tensor clip + SGD path (what the fused launch is tested against)
         if self.device.type == "cuda":
             from . import ops, optim
             self.tuned_gemms = ops.enable_tuned_gemms()  # opt-in here (not an import side effect): lookup-only solution table
             # clip + both SGD updates as one HIP launch (csrc/optim.hip); other optimizers / clip types: torch's multi-tensor path
-            if os.environ.get("LGD_FUSED_SGD", "1") != "0" and optim.supported([self.stu_optimizer, self.tea_optimizer], self.clip):
+            if self.fused_sgd_enabled and optim.supported([self.stu_optimizer, self.tea_optimizer], self.clip):
                 self._fused_sgd = optim.FusedClipSGD([self.stu_optimizer, self.tea_optimizer],
                                                      self.clip.CLIP_VALUE if self.clip.ENABLED else None)
         else:
             self.tuned_gemms = False
-        # hipGraph replay of the student's backbone + FPN forward / backward (lgd_amd/graphs.py): opt-in, pays at 2 images per GPU
-        if graph_backbone is None:
-            graph_backbone = os.environ.get("LGD_GRAPH_BACKBONE", "0") == "1"
-        self.graph_backbone = bool(graph_backbone) and self.device.type == "cuda"
-        if self.graph_backbone:
-            from .graphs import GraphedBackbone
-            s = self.raw_model.student
-            s._graphed_backbone = GraphedBackbone(s.raw_backbone, s.fpn)
 
     # ---- phases ----------------------------------------------------------------------------
     def _set_backbone_frozen(self, frozen):
@@ -230,7 +223,11 @@ class Trainer:
             dev_ids = [self.device.index] if self.device.type == "cuda" else None
             self.model = DistributedDataParallel(net, device_ids=dev_ids, broadcast_buffers=False,
                                                  find_unused_parameters=False, gradient_as_bucket_view=True,
-                                                 bucket_cap_mb=int(os.environ.get("LGD_BUCKET_MB", "64")))
+                                                 bucket_cap_mb=int(os.environ.get("LGD_BUCKET_MB", "32")))
+            # 32 MB: the bucket that becomes ready LAST does so 0.07 ms before backward ends on both BASELINE shapes (tools/
+            # ddp_bucket_times.py, profiles/r03_ddp_world1_ab_and_bucket_times.txt), so its all-reduce is the part of the exchange
+            # no compute can hide and its size is what an N-rank step pays; the earlier buckets have 5-15 ms of backward left.
+            # (LGD_BUCKET_MB: deployment knob for other fabrics.)
         else:
             self.model = net
 
@@ -338,9 +335,6 @@ class Trainer:
 
     def load_state_dict(self, sd):
         self.raw_model.load_state_dict(sd["model"])
-        g = getattr(self.raw_model.student, "_graphed_backbone", None)
-        if g is not None:
-            g.reset()  # frozen weights / FrozenBN buffers feed caches the captured kernels read
         self.stu_optimizer.load_state_dict(optimizer_state_from_reference(sd["stu_optimizer"], self.stu_optimizer))
         self.tea_optimizer.load_state_dict(optimizer_state_from_reference(sd["tea_optimizer"], self.tea_optimizer))
         load_scheduler_state(self.stu_scheduler, sd["stu_scheduler"])

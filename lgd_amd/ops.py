@@ -1010,7 +1010,7 @@ def enable_tuned_gemms(path=None):
 
 _TUNED_GEMM = False  # set by enable_tuned_gemms(); Trainer / bench.py opt in, importing this module changes nothing
 # output tile of the minimal-filtering form: 6 -> F(6x6,3x3) (64 frequencies, 1.78 multiplies per output pixel), 4 -> F(4x4,3x3) (36, 2.25)
-_WINO_TILE = int(os.environ.get("LGD_WINO_TILE", "6"))
+_WINO_TILE = 6
 # smallest problem (2x2-pixel blocks over all maps of the call) that takes the Winograd path; measured at config 4 (R-101, 2 img/GPU,
 # whose res5 3x3 convolutions have 546): 2000 -> 35.7, 500 -> 35.1, 100 -> 35.3 ms/step in one call
 _WINO_MIN_TILES = 500
@@ -1483,8 +1483,9 @@ def kernel_alg_bytes():
 
 def kernel_timer_collect():
     """{kernel name: (launches, total_ms, min_ms, max_ms)} since the last collect (synchronises the recorded events); the
-    library GEMMs of the Winograd convolutions (torch.bmm, timed with events on torch's current stream = their launch
-    stream) appear as 'wino_gemm_fwd' / 'wino_gemm_dx' / 'wino_gemm_dw'."""
+    channel GEMMs of the Winograd convolutions (rocBLAS, issued and timed inside the library) appear as 'wino_gemm_fwd' /
+    'wino_gemm_dx' / 'wino_gemm_dw'; the student's pointwise convolutions (torch.bmm, timed with events on torch's current stream =
+    their launch stream) as 'pw_gemm_*'."""
     import ctypes
     lib = hip.load()
     names = ctypes.create_string_buffer(8192)

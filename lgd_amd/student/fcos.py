@@ -207,12 +207,8 @@ class FCOSCT(nn.Module):
     def backbone_features(self, batched_inputs):
         """bottom-up + FPN only (see RetinaNetCT.backbone_features)."""
         images = self.preprocess_image(batched_inputs)
-        graphed = getattr(self, "_graphed_backbone", None)  # lgd_amd/graphs.py: hipGraph replay (opt-in, small-batch configs)
-        if graphed is not None and self.training and torch.is_grad_enabled():
-            raw_features, features = graphed(images.tensor)
-        else:
-            raw_features = self.raw_backbone(images.tensor)
-            features = self.fpn(raw_features)
+        raw_features = self.raw_backbone(images.tensor)
+        features = self.fpn(raw_features)
         features = {f: features[f] for f in self.in_features}
         gt_instances = None
         if self.training:

@@ -131,7 +131,6 @@ class DeformBottleneck(Bottleneck):
         nn.init.constant_(self.conv2_offset.bias, 0)
 
     def forward(self, x):
-        from .deform import modulated_deform_conv2d
         shared = self.conv1._pointwise_s2 and self.shortcut is not None and self.shortcut._pointwise_s2
         if shared:
             x = ConvBN.subsample2(x)
@@ -144,8 +143,10 @@ class DeformBottleneck(Bottleneck):
             offset, mask = om, torch.ones_like(om[:, :9])
         c2 = self.conv2
         scale, shift = c2.norm.scale_shift()
-        out = modulated_deform_conv2d(out, offset, mask, c2.weight * scale.view(-1, 1, 1, 1), None, c2.stride[0],
-                                      c2.padding[0], c2.dilation[0])
+        # modulated deformable convolution (DCNv2) [ref: configs/Distillation/RetinaNet/retinanet_R_101_dcnv2_*.yaml:7-8; d2-memory:
+        # ModulatedDeformConv]: out[n,o,y,x] = sum_{c,k} W[o,c,k] mask[n,k,y,x] bilinear(in[n,c], y s - p + ky d + dy_k, x s - p + kx d + dx_k),
+        # offsets stored as (dy, dx) channel pairs per tap k = 3 ky + kx; HIP gather kernel -> column matrix -> library GEMM (csrc/dcn.hip)
+        out = ops.deform_conv3x3(out, offset, mask, c2.weight * scale.view(-1, 1, 1, 1), None, c2.stride[0], c2.padding[0], c2.dilation[0])
         out = ops.bias_act(out, shift, None, True) if out.is_cuda else F.relu_(out + shift.view(1, -1, 1, 1))   # one pass
         sc = self.shortcut(x, subsampled=shared) if self.shortcut is not None else x
         return self.conv3(out, relu=True, residual=sc)

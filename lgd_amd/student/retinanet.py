@@ -275,12 +275,8 @@ class RetinaNetCT(nn.Module):
         distillator defers the student's head pass until the teacher features exist and runs the head ONCE over both
         (ref: distillator.py:107-112 re-runs student.predict on the teacher features)."""
         images = self.preprocess_image(batched_inputs)
-        graphed = getattr(self, "_graphed_backbone", None)  # lgd_amd/graphs.py: hipGraph replay (opt-in, small-batch configs)
-        if graphed is not None and self.training and torch.is_grad_enabled():
-            raw_features, features = graphed(images.tensor)
-        else:
-            raw_features = self.raw_backbone(images.tensor)
-            features = self.fpn(raw_features)
+        raw_features = self.raw_backbone(images.tensor)
+        features = self.fpn(raw_features)
         features = {f: features[f] for f in self.head_in_features}
         gt_instances = None
         if self.training:

@@ -41,7 +41,7 @@ def _teacher(name):
 
 
 # every golden case on the Winograd kernels (forced: the small cases have fewer tiles than the production threshold), the
-# small ones once more on the library convolutions (LGD_WINO=0 back-end)
+# small ones once more on the library convolutions (ops.conv3x3_backend(winograd=False))
 _RUNS = [(n, "winograd") for n in cm.CASES] + [(n, "library") for n in cm.SMALL_CASES]
 
 
@@ -175,7 +175,7 @@ _FC_KEYS = _RN_KEYS | {"loss_centerness", "loss_centerness.tea"}
 
 @pytest.fixture
 def conv_backend(request):
-    """'winograd': winograd.hip forced onto the small test problems (production threshold: 500 tiles); 'library': LGD_WINO=0."""
+    """'winograd': winograd.hip forced onto the small test problems (production threshold: 500 tiles); 'library': ops.conv3x3_backend(winograd=False)."""
     from lgd_amd import ops
     prev = ops.conv3x3_backend(winograd=(request.param == "winograd"), min_tiles=0)
     yield request.param
@@ -556,9 +556,9 @@ def test_bench_stdout_is_one_json_record():
     assert rec["config"]["workload"] and "model" not in rec["config"]
 
 
-def test_trainer_fused_sgd_equals_torch_optimizers(monkeypatch):
+def test_trainer_fused_sgd_equals_torch_optimizers():
     """Trainer.step with the one-launch clip + SGD (csrc/optim.hip, the default) against the same trainer on torch's
-    clamp_ / SGD(foreach) path (LGD_FUSED_SGD=0) from the same weights, three steps across both phase switches
+    clamp_ / SGD(foreach) path (Trainer(fused_sgd=False)) from the same weights, three steps across both phase switches
     [ref: train.py:191-207]; the checkpoint payload keeps the reference's optimizer layout either way."""
     import copy
     from lgd_amd import config
@@ -574,8 +574,7 @@ def test_trainer_fused_sgd_equals_torch_optimizers(monkeypatch):
     its = (0, 25000, 40000)
     fused = Trainer(cfg, base, distributed=False)
     assert fused._fused_sgd is not None
-    monkeypatch.setenv("LGD_FUSED_SGD", "0")
-    plain = Trainer(cfg, twin, distributed=False)
+    plain = Trainer(cfg, twin, distributed=False, fused_sgd=False)
     assert plain._fused_sgd is None
     for it in its:
         fused.step(data, it)
@@ -598,55 +597,9 @@ def test_trainer_fused_sgd_equals_torch_optimizers(monkeypatch):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
 
 
-@pytest.mark.timeout(900)
-def test_graphed_backbone_equals_eager():
-    """lgd_amd/graphs.py: the student's backbone + FPN forward / backward replayed as hipGraphs (opt-in, for the 2 img/GPU
-    configs) must train exactly like the eager path: same parameters after steps across the backbone-freeze phase switch
-    (new requires_grad pattern -> new capture), a second image shape (new capture) and back (cached graph replayed);
-    load_state_dict drops the graphs (frozen weights / FrozenBN buffers feed caches the captured kernels read)."""
-    import copy
-    from lgd_amd import config
-    from lgd_amd.data import synthetic_batch
-    from lgd_amd.distillator import build_model
-    from lgd_amd.engine import Trainer
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", DEV])
-    torch.manual_seed(0)
-    base = build_model(cfg)
-    twin = copy.deepcopy(base)
-    eager = Trainer(cfg, base, distributed=False, graph_backbone=False)
-    graphed = Trainer(cfg, twin, distributed=False, graph_backbone=True)
-    g = twin.student._graphed_backbone
-    assert getattr(base.student, "_graphed_backbone", None) is None
-    a_data, b_data = synthetic_batch(2, 256, 320, 5, seed=6), synthetic_batch(2, 224, 352, 3, seed=7)
-    plan = [(0, a_data, 1), (1, a_data, 1), (25000, a_data, 2), (25001, b_data, 3), (25002, a_data, 3), (40000, a_data, 3)]
-    for it, data, captures in plan:
-        le = eager.step(data, it)
-        lg = graphed.step(data, it)
-        assert g.captures == captures, (it, g.captures)
-        for k in le:
-            assert torch.allclose(le[k], lg[k], rtol=2e-4, atol=1e-6), (it, k, float(le[k]), float(lg[k]))
-    worst = 0.0
-    for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
-        worst = max(worst, float((a - b).abs().max() / (a.abs().max() + 1e-12)))
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
-    print("graphed backbone vs eager: worst relative parameter difference %.2e after %d steps, %d captures" % (worst, len(plan), g.captures))
-    # eval mode falls back to the eager forward; a checkpoint load drops the graphs
-    twin.eval()
-    with torch.no_grad():
-        twin(a_data)
-    twin.train()
-    graphed.load_state_dict(copy.deepcopy(eager.state_dict()))
-    graphed.step(a_data, 40000)
-    eager.step(a_data, 40000)
-    assert g.captures == 4
-    for (n, a), (_, b) in zip(base.named_parameters(), twin.named_parameters()):
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
-
-
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("yaml_name", ["lgd_retinanet_r50.yaml", "lgd_fcos_r50.yaml"])   # (R-101-DCNv2 passes too: 3.5 min of library conv search)
-def test_full_size_step_shipped_path_vs_library_convolutions(monkeypatch, yaml_name):
+def test_full_size_step_shipped_path_vs_library_convolutions(yaml_name):
     """Two training steps of the distillator meta-arch (BASELINE configs 2 / 3) at the BASELINE image size (2 x 800 x 1333, 10 boxes; every 3x3 convolution of the
     backbone, FPN, head and teacher is above the Winograd threshold) on the shipped path -- F(4x4,3x3) transforms with the folded
     pre-activations, conv1 + shortcut nodes with beta = 1 accumulation, FPN laterals as GEMMs, fused stem epilogue, one-launch clip +
@@ -671,8 +624,7 @@ def test_full_size_step_shipped_path_vs_library_convolutions(monkeypatch, yaml_n
         assert a._fused_sgd is not None
         la = [{k: float(v) for k, v in a.step(data, it0 + i).items()} for i in range(2)]
         ops.conv3x3_backend(winograd=False)
-        monkeypatch.setenv("LGD_FUSED_SGD", "0")
-        b = Trainer(cfg, twin, distributed=False)
+        b = Trainer(cfg, twin, distributed=False, fused_sgd=False)
         assert b._fused_sgd is None
         lb = [{k: float(v) for k, v in b.step(data, it0 + i).items()} for i in range(2)]
     finally:
@@ -931,7 +883,7 @@ def test_fcos_head_gradients_fp64_under_product_masks(tile):
         SO.F = real_F
     assert pinned.used == len(order) and max(pinned.flip_frac) < 2e-3, pinned.flip_frac
     rt = sum((t * torch.from_numpy(probes[kind][i]).double()).sum() for kind, maps in ref.items() for i, t in enumerate(maps))
-    assert abs(float(total.detach()) - float(rt.detach())) <= 1e-5 * abs(float(rt.detach()))
+    assert abs(float(total.detach()) - float(rt.detach())) <= 1e-4 * abs(float(rt.detach()))   # a signed sum of 290k fp32 outputs
     rt.backward()
     errs = {"feature level %d" % i: cm.rel_err(a.grad, b.grad) for i, (a, b) in enumerate(zip(feats, f64))}
     errs.update({n: cm.rel_err(prm.grad, p[n].grad) for n, prm in head.named_parameters()})
@@ -942,3 +894,41 @@ def test_fcos_head_gradients_fp64_under_product_masks(tile):
     # so cancellation carries the fp32 rounding of its terms into the relative error (measured 1.3e-4 at the 12 x 16 level): 5e-4
     bad = {n: e for n, e in errs.items() if e > (5e-4 if n.endswith(".scale") else 1e-4)}
     assert not bad, bad
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_multiscale_dcn_step():
+    """BASELINE config 5 as its recipe states it: RetinaNet R-101-DCNv2 + LGD, 2 images per GPU whose short side is drawn per image from
+    INPUT.MIN_SIZE_TRAIN (640..800, max 1333; configs/Base-RetinaNet.yaml:26), so the two images differ in size and the batch is padded
+    to its own maximum.  Two optimizer steps of the shipped path (dcn.hip deformable convolutions in res3-5, F(6x6,3x3) everywhere
+    else) from the same weights as the same model on the F(4x4,3x3) kernels -- two independent implementations of every 3x3
+    convolution around the SAME deformable kernels, whose own arithmetic is held to the definition in test_kernels_gpu.py: every
+    loss finite and equal to 2e-4 after the second step (i.e. after one full update through all gradients)."""
+    import copy
+    from lgd_amd import config, ops
+    from lgd_amd.data import multiscale_sizes, synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_retinanet_r101_dcnv2.yaml"), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    base = build_model(cfg)
+    twin = copy.deepcopy(base)
+    sizes = multiscale_sizes(2, 800, 1333, tuple(cfg.INPUT.MIN_SIZE_TRAIN), cfg.INPUT.MAX_SIZE_TRAIN, seed=5)
+    assert sizes[0] != sizes[1] and all(min(s) in cfg.INPUT.MIN_SIZE_TRAIN for s in sizes), sizes
+    data = synthetic_batch(2, 800, 1333, 10, seed=3, sizes=sizes)
+    d = cfg.MODEL.DISTILLATOR
+    it0 = max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS)
+    prev = ops.conv3x3_backend(winograd=True, tile=6)
+    try:
+        a = Trainer(cfg, base, distributed=False)
+        la = [{k: float(v) for k, v in a.step(data, it0 + i).items()} for i in range(2)]
+        ops.conv3x3_backend(tile=4)
+        b = Trainer(cfg, twin, distributed=False)
+        lb = [{k: float(v) for k, v in b.step(data, it0 + i).items()} for i in range(2)]
+    finally:
+        ops.conv3x3_backend(*prev)
+    for i in range(2):
+        for k in la[i]:
+            assert np.isfinite(la[i][k]) and abs(la[i][k] - lb[i][k]) <= 2e-4 * abs(lb[i][k]) + 1e-6, (i, k, la[i][k], lb[i][k])
+    print("config 5, multi-scale %s: step-2 losses F(6x6) %s / F(4x4) %s" % (sizes, la[1], lb[1]))

@@ -3,7 +3,7 @@
 # consecutive kernels of the last steps with the kernels on either side.   usage: bash tools/gap_profile.sh [bench args]
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/gap_prof
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/gap_prof -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timing "$@" > /tmp/gap_prof.log 2>&1 || tail -3 /tmp/gap_prof.log
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/gap_prof -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-host-pass "$@" > /tmp/gap_prof.log 2>&1 || tail -3 /tmp/gap_prof.log
 F=$(ls /tmp/gap_prof/*/*kernel_trace.csv | head -1)
 python - "$F" <<'PY' | tee $O/gap_profile.log
 import csv, re, sys

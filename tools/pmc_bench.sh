@@ -6,10 +6,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export MIOPEN_FIND_MODE=2   # the library's conv search is irrelevant to the counters of the hand-written kernels
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-timing > /tmp/pmc_$c.log 2>&1 || { tail -5 /tmp/pmc_$c.log; exit 1; }
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-host-pass > /tmp/pmc_$c.log 2>&1 || { tail -5 /tmp/pmc_$c.log; exit 1; }
 done
 F=$(ls /tmp/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1)
 W=$(ls /tmp/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
 mkdir -p $R/gpurun_out
-python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r02_bench_pmc_fetch_write.csv $R/gpurun_out/r02_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing (BASELINE configs[1], B=8 800x1333; end of round 2 launch mix)"
-cat $R/gpurun_out/r02_bench_pmc_fetch_write.csv
+python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r03_bench_pmc_fetch_write.csv $R/gpurun_out/r03_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing --no-host-pass (BASELINE configs[1], B=8 800x1333; round 3 launch mix: F(6x6,3x3))"
+cat $R/gpurun_out/r03_bench_pmc_fetch_write.csv

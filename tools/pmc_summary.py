@@ -37,14 +37,10 @@ TIMER_NAMES = {
     "paint_kernel<0>": ["gn_pool_bwd_stats_kernel"], "paint_kernel<1>": ["gn_pool_bwd_apply_kernel"], "paint_kernel<2>": ["box_paint_kernel"],
     "box_sum_kernel<1>": ["box_sum_kernel", "gn_pool_kernel"], "box_sum_kernel<2>": ["box_sum_kernel", "gn_pool_kernel"],
     "rowln_kernel<0>": ["rowln_kernel"], "rowln_kernel<1>": ["rowln_bwd_kernel"],
-    "wino_in_kernel<false, false>": ["wino_in_kernel"], "wino_in_kernel<false, true>": ["wino_in_kernel"],
-    "wino_in_kernel<true, false>": ["wino_in_dual_kernel"], "wino_in_kernel<true, true>": ["wino_in_dual_kernel"],
-    "wino4_in_kernel<false, 0>": ["wino_in_kernel"], "wino4_in_kernel<false, 1>": ["wino_in_kernel"], "wino4_in_kernel<false, 2>": ["wino_in_kernel"],
-    "wino4_in_kernel<true, 0>": ["wino_in_dual_kernel"], "wino4_in_kernel<true, 1>": ["wino_in_dual_kernel"], "wino4_in_kernel<true, 2>": ["wino_in_dual_kernel"],
     "gg_stats_kernel<0>": ["gn_group_stats_kernel"], "gg_stats_kernel<1>": ["gn_group_bwd_stats_kernel"],
     "gg_apply_kernel<0>": ["gn_group_apply_kernel"], "gg_apply_kernel<1>": ["gn_group_bwd_apply_kernel"],
     "gg_finalize_kernel<0>": ["gn_group_finalize_kernel"], "gg_finalize_kernel<1>": ["gn_group_bwd_finalize_kernel"],
-    "wino4_out_kernel": ["wino_out_kernel"], "wino4_out_kernel<false>": ["wino_out_kernel"], "wino4_out_kernel<true>": ["wino_out_kernel"],
+    "wino4_out_kernel": ["wino_out_kernel"], "wino6_out_kernel": ["wino_out_kernel"], "wino6_out_t_kernel": ["wino_out_t_kernel"],
     "bias_act_kernel<4>": ["bias_act_kernel"], "bias_act_kernel<1>": ["bias_act_kernel"],
     "relu_mask_kernel<4>": ["relu_mask_kernel"], "relu_mask_kernel<1>": ["relu_mask_kernel"], "wino4_out_t_kernel": ["wino_out_t_kernel"],
     "wino4_in_t_kernel": ["wino_in_t_kernel"],
@@ -55,15 +51,14 @@ def short(name):
     n = name.replace("lgd::", "")
     if n in TIMER_NAMES:
         return TIMER_NAMES[n]
-    m = re.match(r"wino4_in_kernel<(true|false), \d(, (true|false))?>$", n)      # <DUAL, MASK[, PRE]>
-    if m:
-        return ["wino_in_dual_kernel" if m.group(1) == "true" else "wino_in_kernel"]
-    m = re.match(r"wino4_in_t_kernel<(true|false)>$", n)                            # <FUSE>
+    if re.match(r"wino[46]_in_kernel<(true|false)>$", n):                            # <PRE>
+        return ["wino_in_kernel"]
+    m = re.match(r"wino[46]_in_t_kernel<(true|false)>$", n)                         # <FUSE>
     if m:
         return ["wino_in_t_out_t_kernel" if m.group(1) == "true" else "wino_in_t_kernel"]
     base = re.sub(r"<.*$", "", n)
-    return [{"stem_pool_pair_kernel": "stem_pool_kernel", "wino4_filter_fwd_kernel": "wino_filter_kernel",
-             "wino4_filter_bwd_kernel": "wino_filter_bwd_kernel", "relu_bits_kernel": "relu_bits_kernel"}.get(base, base)]
+    return [{"stem_pool_pair_kernel": "stem_pool_kernel", "wino4_filter_fwd_kernel": "wino_filter_kernel", "wino6_filter_fwd_kernel": "wino_filter_kernel",
+             "wino4_filter_bwd_kernel": "wino_filter_bwd_kernel", "wino6_filter_bwd_kernel": "wino_filter_bwd_kernel", "relu_bits_kernel": "relu_bits_kernel"}.get(base, base)]
 
 
 def traffic_json(summary_csv, out_json, note):
