@@ -815,8 +815,12 @@ def test_teacher_gradients_fp64_under_product_masks(name):
     assert pinned.used == len(order)
     assert max(pinned.flip_frac) < 2e-3, pinned.flip_frac   # the masks ARE the oracle's, up to the units within rounding of zero
     pr = cm.probes(tea)
-    ref_total = loss + sum((tea[k] * pr[k].double()).sum() for k in tea)
-    assert abs(total - float(ref_total.detach())) <= 1e-5 * abs(float(ref_total.detach()))
+    terms = [(tea[k] * pr[k].double()).sum() for k in tea]
+    ref_total = loss + sum(terms)
+    # the probe sums are signed and cancel against the loss (c3_full: total -0.155 from a loss of ~2): the bar is relative to the
+    # magnitude of what is summed, not to the residue
+    scale = abs(float(loss.detach())) + sum(abs(float(t.detach())) for t in terms)
+    assert abs(total - float(ref_total.detach())) <= 1e-5 * scale, (total, float(ref_total.detach()), scale)
     ref_total.backward()
     errs = {k: cm.rel_err(gfeat[k], feats[k].grad) for k in O.LEVELS}
     assert all(e <= 1e-4 for e in errs.values()), errs   # ALL five levels (measured ~1e-5)
