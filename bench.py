@@ -272,7 +272,7 @@ def main():
         alg = {"in_moments_kernel": 2 * P, "in_mse_bwd_kernel": 3 * P, "box_sum_kernel": P, "box_paint_kernel": P,
                "gn_stats_kernel": P, "gn_apply_kernel": 2 * P, "gn_bwd_stats_kernel": 2 * P, "gn_bwd_apply_kernel": 3 * P,
                "ctx_relu_kernel": 2 * P, "ctx_relu_bwd_kernel": 3 * P,
-               "gn_pool_kernel": P, "gn_pool_bwd_stats_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
+               "gn_pool_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
         # focal loss: logits (N, 9*80, H, W) read once (fwd) / read + written (bwd); int32 label planes (N, 9, H, W) on top
         Pf = Bg * px_pyr * 9 * 4
         alg.update({"focal_fwd_kernel": 80 * Pf + Pf, "focal_bwd_kernel": 2 * 80 * Pf + Pf})

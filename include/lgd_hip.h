@@ -81,8 +81,11 @@ size_t lgd_geom_bands_off(int L, int B, int T, int max_n);
  *   painted [ref: dynamic_teacher.py:123,131]).
  * feats_host / outs_host: host arrays of L device pointers.
  */
+size_t lgd_box_pool_ws_floats(const int32_t* level_hw_host, int L, int B, int C, int max_n,
+                              int outputs /* 1: lgd_box_sum, 2: lgd_gn_pool_fwd */);
 int lgd_box_sum(const float* const* feats_host, const int32_t* level_hw_host, int L, int B, int C, int T,
-                int max_n, const int32_t* img_off, const int32_t* geom, float* out /* [L][T][C] */,
+                int max_n, const int32_t* img_off, const int32_t* geom,
+                float* ws /* lgd_box_pool_ws_floats(..., 1) floats: per-chunk partial sums */, float* out /* [L][T][C] */,
                 int normalize, int skip_last, void* stream);
 int lgd_box_paint(const float* vals /* [L][T][C] */, const int32_t* level_hw_host, int L, int B, int C, int T,
                   int max_n, const int32_t* img_off, const int32_t* geom, float* const* outs_host,
@@ -92,16 +95,20 @@ int lgd_box_paint(const float* vals /* [L][T][C] */, const int32_t* level_hw_hos
  * The appearance encoder pools `student_proj_2D(feat)` = conv3x3 -> GN(1) -> ReLU  [ref: dynamic_teacher.py:57,235,
  * 249-253] and nothing else reads that map, so the normalised map is never written: after lgd_gn1 statistics
  * (gn_stats [L*B][2] mean, rstd -- e.g. from lgd_gn1_fwd's stats pass), lgd_gn_pool_fwd streams the CONV OUTPUT x
- * once, applies (x-mean)*rstd and ReLU in registers and accumulates the box means: out [L][T][C].
+ * once, applies (x-mean)*rstd and ReLU in registers and accumulates the box means: out [L][T][C]; next to them it
+ * keeps raw [2][L][T][C]: per (box, channel) the sum of relu(xhat) and the number of pixels with xhat > 0
+ * (ws: lgd_box_pool_ws_floats(..., 2) floats).
  * lgd_gn_pool_bwd: dx for the conv output from dpool [L][T][C]; the painted gradient is composed per row band on
- * the fly (never materialised); ws = 2*L*B*C doubles, bstats = [L*B][2] scratch.
- * HBM traffic: fwd P (+P for the statistics), bwd 2P read + P write  (unfused: 4P / 6P).
+ * the fly (never materialised); the GroupNorm backward's two means come from dpool and raw (no pass over x);
+ * bstats = [L*B][2] scratch.
+ * HBM traffic: fwd P (+P for the statistics), bwd P read + P write  (unfused: 4P / 6P).
  */
 int lgd_gn_pool_fwd(const float* const* x_host, const float* gn_stats, const int32_t* level_hw_host, int L, int B,
-                    int C, int T, int max_n, const int32_t* img_off, const int32_t* geom, float* out, void* stream);
-int lgd_gn_pool_bwd(const float* const* x_host, const float* gn_stats, const float* dpool,
+                    int C, int T, int max_n, const int32_t* img_off, const int32_t* geom, float* ws, float* out,
+                    float* raw, void* stream);
+int lgd_gn_pool_bwd(const float* const* x_host, const float* gn_stats, const float* dpool, const float* raw,
                     const int32_t* level_hw_host, int L, int B, int C, int T, int max_n, const int32_t* img_off,
-                    const int32_t* geom, double* ws, float* bstats, float* const* dx_host, void* stream);
+                    const int32_t* geom, float* bstats, float* const* dx_host, void* stream);
 
 /* ------------------------------------------------------------------ K4: InstanceNorm x2 + MSE
  * [ref: models/base_distillator.py:59-64  norm_stu / norm_tea (InstanceNorm2d(256, affine=False),

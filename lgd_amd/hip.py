@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -30,7 +30,8 @@ SIGNATURES = {
     "lgd_geom_nbp_off": (c_sz, [c_i, c_i, c_i, c_i]),
     "lgd_geom_bands_off": (c_sz, [c_i, c_i, c_i, c_i]),
     "lgd_box_prep": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp, c_fp]),
-    "lgd_box_sum": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
+    "lgd_box_pool_ws_floats": (c_sz, [c_fp, c_i, c_i, c_i, c_i, c_i]),
+    "lgd_box_sum": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
     "lgd_box_paint": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
     "lgd_distill_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
     "lgd_distill_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
@@ -38,8 +39,8 @@ SIGNATURES = {
     "lgd_gn1_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
     "lgd_gn1_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn1_stats": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
-    "lgd_gn_pool_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
-    "lgd_gn_pool_bwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gn_pool_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gn_pool_bwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn1_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn_group_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
     "lgd_gn_group_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp]),

@@ -81,8 +81,9 @@ def _box_sum(geom, maps, normalize, skip_last):
     geom._check(maps)
     C = maps[0].shape[1]
     out = torch.empty((geom.L, geom.T, C), dtype=torch.float32, device=maps[0].device)
+    ws = torch.empty(lib.lgd_box_pool_ws_floats(geom._hw, geom.L, geom.B, C, geom.max_n, 1), dtype=torch.float32, device=maps[0].device)
     hip.check(lib.lgd_box_sum(hip.ptr_array(maps), geom._hw, geom.L, geom.B, C, geom.T, geom.max_n,
-                              hip.ptr(geom.img_off), hip.ptr(geom.geom), hip.ptr(out), int(normalize), int(skip_last),
+                              hip.ptr(geom.img_off), hip.ptr(geom.geom), hip.ptr(ws), hip.ptr(out), int(normalize), int(skip_last),
                               hip.stream_ptr()), "lgd_box_sum")
     return out
 
@@ -255,9 +256,12 @@ class _GnReluPool(torch.autograd.Function):
         stats = torch.empty((L * B, 2), dtype=torch.float32, device=dev)
         hip.check(lib.lgd_gn1_stats(hip.ptr_array(xs), hw, L, B, C, hip.ptr(ws), hip.ptr(stats), hip.stream_ptr()), "lgd_gn1_stats")
         out = torch.empty((L, geom.T, C), dtype=torch.float32, device=dev)
+        # per (box, channel): sum of relu(xhat) and number of active pixels -- the backward's GroupNorm means without a pass over x
+        raw = torch.empty((2, L, geom.T, C), dtype=torch.float32, device=dev)
+        pws = torch.empty(lib.lgd_box_pool_ws_floats(hw, L, B, C, geom.max_n, 2), dtype=torch.float32, device=dev)
         hip.check(lib.lgd_gn_pool_fwd(hip.ptr_array(xs), hip.ptr(stats), hw, L, B, C, geom.T, geom.max_n, hip.ptr(geom.img_off),
-                                      hip.ptr(geom.geom), hip.ptr(out), hip.stream_ptr()), "lgd_gn_pool_fwd")
-        ctx.save_for_backward(stats, *xs)
+                                      hip.ptr(geom.geom), hip.ptr(pws), hip.ptr(out), hip.ptr(raw), hip.stream_ptr()), "lgd_gn_pool_fwd")
+        ctx.save_for_backward(stats, raw, *xs)
         ctx.geom, ctx.meta = geom, (L, B, C, hw)
         return out
 
@@ -266,14 +270,13 @@ class _GnReluPool(torch.autograd.Function):
         lib = hip.load()
         L, B, C, hw = ctx.meta
         geom = ctx.geom
-        stats, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        stats, raw, xs = ctx.saved_tensors[0], ctx.saved_tensors[1], ctx.saved_tensors[2:]
         dpool = hip.dense_f32(dpool)
         dev = xs[0].device
-        ws = torch.empty(2 * L * B * C, dtype=torch.float64, device=dev)
         bstats = torch.empty((L * B, 2), dtype=torch.float32, device=dev)
         dxs = [torch.empty_like(x) for x in xs]
-        hip.check(lib.lgd_gn_pool_bwd(hip.ptr_array(xs), hip.ptr(stats), hip.ptr(dpool), hw, L, B, C, geom.T, geom.max_n,
-                                      hip.ptr(geom.img_off), hip.ptr(geom.geom), hip.ptr(ws), hip.ptr(bstats), hip.ptr_array(dxs),
+        hip.check(lib.lgd_gn_pool_bwd(hip.ptr_array(xs), hip.ptr(stats), hip.ptr(dpool), hip.ptr(raw), hw, L, B, C, geom.T, geom.max_n,
+                                      hip.ptr(geom.img_off), hip.ptr(geom.geom), hip.ptr(bstats), hip.ptr_array(dxs),
                                       hip.stream_ptr()), "lgd_gn_pool_bwd")
         return (None, *dxs)
 

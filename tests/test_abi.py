@@ -56,8 +56,8 @@ def test_invalid_arguments_are_rejected(lib):
     from lgd_amd import hip
     hw = hip.int_array([8, 8])
     assert lib.lgd_box_prep(None, None, 1, 1, 1, 64, 64, hw, 1, None, None) == -1
-    assert lib.lgd_box_sum(None, hw, 1, 1, 256, 1, 1, None, None, None, 1, 0, None) == -1
-    assert lib.lgd_box_sum(None, hw, 17, 1, 256, 1, 1, None, None, None, 1, 0, None) == -1  # L > LGD_MAX_LEVELS
+    assert lib.lgd_box_sum(None, hw, 1, 1, 256, 1, 1, None, None, None, None, 1, 0, None) == -1
+    assert lib.lgd_box_sum(None, hw, 17, 1, 256, 1, 1, None, None, None, None, 1, 0, None) == -1  # L > LGD_MAX_LEVELS
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -67,7 +67,7 @@ t = ops.kernel_timer_collect()
 ops.kernel_timer_enable(False)
 alg = {"in_moments_kernel": 2 * P, "in_mse_bwd_kernel": 3 * P, "box_sum_kernel": P, "box_paint_kernel": P, "gn_stats_kernel": P,
        "gn_apply_kernel": 2 * P, "gn_bwd_stats_kernel": 2 * P, "gn_bwd_apply_kernel": 3 * P, "ctx_relu_kernel": 2 * P, "ctx_relu_bwd_kernel": 3 * P,
-       "gn_pool_kernel": P, "gn_pool_bwd_stats_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
+       "gn_pool_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
 tl = ops._WINO_TILE
 FB = 4 * (tl + 2) ** 2 * C * sum(B * ((h + tl - 1) // tl) * ((w + tl - 1) // tl) for h, w in level_hw)  # one frequency buffer
 MB = ops._WINO_MASK_DTYPE[tl].itemsize * C * (FB // (4 * (tl + 2) ** 2 * C))  # ReLU mask table: one entry per tile
