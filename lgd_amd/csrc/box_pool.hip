@@ -51,12 +51,9 @@ struct PoolArgs {
 };
 
 typedef float pool_f2 __attribute__((ext_vector_type(2)));
-#ifndef LGD_POOL_DEPTH
-#define LGD_POOL_DEPTH 2        // 64-pixel windows in flight per wave
-#endif
-#ifndef LGD_POOL_F16MASK
-#define LGD_POOL_F16MASK 0      // box_sum: mask operand in LDS as f16 (1) or f32 (0)
-#endif
+// Measured and neutral (tools/pool_variants.sh, HBM-cold and inside the step: box_sum 39.3 - 40.4 us, gn_pool 41.6 - 43.9 us in every
+// variant): three windows in flight per wave instead of two, the box_sum mask operand as f16 (one more resident workgroup per CU),
+// 1024-pixel chunks (half the partial sums).  A pure streaming reduction of the same bytes (gn_stats) takes 37 us.
 template <int GN> struct PoolA { typedef pool_f4 T; };
 template <> struct PoolA<1> { typedef pool_h4 T; };   // 0/1 are exact in f16: one LDS copy serves the fp32 and the f16 product (an f32 copy
                                                       // would save 8 converts per window but costs a resident workgroup per CU: 43 -> 46 us)
@@ -68,7 +65,7 @@ __device__ __forceinline__ int pool_tile(const PoolArgs& a, int l, int b, int ti
 
 template <int GN, int CH>
 __global__ __launch_bounds__(256) void box_pool_kernel(PoolArgs a) {
-    typedef typename PoolA<GN | LGD_POOL_F16MASK>::T AT;
+    typedef typename PoolA<GN>::T AT;
     __shared__ AT Am[CH / 16][64];          // mask operand of the chunk: step s (16 pixels), lane (box = l & 15, kg = l >> 4) -> 4 pixels
     __shared__ float Ts[4][16 * 68];        // per wave: 16 channel rows x 64 pixels (+4 pad)
     int slot = 0;
@@ -102,10 +99,9 @@ __global__ __launch_bounds__(256) void box_pool_kernel(PoolArgs a) {
         #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = __builtin_nontemporal_load(reinterpret_cast<const pool_f4u*>(img + rowoff[r] + 64 * w));
     };
-    pool_f4 va[4], vb[4], vc[4];
+    pool_f4 va[4], vb[4];
     if (active && 0 < nwf) fetch(va, 0);    // in flight while the mask operand is generated
     if (active && 1 < nwf) fetch(vb, 1);
-    if (LGD_POOL_DEPTH == 3 && active && 2 < nwf) fetch(vc, 2);
     {
         const int box = tile * 16 + m;
         int4 r = make_int4(0, -1, 0, -1);
@@ -172,16 +168,7 @@ __global__ __launch_bounds__(256) void box_pool_kernel(PoolArgs a) {
         #pragma unroll
         for (int s = 0; s < 4; ++s) step(A[s], x[s]);
     };
-    if (LGD_POOL_DEPTH == 3) {
-        for (int w = 0; w < nwf; w += 3) {
-            work(va, w);
-            if (w + 3 < nwf) fetch(va, w + 3);
-            if (w + 1 < nwf) work(vb, w + 1);
-            if (w + 4 < nwf) fetch(vb, w + 4);
-            if (w + 2 < nwf) work(vc, w + 2);
-            if (w + 5 < nwf) fetch(vc, w + 5);
-        }
-    } else for (int w = 0; w < nwf; w += 2) {
+    for (int w = 0; w < nwf; w += 2) {
         work(va, w);
         if (w + 2 < nwf) fetch(va, w + 2);
         if (w + 1 < nwf) work(vb, w + 1);
@@ -259,9 +246,12 @@ static constexpr int kPoolChunkBig = 512, kPoolChunkSmall = 256;
 // chunk length: 512 pixels once that gives the chip >= ~1.2 workgroups per resident slot, else 256 (2 images per GPU)
 static int pool_chunk(const int32_t* level_hw_host, int L, int B, int C, int max_n) {
     const int ntile = max_n > 16 ? (max_n + 15) / 16 : 1, ncp = (C + 63) / 64;
-    long blocks = 0;
-    for (int l = 0; l < L; ++l) blocks += (long)B * ntile * ncp * ((level_hw_host[2 * l] * level_hw_host[2 * l + 1] + kPoolChunkBig - 1) / kPoolChunkBig);
-    return blocks >= 1200 ? kPoolChunkBig : kPoolChunkSmall;
+    auto blocks = [&](int ch) {
+        long n = 0;
+        for (int l = 0; l < L; ++l) n += (long)B * ntile * ncp * ((level_hw_host[2 * l] * level_hw_host[2 * l + 1] + ch - 1) / ch);
+        return n;
+    };
+    return blocks(kPoolChunkBig) >= 1200 ? kPoolChunkBig : kPoolChunkSmall;
 }
 
 static int pool_fill(PoolArgs& a, const float* const* maps_host, const int32_t* level_hw_host, int L, int B, int C, int T, int max_n,
