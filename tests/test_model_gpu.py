@@ -101,6 +101,8 @@ def test_appearance_and_attention_match_reference(run):
 
 def test_teacher_features_match_reference(run):
     g, tea = run["g"], run["tea"]
+    errs = {k: cm.rel_err(cm.sample(tea[k], run["stride"])[0], g["tea_s_" + k]) for k in O.LEVELS}
+    print("teacher features vs the reference's golden [%s]: %s (bar %.0e)" % (run["name"] + " / " + str(run["backend"]), " ".join("%s %.1e" % kv for kv in errs.items()), TOL))
     for k in O.LEVELS:
         s, _, sq = cm.sample(tea[k], run["stride"])
         assert cm.rel_err(s, g["tea_s_" + k]) < TOL, k
