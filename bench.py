@@ -275,7 +275,7 @@ def main():
                "gn_pool_kernel": P, "gn_pool_bwd_apply_kernel": 2 * P}
         # focal loss: logits (N, 9*80, H, W) read once (fwd) / read + written (bwd); int32 label planes (N, 9, H, W) on top
         Pf = Bg * px_pyr * 9 * 4
-        alg.update({"focal_fwd_kernel": 80 * Pf + Pf, "focal_bwd_kernel": 2 * 80 * Pf + Pf})
+        alg.update({"focal_fwd_kernel": 80 * Pf + Pf, "focal_bwd_kernel": 2 * 80 * Pf + Pf, "focal_fwd_grad_kernel": 2 * 80 * Pf + Pf})
         alg.update({k: v / max(ktimes[k][0], 1) for k, v in kbytes.items() if k in ktimes})  # mean bytes per launch
         kernels = {}
         for name, (n, ms, lo, hi) in ktimes.items():

@@ -238,11 +238,19 @@ int lgd_segmax_bwd(const float* dout, const int32_t* off, const int32_t* arg, in
  *  thirdparty_heads/fcos.py:146-152]  logits_l: (N, A*K, H_l, W_l) fp32 NCHW as the head's conv emits them;
  * labels_l: (N, A, H_l, W_l) int32, class index in [0,K), K = background, < 0 = ignored anchor.
  * loss = sum over non-ignored anchors and classes; backward writes grad_loss[0] * dloss/dlogits in NCHW.
+ * lgd_focal_loss_fwd_grad: the sum AND grad_scale[0] * dsum/dlogits (grad_scale: device scalar, NULL = 1) in one pass over the
+ * logits -- for a loss that is divided by a normaliser known when it is evaluated (detectron2's EMA of the positive count,
+ * FCOS's foreground count) and whose upstream gradient in the step is 1; its backward is lgd_scale_unless_one(grads, upstream):
+ * x_l *= g[0] for the L tensors unless g[0] == 1 (then every workgroup leaves after one load).
  */
 size_t lgd_focal_ws_doubles(const int32_t* level_hw_host, int L, int N, int A, int K);
 int lgd_focal_loss_fwd(const float* const* logits_host, const int32_t* const* labels_host,
                        const int32_t* level_hw_host, int L, int N, int A, int K, float alpha, float gamma,
                        double* ws, float* loss, void* stream);
+int lgd_focal_loss_fwd_grad(const float* const* logits_host, const int32_t* const* labels_host,
+                            const int32_t* level_hw_host, int L, int N, int A, int K, float alpha, float gamma,
+                            const float* grad_scale, double* ws, float* loss, float* const* grad_logits_host, void* stream);
+int lgd_scale_unless_one(float* const* x_host, const long long* n_host, int L, const float* g, void* stream);
 int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* labels_host,
                        const int32_t* level_hw_host, int L, int N, int A, int K, float alpha, float gamma,
                        const float* grad_loss, float* const* grad_logits_host, void* stream);

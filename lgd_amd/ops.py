@@ -665,11 +665,56 @@ class _FocalSum(torch.autograd.Function):
         return (None, None, None, None, None, *grads, *([None] * L))
 
 
-def focal_loss_sum(raw_logits, label_planes, A, K, alpha, gamma):
+class _FocalSumNorm(torch.autograd.Function):
+    """focal sum / normaliser with the gradient written by the FORWARD pass (lgd_focal_loss_fwd_grad): the normaliser is a buffer
+    (no gradient) known when the loss is evaluated and the upstream gradient of a loss term in the training step is 1, so
+    (1 / normaliser) dsum/dlogits is final when the logits stream for the sum; the backward only rescales if its upstream != 1."""
+
+    @staticmethod
+    def forward(ctx, A, K, alpha, gamma, n_levels, normalizer, *tensors):
+        import ctypes
+        lib = hip.load()
+        logits = [hip.dense_f32(t) for t in tensors[:n_levels]]
+        labels = list(tensors[n_levels:])
+        hip.require_gpu(*logits, *labels)
+        N = logits[0].shape[0]
+        for x, y in zip(logits, labels):
+            if x.shape[0] != N or x.shape[1] != A * K or y.dtype != torch.int32 or tuple(y.shape) != (N, A) + tuple(x.shape[-2:]) \
+                    or not y.is_contiguous():
+                raise hip.LgdHipError("focal loss: logits (N,A*K,H,W) / int32 labels (N,A,H,W) expected, got %s / %s %s"
+                                      % (tuple(x.shape), tuple(y.shape), y.dtype))
+        hw = hip.int_array([v for m in logits for v in m.shape[-2:]])
+        dev = logits[0].device
+        inv = torch.reciprocal(normalizer.detach().to(torch.float32).reshape(()))
+        ws = torch.empty(lib.lgd_focal_ws_doubles(hw, n_levels, N, A, K), dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        grads = [torch.empty_like(x) for x in logits]
+        hip.check(lib.lgd_focal_loss_fwd_grad(hip.ptr_array(logits), hip.ptr_array(labels), hw, n_levels, N, A, K, float(alpha),
+                                              float(gamma), hip.ptr(inv), hip.ptr(ws), hip.ptr(loss), hip.ptr_array(grads),
+                                              hip.stream_ptr()), "lgd_focal_loss_fwd_grad")
+        ctx.save_for_backward(*grads)
+        ctx.sizes = (ctypes.c_longlong * n_levels)(*[g.numel() for g in grads])
+        return loss * inv
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = hip.load()
+        grads = list(ctx.saved_tensors)
+        g = g.contiguous().to(torch.float32)
+        hip.check(lib.lgd_scale_unless_one(hip.ptr_array(grads), ctx.sizes, len(grads), hip.ptr(g), hip.stream_ptr()), "lgd_scale_unless_one")
+        return (None, None, None, None, None, None, *grads, *([None] * len(grads)))
+
+
+def focal_loss_sum(raw_logits, label_planes, A, K, alpha, gamma, normalizer=None):
     """sum of fvcore's sigmoid focal loss over non-ignored anchors and classes, evaluated in place on the head's raw
-    (N, A*K, H, W) outputs; label_planes: per level (N, A, H, W) int32 (K = background, < 0 = ignore)."""
+    (N, A*K, H, W) outputs; label_planes: per level (N, A, H, W) int32 (K = background, < 0 = ignore).
+    normalizer (a scalar tensor without gradient: detectron2's EMA of the positive count, FCOS's foreground count): returns
+    sum / normalizer and writes the logits' gradient during the forward pass (one pass over the logits instead of two)."""
     raw_logits, label_planes = list(raw_logits), list(label_planes)
-    return _FocalSum.apply(int(A), int(K), float(alpha), float(gamma), len(raw_logits), *raw_logits, *label_planes)
+    if normalizer is not None and torch.is_grad_enabled() and any(x.requires_grad for x in raw_logits):
+        return _FocalSumNorm.apply(int(A), int(K), float(alpha), float(gamma), len(raw_logits), normalizer, *raw_logits, *label_planes)
+    out = _FocalSum.apply(int(A), int(K), float(alpha), float(gamma), len(raw_logits), *raw_logits, *label_planes)
+    return out if normalizer is None else out / normalizer
 
 
 class _BoxRegSum(torch.autograd.Function):

@@ -196,7 +196,7 @@ class FCOSCT(nn.Module):
         num_fg, num_targets = counts[0].clamp(min=1.0), counts[1].clamp(min=1.0)
         hw = [tuple(x.shape[-2:]) for x in pred_class_logits]
         loss_cls = ops.focal_loss_sum(pred_class_logits, ops.label_planes(gt_classes, hw, 1), 1, self.num_classes,
-                                      self.focal_loss_alpha, self.focal_loss_gamma) / num_fg
+                                      self.focal_loss_alpha, self.focal_loss_gamma, normalizer=num_fg)
         safe_t = torch.where(fg[..., None], gt_shifts_deltas, torch.ones_like(gt_shifts_deltas))
         safe_p = torch.where(fg[..., None], deltas, torch.ones_like(deltas))
         loss_box = (torch.where(fg, giou_ltrb_loss(safe_p, safe_t) * gt_ctr, torch.zeros_like(gt_ctr))).sum() / num_targets

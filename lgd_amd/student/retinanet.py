@@ -265,10 +265,11 @@ class RetinaNetCT(nn.Module):
         self.loss_normalizer = (self.loss_normalizer_momentum * self.loss_normalizer
                                 + (1 - self.loss_normalizer_momentum) * num_pos.clamp(min=1.0)).detach()
         nA = raw[0].shape[1] // self.num_classes
-        loss_cls = ops.focal_loss_sum(raw, c["planes"], nA, self.num_classes, self.focal_loss_alpha, self.focal_loss_gamma)
+        loss_cls = ops.focal_loss_sum(raw, c["planes"], nA, self.num_classes, self.focal_loss_alpha, self.focal_loss_gamma,
+                                      normalizer=self.loss_normalizer)   # = sum / normalizer, gradient written in the same pass
         loss_box = ops.box_reg_loss_sum(raw_d, c["planes"], A, c["matched"], nA, self.num_classes,
                                         self.smooth_l1_beta, self.bbox_reg_weights)
-        return {"loss_cls": loss_cls / self.loss_normalizer, "loss_box_reg": loss_box / self.loss_normalizer}
+        return {"loss_cls": loss_cls, "loss_box_reg": loss_box / self.loss_normalizer}
 
     def backbone_features(self, batched_inputs):
         """bottom-up + FPN only (no head pass): (raw_features, features dict, images, gt_instances | None).  The

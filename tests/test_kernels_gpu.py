@@ -404,6 +404,36 @@ def test_focal_loss_sum_fwd_bwd(N, A, K, level_hw, gamma):
         assert cm.rel_err(a.grad, b.grad) < FTOL
 
 
+@pytest.mark.parametrize("N,A,K,level_hw,gamma", [(2, 9, 80, [(16, 20), (8, 10), (3, 5)], 2.0), (1, 3, 7, [(9, 13)], 1.5)])
+@pytest.mark.parametrize("upstream", [1.0, 0.37])
+def test_focal_loss_normalised_one_pass(N, A, K, level_hw, gamma, upstream):
+    """focal_loss_sum(..., normalizer=n): sum / n with the gradient written by the forward pass == the restatement / n, value and
+    gradients, for an upstream gradient of exactly 1 (the training step: the backward launch changes nothing) and != 1 (rescaled);
+    and == the two-pass kernels."""
+    from lgd_amd import ops
+    rng = np.random.default_rng(5)
+    R = sum(h * w * A for h, w in level_hw)
+    labels = torch.from_numpy(rng.integers(-1, K + 1, size=(N, R)))
+    raw = [torch.from_numpy(synth.det_uniform((N, A * K, h, w), 710 + i)) * 6 for i, (h, w) in enumerate(level_hw)]
+    norm = torch.tensor(37.5)
+    planes = ops.label_planes(labels.to(DEV), level_hw, A)
+    rg = [x.to(DEV).requires_grad_(True) for x in raw]
+    loss = ops.focal_loss_sum(rg, planes, A, K, 0.25, gamma, normalizer=norm.to(DEV))
+    rc = [x.clone().requires_grad_(True) for x in raw]
+    ref = SO.sigmoid_focal_sum(torch.cat([SO.flatten_head_output(x, K) for x in rc], 1), labels, K, 0.25, gamma) / norm
+    assert abs(loss.item() - ref.item()) / ref.item() < 1e-5
+    (loss * upstream).backward()
+    (ref * upstream).backward()
+    for a, b in zip(rg, rc):
+        assert cm.rel_err(a.grad, b.grad) < FTOL
+    r2 = [x.to(DEV).requires_grad_(True) for x in raw]
+    two = ops.focal_loss_sum(r2, planes, A, K, 0.25, gamma) / norm.to(DEV)
+    (two * upstream).backward()
+    assert abs(two.item() - loss.item()) <= 2e-7 * abs(two.item())
+    for a, b in zip(rg, r2):
+        assert cm.rel_err(a.grad, b.grad) < 1e-6
+
+
 # ------------------------------------------------------------------------------------------- K6 label-encoder ops
 @pytest.mark.parametrize("name", list(cm.CASES) + ["c2_masks_800x1344"])
 def test_box_descriptors_bit_exact(name):

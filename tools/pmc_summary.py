@@ -33,7 +33,7 @@ TIMER_NAMES = {
     "gn_apply_kernel<0>": ["gn_apply_kernel"], "gn_apply_kernel<1>": ["gn_bwd_apply_kernel"],
     "gn_finalize_kernel<0>": ["gn_finalize_kernel"], "gn_finalize_kernel<1>": ["gn_bwd_finalize_kernel"],
     "ctx_relu_kernel<0>": ["ctx_relu_kernel"], "ctx_relu_kernel<1>": ["ctx_relu_bwd_kernel"],
-    "focal_kernel<0>": ["focal_fwd_kernel"], "focal_kernel<1>": ["focal_bwd_kernel"],
+    "focal_kernel<0>": ["focal_fwd_kernel"], "focal_kernel<1>": ["focal_bwd_kernel"], "focal_kernel<2>": ["focal_fwd_grad_kernel"],
     "paint_kernel<1>": ["gn_pool_bwd_apply_kernel"], "paint_kernel<2>": ["box_paint_kernel"],
     "rowln_kernel<0>": ["rowln_kernel"], "rowln_kernel<1>": ["rowln_bwd_kernel"],
     "gg_stats_kernel<0>": ["gn_group_stats_kernel"], "gg_stats_kernel<1>": ["gn_group_bwd_stats_kernel"],
