@@ -80,7 +80,7 @@ __device__ __forceinline__ LaneBox load_lane_box(const Plane& p, int pass, int l
 // HBM latency per band: ~20 bands x 2 us on a p3 plane, 0.38 of the HBM peak); the pattern is recomposed at a boundary by
 // wave-uniform control flow: 84 -> 72 us (apply) HBM-cold.
 template <int VW, int MODE>
-__device__ __forceinline__ void paint_rows(const BoxArgs& a, const Plane& p) {
+__device__ __forceinline__ void paint_rows(const BoxArgs& a, const Plane& p, const int ra, const int rb) {
     constexpr int G = LGD_BAND_G;
     const int lane = threadIdx.x & 63;
     const size_t base = ((size_t)p.b * a.C + p.c) * p.H * p.W;
@@ -109,7 +109,6 @@ __device__ __forceinline__ void paint_rows(const BoxArgs& a, const Plane& p) {
     auto band = [&](int k) {  // wave-uniform by construction
         return __builtin_amdgcn_readfirstlane(p.nbp <= 64 ? __builtin_amdgcn_readlane(bandreg, k) : (k < p.nbp ? p.bands[k] : p.H));
     };
-    const int ra = 0, rb = p.H;
     for (int xc = 0; rb > ra && xc < p.W; xc += 64 * VW) {
         const int xl = xc + lane * VW;
         const bool on = xl < p.W;
@@ -187,13 +186,23 @@ __device__ __forceinline__ void paint_rows(const BoxArgs& a, const Plane& p) {
     }
 }
 
-template <int MODE>   // one wave per plane
+// SPLIT = 1: one wave per plane.  SPLIT = 4 (few planes: 2 images per GPU): the four waves of a workgroup take a quarter of ONE plane's
+// rows each -- a wave retires a row store every ~170 ns whatever else runs, so a 100-row p3 plane is a 17 us chain that 512 planes
+// cannot hide (box_paint 22 -> 12 us, gn_pool backward apply 46 -> 27 us at config 4); with 2048 planes per level the extra band
+// walks cost more than the shorter chains save (66 / 92 us against 37 / 68 us at 8 images).
+template <int MODE, int SPLIT>
 __global__ __launch_bounds__(256) void paint_kernel(BoxArgs a) {
-    const Plane p = locate(a, 4);
-    if ((p.W & 3) == 0) paint_rows<4, MODE>(a, p);
-    else if ((p.W & 1) == 0) paint_rows<2, MODE>(a, p);
-    else paint_rows<1, MODE>(a, p);
+    const Plane p = locate(a, SPLIT == 4 ? 1 : 4);
+    int ra = 0, rb = p.H;
+    if (SPLIT == 4) {
+        const int rows = (p.H + 3) >> 2, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        ra = min(p.H, wave * rows); rb = min(p.H, ra + rows);
+    }
+    if ((p.W & 3) == 0) paint_rows<4, MODE>(a, p, ra, rb);
+    else if ((p.W & 1) == 0) paint_rows<2, MODE>(a, p, ra, rb);
+    else paint_rows<1, MODE>(a, p, ra, rb);
 }
+static inline bool paint_split(int B, int C) { return (long)B * C <= 1024; }
 
 // per (level, image): m1 = mean(g), m2 = mean(g * xhat) of g = paint(dpool / count) * [x > mean] WITHOUT a pass over x:
 //   sum_px g = sum over (box, channel) of dpool / count * R1,   sum_px g * xhat = sum of dpool / count * R2,
@@ -264,7 +273,8 @@ int lgd_gn_pool_bwd(const float* const* x_host, const float* gn_stats, const flo
                     const int32_t* level_hw_host, int L, int B, int C, int T, int max_n, const int32_t* img_off, const int32_t* geom,
                     float* bstats, float* const* dx_host, void* stream) {
     lgd::BoxArgs a;
-    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, 1, 0, 4);
+    const bool split = lgd::paint_split(B, C);
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, 1, 0, split ? 1 : 4);
     if (nblk < 0 || !x_host || !gn_stats || !dpool || !raw || !bstats || !dx_host) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) {
         if (!x_host[l] || !dx_host[l]) return LGD_EINVAL;
@@ -273,7 +283,8 @@ int lgd_gn_pool_bwd(const float* const* x_host, const float* gn_stats, const flo
     a.vals = dpool; a.gn_stats = gn_stats; a.gn_bstats = bstats; a.raw = raw;
     hipStream_t s = (hipStream_t)stream;
     LGD_LAUNCH("gn_pool_bwd_stats_kernel", lgd::gn_pool_bwd_stats_kernel, dim3(L * B), dim3(256), 0, s, a, bstats);
-    LGD_LAUNCH("gn_pool_bwd_apply_kernel", lgd::paint_kernel<1>, dim3(nblk), dim3(256), 0, s, a);
+    if (split) LGD_LAUNCH("gn_pool_bwd_apply_kernel", (lgd::paint_kernel<1, 4>), dim3(nblk), dim3(256), 0, s, a);
+    else LGD_LAUNCH("gn_pool_bwd_apply_kernel", (lgd::paint_kernel<1, 1>), dim3(nblk), dim3(256), 0, s, a);
     return lgd::check_launch();
 }
 
@@ -281,11 +292,13 @@ int lgd_box_paint(const float* vals, const int32_t* level_hw_host, int L, int B,
                   const int32_t* img_off, const int32_t* geom, float* const* outs_host, int normalize, int skip_last,
                   void* stream) {
     lgd::BoxArgs a;
-    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last, 4);
+    const bool split = lgd::paint_split(B, C);
+    const int nblk = lgd::fill_args(a, level_hw_host, L, B, C, T, max_n, img_off, geom, normalize, skip_last, split ? 1 : 4);
     if (nblk < 0 || !outs_host || !vals) return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!outs_host[l]) return LGD_EINVAL; a.out[l] = outs_host[l]; }
     a.vals = vals;
-    LGD_LAUNCH("box_paint_kernel", lgd::paint_kernel<2>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    if (split) LGD_LAUNCH("box_paint_kernel", (lgd::paint_kernel<2, 4>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    else LGD_LAUNCH("box_paint_kernel", (lgd::paint_kernel<2, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 
