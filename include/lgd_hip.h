@@ -164,6 +164,10 @@ int lgd_gn1_bwd(const float* const* x_host, const float* const* dy_host, const i
 size_t lgd_gn_group_ws_doubles(const int32_t* level_hw_host, int L, int B, int C);
 int lgd_gn_group_fwd(const float* const* x_host, const int32_t* level_hw_host, int L, int B, int C, int G, const float* gamma,
                      const float* beta, int relu, double* ws, float* stats, float* const* y_host, void* stream);
+/* statistics of lgd_gn_group_fwd alone, folded with gamma / beta into affine [L][B][C][2] = (rstd * gamma, beta - mean * rstd * gamma):
+ * what lgd_wino_in(pre_affine) applies while it loads (the normalised maps are never written) */
+int lgd_gn_group_stats_affine(const float* const* x_host, const int32_t* level_hw_host, int L, int B, int C, int G,
+                              const float* gamma, const float* beta, double* ws, float* stats, float* affine, void* stream);
 int lgd_gn_group_bwd(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L, int B, int C,
                      int G, const float* gamma, const float* beta, int relu, const float* stats, double* ws, float* bstats,
                      float* plane_sums, float* const* dx_host, void* stream);
@@ -281,11 +285,16 @@ int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* la
  *   convolution and nothing else (conv1 -> FrozenBN -> ReLU -> conv2 of a bottleneck block): lgd_wino_in transforms
  *   relu(x + pre_bias[c]) -- the epilogue pass of the producing convolution is folded into this load -- and writes the activation
  *   mask per tile to pre_bits (may be NULL when no backward follows); lgd_wino_in_t takes pre_bits and returns the
- *   gradient of the RAW maps (zero where the activation was <= 0). */
+ *   gradient of the RAW maps (zero where the activation was <= 0).
+ * pre_affine (may be NULL; excludes pre_bias): [L][N][C][2] (scale, shift) per (map, sample, channel) -- the maps are the inputs
+ *   of a GroupNorm + ReLU whose statistics are folded into scale = rstd * gamma, shift = beta - mean * rstd * gamma
+ *   (lgd_gn_group_stats_affine; the FCOS towers' conv -> GroupNorm(32) -> ReLU -> conv, thirdparty_heads/fcos.py:455-470):
+ *   lgd_wino_in transforms relu(x * scale + shift), the normalised map is never written; pre_bits as above -- lgd_wino_in_t then
+ *   returns the gradient w.r.t. the GroupNorm OUTPUT (before the ReLU), which lgd_gn_group_bwd(relu = 0) takes. */
 size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N, int tile);
 size_t lgd_wino_mask_bytes(int tile);
 int lgd_wino_in(const float* const* x_host, const int32_t* level_hw_host, int L, int N, int C, int tile, float* V,
-                const float* pre_bias, void* pre_bits, void* stream);
+                const float* pre_bias, const float* pre_affine, void* pre_bits, void* stream);
 int lgd_wino_out(const float* M, const float* bias, const int32_t* level_hw_host, int L, int N, int C, int tile,
                  int relu, float* const* y_host, void* relu_bits, void* stream);
 int lgd_wino_out_t(const float* const* dy_host, const void* relu_bits, const int32_t* level_hw_host, int L, int N, int C, int tile,

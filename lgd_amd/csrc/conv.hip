@@ -119,7 +119,7 @@ int lgd_conv3x3_fwd(const lgd_conv3x3_fwd_args* a, void* stream) {
         if (rc != LGD_OK) return rc;
         c0 += a->Co[k];
     }
-    rc = lgd_wino_in(a->x, a->level_hw, L, a->N, a->Ci, tile, a->V, a->pre_bias, a->pre_bits, stream);
+    rc = lgd_wino_in(a->x, a->level_hw, L, a->N, a->Ci, tile, a->V, a->pre_bias, nullptr, a->pre_bits, stream);
     if (rc != LGD_OK) return rc;
     rc = lgd::wino_gemm("wino_gemm_fwd", 0, a->U, a->V, a->M, Ct, a->Ci, T, nf, a->sol_fwd, (hipStream_t)stream);
     if (rc != LGD_OK) return rc;

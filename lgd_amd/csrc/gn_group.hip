@@ -33,6 +33,7 @@ struct GgArgs {
     float* stats;                   // [L*B*G][2] mean, rstd
     float* bstats;                  // [L*B*G][2] m1, m2 (backward)
     float* plane_sums;              // [L*B*C][2] sum g, sum g*xhat (backward)
+    float* affine;                  // optional (forward finalize): [L*B][C][2] rstd*gamma, beta - mean*rstd*gamma
 };
 
 struct GgWhere { int l, plane, chunk; };
@@ -126,8 +127,17 @@ __global__ __launch_bounds__(64) void gg_finalize_kernel(GgArgs a) {
     if (lane == 0) {
         if (MODE == 0) {
             const double m = t0 / n, var = fmax(t1 / n - m * m, 0.0);
-            a.stats[2 * seg] = (float)m;
-            a.stats[2 * seg + 1] = (float)(1.0 / sqrt(var + (double)kGgEps));
+            const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)kGgEps));
+            a.stats[2 * seg] = mf;
+            a.stats[2 * seg + 1] = rf;
+            if (a.affine) {   // y = gamma * (x - mean) * rstd + beta as x * scale + shift: what the next convolution's input transform applies
+                for (int j = 0; j < cg; ++j) {
+                    const int c = g * cg + j;
+                    const float sc = rf * (a.gamma ? a.gamma[c] : 1.f);
+                    a.affine[2 * ((size_t)lb * a.C + c)] = sc;
+                    a.affine[2 * ((size_t)lb * a.C + c) + 1] = (a.beta ? a.beta[c] : 0.f) - mf * sc;
+                }
+            }
         } else {
             a.bstats[2 * seg] = (float)(t0 / n);
             a.bstats[2 * seg + 1] = (float)(t1 / n);
@@ -201,7 +211,7 @@ static int gg_fill(GgArgs& a, const float* const* x_host, const int32_t* level_h
     if (w > 0x7fffffffLL) return LGD_EINVAL;
     a.wave0[LGD_MAX_LEVELS] = (int)w;
     a.nwaves = (int)w;
-    a.gamma = a.beta = nullptr; a.ws = nullptr; a.stats = a.bstats = a.plane_sums = nullptr;
+    a.gamma = a.beta = nullptr; a.ws = nullptr; a.stats = a.bstats = a.plane_sums = nullptr; a.affine = nullptr;
     return LGD_OK;
 }
 
@@ -229,6 +239,17 @@ int lgd_gn_group_fwd(const float* const* x_host, const int32_t* level_hw_host, i
     LGD_LAUNCH("gn_group_stats_kernel", lgd::gg_stats_kernel<0>, grid, dim3(256), 0, s, a);
     LGD_LAUNCH("gn_group_finalize_kernel", lgd::gg_finalize_kernel<0>, dim3(L * B * G), dim3(64), 0, s, a);
     LGD_LAUNCH("gn_group_apply_kernel", lgd::gg_apply_kernel<0>, grid, dim3(256), 0, s, a);
+    return lgd::check_launch();
+}
+
+int lgd_gn_group_stats_affine(const float* const* x_host, const int32_t* level_hw_host, int L, int B, int C, int G, const float* gamma,
+                              const float* beta, double* ws, float* stats, float* affine, void* stream) {
+    lgd::GgArgs a;
+    if (lgd::gg_fill(a, x_host, level_hw_host, L, B, C, G, 1) != LGD_OK || !ws || !stats || !affine) return LGD_EINVAL;
+    a.gamma = gamma; a.beta = beta; a.ws = ws; a.stats = stats; a.affine = affine;
+    hipStream_t s = (hipStream_t)stream;
+    LGD_LAUNCH("gn_group_stats_kernel", lgd::gg_stats_kernel<0>, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
+    LGD_LAUNCH("gn_group_finalize_kernel", lgd::gg_finalize_kernel<0>, dim3(L * B * G), dim3(64), 0, s, a);
     return lgd::check_launch();
 }
 

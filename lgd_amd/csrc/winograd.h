@@ -12,6 +12,8 @@ struct WinoArgs {
     const float* buf_in;                    // [C][nf][T]
     float* buf_out;                         // [C][nf][T]
     const float* bias;
+    const float* pre_affine;                // optional (input transform, PRE): [L][N][C][2] scale, shift -- the maps are the inputs of a per-(map, sample,
+                                            // channel) affine + ReLU (GroupNorm + ReLU with its statistics folded): relu(x * scale + shift)
     void* bits_out;                         // optional: [C][T] per-tile activation masks, bit tile*i+j = pixel (i, j) of the tile's block > 0
     const void* bits_in;                    //   (uint16 per 4x4 tile, uint64 per 6x6 tile); the same table read as the gradient mask
     long long tile_off[LGD_MAX_LEVELS];     // first tile of the level (multiple of kTilePad)

@@ -71,7 +71,11 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
     const float* p = a.maps_in[l] + ((size_t)n * a.C + c) * H * W;
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const int lane = threadIdx.x & 63;
-    const float prb = PRE ? a.bias[c] : 0.f;
+    float prb = 0.f, prs = 1.f;   // PRE: relu(x * prs + prb); prs = 1 for the per-channel bias form (fma(x, 1, b) = x + b exactly)
+    if constexpr (PRE) {
+        if (a.pre_affine) { const float2 sa = reinterpret_cast<const float2*>(a.pre_affine)[((size_t)l * a.N + n) * a.C + c]; prs = sa.x; prb = sa.y; }
+        else prb = a.bias[c];
+    }
     float d[6][6];
     if constexpr (VEC) {
         // Phase 1: EVERY load of the 6x6 window is issued before anything consumes one -- six aligned float4 rows and, on the wave's end
@@ -111,12 +115,12 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
             float4 v = m[i];
             // PRE: rows beyond the map stay the zero padding of the ACTIVATION: relu(0 + -inf) = 0, no branch
             const float pbv = PRE ? (yok ? prb : -INFINITY) : 0.f;
-            if constexpr (PRE) { v.x = fmaxf(v.x + pbv, 0.f); v.y = fmaxf(v.y + pbv, 0.f); v.z = fmaxf(v.z + pbv, 0.f); v.w = fmaxf(v.w + pbv, 0.f); }
+            if constexpr (PRE) { v.x = fmaxf(fmaf(v.x, prs, pbv), 0.f); v.y = fmaxf(fmaf(v.y, prs, pbv), 0.f); v.z = fmaxf(fmaf(v.z, prs, pbv), 0.f); v.w = fmaxf(fmaf(v.w, prs, pbv), 0.f); }
             // halo columns = the neighbour lanes' edge values (same image row unless first / last tile of the row): one DPP move each
             // (measured equal to ds_bpermute shuffles, 136.1 vs 136.4 us)
             float e0 = wave_shr1(v.w), e5 = wave_shl1(v.x);
-            if (needL) { e0 = hl[i]; if constexpr (PRE) e0 = fmaxf(e0 + pbv, 0.f); }
-            if (needR) { e5 = hr[i]; if constexpr (PRE) e5 = fmaxf(e5 + pbv, 0.f); }
+            if (needL) { e0 = hl[i]; if constexpr (PRE) e0 = fmaxf(fmaf(e0, prs, pbv), 0.f); }
+            if (needR) { e5 = hr[i]; if constexpr (PRE) e5 = fmaxf(fmaf(e5, prs, pbv), 0.f); }
             if (tx == 0) e0 = 0.f;
             if (tx == TW - 1) e5 = 0.f;
             d[i][0] = e0; d[i][1] = v.x; d[i][2] = v.y; d[i][3] = v.z; d[i][4] = v.w; d[i][5] = e5;
@@ -144,7 +148,7 @@ __device__ __forceinline__ void wino4_in_body(const WinoArgs& a, int l, float* l
                 for (int j = 0; j < 6; ++j) {
                     const int x = x0 + j;
                     const bool ok = yok && x >= 0 && x < W;
-                    d[i][j] = fmaxf(d[i][j] + (ok ? prb : -INFINITY), 0.f);
+                    d[i][j] = fmaxf(fmaf(d[i][j], prs, ok ? prb : -INFINITY), 0.f);
                 }
             }
         }
@@ -620,7 +624,7 @@ long long wino_level_tiles(int N, int H, int W, int tile) {
 int wino_fill(WinoArgs& a, const int32_t* level_hw, int L, int N, int C, int tile, unsigned* blocks) {
     if (!level_hw || L < 1 || L > LGD_MAX_LEVELS || N < 1 || C < 1 || C > 65535 || (tile != 4 && tile != 6)) return LGD_EINVAL;
     a.L = L; a.N = N; a.C = C; a.relu = 0;
-    a.bias = nullptr; a.buf_in = nullptr; a.buf_out = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
+    a.bias = nullptr; a.pre_affine = nullptr; a.buf_in = nullptr; a.buf_out = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
     long long off = 0;
     unsigned blk = 0;
     for (int l = 0; l < LGD_MAX_LEVELS; ++l) {
@@ -660,12 +664,12 @@ size_t lgd_wino_tiles(const int32_t* level_hw_host, int L, int N, int tile) {
 size_t lgd_wino_mask_bytes(int tile) { return tile == 6 ? 8 : (tile == 4 ? 2 : 0); }
 
 int lgd_wino_in(const float* const* x_host, const int32_t* level_hw_host, int L, int N, int C, int tile, float* V,
-                const float* pre_bias, void* pre_bits, void* stream) {
+                const float* pre_bias, const float* pre_affine, void* pre_bits, void* stream) {
     lgd::WinoArgs a;
     unsigned blocks;
     if (!x_host || !V || lgd::wino_fill(a, level_hw_host, L, N, C, tile, &blocks) != LGD_OK) return LGD_EINVAL;
-    if (pre_bits && !pre_bias) return LGD_EINVAL;
-    a.bias = pre_bias; a.bits_out = pre_bits;
+    if ((pre_bits && !pre_bias && !pre_affine) || (pre_bias && pre_affine)) return LGD_EINVAL;
+    a.bias = pre_bias; a.pre_affine = pre_affine; a.bits_out = pre_bits;
     for (int l = 0; l < L; ++l) {
         if (!x_host[l]) return LGD_EINVAL;
         a.maps_in[l] = x_host[l];
@@ -673,8 +677,8 @@ int lgd_wino_in(const float* const* x_host, const int32_t* level_hw_host, int L,
     a.buf_out = V;
     const dim3 grid(blocks, C), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (tile == 6) lgd::wino6_launch_in(a, blocks, pre_bias != nullptr, st);
-    else if (pre_bias) { LGD_LAUNCH("wino_in_kernel", (lgd::wino4_in_kernel<true>), grid, block, 0, st, a); }
+    if (tile == 6) lgd::wino6_launch_in(a, blocks, pre_bias != nullptr || pre_affine != nullptr, st);
+    else if (pre_bias || pre_affine) { LGD_LAUNCH("wino_in_kernel", (lgd::wino4_in_kernel<true>), grid, block, 0, st, a); }
     else { LGD_LAUNCH("wino_in_kernel", (lgd::wino4_in_kernel<false>), grid, block, 0, st, a); }
     return lgd::check_launch();
 }

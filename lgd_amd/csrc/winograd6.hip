@@ -158,7 +158,11 @@ __device__ __forceinline__ void wino6_in_body(const WinoArgs& a, int l, float* l
     const float* p = a.maps_in[l] + ((size_t)n * a.C + c) * H * W;
     const int y0 = 6 * ty - 1, x0 = 6 * tx;   // x0 = the tile's own first column = window column 1
     const int lane = threadIdx.x & 63;
-    const float prb = PRE ? a.bias[c] : 0.f;
+    float prb = 0.f, prs = 1.f;   // PRE: relu(x * prs + prb); prs = 1 for the per-channel bias form (fma(x, 1, b) = x + b exactly)
+    if constexpr (PRE) {
+        if (a.pre_affine) { const float2 sa = reinterpret_cast<const float2*>(a.pre_affine)[((size_t)l * a.N + n) * a.C + c]; prs = sa.x; prb = sa.y; }
+        else prb = a.bias[c];
+    }
     float d[8][8];
     if constexpr (VEC) {
         // every load of the window is issued before anything consumes one (one exposed HBM latency per workgroup, not one per row)
@@ -204,12 +208,12 @@ __device__ __forceinline__ void wino6_in_body(const WinoArgs& a, int l, float* l
                 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const bool inA = odd ? j >= 2 : j < 4;
-                    own[j] = fmaxf(own[j] + (inA ? pa : pb), 0.f);
+                    own[j] = fmaxf(fmaf(own[j], prs, inA ? pa : pb), 0.f);
                 }
             }
             float e0 = wave_shr1(own[5]), e7 = wave_shl1(own[0]);
-            if (needL) { e0 = hl[i]; if constexpr (PRE) e0 = fmaxf(e0 + pbv, 0.f); }
-            if (needR) { e7 = hr[i]; if constexpr (PRE) e7 = fmaxf(e7 + pbv, 0.f); }
+            if (needL) { e0 = hl[i]; if constexpr (PRE) e0 = fmaxf(fmaf(e0, prs, pbv), 0.f); }
+            if (needR) { e7 = hr[i]; if constexpr (PRE) e7 = fmaxf(fmaf(e7, prs, pbv), 0.f); }
             if (tx == 0) e0 = 0.f;
             if (tx == TW - 1) e7 = 0.f;
             d[i][0] = e0; d[i][7] = e7;
@@ -238,7 +242,7 @@ __device__ __forceinline__ void wino6_in_body(const WinoArgs& a, int l, float* l
                 for (int j = 0; j < 8; ++j) {
                     const int x = x0 - 1 + j;
                     const bool ok = yok && x >= 0 && x < W;
-                    d[i][j] = fmaxf(d[i][j] + (ok ? prb : -INFINITY), 0.f);
+                    d[i][j] = fmaxf(fmaf(d[i][j], prs, ok ? prb : -INFINITY), 0.f);
                 }
             }
         }

@@ -44,6 +44,7 @@ SIGNATURES = {
     "lgd_gn1_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn_group_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
     "lgd_gn_group_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gn_group_stats_affine": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn_group_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_fcos_targets": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_ctx_relu_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
@@ -65,7 +66,7 @@ SIGNATURES = {
     "lgd_focal_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
     "lgd_wino_tiles": (c_sz, [c_fp, c_i, c_i, c_i]),
     "lgd_wino_mask_bytes": (c_sz, [c_i]),
-    "lgd_wino_in": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_wino_in": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_out": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_wino_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_in_t": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),

@@ -341,6 +341,68 @@ def group_norm_relu(xs, groups, weight=None, bias=None, relu=True):
     return list(_GroupNormRelu.apply(int(groups), bool(relu), weight, bias, *xs))
 
 
+class _GroupNormFold(torch.autograd.Function):
+    """nn.GroupNorm(groups, C) + ReLU in front of a 3x3 convolution WITHOUT its apply pass: the statistics are folded with gamma / beta
+    into a per-(map, sample, channel) scale and shift (lgd_gn_group_stats_affine) that the convolution's input transform applies while it
+    loads (conv3x3_levels(..., pre=affine)); the normalised maps are never written or re-read (2 map transfers of 3 per tower layer).
+    forward -> (affine (L*B, C, 2), the maps themselves); backward: the convolution returns the gradient w.r.t. the GroupNorm OUTPUT
+    (its adjoint input transform applies the activation bits the forward transform wrote), lgd_gn_group_bwd(relu = 0) turns it into the
+    gradient of the raw maps, d gamma and d beta."""
+
+    @staticmethod
+    def forward(ctx, groups, weight, bias, *xs):
+        lib = hip.load()
+        hip.require_gpu(*xs)
+        xs = [hip.dense_f32(x) for x in xs]
+        L = len(xs)
+        B, C, hw = _levels_meta(xs)
+        weight = hip.dense_f32(weight) if weight is not None else None
+        bias = hip.dense_f32(bias) if bias is not None else None
+        dev = xs[0].device
+        ws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)
+        stats = torch.empty((L * B * groups, 2), dtype=torch.float32, device=dev)
+        affine = torch.empty((L * B, C, 2), dtype=torch.float32, device=dev)
+        _count_bytes("gn_group_stats_kernel", 4 * sum(x.numel() for x in xs))
+        hip.check(lib.lgd_gn_group_stats_affine(hip.ptr_array(xs), hw, L, B, C, groups, hip.ptr(weight) if weight is not None else None,
+                                                hip.ptr(bias) if bias is not None else None, hip.ptr(ws), hip.ptr(stats), hip.ptr(affine),
+                                                hip.stream_ptr()), "lgd_gn_group_stats_affine")
+        ctx.save_for_backward(stats, weight, bias, *xs)
+        ctx.meta = (groups, L, B, C, hw)
+        ctx.mark_non_differentiable(affine)
+        return (affine, *[x.view_as(x) for x in xs])
+
+    @staticmethod
+    def backward(ctx, _gaff, *dys):
+        lib = hip.load()
+        groups, L, B, C, hw = ctx.meta
+        stats, weight, bias, *xs = ctx.saved_tensors
+        dys = [hip.dense_f32(d) for d in dys]
+        dev = xs[0].device
+        ws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)
+        bstats = torch.empty((L * B * groups, 2), dtype=torch.float32, device=dev)
+        psums = torch.empty((L * B, C, 2), dtype=torch.float32, device=dev)
+        dxs = [torch.empty_like(x) for x in xs]
+        nb = 4 * sum(x.numel() for x in xs)
+        _count_bytes("gn_group_bwd_stats_kernel", 2 * nb)
+        _count_bytes("gn_group_bwd_apply_kernel", 3 * nb)
+        hip.check(lib.lgd_gn_group_bwd(hip.ptr_array(xs), hip.ptr_array(dys), hw, L, B, C, groups,
+                                       hip.ptr(weight) if weight is not None else None, hip.ptr(bias) if bias is not None else None,
+                                       0, hip.ptr(stats), hip.ptr(ws), hip.ptr(bstats), hip.ptr(psums), hip.ptr_array(dxs),
+                                       hip.stream_ptr()), "lgd_gn_group_bwd")
+        s = psums.sum(0) if (weight is not None or bias is not None) else None
+        dw = s[:, 1].contiguous() if weight is not None and ctx.needs_input_grad[1] else None
+        db = s[:, 0].contiguous() if bias is not None and ctx.needs_input_grad[2] else None
+        return (None, dw, db, *dxs)
+
+
+def group_norm_fold(xs, groups, weight=None, bias=None):
+    """GroupNorm(groups, C) + ReLU of a list of maps, to be applied by the NEXT 3x3 convolution's input transform: returns (affine, maps);
+    pass both on: conv3x3_levels(maps, w, b, pre=affine) / conv3x3_shared_input(maps, filters, pre=affine)
+    [ref: thirdparty_heads/fcos.py:455-470 tower layers conv -> GroupNorm(32) -> ReLU -> conv]."""
+    out = _GroupNormFold.apply(int(groups), weight, bias, *xs)
+    return out[0], list(out[1:])
+
+
 class _CtxRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cvec, *xs):
@@ -841,7 +903,9 @@ class _Conv3x3K(torch.autograd.Function):
     channel factor (a buffer, no gradient) per filter, applied to the filter inside its transform; pre: None, or a per-INPUT-
     channel bias (a buffer): the maps are then pre-activations and the convolution runs on relu(x + pre[c]) -- the bias + ReLU epilogue
     of the producing 1x1 convolution folded into the input transform, its backward mask into the adjoint transform, so the
-    gradient returned for x is the gradient of the RAW map."""
+    gradient returned for x is the gradient of the RAW map.  pre of shape (L*N, Ci, 2): per (map, sample, channel) scale and shift of a
+    GroupNorm + ReLU that precedes the convolution (group_norm_fold); the gradient returned for x is then the gradient w.r.t. the
+    GroupNorm OUTPUT, which group_norm_fold's backward turns into the gradient of the raw map."""
 
     @staticmethod
     def forward(ctx, K, relu, tile, scales, pre, *args):
@@ -865,11 +929,14 @@ class _Conv3x3K(torch.autograd.Function):
         U, Ut = _wino_filters(lib, ws, scales, Ci, dev, tile)
         V = _freq_buf(nf, Ci, T, dev)
         pre = hip.dense_f32(pre) if pre is not None else None
+        affine = pre is not None and pre.dim() == 3   # (L*N, Ci, 2) scale / shift per (map, sample, channel): a folded GroupNorm + ReLU
+        if affine and tuple(pre.shape) != (L * N, Ci, 2):
+            raise hip.LgdHipError("affine pre-activation must be (L*N, C, 2) = (%d, %d, 2), got %s" % (L * N, Ci, tuple(pre.shape)))
         pre_bits = (torch.empty((Ci, T), dtype=mdt, device=dev)
                     if pre is not None and any(ctx.needs_input_grad[5 + 2 * K:]) else None)
         hip.check(lib.lgd_wino_in(hip.ptr_array(xs), hw, L, N, Ci, tile, hip.ptr(V),
-                                  hip.ptr(pre) if pre is not None else None, hip.ptr(pre_bits) if pre_bits is not None else None,
-                                  hip.stream_ptr()), "lgd_wino_in")
+                                  hip.ptr(pre) if pre is not None and not affine else None, hip.ptr(pre) if affine else None,
+                                  hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in")
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
         fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
         _count_bytes("wino_in_kernel", (px + fb) * Ci)
@@ -969,7 +1036,7 @@ class _Conv3x3Chain(torch.autograd.Function):
             Co, Ci = ws[k].shape[0], ws[k].shape[1]
             U, Ut = _wino_filters(lib, [ws[k]], [None], Ci, dev, tile)
             V = _freq_buf(nf, Ci, T, dev)
-            hip.check(lib.lgd_wino_in(hip.ptr_array(cur), hw, L, N, Ci, tile, hip.ptr(V), None, None, hip.stream_ptr()), "lgd_wino_in")
+            hip.check(lib.lgd_wino_in(hip.ptr_array(cur), hw, L, N, Ci, tile, hip.ptr(V), None, None, None, hip.stream_ptr()), "lgd_wino_in")
             _count_bytes("wino_in_kernel", (px + fb) * Ci)
             M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
             bits = torch.empty((Co, T), dtype=mdt, device=dev) if relus[k] else None
@@ -1100,20 +1167,37 @@ def conv3x3_levels(xs, w, b=None, relu=False, scale=None, pre=None):
     if _wino_ok(xs, w):
         return list(_Conv3x3.apply(w, b, bool(relu), _WINO_TILE, *xs, scale=scale, pre=pre))
     if pre is not None:
-        xs = [bias_act(x, pre, None, True) for x in xs]
+        xs = _apply_pre(xs, pre)
     if scale is not None:
         w = w * scale.view(-1, 1, 1, 1)
     ys = [F.conv2d(x, w, b, 1, 1) for x in xs]
     return [F.relu_(y) for y in ys] if relu else ys
 
 
-def conv3x3_shared_input(xs, filters, relu=False):
+def _apply_pre(xs, pre):
+    """the pre-activation of conv3x3_levels as its own pass (problems that stay on the library's convolutions): per-channel bias + ReLU,
+    or the (L*N, C, 2) scale / shift of a folded GroupNorm + ReLU"""
+    if pre.dim() == 1:
+        return [bias_act(x, pre, None, True) for x in xs]
+    # the gradient handed back for x must be the gradient w.r.t. the affine OUTPUT (mask only, as the adjoint input transform of the
+    # Winograd path returns it; group_norm_fold's backward does the rest): value of the affine, derivative 1
+    N = xs[0].shape[0]
+    out = []
+    for l, x in enumerate(xs):
+        t = x.detach() * pre[l * N:(l + 1) * N, :, 0, None, None] + pre[l * N:(l + 1) * N, :, 1, None, None]
+        out.append(F.relu(x + (t - x.detach())))
+    return out
+
+
+def conv3x3_shared_input(xs, filters, relu=False, pre=None):
     """several 3x3 / stride 1 / padding 1 filters [(w, b), ...] [+ ReLU] on the SAME list of maps: one input transform, one
     stacked GEMM, one adjoint input transform for the summed input gradient (see _Conv3x3K).  Returns one list of maps per filter."""
     xs = list(xs)
     if len(filters) > 1 and all(_wino_ok(xs, w) for w, _ in filters):
-        ys = _Conv3x3K.apply(len(filters), bool(relu), _WINO_TILE, None, None, *[t for wb in filters for t in wb], *xs)
+        ys = _Conv3x3K.apply(len(filters), bool(relu), _WINO_TILE, None, pre, *[t for wb in filters for t in wb], *xs)
         return [list(ys[k * len(xs):(k + 1) * len(xs)]) for k in range(len(filters))]
+    if pre is not None:
+        xs = _apply_pre(xs, pre)
     return [conv3x3_levels(xs, w, b, relu) for w, b in filters]
 
 
@@ -1164,8 +1248,8 @@ class Conv3x3(torch.nn.Conv2d):
     def forward(self, x):
         return conv3x3(x, self.weight, self.bias)
 
-    def levels(self, xs, relu=False):
-        return conv3x3_levels(xs, self.weight, self.bias, relu)
+    def levels(self, xs, relu=False, pre=None):
+        return conv3x3_levels(xs, self.weight, self.bias, relu, pre=pre)
 
 
 # ------------------------------------------------------------------------------------------------ timing

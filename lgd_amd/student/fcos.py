@@ -55,25 +55,28 @@ class FCOSHead(nn.Module):
 
     def forward(self, features):
         """features: the L pyramid levels, or 2L maps (student + teacher pyramids, one pass).  Every tower layer is ONE
-        Winograd conv over all maps + ONE fused GroupNorm(32)+ReLU call over all maps."""
+        Winograd conv over all maps + ONE GroupNorm(32) statistics pass over all maps; the normalisation + ReLU itself runs inside the
+        next convolution's input transform."""
         nl = len(self.fpn_strides)
         c = b = list(features)
+        pc = pb = None   # (scale, shift) of the previous layer's GroupNorm + ReLU, applied by the next convolution's input transform
         for i in range(0, len(self.cls_subnet), 3):
             gc, gb = self.cls_subnet[i + 1], self.bbox_subnet[i + 1]
             if i == 0:  # the towers' first convs read the same maps: one input transform / stacked GEMM / summed input gradient
                 c, b = ops.conv3x3_shared_input(c, [(self.cls_subnet[0].weight, self.cls_subnet[0].bias),
                                                     (self.bbox_subnet[0].weight, self.bbox_subnet[0].bias)])
             else:
-                c, b = self.cls_subnet[i].levels(c), self.bbox_subnet[i].levels(b)
-            c = ops.group_norm_relu(c, gc.num_groups, gc.weight, gc.bias, relu=True)
-            b = ops.group_norm_relu(b, gb.num_groups, gb.weight, gb.bias, relu=True)
+                c, b = self.cls_subnet[i].levels(c, pre=pc), self.bbox_subnet[i].levels(b, pre=pb)
+            # GroupNorm(32) + ReLU: statistics only; the apply pass is folded into the next convolution's load (ops.group_norm_fold)
+            pc, c = ops.group_norm_fold(c, gc.num_groups, gc.weight, gc.bias)
+            pb, b = ops.group_norm_fold(b, gb.num_groups, gb.weight, gb.bias)
         # centerness shares its input with bbox_pred (or cls_score): same sharing
         if self.centerness_on_reg:
-            logits = self.cls_score.levels(c)
-            regs, ctr = ops.conv3x3_shared_input(b, [(self.bbox_pred.weight, self.bbox_pred.bias), (self.centerness.weight, self.centerness.bias)])
+            logits = self.cls_score.levels(c, pre=pc)
+            regs, ctr = ops.conv3x3_shared_input(b, [(self.bbox_pred.weight, self.bbox_pred.bias), (self.centerness.weight, self.centerness.bias)], pre=pb)
         else:
-            regs = self.bbox_pred.levels(b)
-            logits, ctr = ops.conv3x3_shared_input(c, [(self.cls_score.weight, self.cls_score.bias), (self.centerness.weight, self.centerness.bias)])
+            regs = self.bbox_pred.levels(b, pre=pb)
+            logits, ctr = ops.conv3x3_shared_input(c, [(self.cls_score.weight, self.cls_score.bias), (self.centerness.weight, self.centerness.bias)], pre=pc)
         reg = []
         for i, r in enumerate(regs):
             lvl = i % nl

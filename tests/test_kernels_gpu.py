@@ -1142,6 +1142,40 @@ def test_group_norm_relu_fwd_bwd(B, C, G, level_hw, relu, affine):
         assert cm.rel_err(ga.grad, ga64.grad) < 1e-4 and cm.rel_err(be.grad, be64.grad) < 1e-4
 
 
+@pytest.mark.parametrize("tile", [4, 6, 0])
+@pytest.mark.parametrize("B,C,Co,G,level_hw", [(2, 64, 64, 8, [(13, 21), (7, 11)]), (2, 256, 80, 32, [(20, 28), (10, 12), (5, 7)])])
+def test_group_norm_folded_into_conv3x3(tile, B, C, Co, G, level_hw):
+    """conv3x3(relu(GroupNorm(x))) with the normalisation + ReLU applied by the convolution's input transform (ops.group_norm_fold +
+    conv3x3_levels(pre=affine): the normalised maps are never written) against the fp64 definition: output, gradients of x, gamma, beta,
+    the filter and its bias; tile 0: the same composition on the library's convolutions (problems below the Winograd threshold)."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    xs = [torch.from_numpy(synth.det_uniform((B, C, h, w), 1400 + i, -2.0, 3.0)).to(DEV).requires_grad_(True) for i, (h, w) in enumerate(level_hw)]
+    gys = [torch.from_numpy(synth.det_uniform((B, Co, h, w), 1420 + i, -1.0, 1.0)).to(DEV) for i, (h, w) in enumerate(level_hw)]
+    ga = torch.from_numpy(synth.det_uniform((C,), 1440, 0.5, 1.5)).to(DEV).requires_grad_(True)
+    be = torch.from_numpy(synth.det_uniform((C,), 1441, -0.5, 0.5)).to(DEV).requires_grad_(True)
+    w = (torch.from_numpy(synth.det_uniform((Co, C, 3, 3), 1442, -1.0, 1.0)) * (2.0 / (9 * C)) ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(synth.det_uniform((Co,), 1443, -0.1, 0.1)).to(DEV).requires_grad_(True)
+    prev = ops.conv3x3_backend(winograd=tile != 0, min_tiles=0, tile=tile or None)
+    try:
+        aff, maps = ops.group_norm_fold(xs, G, ga, be)
+        ys = ops.conv3x3_levels(maps, w, b, pre=aff)
+        torch.autograd.backward(ys, gys)
+    finally:
+        ops.conv3x3_backend(*prev)
+    x64 = [x.detach().double().requires_grad_(True) for x in xs]
+    p64 = [t.detach().double().requires_grad_(True) for t in (ga, be, w, b)]
+    ref = [F.conv2d(SO.group_norm_relu(x, G, p64[0], p64[1], True), p64[2], p64[3], 1, 1) for x in x64]
+    torch.autograd.backward(ref, [g.double() for g in gys])
+    tol = 1e-4 if tile == 6 else 5e-5
+    for y, r, x, xr in zip(ys, ref, xs, x64):
+        assert cm.rel_err(y, r) < tol
+        ok, msg = cm.kink_robust_close(x.grad, xr.grad, tol=2 * tol, max_outlier_frac=1e-3, max_rel=5e-3)
+        assert ok, msg
+    for t, r in zip((ga, be, w, b), p64):
+        assert cm.rel_err(t.grad, r.grad) < 2 * tol
+
+
 # ------------------------------------------------------------------------------------------- FCOS target assignment
 def counts_mask(counts, R):
     """(B,R) bool: images that have ground truth (images without boxes get zero targets, not the formula)."""

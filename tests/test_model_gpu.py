@@ -857,20 +857,25 @@ def test_fcos_head_gradients_fp64_under_product_masks(tile):
     feats = [torch.from_numpy(f).to(DEV).requires_grad_(True) for f in feats_np]
     L = len(feats)
     gn_masks = []
-    real_gn = ops.group_norm_relu
+    real_fold = ops.group_norm_fold
 
-    def gn(xs, *a, **k):
-        ys = real_gn(xs, *a, **k)
-        gn_masks.append([(y.detach() > 0).cpu() for y in ys])
-        return ys
+    def fold(xs, *a, **k):
+        # the GroupNorm + ReLU runs inside the next convolution's input transform as relu(fma(x, scale, shift)) with the (scale, shift)
+        # this call returns; the sign of an fp32 fma is the sign of the exact value, which fp64 holds (products of two floats are exact)
+        aff, ys = real_fold(xs, *a, **k)
+        N = xs[0].shape[0]
+        a64 = aff.double()
+        gn_masks.append([((x.detach().double() * a64[lv * N:(lv + 1) * N, :, 0, None, None] + a64[lv * N:(lv + 1) * N, :, 1, None, None]) > 0).cpu()
+                         for lv, x in enumerate(xs)])
+        return aff, ys
     prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=tile)
-    ops.group_norm_relu = gn
+    ops.group_norm_fold = fold
     try:
         outs = dict(zip(("logits", "reg", "ctr"), head(feats)))
         total = sum((t * torch.from_numpy(probes[kind][i]).to(DEV)).sum() for kind, maps in outs.items() for i, t in enumerate(maps))
         total.backward()
     finally:
-        ops.group_norm_relu = real_gn
+        ops.group_norm_fold = real_fold
         ops.conv3x3_backend(*prev)
     assert len(gn_masks) == 8   # per tower layer: the cls tower's call, then the bbox tower's
     reg_masks = [(t.detach() > 0).cpu() for t in outs["reg"]]
