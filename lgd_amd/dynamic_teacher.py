@@ -48,10 +48,10 @@ def get_CONVS(nr_layers, channels, has_norm, has_relu=True, nr_groups=1, affine_
     return nn.Sequential(*[unit() for _ in range(nr_layers)])
 
 
-def _lin_ln_relu(layer, x, relu=True):
+def _lin_ln_relu(layer, x):
     """Linear / pointwise Conv1d (length-1 sequences == row-wise linear map) -> LayerNorm(no affine) -> ReLU:
-    fp32 MFMA GEMM kernel + one fused row-LN(+ReLU) kernel."""
-    return ops.row_ln(ops.linear(x, layer.weight, layer.bias), relu)
+    fp32 MFMA GEMM kernel + one fused row-LN + ReLU kernel, one autograd node."""
+    return ops.mlp_ln_relu(x, [(layer.weight, layer.bias)])
 
 
 # ----------------------------------------------------------------------------------------- STN
@@ -69,12 +69,11 @@ class STN(nn.Module):
         self.k = k
 
     def forward(self, x):
-        h = _lin_ln_relu(self.conv1, x)
-        h = _lin_ln_relu(self.conv2, h)
-        h = _lin_ln_relu(self.conv3, h)  # the max over the length-1 axis (spatial_transformer.py:34) is a no-op
-        h = _lin_ln_relu(self.fc1, h)
-        h = _lin_ln_relu(self.fc2, h)
-        return ops.linear(h, self.fc3.weight, self.fc3.bias).view(-1, self.k, self.k)
+        # the max over the length-1 axis between conv3 and fc1 (spatial_transformer.py:34) is a no-op: five Linear -> LN -> ReLU layers
+        # and fc3 as ONE autograd node (ops.mlp_ln_relu)
+        h = ops.mlp_ln_relu(x, [(m.weight, m.bias) for m in (self.conv1, self.conv2, self.conv3, self.fc1, self.fc2)],
+                            last=(self.fc3.weight, self.fc3.bias))
+        return h.view(-1, self.k, self.k)
 
 
 # ----------------------------------------------------------------------------------------- label encoder
@@ -142,7 +141,7 @@ class LabelEncoder(nn.Module):
         hfeat = _lin_ln_relu(self.conv1, x1)
         m2 = self.stn_feat(hfeat)
         xf = ops.row_vecmat(hfeat, m2)                   # label_encoder.py:248
-        h3 = _lin_ln_relu(self.conv3, _lin_ln_relu(self.conv2, xf))
+        h3 = ops.mlp_ln_relu(xf, [(self.conv2.weight, self.conv2.bias), (self.conv3.weight, self.conv3.bias)])
         g = ops.segment_max_broadcast(h3, img_off)       # per-image max, broadcast back to the image's rows
         out = _lin_ln_relu(self.conv4, torch.cat([xf, g], 1))
         return out, m1, m2, boxes, {"h": h, "w": w}, inst_labels, counts

@@ -615,6 +615,106 @@ def row_ln(x, relu):
     return _RowLn.apply(x, bool(relu))
 
 
+class _MlpLnRelu(torch.autograd.Function):
+    """A ladder of Linear -> LayerNorm(no affine) -> ReLU layers [+ a last Linear without normalisation] as ONE autograd node: the same
+    launches as linear() / row_ln() per layer (lgd_gemm_batch, lgd_rowln_fwd / _bwd), issued back to back from one Python frame.  The
+    label encoder is 15 such pairs on ~10^2 rows -- kernels of 7-20 us whose per-layer autograd.Function round trips (~30 us of host
+    each, forward and backward) were the largest recurring gap of the step at 2 images per GPU.
+    apply(n_ln, has_last, x, w_1, b_1, ..., w_n, b_n): n_ln normalised layers, then one plain layer if has_last."""
+
+    @staticmethod
+    def forward(ctx, n_ln, has_last, x, *params):
+        lib = hip.load()
+        hip.require_gpu(x, *[t for t in params if t is not None])
+        x = hip.dense_f32(x)
+        n = n_ln + (1 if has_last else 0)
+        ws = [hip.dense_f32(params[2 * i]).reshape(params[2 * i].shape[0], -1) for i in range(n)]
+        bs = [hip.dense_f32(params[2 * i + 1]) if params[2 * i + 1] is not None else None for i in range(n)]
+        M = x.shape[0]
+        dev = x.device
+        st = hip.stream_ptr()
+        ins, pres, stats = [], [], []
+        cur = x
+        for i in range(n):
+            N, K = ws[i].shape
+            if cur.shape[1] != K:
+                raise hip.LgdHipError("layer %d expects %d inputs, got %d" % (i, K, cur.shape[1]))
+            y = torch.empty((M, N), dtype=torch.float32, device=dev)
+            _gemm_batch([_gemm((cur, 0), (K, 1), (ws[i], 0), (K, 1), (y, 0), (N, 1), M, N, K, bias=(bs[i], 0) if bs[i] is not None else None)])
+            ins.append(cur)
+            if i < n_ln:
+                z = torch.empty_like(y)
+                sv = torch.empty((M, 2), dtype=torch.float32, device=dev)
+                hip.check(lib.lgd_rowln_fwd(hip.ptr(y), M, N, 1, hip.ptr(z), hip.ptr(sv), st), "lgd_rowln_fwd")
+                pres.append(y)
+                stats.append(sv)
+                cur = z
+            else:
+                cur = y
+        ctx.save_for_backward(*ins, *pres, *stats, *ws)
+        ctx.meta = (n_ln, n, [b is not None for b in bs])
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = hip.load()
+        n_ln, n, has_b = ctx.meta
+        t = ctx.saved_tensors
+        ins, pres, stats, ws = t[:n], t[n:n + n_ln], t[n + n_ln:n + 2 * n_ln], t[n + 2 * n_ln:]
+        dy = hip.dense_f32(dy)
+        dev = dy.device
+        st = hip.stream_ptr()
+        M = dy.shape[0]
+        grads = [None] * (2 * n)
+        need_x = ctx.needs_input_grad[2]
+        for i in range(n - 1, -1, -1):
+            N, K = ws[i].shape
+            if i < n_ln:   # through ReLU + LayerNorm to the gradient of the layer's GEMM output
+                d = torch.empty_like(dy)
+                hip.check(lib.lgd_rowln_bwd(hip.ptr(pres[i]), hip.ptr(dy), hip.ptr(stats[i]), M, N, 1, hip.ptr(d), st), "lgd_rowln_bwd")
+                dy = d
+            x = ins[i]
+            probs = []
+            if ctx.needs_input_grad[3 + 2 * i]:
+                dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+                db = torch.empty((N,), dtype=torch.float32, device=dev) if has_b[i] and ctx.needs_input_grad[4 + 2 * i] else None
+                probs.append(_gemm((dy, 0), (1, N), (x, 0), (1, K), (dw, 0), (K, 1), N, K, M, rowsum=(db, 0) if db is not None else None))
+                grads[2 * i], grads[2 * i + 1] = dw, db
+            dxp = None
+            if i > 0 or need_x:
+                # dX = dY W reduces over N; a wide layer on few rows (T-Net fc3: N = 7056) is cut into slices (see _Linear.backward)
+                S = min(14, max(1, N // 512)) if (N > 1024 and ((M + 63) // 64) * ((K + 63) // 64) < 64) else 1
+                step = ((N + S - 1) // S + 3) // 4 * 4
+                S = (N + step - 1) // step
+                dxp = torch.empty((S, M, K), dtype=torch.float32, device=dev)
+                for j in range(S):
+                    n0, n1 = j * step, min(N, (j + 1) * step)
+                    probs.append(_gemm((dy, n0), (N, 1), (ws[i], n0 * K), (1, K), (dxp, j * M * K), (K, 1), M, K, n1 - n0))
+            if probs:
+                _gemm_batch(probs)
+            if dxp is not None:
+                dy = dxp[0] if dxp.shape[0] == 1 else dxp.sum(0)
+        dx = dy if need_x else None
+        return (None, None, dx, *grads)
+
+
+def mlp_ln_relu(x, layers, last=None):
+    """row_ln(linear(x, w, b), relu=True) for every (w, b) of `layers` in sequence, then linear(., *last) if given, as one autograd node
+    (weights may be Conv1d-shaped (N, K, 1): pointwise convolutions on length-1 sequences).  [ref: spatial_transformer.py:30-40,
+    label_encoder.py:243-270]"""
+    if not _MLP_FUSED:   # the same launches, one autograd node per op (tests observe the per-layer activations through row_ln)
+        for w, b in layers:
+            x = row_ln(linear(x, w, b), True)
+        return linear(x, *last) if last is not None else x
+    params = []
+    for w, b in list(layers) + ([last] if last is not None else []):
+        params += [w.reshape(w.shape[0], -1) if w.dim() != 2 else w, b]
+    return _MlpLnRelu.apply(len(layers), last is not None, x, *params)
+
+
+_MLP_FUSED = True
+
+
 class _RowVecMat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, M):

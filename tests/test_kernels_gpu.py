@@ -434,6 +434,37 @@ def test_focal_loss_normalised_one_pass(N, A, K, level_hw, gamma, upstream):
         assert cm.rel_err(a.grad, b.grad) < 1e-6
 
 
+def test_mlp_ladder_equals_layers():
+    """ops.mlp_ln_relu (the label encoder's Linear -> LayerNorm -> ReLU ladders as ONE autograd node) issues the same launches as
+    row_ln(linear(.)) layer by layer: outputs and every gradient bit-identical, with and without the last plain layer, incl. the wide
+    T-Net fc3 (7056 outputs: sliced dX)."""
+    from lgd_amd import ops
+    dims = [84, 64, 128, 1024, 512, 256, 7056]
+    T = 23
+    x0 = torch.from_numpy(synth.det_uniform((T, dims[0]), 1500, -1.0, 1.0))
+    ws = [torch.from_numpy(synth.det_uniform((dims[i + 1], dims[i]), 1510 + i, -1.0, 1.0)) * (1.0 / dims[i]) ** 0.5 for i in range(6)]
+    bs = [torch.from_numpy(synth.det_uniform((dims[i + 1],), 1520 + i, -0.1, 0.1)) for i in range(6)]
+    for last in (True, False):
+        res = []
+        for fused in (True, False):
+            x = x0.to(DEV).requires_grad_(True)
+            w = [t.to(DEV).requires_grad_(True) for t in ws]
+            b = [t.to(DEV).requires_grad_(True) for t in bs]
+            ops._MLP_FUSED = fused
+            try:
+                nl = 5 if last else 6
+                y = ops.mlp_ln_relu(x, list(zip(w[:nl], b[:nl])), last=(w[5], b[5]) if last else None)
+            finally:
+                ops._MLP_FUSED = True
+            g = torch.from_numpy(synth.det_uniform(tuple(y.shape), 1530, -1.0, 1.0)).to(DEV)
+            y.backward(g)
+            res.append([y.detach(), x.grad] + [t.grad for t in w[:6 if not last else 6]] + [t.grad for t in b])
+        for a, c in zip(*res):
+            assert (a is None) == (c is None)
+            if a is not None:
+                assert torch.equal(a, c)
+
+
 # ------------------------------------------------------------------------------------------- K6 label-encoder ops
 @pytest.mark.parametrize("name", list(cm.CASES) + ["c2_masks_800x1344"])
 def test_box_descriptors_bit_exact(name):

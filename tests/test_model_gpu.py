@@ -769,6 +769,7 @@ def _run_product_capturing_masks(name, coef):
     try:
         for k, f in patched.items():
             setattr(ops, k, f)
+        ops._MLP_FUSED = False   # the label encoder's ladders layer by layer (same launches: test_mlp_ladder_equals_layers), so that row_ln is seen
         teacher = _teacher(name)
         d = D(coef)
         d.adapter["distill"].load_state_dict(cm.adapter_params(), strict=True)
@@ -782,6 +783,7 @@ def _run_product_capturing_masks(name, coef):
         total = loss + sum((tea[k] * pr[k].to(DEV)).sum() for k in O.LEVELS)
         total.backward()
     finally:
+        ops._MLP_FUSED = True
         for k, f in real.items():
             setattr(ops, k, f)
         ops.conv3x3_backend(*prev)
