@@ -315,9 +315,10 @@ int lgd_box_sum(const float* const* feats_host, const int32_t* level_hw_host, in
     lgd::PoolArgs a;
     const int CH = lgd::pool_chunk(level_hw_host, L, B, C, max_n);
     const int nblk = lgd::pool_fill(a, feats_host, level_hw_host, L, B, C, T, max_n, img_off, geom, CH);
-    if (nblk < 0 || !ws || !out) return LGD_EINVAL;
+    if (nblk < 0) return LGD_EINVAL;
+    if (T == 0) return LGD_OK;      // no boxes at all: nothing to write (out and ws are empty)
+    if (!ws || !out) return LGD_EINVAL;
     a.part = ws; a.out = out; a.normalize = normalize; a.skip_last = skip_last;
-    if (T == 0) return LGD_OK;
     lgd::pool_launch<0>("box_sum_kernel", a, nblk, CH, (hipStream_t)stream);
     return lgd::check_launch();
 }
@@ -328,9 +329,10 @@ int lgd_gn_pool_fwd(const float* const* x_host, const float* gn_stats, const int
     lgd::PoolArgs a;
     const int CH = lgd::pool_chunk(level_hw_host, L, B, C, max_n);
     const int nblk = lgd::pool_fill(a, x_host, level_hw_host, L, B, C, T, max_n, img_off, geom, CH);
-    if (nblk < 0 || !gn_stats || !ws || !out || !raw) return LGD_EINVAL;
-    a.part = ws; a.out = out; a.raw = raw; a.gn_stats = gn_stats; a.normalize = 1;
+    if (nblk < 0) return LGD_EINVAL;
     if (T == 0) return LGD_OK;
+    if (!gn_stats || !ws || !out || !raw) return LGD_EINVAL;
+    a.part = ws; a.out = out; a.raw = raw; a.gn_stats = gn_stats; a.normalize = 1;
     lgd::pool_launch<1>("gn_pool_kernel", a, nblk, CH, (hipStream_t)stream);
     return lgd::check_launch();
 }
