@@ -65,75 +65,122 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(DcnArgs a) {
     }
 }
 
-// thread per (n, tap, pixel) and channel slice (blockIdx.y): loops over the slice's channels; dx by atomic scatter, d offset /
-// d mask summed in registers (one atomic per slice when the channels are split to fill the GPU on the small stages).
-// The kernel is bound by the L2's float-atomic rate (~210 G lane-atomics/s: four per channel and sample).  Neighbouring lanes are
-// neighbouring output pixels of one tap, and with smooth offsets lane L+1's top-left cell IS lane L's top-right cell: in that case
-// lane L hands its two right-column contributions to lane L+1 (one DPP shift each), which adds them to its own left-column ones
-// before the atomic -- two atomics per lane instead of four wherever the sampling grid is locally regular, any offsets stay exact
-// (the hand-over happens only where the two cells coincide).
+// thread per (n, tap, column, group of R output rows) and channel slice (blockIdx.y): loops over the slice's channels; dx by atomic
+// scatter, d offset / d mask summed in registers (one atomic per slice when the channels are split to fill the GPU on the small stages).
+// The kernel is bound by the L2's float atomics, and their cost is per 64-byte REQUEST, not per lane (measured: an 8 x 8 pixel tile per
+// wave with 81 lane-atomics per 64 lanes instead of 130 ran 1.7x slower -- 18 requests per channel against 10).  So the work is arranged
+// to issue few, full requests:
+//   * lanes are neighbouring output pixels of one row; with smooth offsets lane L+1's top-left cell IS lane L's top-right cell: lane L
+//     hands its two right-column contributions to lane L+1 (one DPP shift each), which adds them to its own left-column ones;
+//   * a lane walks R = 4 vertically adjacent pixels; where row r+1's top-left cell IS row r's bottom-left cell, row r's bottom
+//     contributions are carried in registers into row r+1's top ones: R + 1 row requests per channel instead of 2 R.
+// Any offsets stay exact: the hand-overs happen only where the integer cell coordinates coincide, and a slot that holds exactly
+// zero issues nothing.
+#ifndef LGD_DCN_ROWS
+#define LGD_DCN_ROWS 4
+#endif
+constexpr int kDcnRows = LGD_DCN_ROWS;
+struct DcnPix {
+    float m, wy0, wy1, wx0, wx1, gy, gx, gm;
+    long long o00;
+    int y0, x0, pix;
+    bool in, ok00, ok01, ok10, ok11, takeL, giveR, live, down;   // down: this row's bottom cells are the next row's top cells
+};
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
-    const int HoWo = a.Ho * a.Wo;
-    const long long total = (long long)a.N * 9 * HoWo;
+    constexpr int R = kDcnRows;
+    const int HoWo = a.Ho * a.Wo, RG = (a.Ho + R - 1) / R;
+    const long long total = (long long)a.N * 9 * RG * a.Wo;
     const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = i0 < total;
-    const long long i = live ? i0 : total - 1;      // no early exit: the lanes exchange values below
-    const int pix = (int)(i % HoWo), k = (int)((i / HoWo) % 9), n = (int)(i / ((long long)HoWo * 9));
-    const int ho = pix / a.Wo, wo = pix % a.Wo, ky = k / 3, kx = k % 3;
-    const float* off = a.offset + (size_t)n * 18 * HoWo + pix;
-    const float m = a.mask ? a.mask[((size_t)n * 9 + k) * HoWo + pix] : 1.f;
-    const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + off[(size_t)(2 * k) * HoWo];
-    const float pxx = (float)(wo * a.stride - a.pad + kx * a.dil) + off[(size_t)(2 * k + 1) * HoWo];
-    const Bilin b = bilin_setup(py, pxx, a.H, a.W);
-    const bool in = live && b.in;
-    const float wy0 = 1.f - b.wy1, wx0 = 1.f - b.wx1;
-    const bool y0ok = in && b.y0 >= 0 && b.y0 < a.H, y1ok = in && b.y0 + 1 >= 0 && b.y0 + 1 < a.H;
-    const bool x0ok = b.x0 >= 0 && b.x0 < a.W, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < a.W;
-    const bool ok00 = y0ok && x0ok, ok01 = y0ok && x1ok, ok10 = y1ok && x0ok, ok11 = y1ok && x1ok;
-    const long long o00 = (long long)b.y0 * a.W + b.x0;          // may be negative where the sample hangs over the border
-    // lane L+1 takes over lane L's right column iff it samples the same image, the same rows and the column one to the right
+    const bool alive = i0 < total;
+    const long long i = alive ? i0 : total - 1;      // no early exit: the lanes exchange values below
+    const int wo = (int)(i % a.Wo), rg = (int)((i / a.Wo) % RG), k = (int)((i / ((long long)a.Wo * RG)) % 9);
+    const int n = (int)(i / ((long long)a.Wo * RG * 9));
+    const int ky = k / 3, kx = k % 3;
     const int lane = threadIdx.x & 63;
-    const unsigned ln = wave_shr1((unsigned)n), ly = wave_shr1((unsigned)b.y0), lx = wave_shr1((unsigned)b.x0), lin = wave_shr1(in ? 1u : 0u);
-    const bool takeL = lane > 0 && in && lin && ln == (unsigned)n && ly == (unsigned)b.y0 && lx + 1u == (unsigned)b.x0;
-    // (its own statement: inside `lane < 63 && ...` the shift would run with lane 63 masked off, and lane 62 would read 0 from it)
-    const unsigned rtake = wave_shl1(takeL ? 1u : 0u);
-    const bool giveR = (lane < 63) & (rtake != 0u);
-    float gy = 0.f, gx = 0.f, gm = 0.f;
+    const unsigned ln = wave_shr1((unsigned)n);
+    DcnPix q[R];
+    #pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int ho = rg * R + r;
+        DcnPix& t = q[r];
+        t.live = alive && ho < a.Ho;
+        t.pix = t.live ? ho * a.Wo + wo : 0;
+        const float* off = a.offset + (size_t)n * 18 * HoWo + t.pix;
+        t.m = a.mask ? a.mask[((size_t)n * 9 + k) * HoWo + t.pix] : 1.f;
+        const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + off[(size_t)(2 * k) * HoWo];
+        const float pxx = (float)(wo * a.stride - a.pad + kx * a.dil) + off[(size_t)(2 * k + 1) * HoWo];
+        const Bilin b = bilin_setup(py, pxx, a.H, a.W);
+        t.in = t.live && b.in;
+        t.y0 = b.y0; t.x0 = b.x0; t.wy1 = b.wy1; t.wx1 = b.wx1; t.wy0 = 1.f - b.wy1; t.wx0 = 1.f - b.wx1;
+        const bool y0ok = t.in && b.y0 >= 0 && b.y0 < a.H, y1ok = t.in && b.y0 + 1 >= 0 && b.y0 + 1 < a.H;
+        const bool x0ok = b.x0 >= 0 && b.x0 < a.W, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < a.W;
+        t.ok00 = y0ok && x0ok; t.ok01 = y0ok && x1ok; t.ok10 = y1ok && x0ok; t.ok11 = y1ok && x1ok;
+        t.o00 = (long long)b.y0 * a.W + b.x0;          // may be negative where the sample hangs over the border
+        // lane L+1 takes over lane L's right column iff it samples the same image, the same rows and the column one to the right
+        // (the shifts as statements of their own: a DPP move that ends up under a lane mask reads 0 from the masked-off source lanes)
+        const unsigned ly = wave_shr1((unsigned)b.y0), lx = wave_shr1((unsigned)b.x0), lin = wave_shr1(t.in ? 1u : 0u);
+        t.takeL = lane > 0 && t.in && lin && ln == (unsigned)n && ly == (unsigned)b.y0 && lx + 1u == (unsigned)b.x0;
+        const unsigned rtake = wave_shl1(t.takeL ? 1u : 0u);
+        t.giveR = (lane < 63) & (rtake != 0u);
+        t.gy = t.gx = t.gm = 0.f;
+    }
+    #pragma unroll
+    for (int r = 0; r < R; ++r)
+        q[r].down = r + 1 < R && q[r].in && q[r + 1].in && q[r + 1].y0 == q[r].y0 + 1 && q[r + 1].x0 == q[r].x0;
     const int c0 = blockIdx.y * a.cchunk, c1 = min(a.C, c0 + a.cchunk);
-    for (int c = c0; c < c1; ++c) {                                // wave-uniform trip count: every lane runs the exchange
+    for (int c = c0; c < c1; ++c) {                                // wave-uniform trip count: every lane runs the exchanges
         const size_t plane = ((size_t)n * a.C + c) * a.H * a.W;
         const float* p = a.x + plane;
         float* dp = a.dx + plane;
-        const float g = in ? a.dcol[(((size_t)n * a.C + c) * 9 + k) * HoWo + pix] : 0.f;
-        const float v00 = ok00 ? p[o00] : 0.f, v01 = ok01 ? p[o00 + 1] : 0.f;
-        const float v10 = ok10 ? p[o00 + a.W] : 0.f, v11 = ok11 ? p[o00 + a.W + 1] : 0.f;
-        const float gmk = g * m;
-        float a00 = ok00 ? gmk * wy0 * wx0 : 0.f, a01 = ok01 ? gmk * wy0 * b.wx1 : 0.f;
-        float a10 = ok10 ? gmk * b.wy1 * wx0 : 0.f, a11 = ok11 ? gmk * b.wy1 * b.wx1 : 0.f;
-        // the left neighbour's right column = my left column's cells (valid iff mine are).  Selects, not a branch, and the shifts as
-        // statements of their own: a DPP move that ends up under a lane mask reads 0 from the masked-off source lanes
-        const float r01 = wave_shr1(a01), r11 = wave_shr1(a11);
-        a00 += takeL ? r01 : 0.f;
-        a10 += takeL ? r11 : 0.f;
-        if (ok00) unsafeAtomicAdd(dp + o00, a00);
-        if (ok10) unsafeAtomicAdd(dp + o00 + a.W, a10);
-        if (!giveR) {
-            if (ok01) unsafeAtomicAdd(dp + o00 + 1, a01);
-            if (ok11) unsafeAtomicAdd(dp + o00 + a.W + 1, a11);
+        const float* dc = a.dcol + (((size_t)n * a.C + c) * 9 + k) * HoWo;
+        float g[R], v00[R], v01[R], v10[R], v11[R];
+        #pragma unroll
+        for (int r = 0; r < R; ++r) {                              // all loads of the channel first
+            const DcnPix& t = q[r];
+            g[r] = t.in ? dc[t.pix] : 0.f;
+            v00[r] = t.ok00 ? p[t.o00] : 0.f; v01[r] = t.ok01 ? p[t.o00 + 1] : 0.f;
+            v10[r] = t.ok10 ? p[t.o00 + a.W] : 0.f; v11[r] = t.ok11 ? p[t.o00 + a.W + 1] : 0.f;
         }
-        gy += gmk * (wx0 * (v10 - v00) + b.wx1 * (v11 - v01));
-        gx += gmk * (wy0 * (v01 - v00) + b.wy1 * (v11 - v10));
-        gm += g * (wy0 * (wx0 * v00 + b.wx1 * v01) + b.wy1 * (wx0 * v10 + b.wx1 * v11));
+        float c10 = 0.f, c11 = 0.f;                                // bottom contributions carried into the next row's top cells
+        #pragma unroll
+        for (int r = 0; r < R; ++r) {
+            DcnPix& t = q[r];
+            const float gmk = g[r] * t.m;
+            float a00 = t.ok00 ? gmk * t.wy0 * t.wx0 : 0.f, a01 = t.ok01 ? gmk * t.wy0 * t.wx1 : 0.f;
+            float a10 = t.ok10 ? gmk * t.wy1 * t.wx0 : 0.f, a11 = t.ok11 ? gmk * t.wy1 * t.wx1 : 0.f;
+            // right column -> right neighbour's left column.  Selects, not branches
+            const float r01 = wave_shr1(a01), r11 = wave_shr1(a11);
+            a00 += t.takeL ? r01 : 0.f;
+            a10 += t.takeL ? r11 : 0.f;
+            a01 = t.giveR ? 0.f : a01;
+            a11 = t.giveR ? 0.f : a11;
+            a00 += c10; a01 += c11;                                // the row above's bottom cells (zero unless they coincide with these)
+            if (t.ok00 && a00 != 0.f) unsafeAtomicAdd(dp + t.o00, a00);
+            if (t.ok01 && a01 != 0.f) unsafeAtomicAdd(dp + t.o00 + 1, a01);
+            if (t.down) { c10 = a10; c11 = a11; }
+            else {
+                c10 = c11 = 0.f;
+                if (t.ok10 && a10 != 0.f) unsafeAtomicAdd(dp + t.o00 + a.W, a10);
+                if (t.ok11 && a11 != 0.f) unsafeAtomicAdd(dp + t.o00 + a.W + 1, a11);
+            }
+            t.gy += gmk * (t.wx0 * (v10[r] - v00[r]) + t.wx1 * (v11[r] - v01[r]));
+            t.gx += gmk * (t.wy0 * (v01[r] - v00[r]) + t.wy1 * (v11[r] - v10[r]));
+            t.gm += g[r] * (t.wy0 * (t.wx0 * v00[r] + t.wx1 * v01[r]) + t.wy1 * (t.wx0 * v10[r] + t.wx1 * v11[r]));
+        }
     }
-    if (!live) return;
-    float* oy = a.doffset + ((size_t)n * 18 + 2 * k) * HoWo + pix;
-    float* om = a.dmask ? a.dmask + ((size_t)n * 9 + k) * HoWo + pix : nullptr;
-    if (gridDim.y == 1) {
-        oy[0] = gy; oy[HoWo] = gx;
-        if (om) om[0] = gm;
-    } else if (b.in) {  // outputs zeroed by the host entry
-        unsafeAtomicAdd(oy, gy); unsafeAtomicAdd(oy + HoWo, gx);
-        if (om) unsafeAtomicAdd(om, gm);
+    #pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const DcnPix& t = q[r];
+        if (!t.live) continue;
+        float* oy = a.doffset + ((size_t)n * 18 + 2 * k) * HoWo + t.pix;
+        float* om = a.dmask ? a.dmask + ((size_t)n * 9 + k) * HoWo + t.pix : nullptr;
+        if (gridDim.y == 1) {
+            oy[0] = t.gy; oy[HoWo] = t.gx;
+            if (om) om[0] = t.gm;
+        } else if (t.in) {  // outputs zeroed by the host entry
+            unsafeAtomicAdd(oy, t.gy); unsafeAtomicAdd(oy + HoWo, t.gx);
+            if (om) unsafeAtomicAdd(om, t.gm);
+        }
     }
 }
 
@@ -169,7 +216,7 @@ int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const
     a.dcol = dcol; a.dx = dx; a.doffset = doffset; a.dmask = mask ? dmask : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return LGD_ELAUNCH;
-    const long long total = (long long)N * 9 * a.Ho * a.Wo;
+    const long long total = (long long)N * 9 * ((a.Ho + lgd::kDcnRows - 1) / lgd::kDcnRows) * a.Wo;   // a thread walks kDcnRows output rows
     // split the channel loop until ~0.5 M threads are in flight (res5 has only 19 K (n, tap, pixel) triples)
     int slices = (int)((500000 + total - 1) / total);
     slices = slices < 1 ? 1 : (slices > C / 8 ? (C / 8 > 0 ? C / 8 : 1) : slices);
