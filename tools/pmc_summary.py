@@ -34,7 +34,6 @@ TIMER_NAMES = {
     "gn_finalize_kernel<0>": ["gn_finalize_kernel"], "gn_finalize_kernel<1>": ["gn_bwd_finalize_kernel"],
     "ctx_relu_kernel<0>": ["ctx_relu_kernel"], "ctx_relu_kernel<1>": ["ctx_relu_bwd_kernel"],
     "focal_kernel<0>": ["focal_fwd_kernel"], "focal_kernel<1>": ["focal_bwd_kernel"], "focal_kernel<2>": ["focal_fwd_grad_kernel"],
-    "paint_kernel<1>": ["gn_pool_bwd_apply_kernel"], "paint_kernel<2>": ["box_paint_kernel"],
     "rowln_kernel<0>": ["rowln_kernel"], "rowln_kernel<1>": ["rowln_bwd_kernel"],
     "gg_stats_kernel<0>": ["gn_group_stats_kernel"], "gg_stats_kernel<1>": ["gn_group_bwd_stats_kernel"],
     "gg_apply_kernel<0>": ["gn_group_apply_kernel"], "gg_apply_kernel<1>": ["gn_group_bwd_apply_kernel"],
@@ -50,6 +49,9 @@ def short(name):
     n = name.replace("lgd::", "")
     if n in TIMER_NAMES:
         return TIMER_NAMES[n]
+    m = re.match(r"paint_kernel<([12]),", n)                                          # <MODE, SPLIT>
+    if m:
+        return ["gn_pool_bwd_apply_kernel" if m.group(1) == "1" else "box_paint_kernel"]
     m = re.match(r"box_pool_kernel<([01]),", n)                                       # <GN, CH>
     if m:
         return ["gn_pool_kernel" if m.group(1) == "1" else "box_sum_kernel"]
