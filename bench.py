@@ -66,6 +66,7 @@ def parse():
                          "configs/Base-RetinaNet.yaml:26) instead of every image at --height x --width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
+    ap.add_argument("--no-gn-fold", action="store_true", help="FCOS towers: GroupNorm(32) + ReLU as its own passes instead of inside the next convolution's input transform (A/B runs)")
     ap.add_argument("--head-passes", type=int, default=1, choices=[1, 2],
                     help="1 = one head pass over student + teacher pyramids (default); 2 = the reference's literal two passes")
     ap.add_argument("--cpu-sample-images", type=int, default=1)
@@ -189,6 +190,8 @@ def main():
     torch.manual_seed(0)
     model = build_model(cfg)
     model.fused_head_pass = args.head_passes == 1
+    if args.no_gn_fold and hasattr(model.student.head, "fold_group_norm"):
+        model.student.head.fold_group_norm = False
     trainer = Trainer(cfg, model, device=dev, distributed=True if force_ddp else None, fused_sgd=not args.torch_optimizers)
     d = cfg.MODEL.DISTILLATOR
     it0 = {"distill": max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS),

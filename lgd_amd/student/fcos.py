@@ -52,6 +52,7 @@ class FCOSHead(nn.Module):
                 nn.init.constant_(m.bias, 0)
         nn.init.constant_(self.cls_score.bias, -math.log((1 - f.PRIOR_PROB) / f.PRIOR_PROB))
         self.scales = nn.ModuleList([Scale(1.0) for _ in self.fpn_strides])
+        self.fold_group_norm = True
 
     def forward(self, features):
         """features: the L pyramid levels, or 2L maps (student + teacher pyramids, one pass).  Every tower layer is ONE
@@ -67,9 +68,13 @@ class FCOSHead(nn.Module):
                                                     (self.bbox_subnet[0].weight, self.bbox_subnet[0].bias)])
             else:
                 c, b = self.cls_subnet[i].levels(c, pre=pc), self.bbox_subnet[i].levels(b, pre=pb)
-            # GroupNorm(32) + ReLU: statistics only; the apply pass is folded into the next convolution's load (ops.group_norm_fold)
-            pc, c = ops.group_norm_fold(c, gc.num_groups, gc.weight, gc.bias)
-            pb, b = ops.group_norm_fold(b, gb.num_groups, gb.weight, gb.bias)
+            if self.fold_group_norm:
+                # GroupNorm(32) + ReLU: statistics only; the apply pass is folded into the next convolution's load (ops.group_norm_fold)
+                pc, c = ops.group_norm_fold(c, gc.num_groups, gc.weight, gc.bias)
+                pb, b = ops.group_norm_fold(b, gb.num_groups, gb.weight, gb.bias)
+            else:   # the reference's literal three passes per layer (A/B runs: bench.py --no-gn-fold)
+                c = ops.group_norm_relu(c, gc.num_groups, gc.weight, gc.bias, relu=True)
+                b = ops.group_norm_relu(b, gb.num_groups, gb.weight, gb.bias, relu=True)
         # centerness shares its input with bbox_pred (or cls_score): same sharing
         if self.centerness_on_reg:
             logits = self.cls_score.levels(c, pre=pc)
