@@ -447,8 +447,11 @@ int lgd_box_reg_loss_bwd(const float* const* deltas_host, const int32_t* const* 
  */
 int lgd_dcn_im2col(const float* x, const float* offset, const float* mask, int N, int C, int H, int W, int stride, int pad,
                    int dilation, float* col, void* stream);
+size_t lgd_dcn_ws_bytes(int N, int H, int W);
 int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const float* dcol, int N, int C, int H, int W,
-                   int stride, int pad, int dilation, float* dx, float* doffset, float* dmask, void* stream);
+                   int stride, int pad, int dilation, float* dx, float* doffset, float* dmask,
+                   void* ws /* lgd_dcn_ws_bytes(N, H, W) bytes: dx by gather through per-cell contribution lists; NULL: dx by atomic scatter */,
+                   void* stream);
 
 /* ------------------------------------------------------------------ gradient clipping + SGD of both optimizers, one launch
  * [ref: train.py:200-204 stu_optimizer.step() / tea_optimizer.step(); utils/build.py:494-529 torch.optim.SGD(momentum, weight

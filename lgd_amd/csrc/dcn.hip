@@ -11,6 +11,8 @@
 
 namespace lgd {
 
+constexpr int kDcnSlots = 8;   // list slots per (input cell, tap): a regular sampling grid fills 4
+
 struct DcnArgs {
     const float* x;       // (N, C, H, W)
     const float* offset;  // (N, 18, Ho, Wo)
@@ -22,6 +24,8 @@ struct DcnArgs {
     float* dmask;         // (N, 9, Ho, Wo) or null
     int N, C, H, W, Ho, Wo, stride, pad, dil;
     int cchunk;           // channels per blockIdx.y slice of the backward kernel (C if not split)
+    int* cnt;             // gather path: [N][9][H*W] contributions of tap k that land in an input cell
+    int2* ent;            //              [N][9][kDcnSlots][H*W] (source pixel, weight bits) of the first kDcnSlots of them
 };
 
 struct Bilin { int y0, x0; float wy1, wx1; bool in; };
@@ -86,6 +90,7 @@ struct DcnPix {
     int y0, x0, pix;
     bool in, ok00, ok01, ok10, ok11, takeL, giveR, live, down;   // down: this row's bottom cells are the next row's top cells
 };
+template <bool DX>   // DX = false: d offset / d mask only (dx comes from the gather kernels below)
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
     constexpr int R = kDcnRows;
     const int HoWo = a.Ho * a.Wo, RG = (a.Ho + R - 1) / R;
@@ -148,20 +153,23 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
             const float gmk = g[r] * t.m;
             float a00 = t.ok00 ? gmk * t.wy0 * t.wx0 : 0.f, a01 = t.ok01 ? gmk * t.wy0 * t.wx1 : 0.f;
             float a10 = t.ok10 ? gmk * t.wy1 * t.wx0 : 0.f, a11 = t.ok11 ? gmk * t.wy1 * t.wx1 : 0.f;
-            // right column -> right neighbour's left column.  Selects, not branches
-            const float r01 = wave_shr1(a01), r11 = wave_shr1(a11);
-            a00 += t.takeL ? r01 : 0.f;
-            a10 += t.takeL ? r11 : 0.f;
-            a01 = t.giveR ? 0.f : a01;
-            a11 = t.giveR ? 0.f : a11;
-            a00 += c10; a01 += c11;                                // the row above's bottom cells (zero unless they coincide with these)
-            if (t.ok00 && a00 != 0.f) unsafeAtomicAdd(dp + t.o00, a00);
-            if (t.ok01 && a01 != 0.f) unsafeAtomicAdd(dp + t.o00 + 1, a01);
-            if (t.down) { c10 = a10; c11 = a11; }
-            else {
-                c10 = c11 = 0.f;
-                if (t.ok10 && a10 != 0.f) unsafeAtomicAdd(dp + t.o00 + a.W, a10);
-                if (t.ok11 && a11 != 0.f) unsafeAtomicAdd(dp + t.o00 + a.W + 1, a11);
+            if constexpr (DX) {   // right column -> right neighbour's left column.  Selects, not branches
+                const float r01 = wave_shr1(a01), r11 = wave_shr1(a11);
+                a00 += t.takeL ? r01 : 0.f;
+                a10 += t.takeL ? r11 : 0.f;
+                a01 = t.giveR ? 0.f : a01;
+                a11 = t.giveR ? 0.f : a11;
+            }
+            if constexpr (DX) {
+                a00 += c10; a01 += c11;                            // the row above's bottom cells (zero unless they coincide with these)
+                if (t.ok00 && a00 != 0.f) unsafeAtomicAdd(dp + t.o00, a00);
+                if (t.ok01 && a01 != 0.f) unsafeAtomicAdd(dp + t.o00 + 1, a01);
+                if (t.down) { c10 = a10; c11 = a11; }
+                else {
+                    c10 = c11 = 0.f;
+                    if (t.ok10 && a10 != 0.f) unsafeAtomicAdd(dp + t.o00 + a.W, a10);
+                    if (t.ok11 && a11 != 0.f) unsafeAtomicAdd(dp + t.o00 + a.W + 1, a11);
+                }
             }
             t.gy += gmk * (t.wx0 * (v10[r] - v00[r]) + t.wx1 * (v11[r] - v01[r]));
             t.gx += gmk * (t.wy0 * (v01[r] - v00[r]) + t.wy1 * (v11[r] - v10[r]));
@@ -184,13 +192,91 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
     }
 }
 
+// ---- dx by GATHER (round 3): the atomic scatter above costs 124 of the backward kernel's 197 us at config 5 (measured with the
+// atomics compiled out: 56 us).  The geometry is shared by all channels, so it is inverted once per convolution: thread per (n, tap,
+// output pixel) appends (pixel, mask * bilinear weight) to the list of each of the (<= 4) input cells its sample touches -- lists per
+// (cell, tap) with kDcnSlots slots, [tap][slot][cell] so that neighbouring cells' slots are neighbouring words and, with smooth
+// offsets, point at neighbouring pixels of one d col plane (coalesced gathers).  A contribution that finds its list full (a sampling
+// grid compressed more than 2x) is added by atomics over the channels on the spot: exact for any offsets.  Then thread per (n, cell,
+// 4 channels) sums weight * d col through its lists in fp64 (the slot order within a list is the arrival order: the fp64 sum of <= 72
+// fp32 products rounds to the same fp32 value whatever the order, up to ties) and adds what the spills left in dx.
+__global__ __launch_bounds__(256) void dcn_list_kernel(DcnArgs a) {
+    const int HoWo = a.Ho * a.Wo, HW = a.H * a.W;
+    const long long total = (long long)a.N * 9 * HoWo;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int pix = (int)(i % HoWo), k = (int)((i / HoWo) % 9), n = (int)(i / ((long long)HoWo * 9));
+    const int ho = pix / a.Wo, wo = pix % a.Wo, ky = k / 3, kx = k % 3;
+    const float* off = a.offset + (size_t)n * 18 * HoWo + pix;
+    const float m = a.mask ? a.mask[((size_t)n * 9 + k) * HoWo + pix] : 1.f;
+    const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + off[(size_t)(2 * k) * HoWo];
+    const float pxx = (float)(wo * a.stride - a.pad + kx * a.dil) + off[(size_t)(2 * k + 1) * HoWo];
+    const Bilin b = bilin_setup(py, pxx, a.H, a.W);
+    if (!b.in) return;
+    const float wy[2] = {1.f - b.wy1, b.wy1}, wx[2] = {1.f - b.wx1, b.wx1};
+    int* cnt = a.cnt + ((size_t)n * 9 + k) * HW;
+    int2* ent = a.ent + ((size_t)n * 9 + k) * kDcnSlots * HW;
+    #pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+        #pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int y = b.y0 + dy, x = b.x0 + dx;
+            if (y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
+            const int cell = y * a.W + x;
+            const float w = m * wy[dy] * wx[dx];
+            const int slot = atomicAdd(cnt + cell, 1);
+            if (slot < kDcnSlots) ent[(size_t)slot * HW + cell] = make_int2(pix, __float_as_int(w));
+            else {   // list full: this contribution goes the atomic way, channel by channel
+                for (int c = 0; c < a.C; ++c)
+                    unsafeAtomicAdd(a.dx + ((size_t)n * a.C + c) * HW + cell, w * a.dcol[(((size_t)n * a.C + c) * 9 + k) * HoWo + pix]);
+            }
+        }
+}
+
+constexpr int kDcnGatherCh = 4;   // channels per thread (measured 4 / 8 / 16: 62 / 72 / 170 us per launch at config 5; fp32 sums: 4 us less)
+typedef double dcn_acc_t;
+__global__ __launch_bounds__(256) void dcn_gather_kernel(DcnArgs a) {
+    const int HoWo = a.Ho * a.Wo, HW = a.H * a.W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.N * HW) return;
+    const int cell = (int)(i % HW), n = (int)(i / HW);
+    const int c0 = blockIdx.y * kDcnGatherCh, nc = min(kDcnGatherCh, a.C - c0);
+    dcn_acc_t acc[kDcnGatherCh];
+    #pragma unroll
+    for (int j = 0; j < kDcnGatherCh; ++j) acc[j] = 0;
+    const float* dc = a.dcol + ((size_t)n * a.C + c0) * 9 * HoWo;
+    for (int k = 0; k < 9; ++k) {
+        const int cn = min(a.cnt[((size_t)n * 9 + k) * HW + cell], kDcnSlots);
+        const int2* ent = a.ent + ((size_t)n * 9 + k) * kDcnSlots * HW + cell;
+        // all slots of the tap, then all their d col values, before anything is summed: a loop with the list's own trip count is a chain
+        // of two dependent loads per entry (111 us per launch at config 5; predicated and unrolled: see DESIGN section 9)
+        int2 en[kDcnSlots];
+        #pragma unroll
+        for (int e = 0; e < kDcnSlots; ++e) en[e] = e < cn ? ent[(size_t)e * HW] : make_int2(0, 0);
+        #pragma unroll
+        for (int e = 0; e < kDcnSlots; ++e) {
+            const float w = __int_as_float(en[e].y);          // empty slot: weight 0, pixel 0
+            const float* src = dc + (size_t)k * HoWo + en[e].x;
+            float v[kDcnGatherCh];
+            #pragma unroll
+            for (int j = 0; j < kDcnGatherCh; ++j) v[j] = (e < cn && j < nc) ? src[(size_t)j * 9 * HoWo] : 0.f;
+            #pragma unroll
+            for (int j = 0; j < kDcnGatherCh; ++j) acc[j] += (dcn_acc_t)(w * v[j]);
+        }
+    }
+    float* o = a.dx + ((size_t)n * a.C + c0) * HW + cell;
+    #pragma unroll
+    for (int j = 0; j < kDcnGatherCh; ++j)
+        if (j < nc) o[(size_t)j * HW] += (float)acc[j];   // + what full lists spilled (zero-initialised by the entry point)
+}
+
 static int dcn_fill(DcnArgs& a, const float* x, const float* offset, const float* mask, int N, int C, int H, int W, int stride,
                     int pad, int dil) {
     if (!x || !offset || N < 1 || C < 1 || H < 1 || W < 1 || stride < 1 || dil < 1 || pad < 0) return LGD_EINVAL;
     a.x = x; a.offset = offset; a.mask = mask; a.N = N; a.C = C; a.H = H; a.W = W; a.stride = stride; a.pad = pad; a.dil = dil;
     a.Ho = (H + 2 * pad - dil * 2 - 1) / stride + 1;
     a.Wo = (W + 2 * pad - dil * 2 - 1) / stride + 1;
-    a.col = nullptr; a.dcol = nullptr; a.dx = nullptr; a.doffset = nullptr; a.dmask = nullptr; a.cchunk = C;
+    a.col = nullptr; a.dcol = nullptr; a.dx = nullptr; a.doffset = nullptr; a.dmask = nullptr; a.cchunk = C; a.cnt = nullptr; a.ent = nullptr;
     return (a.Ho < 1 || a.Wo < 1) ? LGD_EINVAL : LGD_OK;
 }
 
@@ -208,8 +294,13 @@ int lgd_dcn_im2col(const float* x, const float* offset, const float* mask, int N
     return lgd::check_launch();
 }
 
+size_t lgd_dcn_ws_bytes(int N, int H, int W) {
+    if (N < 1 || H < 1 || W < 1) return 0;
+    return (size_t)N * 9 * H * W * (sizeof(int) + lgd::kDcnSlots * sizeof(int2)) + 16;
+}
+
 int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const float* dcol, int N, int C, int H, int W,
-                   int stride, int pad, int dilation, float* dx, float* doffset, float* dmask, void* stream) {
+                   int stride, int pad, int dilation, float* dx, float* doffset, float* dmask, void* ws, void* stream) {
     lgd::DcnArgs a;
     if (!dcol || !dx || !doffset || (mask && !dmask) || lgd::dcn_fill(a, x, offset, mask, N, C, H, W, stride, pad, dilation) != LGD_OK)
         return LGD_EINVAL;
@@ -226,7 +317,20 @@ int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const
         if (hipMemsetAsync(doffset, 0, (size_t)N * 18 * a.Ho * a.Wo * sizeof(float), st) != hipSuccess) return LGD_ELAUNCH;
         if (a.dmask && hipMemsetAsync(dmask, 0, (size_t)N * 9 * a.Ho * a.Wo * sizeof(float), st) != hipSuccess) return LGD_ELAUNCH;
     }
-    LGD_LAUNCH("dcn_col2im_kernel", lgd::dcn_col2im_kernel, dim3((unsigned)((total + 255) / 256), slices), dim3(256), 0, st, a);
+    const dim3 grid((unsigned)((total + 255) / 256), slices);
+    if (!ws) {   // no list workspace: dx by atomic scatter inside the same kernel (round 2's path, kept for A/B runs)
+        LGD_LAUNCH("dcn_col2im_kernel", lgd::dcn_col2im_kernel<true>, grid, dim3(256), 0, st, a);
+        return lgd::check_launch();
+    }
+    const size_t HW = (size_t)H * W;
+    a.cnt = reinterpret_cast<int*>(ws);
+    a.ent = reinterpret_cast<int2*>(reinterpret_cast<char*>(ws) + (((size_t)N * 9 * HW * sizeof(int) + 15) & ~(size_t)15));
+    if (hipMemsetAsync(a.cnt, 0, (size_t)N * 9 * HW * sizeof(int), st) != hipSuccess) return LGD_ELAUNCH;
+    const long long samples = (long long)N * 9 * a.Ho * a.Wo;
+    LGD_LAUNCH("dcn_list_kernel", lgd::dcn_list_kernel, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, st, a);
+    LGD_LAUNCH("dcn_gather_kernel", lgd::dcn_gather_kernel, dim3((unsigned)(((long long)N * HW + 255) / 256), (C + lgd::kDcnGatherCh - 1) / lgd::kDcnGatherCh),
+               dim3(256), 0, st, a);
+    LGD_LAUNCH("dcn_col2im_kernel", lgd::dcn_col2im_kernel<false>, grid, dim3(256), 0, st, a);
     return lgd::check_launch();
 }
 

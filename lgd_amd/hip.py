@@ -89,7 +89,8 @@ SIGNATURES = {
     "lgd_box_reg_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
     "lgd_box_reg_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
     "lgd_dcn_im2col": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
-    "lgd_dcn_col2im": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_dcn_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "lgd_dcn_col2im": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_sgd_chunk_elems": (c_i, []),
     "lgd_sgd_clip_step": (c_i, [c_fp, c_fp, c_i, c_i, c_f, c_fp]),
     "lgd_timing_enable": (c_i, [c_i]),

@@ -1449,14 +1449,20 @@ class _DeformConv(torch.autograd.Function):
             dx = torch.empty_like(x)
             doff = torch.empty_like(offset)
             dmask = torch.empty_like(mask) if mask is not None else None
+            # per-cell contribution lists: dx by gather instead of the L2's float atomics (csrc/dcn.hip); _DCN_GATHER = False: atomic scatter
+            ws = torch.empty(lib.lgd_dcn_ws_bytes(N, H, W), dtype=torch.uint8, device=x.device) if _DCN_GATHER else None
             hip.check(lib.lgd_dcn_col2im(hip.ptr(x), hip.ptr(offset), hip.ptr(mask) if mask is not None else None, hip.ptr(dcol),
                                          N, C, H, W, stride, padding, dilation, hip.ptr(dx), hip.ptr(doff),
-                                         hip.ptr(dmask) if dmask is not None else None, hip.stream_ptr()), "lgd_dcn_col2im")
+                                         hip.ptr(dmask) if dmask is not None else None, hip.ptr(ws) if ws is not None else None,
+                                         hip.stream_ptr()), "lgd_dcn_col2im")
         if ctx.needs_input_grad[3]:
             dw = torch.bmm(dy, col.transpose(1, 2)).sum(0).view_as(weight)
         if has_bias and ctx.needs_input_grad[4]:
             db = dy.sum((0, 2))
         return dx, doff, dmask, dw, db, None, None, None
+
+
+_DCN_GATHER = True
 
 
 def deform_conv3x3(x, offset, mask, weight, bias=None, stride=1, padding=1, dilation=1):

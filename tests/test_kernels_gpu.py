@@ -1721,8 +1721,9 @@ def test_bottleneck_blocks_vs_fp64(stride, wino):
         ops.conv3x3_backend(*prev)
 
 
+@pytest.mark.parametrize("gather", [True, False])
 @pytest.mark.parametrize("scale", [0.0, 0.1, 0.3, 0.6, 2.0])
-def test_deform_conv3x3_dx_neighbour_lane_merge(scale):
+def test_deform_conv3x3_dx_neighbour_lane_merge(scale, gather):
     """dcn_col2im hands a lane's right-column contributions to its right neighbour lane wherever the two samples' cells coincide
     (half the atomics on locally regular sampling grids): dx / d offset / d mask against the per-tap restatement for offsets from
     exactly zero (every lane merges) over small (some lanes merge, the case a wrong lane mask breaks) to large (none do)."""
@@ -1734,7 +1735,11 @@ def test_deform_conv3x3_dx_neighbour_lane_merge(scale):
     m = torch.rand(N, 9, H, W, device=DEV, requires_grad=True)
     w = torch.randn(O, C, 3, 3, device=DEV, requires_grad=True)
     gy = torch.randn(N, O, H, W, device=DEV)
-    ops.deform_conv3x3(x, off, m, w, None, 1, 1, 1).backward(gy)
+    ops._DCN_GATHER = gather   # dx through per-cell contribution lists (shipped) / by atomic scatter with the lane hand-overs
+    try:
+        ops.deform_conv3x3(x, off, m, w, None, 1, 1, 1).backward(gy)
+    finally:
+        ops._DCN_GATHER = True
     got = [t.grad.clone() for t in (x, off, m)]
     for t in (x, off, m, w):
         t.grad = None
@@ -1743,3 +1748,34 @@ def test_deform_conv3x3_dx_neighbour_lane_merge(scale):
         if name == "offset" and scale == 0.0:
             continue   # integer sampling positions sit on the kink of the bilinear interpolation: one-sided derivatives differ
         assert float((g - t.grad).abs().max()) <= 2e-4 * float(t.grad.abs().max()) + 1e-6, name
+
+
+@pytest.mark.parametrize("pull", [0.0, 0.5, 0.8, 0.95])
+def test_deform_conv3x3_dx_gather_full_lists_and_determinism(pull):
+    """dx by gather (csrc/dcn.hip: per (input cell, tap) lists of 8 slots): offsets that pull every sample towards the image centre by
+    `pull` compress the sampling grid up to 20x, so most contributions find their list full and take the atomic spill path -- dx must
+    stay exact against the per-tap restatement; without spills (pull 0) two runs are bit-identical."""
+    from lgd_amd import ops
+    torch.manual_seed(3)
+    N, C, O, H, W = 2, 10, 4, 17, 21
+    x = torch.randn(N, C, H, W, device=DEV, requires_grad=True)
+    yy, xx = torch.meshgrid(torch.arange(H, device=DEV, dtype=torch.float32), torch.arange(W, device=DEV, dtype=torch.float32), indexing="ij")
+    off = torch.zeros(N, 18, H, W, device=DEV)
+    off[:, 0::2] = (pull * ((H - 1) / 2 - yy))[None, None] + 0.13
+    off[:, 1::2] = (pull * ((W - 1) / 2 - xx))[None, None] - 0.21
+    off.requires_grad_(True)
+    m = torch.rand(N, 9, H, W, device=DEV, requires_grad=True)
+    w = torch.randn(O, C, 3, 3, device=DEV, requires_grad=True)
+    gy = torch.randn(N, O, H, W, device=DEV)
+    runs = []
+    for _ in range(2):
+        for t in (x, off, m, w):
+            t.grad = None
+        ops.deform_conv3x3(x, off, m, w, None, 1, 1, 1).backward(gy)
+        runs.append(x.grad.clone())
+    if pull == 0.0:
+        assert torch.equal(runs[0], runs[1])
+    for t in (x, off, m, w):
+        t.grad = None
+    SO.modulated_deform_conv2d(x, off, m, w, None, 1, 1, 1).backward(gy)
+    assert float((runs[0] - x.grad).abs().max()) <= 2e-4 * float(x.grad.abs().max()) + 1e-6
