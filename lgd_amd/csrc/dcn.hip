@@ -74,6 +74,37 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(DcnArgs a) {
     }
 }
 
+// ---- dx by GATHER (round 3): the atomic scatter costs 124 of the backward kernel's 197 us at config 5 (measured with the atomics
+// compiled out: 56 us).  The geometry is shared by all channels, so it is inverted once per convolution: the thread of an (n, tap,
+// output pixel) sample appends (pixel, mask * bilinear weight) to the list of each of the (<= 4) input cells its sample touches --
+// lists per (cell, tap) with kDcnSlots slots, [tap][slot][cell] so that neighbouring cells' slots are neighbouring words and, with
+// smooth offsets, point at neighbouring pixels of one d col plane (coalesced gathers).  A contribution that finds its list full (a
+// sampling grid compressed more than 2x) is added by atomics over the channels on the spot: exact for any offsets.  Then
+// dcn_gather_kernel, thread per (n, cell, 4 channels), sums weight * d col through its lists in fp64 (the slot order within a list is
+// the arrival order: the fp64 sum of <= 72 fp32 products rounds to the same fp32 value whatever the order, up to ties) and adds what the
+// spills left in dx.
+__device__ __forceinline__ void dcn_append(const DcnArgs& a, int n, int k, int pix, int y0, int x0, float wy1, float wx1, float m) {
+    const int HoWo = a.Ho * a.Wo, HW = a.H * a.W;
+    const float wy[2] = {1.f - wy1, wy1}, wx[2] = {1.f - wx1, wx1};
+    int* cnt = a.cnt + ((size_t)n * 9 + k) * HW;
+    int2* ent = a.ent + ((size_t)n * 9 + k) * kDcnSlots * HW;
+    #pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+        #pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int y = y0 + dy, x = x0 + dx;
+            if (y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
+            const int cell = y * a.W + x;
+            const float w = m * wy[dy] * wx[dx];
+            const int slot = atomicAdd(cnt + cell, 1);
+            if (slot < kDcnSlots) ent[(size_t)slot * HW + cell] = make_int2(pix, __float_as_int(w));
+            else {   // list full: this contribution goes the atomic way, channel by channel
+                for (int c = 0; c < a.C; ++c)
+                    unsafeAtomicAdd(a.dx + ((size_t)n * a.C + c) * HW + cell, w * a.dcol[(((size_t)n * a.C + c) * 9 + k) * HoWo + pix]);
+            }
+        }
+}
+
 // thread per (n, tap, column, group of R output rows) and channel slice (blockIdx.y): loops over the slice's channels; dx by atomic
 // scatter, d offset / d mask summed in registers (one atomic per slice when the channels are split to fill the GPU on the small stages).
 // The kernel is bound by the L2's float atomics, and their cost is per 64-byte REQUEST, not per lane (measured: an 8 x 8 pixel tile per
@@ -133,6 +164,9 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
         const unsigned rtake = wave_shl1(t.takeL ? 1u : 0u);
         t.giveR = (lane < 63) & (rtake != 0u);
         t.gy = t.gx = t.gm = 0.f;
+        if constexpr (!DX) {   // the contribution lists of the gather path are built here, once (channel slice 0)
+            if (blockIdx.y == 0 && t.in) dcn_append(a, n, k, t.pix, b.y0, b.x0, b.wy1, b.wx1, t.m);
+        }
     }
     #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -195,47 +229,6 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
             if (om) unsafeAtomicAdd(om, t.gm);
         }
     }
-}
-
-// ---- dx by GATHER (round 3): the atomic scatter above costs 124 of the backward kernel's 197 us at config 5 (measured with the
-// atomics compiled out: 56 us).  The geometry is shared by all channels, so it is inverted once per convolution: thread per (n, tap,
-// output pixel) appends (pixel, mask * bilinear weight) to the list of each of the (<= 4) input cells its sample touches -- lists per
-// (cell, tap) with kDcnSlots slots, [tap][slot][cell] so that neighbouring cells' slots are neighbouring words and, with smooth
-// offsets, point at neighbouring pixels of one d col plane (coalesced gathers).  A contribution that finds its list full (a sampling
-// grid compressed more than 2x) is added by atomics over the channels on the spot: exact for any offsets.  Then thread per (n, cell,
-// 4 channels) sums weight * d col through its lists in fp64 (the slot order within a list is the arrival order: the fp64 sum of <= 72
-// fp32 products rounds to the same fp32 value whatever the order, up to ties) and adds what the spills left in dx.
-__global__ __launch_bounds__(256) void dcn_list_kernel(DcnArgs a) {
-    const int HoWo = a.Ho * a.Wo, HW = a.H * a.W;
-    const long long total = (long long)a.N * 9 * HoWo;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int pix = (int)(i % HoWo), k = (int)((i / HoWo) % 9), n = (int)(i / ((long long)HoWo * 9));
-    const int ho = pix / a.Wo, wo = pix % a.Wo, ky = k / 3, kx = k % 3;
-    const float* off = a.offset + (size_t)n * 18 * HoWo + pix;
-    const float m = a.mask ? a.mask[((size_t)n * 9 + k) * HoWo + pix] : 1.f;
-    const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + off[(size_t)(2 * k) * HoWo];
-    const float pxx = (float)(wo * a.stride - a.pad + kx * a.dil) + off[(size_t)(2 * k + 1) * HoWo];
-    const Bilin b = bilin_setup(py, pxx, a.H, a.W);
-    if (!b.in) return;
-    const float wy[2] = {1.f - b.wy1, b.wy1}, wx[2] = {1.f - b.wx1, b.wx1};
-    int* cnt = a.cnt + ((size_t)n * 9 + k) * HW;
-    int2* ent = a.ent + ((size_t)n * 9 + k) * kDcnSlots * HW;
-    #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-        #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int y = b.y0 + dy, x = b.x0 + dx;
-            if (y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
-            const int cell = y * a.W + x;
-            const float w = m * wy[dy] * wx[dx];
-            const int slot = atomicAdd(cnt + cell, 1);
-            if (slot < kDcnSlots) ent[(size_t)slot * HW + cell] = make_int2(pix, __float_as_int(w));
-            else {   // list full: this contribution goes the atomic way, channel by channel
-                for (int c = 0; c < a.C; ++c)
-                    unsafeAtomicAdd(a.dx + ((size_t)n * a.C + c) * HW + cell, w * a.dcol[(((size_t)n * a.C + c) * 9 + k) * HoWo + pix]);
-            }
-        }
 }
 
 constexpr int kDcnGatherCh = 4;   // channels per thread (measured 4 / 8 / 16: 62 / 72 / 170 us per launch at config 5; fp32 sums: 4 us less)
@@ -336,11 +329,9 @@ int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const
     a.cnt = reinterpret_cast<int*>(ws);
     a.ent = reinterpret_cast<int2*>(reinterpret_cast<char*>(ws) + (((size_t)N * 9 * HW * sizeof(int) + 15) & ~(size_t)15));
     if (hipMemsetAsync(a.cnt, 0, (size_t)N * 9 * HW * sizeof(int), st) != hipSuccess) return LGD_ELAUNCH;
-    const long long samples = (long long)N * 9 * a.Ho * a.Wo;
-    LGD_LAUNCH("dcn_list_kernel", lgd::dcn_list_kernel, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, st, a);
+    LGD_LAUNCH("dcn_col2im_kernel", lgd::dcn_col2im_kernel<false>, grid, dim3(256), 0, st, a);   // d offset, d mask + the lists
     LGD_LAUNCH("dcn_gather_kernel", lgd::dcn_gather_kernel, dim3((unsigned)(((long long)N * HW + 255) / 256), (C + lgd::kDcnGatherCh - 1) / lgd::kDcnGatherCh),
                dim3(256), 0, st, a);
-    LGD_LAUNCH("dcn_col2im_kernel", lgd::dcn_col2im_kernel<false>, grid, dim3(256), 0, st, a);
     return lgd::check_launch();
 }
 
