@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
     ap.add_argument("--no-gn-fold", action="store_true", help="FCOS towers: GroupNorm(32) + ReLU as its own passes instead of inside the next convolution's input transform (A/B runs)")
+    ap.add_argument("--no-fcos-fused-loss", action="store_true", help="FCOS: GIoU / centerness losses as the composed torch form instead of one kernel on the raw head outputs (A/B runs)")
     ap.add_argument("--head-passes", type=int, default=1, choices=[1, 2],
                     help="1 = one head pass over student + teacher pyramids (default); 2 = the reference's literal two passes")
     ap.add_argument("--cpu-sample-images", type=int, default=1)
@@ -190,6 +191,8 @@ def main():
     torch.manual_seed(0)
     model = build_model(cfg)
     model.fused_head_pass = args.head_passes == 1
+    if args.no_fcos_fused_loss and hasattr(model.student, "fused_reg_loss"):
+        model.student.fused_reg_loss = False
     if args.no_gn_fold and hasattr(model.student.head, "fold_group_norm"):
         model.student.head.fold_group_norm = False
     trainer = Trainer(cfg, model, device=dev, distributed=True if force_ddp else None, fused_sgd=not args.torch_optimizers)

@@ -259,6 +259,21 @@ int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* la
                        const int32_t* level_hw_host, int L, int N, int A, int K, float alpha, float gamma,
                        const float* grad_loss, float* const* grad_logits_host, void* stream);
 
+/* ------------------------------------------------------------------ FCOS regression (GIoU) + centerness (BCE) losses (section 8f-1)
+ * [ref: thirdparty_heads/fcos.py:533-546 (per-level Scale, relu(.) * stride or exp(.)), 107-175 (losses)]
+ * reg_l: (N, 4, H_l, W_l) RAW bbox_pred outputs, ctr_l: (N, 1, H_l, W_l) centerness logits; scales [L] (device), strides [L] (host);
+ * gt_classes (N, R) int64 (foreground: 0 <= c < K), gt_deltas (N, R, 4) ltrb, gt_centerness (N, R), R = sum H_l W_l;
+ * inv_norm2 (device): 1 / max(1, sum of centerness targets), 1 / max(1, number of foreground locations) [rank means].
+ * out [2 + L] = loss_box_reg, loss_centerness (both normalised), d loss_box_reg / d scale_l; grad_reg_l / grad_ctr_l: the gradients
+ * of the two normalised losses w.r.t. the raw maps (dense), written in the same pass (upstream gradient 1; rescale with
+ * lgd_scale_unless_one otherwise).  ws: lgd_fcos_loss_ws_doubles(...) doubles.
+ */
+size_t lgd_fcos_loss_ws_doubles(const int32_t* level_hw_host, int L, int N);
+int lgd_fcos_loss_fwd_grad(const float* const* reg_host, const float* const* ctr_host, const int32_t* level_hw_host,
+                           const float* strides_host, int L, int N, int K, int R, const float* scales, int norm_reg_targets,
+                           const long long* gt_classes, const float* gt_deltas, const float* gt_centerness, const float* inv_norm2,
+                           double* ws, float* out, float* const* grad_reg_host, float* const* grad_ctr_host, void* stream);
+
 /* ------------------------------------------------------------------ K8: 3x3 convolutions (Winograd data transforms)
  * Replaces the data movement of nn.Conv2d(C, C', 3, padding=1) on the path: dynamic_teacher.py:57,61,67-73
  * (student_proj_2D, local_inst_proj_2D, refinement_module), models/adapters/sequential_convs.py:10-12 and the

@@ -63,6 +63,8 @@ SIGNATURES = {
     "lgd_focal_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
     "lgd_focal_loss_fwd_grad": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_scale_unless_one": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp]),
+    "lgd_fcos_loss_ws_doubles": (c_sz, [c_fp, c_i, c_i]),
+    "lgd_fcos_loss_fwd_grad": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_focal_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
     "lgd_wino_tiles": (c_sz, [c_fp, c_i, c_i, c_i]),
     "lgd_wino_mask_bytes": (c_sz, [c_i]),

@@ -879,6 +879,72 @@ def focal_loss_sum(raw_logits, label_planes, A, K, alpha, gamma, normalizer=None
     return out if normalizer is None else out / normalizer
 
 
+class _FcosRegCtrLoss(torch.autograd.Function):
+    """FCOS loss_box_reg (GIoU, centerness-weighted) and loss_centerness (BCE) on the head's RAW outputs in one launch, the head's
+    Scale / ReLU / stride epilogue folded in and the gradients written by the forward pass (lgd_fcos_loss_fwd_grad; the normalisers are
+    known when the loss is evaluated, the upstream gradients are 1 in the training step; lgd_scale_unless_one rescales otherwise).
+    apply(K, norm_reg, strides, scales (L,), gt_classes (N,R), gt_deltas (N,R,4), gt_centerness (N,R), inv_norm (2,), reg_1..L, ctr_1..L)
+    -> (loss_box_reg, loss_centerness)."""
+
+    @staticmethod
+    def forward(ctx, K, norm_reg, strides, scales, gt_classes, gt_deltas, gt_ctr, inv_norm, *maps):
+        lib = hip.load()
+        L = len(maps) // 2
+        regs = [hip.dense_f32(t) for t in maps[:L]]
+        ctrs = [hip.dense_f32(t) for t in maps[L:]]
+        hip.require_gpu(*regs, *ctrs)
+        N = regs[0].shape[0]
+        R = sum(t.shape[2] * t.shape[3] for t in regs)
+        for r_, c_ in zip(regs, ctrs):
+            if r_.shape[0] != N or r_.shape[1] != 4 or tuple(c_.shape) != (N, 1) + tuple(r_.shape[2:]):
+                raise hip.LgdHipError("FCOS loss: regression (N,4,H,W) / centerness (N,1,H,W) expected, got %s / %s" % (tuple(r_.shape), tuple(c_.shape)))
+        gt_classes = gt_classes.contiguous()
+        gt_deltas, gt_ctr = hip.dense_f32(gt_deltas), hip.dense_f32(gt_ctr)
+        if gt_classes.dtype != torch.int64 or tuple(gt_classes.shape) != (N, R) or tuple(gt_deltas.shape) != (N, R, 4) or tuple(gt_ctr.shape) != (N, R):
+            raise hip.LgdHipError("FCOS loss: targets (N,R) int64 / (N,R,4) / (N,R) expected for N=%d R=%d" % (N, R))
+        scales = hip.dense_f32(scales.detach()).reshape(-1)
+        inv_norm = hip.dense_f32(inv_norm.detach()).reshape(-1)
+        if scales.numel() != L or inv_norm.numel() != 2 or len(strides) != L:
+            raise hip.LgdHipError("FCOS loss: %d scales / strides and 2 normalisers expected" % L)
+        hw = hip.int_array([d for t in regs for d in t.shape[2:]])
+        st = (ctypes.c_float * L)(*[float(v) for v in strides])
+        dev = regs[0].device
+        ws = torch.empty(lib.lgd_fcos_loss_ws_doubles(hw, L, N), dtype=torch.float64, device=dev)
+        out = torch.empty(2 + L, dtype=torch.float32, device=dev)
+        g_reg = [torch.empty_like(t) for t in regs]
+        g_ctr = [torch.empty_like(t) for t in ctrs]
+        hip.check(lib.lgd_fcos_loss_fwd_grad(hip.ptr_array(regs), hip.ptr_array(ctrs), hw, st, L, N, int(K), R, hip.ptr(scales), int(norm_reg),
+                                             hip.ptr(gt_classes), hip.ptr(gt_deltas), hip.ptr(gt_ctr), hip.ptr(inv_norm), hip.ptr(ws),
+                                             hip.ptr(out), hip.ptr_array(g_reg), hip.ptr_array(g_ctr), hip.stream_ptr()), "lgd_fcos_loss_fwd_grad")
+        ctx.save_for_backward(out, *g_reg, *g_ctr)
+        ctx.L = L
+        ctx.sizes = ((ctypes.c_longlong * L)(*[t.numel() for t in g_reg]), (ctypes.c_longlong * L)(*[t.numel() for t in g_ctr]))
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_box, g_c):
+        lib = hip.load()
+        L = ctx.L
+        out, *g = ctx.saved_tensors
+        g_reg, g_ctr = list(g[:L]), list(g[L:])
+        g_box = (g_box if g_box is not None else torch.zeros((), device=out.device)).contiguous().to(torch.float32)
+        g_c = (g_c if g_c is not None else torch.zeros((), device=out.device)).contiguous().to(torch.float32)
+        hip.check(lib.lgd_scale_unless_one(hip.ptr_array(g_reg), ctx.sizes[0], L, hip.ptr(g_box), hip.stream_ptr()), "lgd_scale_unless_one")
+        hip.check(lib.lgd_scale_unless_one(hip.ptr_array(g_ctr), ctx.sizes[1], L, hip.ptr(g_c), hip.stream_ptr()), "lgd_scale_unless_one")
+        d_scales = out[2:] * g_box if ctx.needs_input_grad[3] else None
+        return (None, None, None, d_scales, None, None, None, None, *g_reg, *g_ctr)
+
+
+def fcos_reg_ctr_loss(raw_regs, ctrs, scales, strides, gt_classes, gt_deltas, gt_centerness, inv_num_targets, inv_num_fg, num_classes,
+                      norm_reg_targets=True):
+    """(loss_box_reg, loss_centerness) of FCOS from the RAW bbox_pred maps (N,4,H_l,W_l) and the centerness logits (N,1,H_l,W_l):
+    per-level Scale, ReLU * stride (or exp), GIoU against the ltrb targets weighted by the centerness targets, BCE of the centerness,
+    both normalised, in one launch [ref: thirdparty_heads/fcos.py:533-546, 107-175].  scales: (L,) tensor (gradient flows)."""
+    inv = torch.stack((inv_num_targets.reshape(()), inv_num_fg.reshape(())))
+    return _FcosRegCtrLoss.apply(int(num_classes), bool(norm_reg_targets), tuple(float(s) for s in strides), scales, gt_classes, gt_deltas,
+                                 gt_centerness, inv, *raw_regs, *ctrs)
+
+
 class _BoxRegSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, K, beta, weights, n_levels, anchors, matched, *tensors):

@@ -54,8 +54,9 @@ class FCOSHead(nn.Module):
         self.scales = nn.ModuleList([Scale(1.0) for _ in self.fpn_strides])
         self.fold_group_norm = True
 
-    def forward(self, features):
-        """features: the L pyramid levels, or 2L maps (student + teacher pyramids, one pass).  Every tower layer is ONE
+    def forward(self, features, raw_reg=False):
+        """features: the L pyramid levels, or 2L maps (student + teacher pyramids, one pass).  raw_reg: return the bbox_pred maps without
+        the per-level Scale / ReLU * stride epilogue (the training losses apply it inside their kernel, ops.fcos_reg_ctr_loss).  Every tower layer is ONE
         Winograd conv over all maps + ONE GroupNorm(32) statistics pass over all maps; the normalisation + ReLU itself runs inside the
         next convolution's input transform."""
         nl = len(self.fpn_strides)
@@ -82,6 +83,8 @@ class FCOSHead(nn.Module):
         else:
             regs = self.bbox_pred.levels(b, pre=pb)
             logits, ctr = ops.conv3x3_shared_input(c, [(self.cls_score.weight, self.cls_score.bias), (self.centerness.weight, self.centerness.bias)], pre=pc)
+        if raw_reg:
+            return logits, list(regs), ctr
         reg = []
         for i, r in enumerate(regs):
             lvl = i % nl
@@ -142,6 +145,7 @@ class FCOSCT(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), persistent=False)
         self._shift_cache = {}
+        self.fused_reg_loss = True   # training: GIoU + centerness losses on the raw head outputs in one kernel (False: the composed torch form)
 
     @property
     def device(self):
@@ -168,7 +172,7 @@ class FCOSCT(nn.Module):
 
     def predict(self, features):
         """[ref: customized_detectors/fcos.py:29-33]"""
-        box_cls, box_delta, box_center = self.head(features)
+        box_cls, box_delta, box_center = self.head(features, raw_reg=self.training and self.fused_reg_loss)
         return self.shift_generator(features), box_cls, box_delta, box_center
 
     @torch.no_grad()
@@ -196,9 +200,21 @@ class FCOSCT(nn.Module):
     def losses(self, gt_classes, gt_shifts_deltas, gt_centerness, pred_class_logits, pred_shift_deltas, pred_centerness):
         """[ref: thirdparty_heads/fcos.py:107-175] without boolean-index gathers / host syncs; the focal loss is the fused
         HIP kernel on the raw (N, K, H, W) logits."""
+        fg = (gt_classes >= 0) & (gt_classes != self.num_classes)
+        if self.training and self.fused_reg_loss:   # pred_shift_deltas: the RAW bbox_pred maps (head(..., raw_reg=True))
+            gt_ctr = torch.where(fg, gt_centerness, torch.zeros_like(gt_centerness))
+            counts = self.reduce_counts(torch.stack((fg.sum().to(torch.float32), gt_ctr.sum())))
+            num_fg, num_targets = counts[0].clamp(min=1.0), counts[1].clamp(min=1.0)
+            hw = [tuple(x.shape[-2:]) for x in pred_class_logits]
+            loss_cls = ops.focal_loss_sum(pred_class_logits, ops.label_planes(gt_classes, hw, 1), 1, self.num_classes,
+                                          self.focal_loss_alpha, self.focal_loss_gamma, normalizer=num_fg)
+            loss_box, loss_ctr = ops.fcos_reg_ctr_loss(pred_shift_deltas, pred_centerness, torch.cat([m.scale for m in self.head.scales]),
+                                                       self.fpn_strides, gt_classes, gt_shifts_deltas, gt_centerness,
+                                                       num_targets.reciprocal(), num_fg.reciprocal(), self.num_classes,
+                                                       self.head.norm_reg_targets)
+            return {"loss_cls": loss_cls, "loss_box_reg": loss_box, "loss_centerness": loss_ctr}
         deltas = _flatten_levels(pred_shift_deltas, 4)
         ctr = _flatten_levels(pred_centerness, 1).squeeze(-1)
-        fg = (gt_classes >= 0) & (gt_classes != self.num_classes)
         gt_ctr = torch.where(fg, gt_centerness, torch.zeros_like(gt_centerness))
         counts = self.reduce_counts(torch.stack((fg.sum().to(torch.float32), gt_ctr.sum())))
         num_fg, num_targets = counts[0].clamp(min=1.0), counts[1].clamp(min=1.0)
@@ -228,7 +244,7 @@ class FCOSCT(nn.Module):
         """predict() on two pyramids with ONE head pass (see RetinaNetCT.predict_pair):
         shifts, (cls_a, delta_a, center_a), (cls_b, delta_b, center_b)."""
         L = len(feats_a)
-        cls, reg, ctr = self.head(list(feats_a) + list(feats_b))
+        cls, reg, ctr = self.head(list(feats_a) + list(feats_b), raw_reg=self.training and self.fused_reg_loss)
         return self.shift_generator(feats_a), (cls[:L], reg[:L], ctr[:L]), (cls[L:], reg[L:], ctr[L:])
 
     def forward(self, batched_inputs):

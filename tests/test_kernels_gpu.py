@@ -1207,6 +1207,60 @@ def test_group_norm_folded_into_conv3x3(tile, B, C, Co, G, level_hw):
         assert cm.rel_err(t.grad, r.grad) < 2 * tol
 
 
+@pytest.mark.parametrize("norm_reg", [True, False])
+@pytest.mark.parametrize("upstream", [(1.0, 1.0), (0.7, 1.3)])
+def test_fcos_reg_ctr_loss_one_pass(norm_reg, upstream):
+    """ops.fcos_reg_ctr_loss (GIoU + centerness BCE on the RAW head outputs, Scale / ReLU * stride folded in, gradients written by the
+    forward pass) against the composed form in fp64 -- oracle giou_ltrb_loss [ref: thirdparty_heads/fcos.py:107-175, 533-546] -- values,
+    gradients of the raw maps, the centerness logits and the per-level scales, for upstream gradients 1 and != 1."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    N, K = 3, 80
+    level_hw = [(13, 17), (7, 9), (4, 5)]
+    strides = [8.0, 16.0, 32.0]
+    R = sum(h * w for h, w in level_hw)
+    rng = np.random.default_rng(11)
+    cls = torch.from_numpy(rng.integers(0, K + 1, size=(N, R)))
+    cls[rng.random((N, R)) < 0.6] = K                       # most locations are background
+    cls[1] = K                                               # an image without foreground
+    gt_d = torch.from_numpy(rng.uniform(1.0, 90.0, size=(N, R, 4)).astype(np.float32))
+    gt_c = torch.from_numpy(rng.uniform(0.05, 1.0, size=(N, R)).astype(np.float32))
+    regs = [torch.from_numpy(synth.det_uniform((N, 4, h, w), 1600 + i, -1.0, 3.0)) for i, (h, w) in enumerate(level_hw)]
+    ctrs = [torch.from_numpy(synth.det_uniform((N, 1, h, w), 1610 + i, -3.0, 3.0)) for i, (h, w) in enumerate(level_hw)]
+    scales = torch.tensor([0.9, 1.1, 1.3])
+    fg = (cls >= 0) & (cls != K)
+    num_fg = fg.sum().clamp(min=1).to(torch.float32)
+    num_t = torch.where(fg, gt_c, torch.zeros_like(gt_c)).sum().clamp(min=1.0)
+    # product
+    rg = [t.to(DEV).requires_grad_(True) for t in regs]
+    cg = [t.to(DEV).requires_grad_(True) for t in ctrs]
+    sg = scales.to(DEV).requires_grad_(True)
+    lb, lc = ops.fcos_reg_ctr_loss(rg, cg, sg, strides, cls.to(DEV), gt_d.to(DEV), gt_c.to(DEV), (1.0 / num_t).to(DEV), (1.0 / num_fg).to(DEV),
+                                   K, norm_reg)
+    (lb * upstream[0] + lc * upstream[1]).backward()
+    # composed form in fp64
+    r64 = [t.double().requires_grad_(True) for t in regs]
+    c64 = [t.double().requires_grad_(True) for t in ctrs]
+    s64 = scales.double().requires_grad_(True)
+    dec = []
+    for lv, r in enumerate(r64):
+        u = r * s64[lv]
+        dec.append(F.relu(u) * strides[lv] if norm_reg else torch.exp(u))
+    flat = torch.cat([t.permute(0, 2, 3, 1).reshape(N, -1, 4) for t in dec], 1)
+    cflat = torch.cat([t.permute(0, 2, 3, 1).reshape(N, -1) for t in c64], 1)
+    safe_p = torch.where(fg[..., None], flat, torch.ones_like(flat))
+    safe_t = torch.where(fg[..., None], gt_d.double(), torch.ones_like(flat))
+    gi = SO.giou_ltrb_loss(safe_p, safe_t)
+    rb = torch.where(fg, gi * gt_c.double(), torch.zeros_like(gi)).sum() / num_t.double()
+    bce = F.binary_cross_entropy_with_logits(cflat, gt_c.double(), reduction="none")
+    rc = torch.where(fg, bce, torch.zeros_like(bce)).sum() / num_fg.double()
+    (rb * upstream[0] + rc * upstream[1]).backward()
+    assert abs(lb.item() - rb.item()) <= 2e-6 * abs(rb.item()) and abs(lc.item() - rc.item()) <= 2e-6 * abs(rc.item())
+    for a, b in zip(rg + cg, r64 + c64):
+        assert cm.rel_err(a.grad, b.grad) < FTOL
+    assert cm.rel_err(sg.grad, s64.grad) < FTOL
+
+
 # ------------------------------------------------------------------------------------------- FCOS target assignment
 def counts_mask(counts, R):
     """(B,R) bool: images that have ground truth (images without boxes get zero targets, not the formula)."""
