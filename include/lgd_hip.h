@@ -423,6 +423,11 @@ int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, i
 /* weight gradient of a pointwise convolution from per-image partial products: out[o][i] = scale[o] * sum_n part[n][o][i]
  * (scale may be NULL); part (N, Co, Ci), out (Co, Ci). */
 int lgd_sum_batch_scale(const float* part, const float* scale, int N, int Co, int Ci, float* out, void* stream);
+/* out_t[r][c] = w_t[r][c] * scale_t[r] for a table of n tensors in one launch (the w * scale filter folds of every trainable 1x1
+ * convolution in front of a FrozenBN, once per step): tasks_dev = n lgd_rows_task records in device memory, blk0_dev[t] = first
+ * workgroup of task t (a workgroup covers 1024 elements), nblocks = their total. */
+typedef struct lgd_rows_task { unsigned long long w, scale, out; int rows, cols; } lgd_rows_task;
+int lgd_scale_rows_multi(const void* tasks_dev, const int32_t* blk0_dev, int n, int nblocks, void* stream);
 int lgd_relu_bits_bwd(const uint32_t* relu_bits, const float* dy, long long total, float* dx, void* stream);
 int lgd_relu_mask_bwd(const float* y, const float* dy, long long total, float* dx, void* stream);
 

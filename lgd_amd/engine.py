@@ -193,6 +193,11 @@ class Trainer:
         self._log_acc, self._log_n = None, 0
         self._finite = None  # device-side AND of isfinite(total loss) over the steps since the last check
         self._fused_sgd = None
+        # one-launch filter folds of the student's trainable 1x1 convolutions (student/resnet.py::StepFolds); LGD_STEP_FOLDS=0: per-op folds
+        self._step_folds = None
+        if os.environ.get("LGD_STEP_FOLDS", "1") != "0" and next(self.raw_model.parameters()).is_cuda:
+            from .student.resnet import StepFolds
+            self._step_folds = StepFolds(self.raw_model)
         self.fused_sgd_enabled = fused_sgd   # False: torch's multi-tensor clip + SGD path (what the fused launch is tested against)
         if self.device.type == "cuda":
             from . import ops, optim
@@ -248,6 +253,8 @@ class Trainer:
         # (the reference runs do_test inside the loop) calls raw_model.eval(), which leaves a DDP wrapper's own flag at True
         if not (self.model.training and self.raw_model.training):
             self.model.train()
+        if self._step_folds is not None:
+            self._step_folds.prepare()   # w * scale of every trainable 1x1 ConvBN of the student: one launch per step
         loss_dict = self.model(data)
         losses = sum(loss_dict.values())
         ok = torch.isfinite(losses.detach())  # the reference asserts this every iteration (train.py:194); here: no host sync

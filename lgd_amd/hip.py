@@ -84,6 +84,7 @@ SIGNATURES = {
     "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_stem_bias_relu_maxpool": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_sum_batch_scale": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_scale_rows_multi": (c_i, [c_fp, c_fp, c_i, c_i, c_fp]),
     "lgd_relu_bits_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_relu_mask_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_anchor_match": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),

@@ -1666,11 +1666,12 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
     (3 map transfers; measured per block at config 2, tools/skip_accum_probe.py: res3 350 -> 200 us, res4 255 -> 208 us)."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, shift, raw=False):
+    def forward(ctx, x, w, scale, shift, raw=False, wf=None):
         hip.require_gpu(x, w)
         lib = hip.load()
         x = hip.dense_f32(x)
-        wf = w * scale.view(-1, 1, 1, 1)
+        if wf is None:   # wf given: this step's fold from StepFolds.prepare() (one launch for all trainable 1x1 convolutions)
+            wf = w * scale.view(-1, 1, 1, 1)
         y = _conv1x1_fwd(x, wf)
         ctx.raw = bool(raw)
         if raw:   # the 3x3 convolution that follows folds + shift and the ReLU into its input transform (and the mask into its adjoint)
@@ -1714,13 +1715,13 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
                                  dz.view(N, Co, -1), **({"out": a3} if own else {})).view_as(x)
         if ctx.needs_input_grad[1] and dz is not None:
             dw = _pointwise_dw(dz, x, scale)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
-def pointwise_conv_bn_skip(x, w, scale, shift, raw=False):
+def pointwise_conv_bn_skip(x, w, scale, shift, raw=False, wf=None):
     """(relu(conv1x1(x, w * scale) + shift), x): conv1 + identity shortcut of a bottleneck block as one node (see above);
     raw: (conv1x1(x, w * scale), x) -- bias and ReLU are left to the consumer (conv3x3(..., pre=shift))."""
-    return _PointwiseConvBNSkip.apply(x, w, scale, shift, bool(raw))
+    return _PointwiseConvBNSkip.apply(x, w, scale, shift, bool(raw), wf)
 
 
 def pointwise_conv_bn(x, w, scale, shift, residual=None, relu=True, wf=None):

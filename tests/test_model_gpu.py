@@ -599,6 +599,72 @@ def test_trainer_fused_sgd_equals_torch_optimizers():
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
 
 
+def test_step_folds_equal_per_op_folds():
+    """StepFolds (student/resnet.py: w * scale of every trainable 1x1 ConvBN in ONE launch per step) against the fold inside each op:
+    the folded filters are bit-identical, the trainer uses them for every trainable 1x1 ConvBN in every phase (losses and the parameters
+    after three steps across the phase switches equal a trainer without them to the run-to-run noise of the step), and a weight
+    written after prepare() falls back to the per-op fold."""
+    import copy
+    from lgd_amd import config
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    from lgd_amd.student.resnet import ConvBN, StepFolds
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    base = build_model(cfg)
+    twin = copy.deepcopy(base)
+    sf = StepFolds(base)
+    sf.prepare()
+    mods = [m for m in base.modules() if isinstance(m, ConvBN) and (m._pointwise or m._pointwise_s2) and m.weight.requires_grad]
+    assert len(mods) >= 20 and len(sf.mods) == len(mods)
+    for m in mods:
+        scale = m.norm.scale_shift()[0]
+        assert torch.equal(m._cached_fold(scale), m.weight.detach() * scale.view(-1, 1, 1, 1))
+    with torch.no_grad():
+        mods[0].weight.mul_(1.5)                      # written after prepare(): the cached fold is stale and must not be used
+    assert mods[0]._cached_fold(mods[0].norm.scale_shift()[0]) is None
+    with torch.no_grad():
+        mods[0].weight.div_(1.5)
+    data = synthetic_batch(2, 256, 320, 5, seed=6)
+    a = Trainer(cfg, base, distributed=False)
+    assert a._step_folds is not None
+    os.environ["LGD_STEP_FOLDS"] = "0"
+    try:
+        b = Trainer(cfg, twin, distributed=False)
+    finally:
+        del os.environ["LGD_STEP_FOLDS"]
+    assert b._step_folds is None
+    hits = []
+    cached = ConvBN._cached_fold
+
+    def counting(self, scale):
+        r = cached(self, scale)
+        if r is not None and self.weight.requires_grad:
+            hits.append(self)
+        return r
+    ConvBN._cached_fold = counting
+    try:
+        for it in (0, 25000, 40000):
+            la = a.step(data, it)
+            want = sum(1 for m in base.modules() if isinstance(m, ConvBN) and (m._pointwise or m._pointwise_s2) and m.weight.requires_grad)
+            # every trainable 1x1 ConvBN took the step's fold (iteration 0: the backbone is frozen, SOLVER.PRE_FREEZE_STUDENT_BACKBONE_ITERS)
+            assert (want > 0 or it == 0) and len(set(map(id, hits))) == want, (it, len(hits), want)
+            hits.clear()
+            lb = b.step(data, it)
+            assert not hits                              # the trainer without StepFolds folds inside each op
+            for k in la:
+                va, vb = float(la[k].detach()), float(lb[k].detach())
+                assert abs(va - vb) <= 1e-5 * max(1.0, abs(vb)), (it, k, va, vb)
+    finally:
+        ConvBN._cached_fold = cached
+    # (the step is not bit-reproducible run to run -- fp32 atomics in the pooling / matching reductions -- so the parameters are compared to the noise
+    #  of those, not bit for bit; the folds themselves are, above)
+    for (n, p), (_, q) in zip(base.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), (n, float((p - q).abs().max()))
+
+
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("yaml_name", ["lgd_retinanet_r50.yaml", "lgd_fcos_r50.yaml"])   # (R-101-DCNv2 passes too: 3.5 min of library conv search)
 def test_full_size_step_shipped_path_vs_library_convolutions(yaml_name):
