@@ -66,6 +66,7 @@ def parse():
                          "configs/Base-RetinaNet.yaml:26) instead of every image at --height x --width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
+    ap.add_argument("--no-gn-bwd-fold", action="store_true", help="FCOS towers: the GroupNorm backward as its own statistics + apply passes instead of inside the producing convolution's adjoint output transform (A/B runs)")
     ap.add_argument("--no-gn-fold", action="store_true", help="FCOS towers: GroupNorm(32) + ReLU as its own passes instead of inside the next convolution's input transform (A/B runs)")
     ap.add_argument("--no-fcos-fused-loss", action="store_true", help="FCOS: GIoU / centerness losses as the composed torch form instead of one kernel on the raw head outputs (A/B runs)")
     ap.add_argument("--head-passes", type=int, default=1, choices=[1, 2],
@@ -195,6 +196,8 @@ def main():
         model.student.fused_reg_loss = False
     if args.no_gn_fold and hasattr(model.student.head, "fold_group_norm"):
         model.student.head.fold_group_norm = False
+    if args.no_gn_bwd_fold and hasattr(model.student.head, "fold_group_norm_bwd"):
+        model.student.head.fold_group_norm_bwd = False
     trainer = Trainer(cfg, model, device=dev, distributed=True if force_ddp else None, fused_sgd=not args.torch_optimizers)
     d = cfg.MODEL.DISTILLATOR
     it0 = {"distill": max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS),

@@ -171,6 +171,13 @@ int lgd_gn_group_stats_affine(const float* const* x_host, const int32_t* level_h
 int lgd_gn_group_bwd(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L, int B, int C,
                      int G, const float* gamma, const float* beta, int relu, const float* stats, double* ws, float* bstats,
                      float* plane_sums, float* const* dx_host, void* stream);
+/* the statistics half of lgd_gn_group_bwd(relu = 0) alone: bstats, plane_sums as above and coef [L][B][C][4] = (ca, cm, mean, cb) with
+ * dx = ca * g - cm - (x - mean) * cb, ca = rstd * gamma, cm = rstd * m1, cb = rstd^2 * m2 -- what lgd_wino_out_t_gn of the convolution
+ * that PRODUCED x applies while it loads g and x: the backward apply pass of a conv -> GroupNorm -> ReLU -> conv tower layer
+ * (thirdparty_heads/fcos.py:455-470) never runs and dx is never written or re-read. */
+int lgd_gn_group_bwd_coef(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L, int B, int C,
+                          int G, const float* gamma, const float* stats, double* ws, float* bstats, float* plane_sums, float* coef,
+                          void* stream);
 
 /* ------------------------------------------------------------------ K3b: ReLU(x + ctx[b,c]) epilogue of the rendering
  * [ref: dynamic_teacher.py:151  F.relu(inst_featmap + ctx_feature[:, :, None, None])]
@@ -316,6 +323,10 @@ int lgd_wino_out_t(const float* const* dy_host, const void* relu_bits, const int
                    float* dM, void* stream);
 int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, int C, int tile, float* const* dx_host,
                   const void* pre_bits, void* stream);
+/* lgd_wino_out_t of a convolution whose outputs y feed a GroupNorm (tile 6 only): g_host are the gradients w.r.t. the GroupNorm OUTPUT,
+ * coef [L][N][C][4] comes from lgd_gn_group_bwd_coef; dM = A (ca * g - cm - (y - mean) * cb) A^T. */
+int lgd_wino_out_t_gn(const float* const* g_host, const float* const* y_host, const float* coef, const int32_t* level_hw_host, int L,
+                      int N, int C, int tile, float* dM, void* stream);
 /* Filter transforms:
  *   lgd_wino_filter_fwd: U[f][co][ci] = (G (scale[co] . g) G^T)[f] at U + f*u_plane + co*Ci + ci, and the same values transposed in
  *     (co, ci) at Ut + f*ut_plane + ci*ut_ld + co (the operand of dV = U^T dM); u_plane / ut_plane / ut_ld let several filters stack

@@ -34,6 +34,8 @@ struct GgArgs {
     float* bstats;                  // [L*B*G][2] m1, m2 (backward)
     float* plane_sums;              // [L*B*C][2] sum g, sum g*xhat (backward)
     float* affine;                  // optional (forward finalize): [L*B][C][2] rstd*gamma, beta - mean*rstd*gamma
+    float* coef;                    // optional (backward finalize): [L*B][C][4] ca = rstd*gamma, cm = rstd*m1, mean, cb = rstd^2*m2 --
+                                    //   dx = ca*g - cm - (x - mean)*cb, applied by the producing convolution's lgd_wino_out_t_gn
 };
 
 struct GgWhere { int l, plane, chunk; };
@@ -139,8 +141,17 @@ __global__ __launch_bounds__(64) void gg_finalize_kernel(GgArgs a) {
                 }
             }
         } else {
-            a.bstats[2 * seg] = (float)(t0 / n);
-            a.bstats[2 * seg + 1] = (float)(t1 / n);
+            const float m1 = (float)(t0 / n), m2 = (float)(t1 / n);
+            a.bstats[2 * seg] = m1;
+            a.bstats[2 * seg + 1] = m2;
+            if (a.coef) {
+                const float mu = a.stats[2 * seg], r = a.stats[2 * seg + 1];
+                for (int j = 0; j < cg; ++j) {
+                    const int c = g * cg + j;
+                    float* k = a.coef + 4 * ((size_t)lb * a.C + c);
+                    k[0] = r * (a.gamma ? a.gamma[c] : 1.f); k[1] = r * m1; k[2] = mu; k[3] = r * r * m2;
+                }
+            }
         }
     }
 }
@@ -211,7 +222,7 @@ static int gg_fill(GgArgs& a, const float* const* x_host, const int32_t* level_h
     if (w > 0x7fffffffLL) return LGD_EINVAL;
     a.wave0[LGD_MAX_LEVELS] = (int)w;
     a.nwaves = (int)w;
-    a.gamma = a.beta = nullptr; a.ws = nullptr; a.stats = a.bstats = a.plane_sums = nullptr; a.affine = nullptr;
+    a.gamma = a.beta = nullptr; a.ws = nullptr; a.stats = a.bstats = a.plane_sums = nullptr; a.affine = nullptr; a.coef = nullptr;
     return LGD_OK;
 }
 
@@ -270,6 +281,23 @@ int lgd_gn_group_bwd(const float* const* x_host, const float* const* dy_host, co
     LGD_LAUNCH("gn_group_bwd_stats_kernel", lgd::gg_stats_kernel<1>, grid, dim3(256), 0, s, a);
     LGD_LAUNCH("gn_group_bwd_finalize_kernel", lgd::gg_finalize_kernel<1>, dim3(L * B * G), dim3(64), 0, s, a);
     LGD_LAUNCH("gn_group_bwd_apply_kernel", lgd::gg_apply_kernel<1>, grid, dim3(256), 0, s, a);
+    return lgd::check_launch();
+}
+
+int lgd_gn_group_bwd_coef(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L, int B, int C,
+                          int G, const float* gamma, const float* stats, double* ws, float* bstats, float* plane_sums, float* coef,
+                          void* stream) {
+    lgd::GgArgs a;
+    if (lgd::gg_fill(a, x_host, level_hw_host, L, B, C, G, 0) != LGD_OK || !dy_host || !stats || !ws || !bstats || !plane_sums || !coef)
+        return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) {
+        if (!dy_host[l]) return LGD_EINVAL;
+        a.dy[l] = dy_host[l];
+    }
+    a.gamma = gamma; a.ws = ws; a.stats = const_cast<float*>(stats); a.bstats = bstats; a.plane_sums = plane_sums; a.coef = coef;
+    hipStream_t s = (hipStream_t)stream;
+    LGD_LAUNCH("gn_group_bwd_stats_kernel", lgd::gg_stats_kernel<1>, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
+    LGD_LAUNCH("gn_group_bwd_finalize_kernel", lgd::gg_finalize_kernel<1>, dim3(L * B * G), dim3(64), 0, s, a);
     return lgd::check_launch();
 }
 

@@ -9,6 +9,9 @@ namespace lgd {
 struct WinoArgs {
     const float* maps_in[LGD_MAX_LEVELS];   // per-level NCHW inputs (wino_in / wino_out_t)
     float* maps_out[LGD_MAX_LEVELS];        // per-level NCHW outputs (wino_out)
+    const float* maps_in2[LGD_MAX_LEVELS];  // optional (wino_out_t, with gn_coef): the convolution's own forward outputs y
+    const float* gn_coef;                   // optional (wino_out_t): [L][N][C][4] (ca, cm, mu, cb) of the GroupNorm that follows the convolution --
+                                            //   maps_in are then gradients w.r.t. the GroupNorm OUTPUT and dy = ca * g - cm - (y - mu) * cb
     const float* buf_in;                    // [C][nf][T]
     float* buf_out;                         // [C][nf][T]
     const float* bias;
@@ -71,7 +74,7 @@ int wino_fill(WinoArgs& a, const int32_t* level_hw, int L, int N, int C, int til
 // F(6x6,3x3) launches (winograd6.hip); `a` filled by wino_fill(tile = 6)
 void wino6_launch_in(const WinoArgs& a, unsigned blocks, bool pre, hipStream_t st);
 void wino6_launch_out(const WinoArgs& a, unsigned blocks, hipStream_t st);
-void wino6_launch_out_t(const WinoArgs& a, unsigned blocks, hipStream_t st);
+void wino6_launch_out_t(const WinoArgs& a, unsigned blocks, hipStream_t st);   // a.gn_coef: the GroupNorm-backward form
 void wino6_launch_in_t(const WinoArgs& a, unsigned blocks, bool fuse, hipStream_t st);
 struct FilterArgs {
     const float* w; const float* scale; const float* dU;

@@ -624,11 +624,11 @@ long long wino_level_tiles(int N, int H, int W, int tile) {
 int wino_fill(WinoArgs& a, const int32_t* level_hw, int L, int N, int C, int tile, unsigned* blocks) {
     if (!level_hw || L < 1 || L > LGD_MAX_LEVELS || N < 1 || C < 1 || C > 65535 || (tile != 4 && tile != 6)) return LGD_EINVAL;
     a.L = L; a.N = N; a.C = C; a.relu = 0;
-    a.bias = nullptr; a.pre_affine = nullptr; a.buf_in = nullptr; a.buf_out = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
+    a.bias = nullptr; a.pre_affine = nullptr; a.gn_coef = nullptr; a.buf_in = nullptr; a.buf_out = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
     long long off = 0;
     unsigned blk = 0;
     for (int l = 0; l < LGD_MAX_LEVELS; ++l) {
-        a.maps_in[l] = nullptr; a.maps_out[l] = nullptr;
+        a.maps_in[l] = nullptr; a.maps_out[l] = nullptr; a.maps_in2[l] = nullptr;
         a.H[l] = a.W[l] = a.TH[l] = a.TW[l] = a.pair[l] = 0; a.tile_off[l] = 0; a.blk_off[l] = 0;
     }
     for (int l = 0; l < L; ++l) {
@@ -712,6 +712,23 @@ int lgd_wino_out_t(const float* const* dy_host, const void* relu_bits, const int
     a.buf_out = dM;
     if (tile == 6) lgd::wino6_launch_out_t(a, blocks, (hipStream_t)stream);
     else { LGD_LAUNCH("wino_out_t_kernel", lgd::wino4_out_t_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
+    return lgd::check_launch();
+}
+
+int lgd_wino_out_t_gn(const float* const* g_host, const float* const* y_host, const float* coef, const int32_t* level_hw_host, int L,
+                      int N, int C, int tile, float* dM, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!g_host || !y_host || !coef || !dM || tile != 6 || lgd::wino_fill(a, level_hw_host, L, N, C, tile, &blocks) != LGD_OK)
+        return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) {
+        if (!g_host[l] || !y_host[l]) return LGD_EINVAL;
+        a.maps_in[l] = g_host[l];
+        a.maps_in2[l] = y_host[l];
+    }
+    a.gn_coef = coef;
+    a.buf_out = dM;
+    lgd::wino6_launch_out_t(a, blocks, (hipStream_t)stream);
     return lgd::check_launch();
 }
 

@@ -423,7 +423,7 @@ __device__ __forceinline__ void expand_block6(const float (&g)[6][6], bool on, f
 }
 
 // dM = A (dy . mask) A^T: the ONE transform of dy the backward pass needs (dU[f] = dM[f] V[f]^T, dV[f] = U[f]^T dM[f])
-template <bool VEC>
+template <bool VEC, bool GN>
 __device__ __forceinline__ void wino6_out_t_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
     const long long units = (long long)a.N * TH * TW, padded = (units + kTilePad - 1) & ~(long long)(kTilePad - 1);
@@ -440,7 +440,48 @@ __device__ __forceinline__ void wino6_out_t_body(const WinoArgs& a, int l, float
     if (a.bits_in) mb = load_bits36(a.bits_in, (size_t)c * plane + (size_t)a.tile_off[l] + uu);
     const int oy = 6 * ty, ox = 6 * tx;
     float g[6][6];
-    if constexpr (VEC) {
+    if constexpr (GN) {
+        // the maps are gradients w.r.t. the OUTPUT of the GroupNorm that follows this convolution: its backward apply
+        // dy = rstd * (gamma * g - m1 - xhat * m2) = ca * g - cm - (y - mu) * cb runs here, on the block as it is loaded (the
+        // gradient of the convolution output is never written or re-read); pixels outside the map stay zero
+        const float* py = a.maps_in2[l] + ((size_t)n * a.C + c) * H * W;
+        const float4 k = *reinterpret_cast<const float4*>(a.gn_coef + 4 * (((size_t)l * a.N + n) * a.C + c));
+        auto gn = [&](float gv, float yv, bool ok) -> float { return ok ? fmaf(k.x, gv, -k.y) - (yv - k.z) * k.w : 0.f; };
+        if constexpr (VEC) {
+            const bool odd = tx & 1;
+            const int xa = ox + (odd ? 2 : 0), xb = ox + (odd ? 0 : 4);
+            const bool va = xa + 4 <= W, vb = xb + 2 <= W;
+            float4 A[6], Ay[6]; float2 B[6], By[6];
+            #pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool yok = oy + i < H;
+                const size_t ro = (size_t)(yok ? oy + i : 0) * W;
+                A[i] = (yok && va) ? ldg_stream4(p + ro + xa) : make_float4(0.f, 0.f, 0.f, 0.f);
+                B[i] = (yok && vb) ? *reinterpret_cast<const float2*>(p + ro + xb) : make_float2(0.f, 0.f);
+                Ay[i] = (yok && va) ? ldg_stream4(py + ro + xa) : make_float4(0.f, 0.f, 0.f, 0.f);
+                By[i] = (yok && vb) ? *reinterpret_cast<const float2*>(py + ro + xb) : make_float2(0.f, 0.f);
+            }
+            #pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool yok = oy + i < H, oa = yok && va, ob = yok && vb;
+                A[i] = make_float4(gn(A[i].x, Ay[i].x, oa), gn(A[i].y, Ay[i].y, oa), gn(A[i].z, Ay[i].z, oa), gn(A[i].w, Ay[i].w, oa));
+                B[i] = make_float2(gn(B[i].x, By[i].x, ob), gn(B[i].y, By[i].y, ob));
+                own6(odd, A[i], B[i], g[i]);
+            }
+        } else {
+            #pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool yok = oy + i < H;
+                const size_t ro = (size_t)(yok ? oy + i : 0) * W;
+                #pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const bool ok = yok && ox + j < W;
+                    const size_t o = ro + (ok ? ox + j : 0);
+                    g[i][j] = gn(ok ? p[o] : 0.f, ok ? py[o] : 0.f, ok);
+                }
+            }
+        }
+    } else if constexpr (VEC) {
         const bool odd = tx & 1;
         const int xa = ox + (odd ? 2 : 0), xb = ox + (odd ? 0 : 4);
         const bool va = xa + 4 <= W, vb = xb + 2 <= W;
@@ -473,8 +514,16 @@ __device__ __forceinline__ void wino6_out_t_body(const WinoArgs& a, int l, float
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_OUTT_WAVES, 8))) void wino6_out_t_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
-    if (a.pair[l]) wino6_out_t_body<true>(a, l, lds);
-    else wino6_out_t_body<false>(a, l, lds);
+    if (a.pair[l]) wino6_out_t_body<true, false>(a, l, lds);
+    else wino6_out_t_body<false, false>(a, l, lds);
+}
+
+// the same with the backward apply of a GroupNorm that follows the convolution folded into the load (WinoArgs::gn_coef)
+__global__ __launch_bounds__(256) void wino6_out_t_gn_kernel(WinoArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[16 * 256];
+    const int l = wino_level(a);
+    if (a.pair[l]) wino6_out_t_body<true, true>(a, l, lds);
+    else wino6_out_t_body<false, true>(a, l, lds);
 }
 
 // dx = adjoint of wino6_in: the 8x8 windows Z_t = B G_t B^T (G = dV) of neighbouring tiles overlap by two pixels and are summed
@@ -768,7 +817,8 @@ void wino6_launch_out(const WinoArgs& a, unsigned blocks, hipStream_t st) {
     LGD_LAUNCH("wino_out_kernel", wino6_out_kernel, dim3(blocks, a.C), dim3(256), 0, st, a);
 }
 void wino6_launch_out_t(const WinoArgs& a, unsigned blocks, hipStream_t st) {
-    LGD_LAUNCH("wino_out_t_kernel", wino6_out_t_kernel, dim3(blocks, a.C), dim3(256), 0, st, a);
+    if (a.gn_coef) { LGD_LAUNCH("wino_out_t_gn_kernel", wino6_out_t_gn_kernel, dim3(blocks, a.C), dim3(256), 0, st, a); }
+    else { LGD_LAUNCH("wino_out_t_kernel", wino6_out_t_kernel, dim3(blocks, a.C), dim3(256), 0, st, a); }
 }
 void wino6_launch_in_t(const WinoArgs& a, unsigned blocks, bool fuse, hipStream_t st) {
     const dim3 grid(blocks, a.C), block(256);

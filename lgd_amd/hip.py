@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -46,6 +46,7 @@ SIGNATURES = {
     "lgd_gn_group_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn_group_stats_affine": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn_group_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gn_group_bwd_coef": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_fcos_targets": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_ctx_relu_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_ctx_relu_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "lgd_wino_out": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_wino_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_in_t": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "lgd_wino_out_t_gn": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_filter_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp]),
     "lgd_wino_filter_bwd": (c_i, [c_fp, ctypes.c_longlong, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_in_t_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),

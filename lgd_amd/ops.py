@@ -1171,6 +1171,138 @@ class _Conv3x3K(torch.autograd.Function):
         return (None, None, None, None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
 
 
+class _Conv3x3GN(torch.autograd.Function):
+    """_Conv3x3K (tile 6, no ReLU, no filter scale) whose K outputs each feed a GroupNorm(groups) + ReLU that the NEXT convolution applies
+    while it loads (group_norm_fold's forward half: statistics -> per-(map, sample, channel) scale / shift), as ONE autograd node, so
+    that the GroupNorm's backward apply pass disappears as well: the node receives the gradients w.r.t. the GroupNorm OUTPUTS (the next
+    convolution's adjoint input transform has applied the ReLU bits), one statistics pass over (y, g) yields the coefficients
+    (lgd_gn_group_bwd_coef) and the adjoint output transform computes dy = ca * g - cm - (y - mean) * cb on the blocks it loads
+    (lgd_wino_out_t_gn): per tower layer the backward moves 2 + 2 maps instead of 2 + 3 + 1 and launches one kernel less
+    [ref: thirdparty_heads/fcos.py:455-470, 520-531].
+    apply(K, tile, groups, pre, w_1, b_1, gamma_1, beta_1, ..., x_1, ..., x_L) -> (affine_1, ..., affine_K, K * L raw maps, filter-major)."""
+
+    @staticmethod
+    def forward(ctx, K, tile, groups, pre, *args):
+        ws, bs = list(args[0:4 * K:4]), list(args[1:4 * K:4])
+        gammas, betas = list(args[2:4 * K:4]), list(args[3:4 * K:4])
+        xs = list(args[4 * K:])
+        if tile != 6:
+            raise hip.LgdHipError("the fused GroupNorm backward exists for F(6x6,3x3) only")
+        hip.require_gpu(*ws, *xs)
+        lib = hip.load()
+        ws = [hip.dense_f32(w) for w in ws]
+        xs = [hip.dense_f32(x) for x in xs]
+        bs = [hip.dense_f32(b) if b is not None else None for b in bs]
+        gammas = [hip.dense_f32(g) if g is not None else None for g in gammas]
+        betas = [hip.dense_f32(b) if b is not None else None for b in betas]
+        L, N, Ci = len(xs), xs[0].shape[0], xs[0].shape[1]
+        Cos = [w.shape[0] for w in ws]
+        Ct = sum(Cos)
+        dev = ws[0].device
+        nf = (tile + 2) ** 2
+        mdt = _WINO_MASK_DTYPE[tile]
+        hw = hip.int_array([d for x in xs for d in x.shape[2:]])
+        T = lib.lgd_wino_tiles(hw, L, N, tile)
+        U, Ut = _wino_filters(lib, ws, [None] * K, Ci, dev, tile)
+        V = _freq_buf(nf, Ci, T, dev)
+        pre = hip.dense_f32(pre) if pre is not None else None
+        affine_in = pre is not None and pre.dim() == 3
+        if affine_in and tuple(pre.shape) != (L * N, Ci, 2):
+            raise hip.LgdHipError("affine pre-activation must be (L*N, C, 2) = (%d, %d, 2), got %s" % (L * N, Ci, tuple(pre.shape)))
+        pre_bits = (torch.empty((Ci, T), dtype=mdt, device=dev) if pre is not None and any(ctx.needs_input_grad[4 + 4 * K:]) else None)
+        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), hw, L, N, Ci, tile, hip.ptr(V),
+                                  hip.ptr(pre) if pre is not None and not affine_in else None, hip.ptr(pre) if affine_in else None,
+                                  hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in")
+        px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)
+        fb = 4 * nf * T
+        _count_bytes("wino_in_kernel", (px + fb) * Ci)
+        M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
+        ys, affs, stats, c0 = [], [], [], 0
+        for k in range(K):
+            yk = [torch.empty((N, Cos[k]) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
+            _count_bytes("wino_out_kernel", (px + fb) * Cos[k])
+            hip.check(lib.lgd_wino_out(hip.ptr(M[:, c0]), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Cos[k], tile, 0,
+                                       hip.ptr_array(yk), None, hip.stream_ptr()), "lgd_wino_out")
+            # (the statistics in the output transform's epilogue -- per-plane fp64 sums by atomics -- were measured: the transform slows down by
+            #  what the pass costs, DESIGN.md section 4-K8.13)
+            gws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, N, Cos[k]), dtype=torch.float64, device=dev)
+            st = torch.empty((L * N * groups, 2), dtype=torch.float32, device=dev)
+            aff = torch.empty((L * N, Cos[k], 2), dtype=torch.float32, device=dev)
+            _count_bytes("gn_group_stats_kernel", px * Cos[k])
+            hip.check(lib.lgd_gn_group_stats_affine(hip.ptr_array(yk), hw, L, N, Cos[k], groups,
+                                                    hip.ptr(gammas[k]) if gammas[k] is not None else None,
+                                                    hip.ptr(betas[k]) if betas[k] is not None else None, hip.ptr(gws), hip.ptr(st), hip.ptr(aff),
+                                                    hip.stream_ptr()), "lgd_gn_group_stats_affine")
+            ys += yk
+            affs.append(aff)
+            stats.append(st)
+            c0 += Cos[k]
+        need_w = any(ctx.needs_input_grad[4:4 + 4 * K:4])
+        ctx.save_for_backward(Ut, V if need_w else None, pre_bits, *stats, *gammas, *ys)
+        ctx.meta = (K, L, N, Ci, Cos, hw, T, [b is not None for b in bs], [b is not None for b in betas],
+                    [tuple(x.shape[2:]) for x in xs], tile, groups, px, fb)
+        ctx.mark_non_differentiable(*affs)
+        return (*affs, *ys)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        K, L, N, Ci, Cos, hw, T, has_bias, has_beta, shapes, tile, groups, px, fb = ctx.meta
+        Ut, V, pre_bits = ctx.saved_tensors[:3]
+        stats = ctx.saved_tensors[3:3 + K]
+        gammas = ctx.saved_tensors[3 + K:3 + 2 * K]
+        ys = ctx.saved_tensors[3 + 2 * K:]
+        gs = grads[K:]
+        Ct = sum(Cos)
+        lib = hip.load()
+        dev = Ut.device
+        nf = (tile + 2) ** 2
+        gs = [hip.dense_f32(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
+              for i, g in enumerate(gs)]
+        nig = ctx.needs_input_grad
+        need_ws = list(nig[4:4 + 4 * K:4])
+        need_bs = [hb and nb for hb, nb in zip(has_bias, nig[5:5 + 4 * K:4])]
+        need_w, need_x = any(need_ws), any(nig[4 + 4 * K:])
+        dws, dbs, dgs, dbes = [None] * K, [None] * K, [None] * K, [None] * K
+        dxs = [None] * L
+        dM = _freq_buf(nf, Ct, T, dev)
+        c0 = 0
+        for k in range(K):
+            gk, yk = gs[k * L:(k + 1) * L], list(ys[k * L:(k + 1) * L])
+            gws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, N, Cos[k]), dtype=torch.float64, device=dev)
+            bst = torch.empty((L * N * groups, 2), dtype=torch.float32, device=dev)
+            psums = torch.empty((L * N, Cos[k], 2), dtype=torch.float32, device=dev)
+            coef = torch.empty((L * N, Cos[k], 4), dtype=torch.float32, device=dev)
+            _count_bytes("gn_group_bwd_stats_kernel", 2 * px * Cos[k])
+            hip.check(lib.lgd_gn_group_bwd_coef(hip.ptr_array(yk), hip.ptr_array(gk), hw, L, N, Cos[k], groups,
+                                                hip.ptr(gammas[k]) if gammas[k] is not None else None, hip.ptr(stats[k]), hip.ptr(gws),
+                                                hip.ptr(bst), hip.ptr(psums), hip.ptr(coef), hip.stream_ptr()), "lgd_gn_group_bwd_coef")
+            _count_bytes("wino_out_t_gn_kernel", (2 * px + fb) * Cos[k])
+            hip.check(lib.lgd_wino_out_t_gn(hip.ptr_array(gk), hip.ptr_array(yk), hip.ptr(coef), hw, L, N, Cos[k], tile, hip.ptr(dM[:, c0]),
+                                            hip.stream_ptr()), "lgd_wino_out_t_gn")
+            if (gammas[k] is not None and nig[6 + 4 * k]) or (has_beta[k] and nig[7 + 4 * k]):
+                s = psums.sum(0)
+                dgs[k] = s[:, 1].contiguous() if gammas[k] is not None and nig[6 + 4 * k] else None
+                dbes[k] = s[:, 0].contiguous() if has_beta[k] and nig[7 + 4 * k] else None
+            c0 += Cos[k]
+        if need_x:
+            _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
+            dV = _timed_bmm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
+            dxs = [torch.empty((N, Ci) + sh, dtype=torch.float32, device=dev) for sh in shapes]
+            hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs),
+                                        hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in_t")
+            del dV
+        if need_w:
+            dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
+            dws = _wino_filter_grads(lib, dU, [None] * K, Cos, need_ws, Ci, tile)
+        if any(need_bs):
+            db = dM[tile + 3].sum(1)   # the frequency of the interpolation point 1: the tile's gradient sum
+            c0 = 0
+            for k in range(K):
+                dbs[k] = db[c0:c0 + Cos[k]] if need_bs[k] else None
+                c0 += Cos[k]
+        return (None, None, None, None, *[g for quad in zip(dws, dbs, dgs, dbes) for g in quad], *dxs)
+
+
 class _Conv3x3Chain(torch.autograd.Function):
     """K convolutions 3x3 / stride 1 / padding 1 in SEQUENCE over the same L maps, conv k [+ ReLU if relus[k]] feeding conv k+1 and
     nothing else (the head towers after their first conv incl. the score conv, the adapter: distillator.py:107-109 ->
@@ -1365,6 +1497,27 @@ def conv3x3_shared_input(xs, filters, relu=False, pre=None):
     if pre is not None:
         xs = _apply_pre(xs, pre)
     return [conv3x3_levels(xs, w, b, relu) for w, b in filters]
+
+
+_GN_FUSED_BWD = True   # False: conv + group_norm_fold as two autograd nodes (tests compare the two)
+
+
+def conv3x3_gn(xs, filters, groups, pre=None):
+    """filters [(w, b, gamma, beta), ...] on the SAME maps, each followed by GroupNorm(groups, gamma, beta) + ReLU that the NEXT convolution
+    applies while it loads: returns [(affine, raw maps), ...] -- pass both on as conv3x3_levels(maps, ..., pre=affine) / conv3x3_gn(maps,
+    ..., pre=affine).  One autograd node per call on the F(6x6,3x3) path (_Conv3x3GN: no GroupNorm apply pass in either direction);
+    elsewhere conv3x3_levels / conv3x3_shared_input + group_norm_fold."""
+    xs = list(xs)
+    L = len(xs)
+    if _GN_FUSED_BWD and _WINO_TILE == 6 and all(_wino_ok(xs, f[0]) for f in filters):
+        K = len(filters)
+        out = _Conv3x3GN.apply(K, _WINO_TILE, int(groups), pre, *[t for f in filters for t in f], *xs)
+        return [(out[k], list(out[K + k * L:K + (k + 1) * L])) for k in range(K)]
+    if len(filters) > 1:
+        ys = conv3x3_shared_input(xs, [(f[0], f[1]) for f in filters], pre=pre)
+    else:
+        ys = [conv3x3_levels(xs, filters[0][0], filters[0][1], pre=pre)]
+    return [group_norm_fold(y, groups, f[2], f[3]) for y, f in zip(ys, filters)]
 
 
 def conv3x3_chain(xs, filters, relus, fused_links=True):

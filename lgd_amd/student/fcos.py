@@ -53,6 +53,7 @@ class FCOSHead(nn.Module):
         nn.init.constant_(self.cls_score.bias, -math.log((1 - f.PRIOR_PROB) / f.PRIOR_PROB))
         self.scales = nn.ModuleList([Scale(1.0) for _ in self.fpn_strides])
         self.fold_group_norm = True
+        self.fold_group_norm_bwd = True   # False: the GroupNorm backward as its own statistics + apply passes (A/B: bench.py --no-gn-bwd-fold)
 
     def forward(self, features, raw_reg=False):
         """features: the L pyramid levels, or 2L maps (student + teacher pyramids, one pass).  raw_reg: return the bbox_pred maps without
@@ -64,11 +65,20 @@ class FCOSHead(nn.Module):
         pc = pb = None   # (scale, shift) of the previous layer's GroupNorm + ReLU, applied by the next convolution's input transform
         for i in range(0, len(self.cls_subnet), 3):
             gc, gb = self.cls_subnet[i + 1], self.bbox_subnet[i + 1]
-            if i == 0:  # the towers' first convs read the same maps: one input transform / stacked GEMM / summed input gradient
-                c, b = ops.conv3x3_shared_input(c, [(self.cls_subnet[0].weight, self.cls_subnet[0].bias),
-                                                    (self.bbox_subnet[0].weight, self.bbox_subnet[0].bias)])
+            wc, wb = self.cls_subnet[i], self.bbox_subnet[i]
+            if self.fold_group_norm and self.fold_group_norm_bwd:
+                # conv + the GroupNorm statistics as one node: the GroupNorm's backward apply runs inside the conv's adjoint output transform
+                fc, fb = (wc.weight, wc.bias, gc.weight, gc.bias), (wb.weight, wb.bias, gb.weight, gb.bias)
+                if i == 0:  # the towers' first convs read the same maps: one input transform / stacked GEMM / summed input gradient
+                    (pc, c), (pb, b) = ops.conv3x3_gn(c, [fc, fb], gc.num_groups)
+                else:
+                    (pc, c), = ops.conv3x3_gn(c, [fc], gc.num_groups, pre=pc)
+                    (pb, b), = ops.conv3x3_gn(b, [fb], gb.num_groups, pre=pb)
+                continue
+            if i == 0:
+                c, b = ops.conv3x3_shared_input(c, [(wc.weight, wc.bias), (wb.weight, wb.bias)])
             else:
-                c, b = self.cls_subnet[i].levels(c, pre=pc), self.bbox_subnet[i].levels(b, pre=pb)
+                c, b = wc.levels(c, pre=pc), wb.levels(b, pre=pb)
             if self.fold_group_norm:
                 # GroupNorm(32) + ReLU: statistics only; the apply pass is folded into the next convolution's load (ops.group_norm_fold)
                 pc, c = ops.group_norm_fold(c, gc.num_groups, gc.weight, gc.bias)

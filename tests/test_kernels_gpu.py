@@ -1207,6 +1207,68 @@ def test_group_norm_folded_into_conv3x3(tile, B, C, Co, G, level_hw):
         assert cm.rel_err(t.grad, r.grad) < 2 * tol
 
 
+@pytest.mark.parametrize("mode", ["one_node", "two_nodes"])
+@pytest.mark.parametrize("B,C,G,level_hw", [(2, 64, 8, [(20, 28), (13, 21), (7, 11)]), (3, 256, 32, [(12, 16), (6, 7), (2, 3)])])
+def test_conv3x3_group_norm_tower_backward_folded(mode, B, C, G, level_hw):
+    """two tower layers conv3x3 -> GroupNorm(G) -> ReLU and a final conv3x3, the first layer with two filters on the same maps (the FCOS
+    towers, thirdparty_heads/fcos.py:455-470) through ops.conv3x3_gn: one autograd node per convolution + GroupNorm whose backward
+    applies the GroupNorm gradient inside the adjoint output transform (lgd_gn_group_bwd_coef + lgd_wino_out_t_gn: aligned and unaligned
+    rows, ragged tiles) -- against the fp64 definition: outputs and the gradients of the maps, every filter, bias, gamma and beta;
+    two_nodes: the same composition as conv + group_norm_fold nodes."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+
+    def P(shape, seed, lo, hi, scale=1.0):
+        return (torch.from_numpy(synth.det_uniform(shape, seed, lo, hi)) * scale).to(DEV).requires_grad_(True)
+    xs = [P((B, C, h, w), 1700 + i, -2.0, 3.0) for i, (h, w) in enumerate(level_hw)]
+    std = (2.0 / (9 * C)) ** 0.5
+    lay = {}
+    for n, seed in (("a1", 1710), ("b1", 1720), ("a2", 1730), ("b2", 1740)):
+        lay[n] = (P((C, C, 3, 3), seed, -1.0, 1.0, std), P((C,), seed + 1, -0.1, 0.1), P((C,), seed + 2, 0.5, 1.5), P((C,), seed + 3, -0.5, 0.5))
+    fin = {n: (P((24, C, 3, 3), seed, -1.0, 1.0, std), P((24,), seed + 1, -0.1, 0.1)) for n, seed in (("a", 1750), ("b", 1760))}
+    gys = {n: [torch.from_numpy(synth.det_uniform((B, 24, h, w), seed + i, -1.0, 1.0)).to(DEV) for i, (h, w) in enumerate(level_hw)]
+           for n, seed in (("a", 1770), ("b", 1780))}
+    prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=6)
+    was = ops._GN_FUSED_BWD
+    ops._GN_FUSED_BWD = mode == "one_node"
+    try:
+        (pa, ma), (pb, mb) = ops.conv3x3_gn(xs, [lay["a1"], lay["b1"]], G)
+        (pa, ma), = ops.conv3x3_gn(ma, [lay["a2"]], G, pre=pa)
+        (pb, mb), = ops.conv3x3_gn(mb, [lay["b2"]], G, pre=pb)
+        ya = ops.conv3x3_levels(ma, *fin["a"], pre=pa)
+        yb = ops.conv3x3_levels(mb, *fin["b"], pre=pb)
+        torch.autograd.backward(list(ya) + list(yb), gys["a"] + gys["b"])
+    finally:
+        ops._GN_FUSED_BWD = was
+        ops.conv3x3_backend(*prev)
+
+    def d(t):
+        return t.detach().double().requires_grad_(True)
+    x64 = [d(x) for x in xs]
+    l64 = {n: tuple(d(t) for t in v) for n, v in lay.items()}
+    f64 = {n: tuple(d(t) for t in v) for n, v in fin.items()}
+
+    def tower(x, n):
+        for k in ("1", "2"):
+            w, b, ga, be = l64[n + k]
+            x = SO.group_norm_relu(F.conv2d(x, w, b, 1, 1), G, ga, be, True)
+        return F.conv2d(x, f64[n][0], f64[n][1], 1, 1)
+    ra, rb = [tower(x, "a") for x in x64], [tower(x, "b") for x in x64]
+    torch.autograd.backward(ra + rb, [g.double() for g in gys["a"] + gys["b"]])
+    tol = 2e-4   # three F(6x6,3x3) convolutions in sequence (1e-4 each against fp64, test_group_norm_folded_into_conv3x3)
+    for y, r in zip(list(ya) + list(yb), ra + rb):
+        assert cm.rel_err(y, r) < tol
+    for x, xr in zip(xs, x64):
+        ok, msg = cm.kink_robust_close(x.grad, xr.grad, tol=2 * tol, max_outlier_frac=2e-3, max_rel=1e-2)
+        assert ok, msg
+    for n in lay:
+        for t, r, what in zip(lay[n], l64[n], ("w", "b", "gamma", "beta")):
+            assert cm.rel_err(t.grad, r.grad) < 3 * tol, (n, what, cm.rel_err(t.grad, r.grad))
+    for n in fin:
+        for t, r in zip(fin[n], f64[n]):
+            assert cm.rel_err(t.grad, r.grad) < 3 * tol
+
+
 @pytest.mark.parametrize("norm_reg", [True, False])
 @pytest.mark.parametrize("upstream", [(1.0, 1.0), (0.7, 1.3)])
 def test_fcos_reg_ctr_loss_one_pass(norm_reg, upstream):

@@ -1019,25 +1019,28 @@ def test_fcos_head_gradients_fp64_under_product_masks(tile):
     feats = [torch.from_numpy(f).to(DEV).requires_grad_(True) for f in feats_np]
     L = len(feats)
     gn_masks = []
-    real_fold = ops.group_norm_fold
+    real_conv_gn = ops.conv3x3_gn
 
-    def fold(xs, *a, **k):
-        # the GroupNorm + ReLU runs inside the next convolution's input transform as relu(fma(x, scale, shift)) with the (scale, shift)
-        # this call returns; the sign of an fp32 fma is the sign of the exact value, which fp64 holds (products of two floats are exact)
-        aff, ys = real_fold(xs, *a, **k)
-        N = xs[0].shape[0]
-        a64 = aff.double()
-        gn_masks.append([((x.detach().double() * a64[lv * N:(lv + 1) * N, :, 0, None, None] + a64[lv * N:(lv + 1) * N, :, 1, None, None]) > 0).cpu()
-                         for lv, x in enumerate(xs)])
-        return aff, ys
+    def conv_gn(xs, *a, **k):
+        # the GroupNorm + ReLU runs inside the next convolution's input transform as relu(fma(y, scale, shift)) with the raw maps y and
+        # the (scale, shift) this call returns per filter (tile 6: one conv + GroupNorm node whose backward applies the GroupNorm gradient
+        # in the adjoint output transform; tile 4: conv and group_norm_fold nodes); the sign of an fp32 fma is the sign of the exact
+        # value, which fp64 holds (products of two floats are exact)
+        out = real_conv_gn(xs, *a, **k)
+        for aff, ys in out:
+            N = ys[0].shape[0]
+            a64 = aff.double()
+            gn_masks.append([((y.detach().double() * a64[lv * N:(lv + 1) * N, :, 0, None, None] + a64[lv * N:(lv + 1) * N, :, 1, None, None]) > 0).cpu()
+                             for lv, y in enumerate(ys)])
+        return out
     prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=tile)
-    ops.group_norm_fold = fold
+    ops.conv3x3_gn = conv_gn
     try:
         outs = dict(zip(("logits", "reg", "ctr"), head(feats)))
         total = sum((t * torch.from_numpy(probes[kind][i]).to(DEV)).sum() for kind, maps in outs.items() for i, t in enumerate(maps))
         total.backward()
     finally:
-        ops.group_norm_fold = real_fold
+        ops.conv3x3_gn = real_conv_gn
         ops.conv3x3_backend(*prev)
     assert len(gn_masks) == 8   # per tower layer: the cls tower's call, then the bbox tower's
     reg_masks = [(t.detach() > 0).cpu() for t in outs["reg"]]
