@@ -473,7 +473,8 @@ int lgd_box_reg_loss_bwd(const float* const* deltas_host, const int32_t* const* 
  * [ref: configs/Distillation/RetinaNet/retinanet_R_101_dcnv2_*.yaml:7-8 -> detectron2 ModulatedDeformConv]
  * lgd_dcn_im2col: col[n][c*9+k][y*Wo+x] = mask[n,k,y,x] * bilinear(x[n,c], y*s - p + ky*d + off[n,2k,y,x], x*s - p + kx*d + off[n,2k+1,y,x])
  *   (zero outside the map; mask may be NULL = 1); the convolution is then W (O x C*9) @ col, a library GEMM issued by the host.
- * lgd_dcn_col2im: from d col (same layout) the gradients dx (N,C,H,W; zeroed here, atomic scatter), d offset (N,18,Ho,Wo) and
+ * lgd_dcn_col2im: from d col (same layout) the gradients dx (N,C,H,W; zeroed here -- dx, d offset, d mask and ws carved in this order out
+ *   of one allocation, gaps under 16 bytes, are zeroed by ONE fill instead of four; atomic scatter), d offset (N,18,Ho,Wo) and
  *   d mask (N,9,Ho,Wo; ignored when mask is NULL).  Ho = (H + 2p - 2d - 1)/s + 1, likewise Wo.
  */
 int lgd_dcn_im2col(const float* x, const float* offset, const float* mask, int N, int C, int H, int W, int stride, int pad,

@@ -1665,11 +1665,21 @@ class _DeformConv(torch.autograd.Function):
         dx = doff = dmask = dw = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
             dcol = torch.bmm(weight.view(1, O, C * 9).transpose(1, 2).expand(N, C * 9, O), dy)
-            dx = torch.empty_like(x)
-            doff = torch.empty_like(offset)
-            dmask = torch.empty_like(mask) if mask is not None else None
-            # per-cell contribution lists: dx by gather instead of the L2's float atomics (csrc/dcn.hip); _DCN_GATHER = False: atomic scatter
-            ws = torch.empty(lib.lgd_dcn_ws_bytes(N, H, W), dtype=torch.uint8, device=x.device) if _DCN_GATHER else None
+            # dx | d offset | d mask | per-cell contribution lists (dx by gather instead of the L2's float atomics, csrc/dcn.hip; _DCN_GATHER =
+            # False: atomic scatter) carved out of ONE allocation in the order the entry point zeroes them: one fill instead of four
+            def r4(n):
+                return (n + 3) // 4 * 4
+            n_dx, n_off, n_m = x.numel(), offset.numel(), (mask.numel() if mask is not None else 0)
+            n_ws = (int(lib.lgd_dcn_ws_bytes(N, H, W)) + 3) // 4 if _DCN_GATHER else 0
+            gap = 0 if _DCN_ONE_FILL else 64    # A/B: 256-byte holes between the regions = four fills, as with four allocations
+            o_off = r4(n_dx) + gap
+            o_m = o_off + n_off + gap
+            o_ws = r4(o_m + n_m) + gap
+            buf = torch.empty(o_ws + n_ws, dtype=torch.float32, device=x.device)
+            dx = buf[:n_dx].view_as(x)
+            doff = buf[o_off:o_off + n_off].view_as(offset)
+            dmask = buf[o_m:o_m + n_m].view_as(mask) if mask is not None else None
+            ws = buf[o_ws:] if _DCN_GATHER else None
             hip.check(lib.lgd_dcn_col2im(hip.ptr(x), hip.ptr(offset), hip.ptr(mask) if mask is not None else None, hip.ptr(dcol),
                                          N, C, H, W, stride, padding, dilation, hip.ptr(dx), hip.ptr(doff),
                                          hip.ptr(dmask) if dmask is not None else None, hip.ptr(ws) if ws is not None else None,
@@ -1682,6 +1692,7 @@ class _DeformConv(torch.autograd.Function):
 
 
 _DCN_GATHER = True
+_DCN_ONE_FILL = os.environ.get("LGD_DCN_ONE_FILL", "1") != "0"
 
 
 def deform_conv3x3(x, offset, mask, weight, bias=None, stride=1, padding=1, dilation=1):
