@@ -143,7 +143,14 @@ class DeformBottleneck(Bottleneck):
         shared = self.conv1._pointwise_s2 and self.shortcut is not None and self.shortcut._pointwise_s2
         if shared:
             x = ConvBN.subsample2(x)
-        out = self.conv1(x, relu=True, subsampled=shared)
+        sc = None
+        if (self.shortcut is None and self.conv1._pointwise and x.is_cuda and x.dtype == torch.float32
+                and torch.is_grad_enabled() and x.requires_grad):
+            # identity block: conv1 and the shortcut as one node, as in Bottleneck (no add pass for the block input's two gradients)
+            scale1, shift1 = self.conv1.norm.scale_shift()
+            out, sc = ops.pointwise_conv_bn_skip(x, self.conv1.weight, scale1, shift1, wf=self.conv1._cached_fold(scale1))
+        else:
+            out = self.conv1(x, relu=True, subsampled=shared)
         om = self.conv2_offset(out)
         if self.modulated:
             o1, o2, m = torch.chunk(om, 3, dim=1)
@@ -157,7 +164,8 @@ class DeformBottleneck(Bottleneck):
         # offsets stored as (dy, dx) channel pairs per tap k = 3 ky + kx; HIP gather kernel -> column matrix -> library GEMM (csrc/dcn.hip)
         out = ops.deform_conv3x3(out, offset, mask, c2.weight * scale.view(-1, 1, 1, 1), None, c2.stride[0], c2.padding[0], c2.dilation[0])
         out = ops.bias_act(out, shift, None, True) if out.is_cuda else F.relu_(out + shift.view(1, -1, 1, 1))   # one pass
-        sc = self.shortcut(x, subsampled=shared) if self.shortcut is not None else x
+        if sc is None:
+            sc = self.shortcut(x, subsampled=shared) if self.shortcut is not None else x
         return self.conv3(out, relu=True, residual=sc)
 
 
