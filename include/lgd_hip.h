@@ -484,6 +484,13 @@ int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const
                    int stride, int pad, int dilation, float* dx, float* doffset, float* dmask,
                    void* ws /* lgd_dcn_ws_bytes(N, H, W) bytes: dx by gather through per-cell contribution lists; NULL: dx by atomic scatter */,
                    void* stream);
+/* packed forms: om / dom (N, 27, Ho, Wo) = the offset convolution's own output and its gradient -- channels 0..17 the offsets, 18..26 the
+ * mask LOGITS (detectron2 DeformBottleneckBlock: chunk(3), offset = cat(o1, o2), mask = sigmoid(m)); the kernels read om in place, apply
+ * the sigmoid and write d logit = d mask * m (1 - m): no cat / sigmoid passes in either direction. */
+int lgd_dcn_im2col_packed(const float* x, const float* om, int N, int C, int H, int W, int stride, int pad, int dilation, float* col,
+                          void* stream);
+int lgd_dcn_col2im_packed(const float* x, const float* om, const float* dcol, int N, int C, int H, int W, int stride, int pad,
+                          int dilation, float* dx, float* dom, void* ws, void* stream);
 
 /* ------------------------------------------------------------------ gradient clipping + SGD of both optimizers, one launch
  * [ref: train.py:200-204 stu_optimizer.step() / tea_optimizer.step(); utils/build.py:494-529 torch.optim.SGD(momentum, weight

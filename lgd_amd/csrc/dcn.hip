@@ -22,11 +22,20 @@ struct DcnArgs {
     float* dx;            // (N, C, H, W), zero-initialised by the caller
     float* doffset;       // (N, 18, Ho, Wo)
     float* dmask;         // (N, 9, Ho, Wo) or null
+    long long off_bs, mask_bs, doff_bs, dmask_bs;   // batch strides (floats): 18 / 9 HoWo for separate tensors, 27 HoWo when offset and mask
+                                                     //   are channels 0..17 / 18..26 of the offset convolution's own output (packed form)
+    int sig;              // packed form: the mask channels hold LOGITS (mask = sigmoid, d mask -> d logit in the backward epilogue)
     int N, C, H, W, Ho, Wo, stride, pad, dil;
     int cchunk;           // channels per blockIdx.y slice of the backward kernel (C if not split)
     int* cnt;             // gather path: [N][9][H*W] contributions of tap k that land in an input cell
     int2* ent;            //              [N][9][kDcnSlots][H*W] (source pixel, weight bits) of the first kDcnSlots of them
 };
+
+__device__ __forceinline__ float dcn_mask(const DcnArgs& a, int n, int k, int pix) {
+    if (!a.mask) return 1.f;
+    const float v = a.mask[(size_t)n * a.mask_bs + (size_t)k * (a.Ho * a.Wo) + pix];
+    return a.sig ? 1.f / (1.f + expf(-v)) : v;
+}
 
 struct Bilin { int y0, x0; float wy1, wx1; bool in; };
 __device__ __forceinline__ Bilin bilin_setup(float py, float px, int H, int W) {
@@ -50,8 +59,8 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(DcnArgs a) {
     if (i >= (long long)a.N * 9 * HoWo) return;
     const int pix = (int)(i % HoWo), k = (int)((i / HoWo) % 9), n = (int)(i / ((long long)HoWo * 9));
     const int ho = pix / a.Wo, wo = pix % a.Wo, ky = k / 3, kx = k % 3;
-    const float* off = a.offset + (size_t)n * 18 * HoWo + pix;
-    const float m = a.mask ? a.mask[((size_t)n * 9 + k) * HoWo + pix] : 1.f;
+    const float* off = a.offset + (size_t)n * a.off_bs + pix;
+    const float m = dcn_mask(a, n, k, pix);
     const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + off[(size_t)(2 * k) * HoWo];
     const float pxx = (float)(wo * a.stride - a.pad + kx * a.dil) + off[(size_t)(2 * k + 1) * HoWo];
     const Bilin b = bilin_setup(py, pxx, a.H, a.W);
@@ -146,8 +155,8 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
         DcnPix& t = q[r];
         t.live = alive && ho < a.Ho;
         t.pix = t.live ? ho * a.Wo + wo : 0;
-        const float* off = a.offset + (size_t)n * 18 * HoWo + t.pix;
-        t.m = a.mask ? a.mask[((size_t)n * 9 + k) * HoWo + t.pix] : 1.f;
+        const float* off = a.offset + (size_t)n * a.off_bs + t.pix;
+        t.m = dcn_mask(a, n, k, t.pix);
         const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + off[(size_t)(2 * k) * HoWo];
         const float pxx = (float)(wo * a.stride - a.pad + kx * a.dil) + off[(size_t)(2 * k + 1) * HoWo];
         const Bilin b = bilin_setup(py, pxx, a.H, a.W);
@@ -219,14 +228,15 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnArgs a) {
     for (int r = 0; r < R; ++r) {
         const DcnPix& t = q[r];
         if (!t.live) continue;
-        float* oy = a.doffset + ((size_t)n * 18 + 2 * k) * HoWo + t.pix;
-        float* om = a.dmask ? a.dmask + ((size_t)n * 9 + k) * HoWo + t.pix : nullptr;
+        float* oy = a.doffset + (size_t)n * a.doff_bs + (size_t)(2 * k) * HoWo + t.pix;
+        float* om = a.dmask ? a.dmask + (size_t)n * a.dmask_bs + (size_t)k * HoWo + t.pix : nullptr;
+        const float gm = a.sig ? t.gm * (t.m * (1.f - t.m)) : t.gm;   // packed form: gradient of the mask LOGIT
         if (gridDim.y == 1) {
             oy[0] = t.gy; oy[HoWo] = t.gx;
-            if (om) om[0] = t.gm;
+            if (om) om[0] = gm;
         } else if (t.in) {  // outputs zeroed by the host entry
             unsafeAtomicAdd(oy, t.gy); unsafeAtomicAdd(oy + HoWo, t.gx);
-            if (om) unsafeAtomicAdd(om, t.gm);
+            if (om) unsafeAtomicAdd(om, gm);
         }
     }
 }
@@ -275,18 +285,18 @@ static int dcn_fill(DcnArgs& a, const float* x, const float* offset, const float
     a.Ho = (H + 2 * pad - dil * 2 - 1) / stride + 1;
     a.Wo = (W + 2 * pad - dil * 2 - 1) / stride + 1;
     a.col = nullptr; a.dcol = nullptr; a.dx = nullptr; a.doffset = nullptr; a.dmask = nullptr; a.cchunk = C; a.cnt = nullptr; a.ent = nullptr;
-    return (a.Ho < 1 || a.Wo < 1) ? LGD_EINVAL : LGD_OK;
+    if (a.Ho < 1 || a.Wo < 1) return LGD_EINVAL;
+    const long long HoWo = (long long)a.Ho * a.Wo;
+    a.off_bs = a.doff_bs = 18 * HoWo; a.mask_bs = a.dmask_bs = 9 * HoWo; a.sig = 0;
+    return LGD_OK;
 }
 
 }  // namespace lgd
 
 extern "C" {
 
-int lgd_dcn_im2col(const float* x, const float* offset, const float* mask, int N, int C, int H, int W, int stride, int pad,
-                   int dilation, float* col, void* stream) {
-    lgd::DcnArgs a;
-    if (!col || lgd::dcn_fill(a, x, offset, mask, N, C, H, W, stride, pad, dilation) != LGD_OK) return LGD_EINVAL;
-    a.col = col;
+static int dcn_im2col_launch(lgd::DcnArgs& a, void* stream) {
+    const int N = a.N, C = a.C;
     const long long total = (long long)N * 9 * a.Ho * a.Wo;
     // split the channel loop until ~0.5 M threads are in flight
     int slices = (int)((500000 + total - 1) / total);
@@ -297,17 +307,39 @@ int lgd_dcn_im2col(const float* x, const float* offset, const float* mask, int N
     return lgd::check_launch();
 }
 
+int lgd_dcn_im2col(const float* x, const float* offset, const float* mask, int N, int C, int H, int W, int stride, int pad,
+                   int dilation, float* col, void* stream) {
+    lgd::DcnArgs a;
+    if (!col || lgd::dcn_fill(a, x, offset, mask, N, C, H, W, stride, pad, dilation) != LGD_OK) return LGD_EINVAL;
+    a.col = col;
+    return dcn_im2col_launch(a, stream);
+}
+
+// packed form: om (N, 27, Ho, Wo) is the offset convolution's own output -- channels 0..17 the offsets, 18..26 the mask LOGITS
+static void dcn_pack(lgd::DcnArgs& a, const float* om) {
+    const long long HoWo = (long long)a.Ho * a.Wo;
+    a.mask = om + 18 * HoWo;
+    a.off_bs = a.mask_bs = a.doff_bs = a.dmask_bs = 27 * HoWo;
+    a.sig = 1;
+}
+
+int lgd_dcn_im2col_packed(const float* x, const float* om, int N, int C, int H, int W, int stride, int pad, int dilation, float* col,
+                          void* stream) {
+    lgd::DcnArgs a;
+    if (!col || lgd::dcn_fill(a, x, om, om, N, C, H, W, stride, pad, dilation) != LGD_OK) return LGD_EINVAL;
+    dcn_pack(a, om);
+    a.col = col;
+    return dcn_im2col_launch(a, stream);
+}
+
 size_t lgd_dcn_ws_bytes(int N, int H, int W) {
     if (N < 1 || H < 1 || W < 1) return 0;
     return (size_t)N * 9 * H * W * (sizeof(int) + lgd::kDcnSlots * sizeof(int2)) + 16;
 }
 
-int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const float* dcol, int N, int C, int H, int W,
-                   int stride, int pad, int dilation, float* dx, float* doffset, float* dmask, void* ws, void* stream) {
-    lgd::DcnArgs a;
-    if (!dcol || !dx || !doffset || (mask && !dmask) || lgd::dcn_fill(a, x, offset, mask, N, C, H, W, stride, pad, dilation) != LGD_OK)
-        return LGD_EINVAL;
-    a.dcol = dcol; a.dx = dx; a.doffset = doffset; a.dmask = mask ? dmask : nullptr;
+static int dcn_col2im_launch(lgd::DcnArgs& a, void* ws, void* stream) {
+    const int N = a.N, C = a.C, H = a.H, W = a.W;
+    float* dx = a.dx; float* doffset = a.doffset; float* dmask = a.dmask;
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)N * 9 * ((a.Ho + lgd::kDcnRows - 1) / lgd::kDcnRows) * a.Wo;   // a thread walks kDcnRows output rows
     // split the channel loop until ~0.5 M threads are in flight (res5 has only 19 K (n, tap, pixel) triples)
@@ -322,7 +354,8 @@ int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const
     struct Zero { char* p; size_t n; } z[4];
     int nz = 0;
     z[nz++] = {reinterpret_cast<char*>(dx), (size_t)N * C * HW * sizeof(float)};
-    if (slices > 1) {
+    if (slices > 1 && a.sig) z[nz++] = {reinterpret_cast<char*>(doffset), (size_t)N * 27 * a.Ho * a.Wo * sizeof(float)};   // packed: one tensor
+    else if (slices > 1) {
         z[nz++] = {reinterpret_cast<char*>(doffset), (size_t)N * 18 * a.Ho * a.Wo * sizeof(float)};
         if (a.dmask) z[nz++] = {reinterpret_cast<char*>(dmask), (size_t)N * 9 * a.Ho * a.Wo * sizeof(float)};
     }
@@ -343,6 +376,24 @@ int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const
     LGD_LAUNCH("dcn_gather_kernel", lgd::dcn_gather_kernel, dim3((unsigned)(((long long)N * HW + 255) / 256), (C + lgd::kDcnGatherCh - 1) / lgd::kDcnGatherCh),
                dim3(256), 0, st, a);
     return lgd::check_launch();
+}
+
+int lgd_dcn_col2im(const float* x, const float* offset, const float* mask, const float* dcol, int N, int C, int H, int W,
+                   int stride, int pad, int dilation, float* dx, float* doffset, float* dmask, void* ws, void* stream) {
+    lgd::DcnArgs a;
+    if (!dcol || !dx || !doffset || (mask && !dmask) || lgd::dcn_fill(a, x, offset, mask, N, C, H, W, stride, pad, dilation) != LGD_OK)
+        return LGD_EINVAL;
+    a.dcol = dcol; a.dx = dx; a.doffset = doffset; a.dmask = mask ? dmask : nullptr;
+    return dcn_col2im_launch(a, ws, stream);
+}
+
+int lgd_dcn_col2im_packed(const float* x, const float* om, const float* dcol, int N, int C, int H, int W, int stride, int pad,
+                          int dilation, float* dx, float* dom, void* ws, void* stream) {
+    lgd::DcnArgs a;
+    if (!dcol || !dx || !dom || lgd::dcn_fill(a, x, om, om, N, C, H, W, stride, pad, dilation) != LGD_OK) return LGD_EINVAL;
+    dcn_pack(a, om);
+    a.dcol = dcol; a.dx = dx; a.doffset = dom; a.dmask = dom + 18 * (long long)a.Ho * a.Wo;
+    return dcn_col2im_launch(a, ws, stream);
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -94,6 +94,8 @@ SIGNATURES = {
     "lgd_box_reg_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
     "lgd_box_reg_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
     "lgd_dcn_im2col": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_dcn_im2col_packed": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_dcn_col2im_packed": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_dcn_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "lgd_dcn_col2im": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_sgd_chunk_elems": (c_i, []),

@@ -1630,7 +1630,9 @@ class _DeformConv(torch.autograd.Function):
     GEMM; backward = GEMM for d col, one kernel for dx / d offset / d mask, GEMM for dW (the column matrix is kept)."""
 
     @staticmethod
-    def forward(ctx, x, offset, mask, weight, bias, stride, padding, dilation):
+    def forward(ctx, x, offset, mask, weight, bias, stride, padding, dilation, packed=False):
+        # packed: `offset` is the offset convolution's own (N, 27, Ho, Wo) output -- channels 0..17 the offsets, 18..26 the mask LOGITS
+        # (the kernels read it in place and apply the sigmoid; the backward returns ONE (N, 27, Ho, Wo) gradient: no chunk / cat / sigmoid passes)
         hip.require_gpu(x, offset, weight)
         lib = hip.load()
         x, offset, weight = hip.dense_f32(x), hip.dense_f32(offset), hip.dense_f32(weight)
@@ -1639,25 +1641,29 @@ class _DeformConv(torch.autograd.Function):
         O = weight.shape[0]
         Ho = (H + 2 * padding - 2 * dilation - 1) // stride + 1
         Wo = (W + 2 * padding - 2 * dilation - 1) // stride + 1
-        if tuple(weight.shape[1:]) != (C, 3, 3) or tuple(offset.shape) != (N, 18, Ho, Wo):
-            raise hip.LgdHipError("deform conv: weight (O,C,3,3) / offset (N,18,Ho,Wo) expected, got %s / %s"
+        if tuple(weight.shape[1:]) != (C, 3, 3) or tuple(offset.shape) != (N, 27 if packed else 18, Ho, Wo) or (packed and mask is not None):
+            raise hip.LgdHipError("deform conv: weight (O,C,3,3) / offset (N,18,Ho,Wo) [packed: (N,27,Ho,Wo), no mask] expected, got %s / %s"
                                   % (tuple(weight.shape), tuple(offset.shape)))
         col = torch.empty((N, C * 9, Ho * Wo), dtype=torch.float32, device=x.device)
-        hip.check(lib.lgd_dcn_im2col(hip.ptr(x), hip.ptr(offset), hip.ptr(mask) if mask is not None else None, N, C, H, W,
-                                     stride, padding, dilation, hip.ptr(col), hip.stream_ptr()), "lgd_dcn_im2col")
+        if packed:
+            hip.check(lib.lgd_dcn_im2col_packed(hip.ptr(x), hip.ptr(offset), N, C, H, W, stride, padding, dilation, hip.ptr(col),
+                                                hip.stream_ptr()), "lgd_dcn_im2col_packed")
+        else:
+            hip.check(lib.lgd_dcn_im2col(hip.ptr(x), hip.ptr(offset), hip.ptr(mask) if mask is not None else None, N, C, H, W,
+                                         stride, padding, dilation, hip.ptr(col), hip.stream_ptr()), "lgd_dcn_im2col")
         # batched GEMM with the filter as a stride-0 batch: torch.matmul(2-D, 3-D) folds the batch by transposing + copying the whole
         # column matrix (and the result back): 135 strided copies = 8 of config 5's 58 ms of kernels per step (rocprofv3)
         out = torch.bmm(weight.view(1, O, C * 9).expand(N, O, C * 9), col).view(N, O, Ho, Wo)
         if bias is not None:
             out = out + bias.view(1, -1, 1, 1)
         ctx.save_for_backward(x, offset, mask, weight, col)
-        ctx.geom = (stride, padding, dilation, bias is not None)
+        ctx.geom = (stride, padding, dilation, bias is not None, bool(packed))
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, offset, mask, weight, col = ctx.saved_tensors
-        stride, padding, dilation, has_bias = ctx.geom
+        stride, padding, dilation, has_bias, packed = ctx.geom
         lib = hip.load()
         N, C, H, W = x.shape
         O = weight.shape[0]
@@ -1680,15 +1686,20 @@ class _DeformConv(torch.autograd.Function):
             doff = buf[o_off:o_off + n_off].view_as(offset)
             dmask = buf[o_m:o_m + n_m].view_as(mask) if mask is not None else None
             ws = buf[o_ws:] if _DCN_GATHER else None
-            hip.check(lib.lgd_dcn_col2im(hip.ptr(x), hip.ptr(offset), hip.ptr(mask) if mask is not None else None, hip.ptr(dcol),
-                                         N, C, H, W, stride, padding, dilation, hip.ptr(dx), hip.ptr(doff),
-                                         hip.ptr(dmask) if dmask is not None else None, hip.ptr(ws) if ws is not None else None,
-                                         hip.stream_ptr()), "lgd_dcn_col2im")
+            if packed:
+                hip.check(lib.lgd_dcn_col2im_packed(hip.ptr(x), hip.ptr(offset), hip.ptr(dcol), N, C, H, W, stride, padding, dilation,
+                                                    hip.ptr(dx), hip.ptr(doff), hip.ptr(ws) if ws is not None else None,
+                                                    hip.stream_ptr()), "lgd_dcn_col2im_packed")
+            else:
+                hip.check(lib.lgd_dcn_col2im(hip.ptr(x), hip.ptr(offset), hip.ptr(mask) if mask is not None else None, hip.ptr(dcol),
+                                             N, C, H, W, stride, padding, dilation, hip.ptr(dx), hip.ptr(doff),
+                                             hip.ptr(dmask) if dmask is not None else None, hip.ptr(ws) if ws is not None else None,
+                                             hip.stream_ptr()), "lgd_dcn_col2im")
         if ctx.needs_input_grad[3]:
             dw = torch.bmm(dy, col.transpose(1, 2)).sum(0).view_as(weight)
         if has_bias and ctx.needs_input_grad[4]:
             db = dy.sum((0, 2))
-        return dx, doff, dmask, dw, db, None, None, None
+        return dx, doff, dmask, dw, db, None, None, None, None
 
 
 _DCN_GATHER = True
@@ -1698,6 +1709,12 @@ _DCN_ONE_FILL = os.environ.get("LGD_DCN_ONE_FILL", "1") != "0"
 def deform_conv3x3(x, offset, mask, weight, bias=None, stride=1, padding=1, dilation=1):
     """DCNv2 (mask given) / DCNv1 (mask None) 3x3 convolution on the GPU."""
     return _DeformConv.apply(x, offset, mask, weight, bias, int(stride), int(padding), int(dilation))
+
+
+def deform_conv3x3_packed(x, om, weight, bias=None, stride=1, padding=1, dilation=1):
+    """DCNv2 driven directly by the offset convolution's (N, 27, Ho, Wo) output: = deform_conv3x3(x, om[:, :18], sigmoid(om[:, 18:]), ...)
+    (chunk(3) -> cat(o1, o2), sigmoid(m) of detectron2's DeformBottleneckBlock) without the cat / sigmoid passes and their backward."""
+    return _DeformConv.apply(x, om, None, weight, bias, int(stride), int(padding), int(dilation), True)
 
 
 # ------------------------------------------------------------------------------------------------ student conv epilogues

@@ -152,17 +152,22 @@ class DeformBottleneck(Bottleneck):
         else:
             out = self.conv1(x, relu=True, subsampled=shared)
         om = self.conv2_offset(out)
-        if self.modulated:
-            o1, o2, m = torch.chunk(om, 3, dim=1)
-            offset, mask = torch.cat((o1, o2), 1), m.sigmoid()
-        else:
-            offset, mask = om, torch.ones_like(om[:, :9])
         c2 = self.conv2
         scale, shift = c2.norm.scale_shift()
         # modulated deformable convolution (DCNv2) [ref: configs/Distillation/RetinaNet/retinanet_R_101_dcnv2_*.yaml:7-8; d2-memory:
         # ModulatedDeformConv]: out[n,o,y,x] = sum_{c,k} W[o,c,k] mask[n,k,y,x] bilinear(in[n,c], y s - p + ky d + dy_k, x s - p + kx d + dx_k),
         # offsets stored as (dy, dx) channel pairs per tap k = 3 ky + kx; HIP gather kernel -> column matrix -> library GEMM (csrc/dcn.hip)
-        out = ops.deform_conv3x3(out, offset, mask, c2.weight * scale.view(-1, 1, 1, 1), None, c2.stride[0], c2.padding[0], c2.dilation[0])
+        wf = c2.weight * scale.view(-1, 1, 1, 1)
+        if self.modulated and out.is_cuda:
+            # chunk(3) -> offset = cat(o1, o2) = channels 0..17, mask = sigmoid(channels 18..26): read in place by the kernels
+            out = ops.deform_conv3x3_packed(out, om, wf, None, c2.stride[0], c2.padding[0], c2.dilation[0])
+        else:
+            if self.modulated:
+                o1, o2, m = torch.chunk(om, 3, dim=1)
+                offset, mask = torch.cat((o1, o2), 1), m.sigmoid()
+            else:
+                offset, mask = om, None
+            out = ops.deform_conv3x3(out, offset, mask, wf, None, c2.stride[0], c2.padding[0], c2.dilation[0])
         out = ops.bias_act(out, shift, None, True) if out.is_cuda else F.relu_(out + shift.view(1, -1, 1, 1))   # one pass
         if sc is None:
             sc = self.shortcut(x, subsampled=shared) if self.shortcut is not None else x

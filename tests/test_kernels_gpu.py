@@ -1895,3 +1895,33 @@ def test_deform_conv3x3_dx_gather_full_lists_and_determinism(pull):
         t.grad = None
     SO.modulated_deform_conv2d(x, off, m, w, None, 1, 1, 1).backward(gy)
     assert float((runs[0] - x.grad).abs().max()) <= 2e-4 * float(x.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("N,C,O,H,W,stride", [(2, 10, 4, 17, 21, 1), (1, 64, 16, 24, 40, 1), (2, 16, 8, 19, 23, 2)])
+def test_deform_conv3x3_packed_offsets_and_mask_logits(N, C, O, H, W, stride):
+    """ops.deform_conv3x3_packed (the kernels read the offset convolution's (N, 27, Ho, Wo) output in place: channels 0..17 offsets,
+    18..26 mask logits, sigmoid and its derivative inside the kernels) against the reference's composition chunk(3) -> cat(o1, o2),
+    sigmoid(m) -> modulated deformable convolution [d2-memory: DeformBottleneckBlock] in fp64 on the per-tap restatement: output and the
+    gradients of the input, of all 27 channels and of the filter; split channel loops (atomic d offset / d logit) and the unsplit form."""
+    from lgd_amd import ops
+    torch.manual_seed(5)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = torch.randn(N, C, H, W, device=DEV, requires_grad=True)
+    om = (torch.randn(N, 27, Ho, Wo, device=DEV) * 1.5).requires_grad_(True)
+    w = (torch.randn(O, C, 3, 3, device=DEV) * (2.0 / (9 * C)) ** 0.5).requires_grad_(True)
+    gy = torch.randn(N, O, Ho, Wo, device=DEV)
+    y = ops.deform_conv3x3_packed(x, om, w, None, stride, 1, 1)
+    y.backward(gy)
+    x64, om64, w64 = (t.detach().double().requires_grad_(True) for t in (x, om, w))
+    o1, o2, m = torch.chunk(om64, 3, dim=1)
+    ref = SO.modulated_deform_conv2d(x64, torch.cat((o1, o2), 1), m.sigmoid(), w64, None, stride, 1, 1)
+    ref.backward(gy.double())
+    assert cm.rel_err(y, ref) < 2e-5
+    for name, a, b in (("dx", x, x64), ("d om", om, om64), ("dw", w, w64)):
+        assert cm.rel_err(a.grad, b.grad) < 1e-4, (name, cm.rel_err(a.grad, b.grad))
+    # and the split form on the same values
+    x2, om2, w2 = (t.detach().clone().requires_grad_(True) for t in (x, om, w))
+    p1, p2, pm = torch.chunk(om2, 3, dim=1)
+    y2 = ops.deform_conv3x3(x2, torch.cat((p1, p2), 1), pm.sigmoid(), w2, None, stride, 1, 1)
+    y2.backward(gy)
+    assert cm.rel_err(y, y2) < 1e-6 and cm.rel_err(om.grad, om2.grad) < 1e-5 and cm.rel_err(x.grad, x2.grad) < 1e-5
