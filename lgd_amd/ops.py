@@ -1428,6 +1428,8 @@ _WINO_TILE = 6
 # whose res5 3x3 convolutions have 546): 2000 -> 35.7, 500 -> 35.1, 100 -> 35.3 ms/step in one call
 _WINO_MIN_TILES = 500
 _WINO_MIN_CH = 64
+_WINO_MIN_CO = 16   # single-map convolutions with fewer output channels stay on the library (16: the 27-channel offset convolution of a DCNv2 block
+                    # runs here -- config 5 43.4 -> 42.75 ms in one call against MIOpen's Winograd forward / data + implicit-GEMM weight kernels)
 _WINO_ON = True
 
 
@@ -1452,7 +1454,7 @@ def _wino_ok(xs, w):
     x = xs[0]
     tiles = sum(x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) for x in xs)
     return (_WINO_ON and x.is_cuda and x.dtype == torch.float32 and tiles >= _WINO_MIN_TILES and x.shape[1] >= _WINO_MIN_CH
-            and (len(xs) > 1 or w.shape[0] >= _WINO_MIN_CH))
+            and (len(xs) > 1 or w.shape[0] >= _WINO_MIN_CO))
 
 
 def conv3x3_levels(xs, w, b=None, relu=False, scale=None, pre=None):

@@ -151,7 +151,11 @@ class DeformBottleneck(Bottleneck):
             out, sc = ops.pointwise_conv_bn_skip(x, self.conv1.weight, scale1, shift1, wf=self.conv1._cached_fold(scale1))
         else:
             out = self.conv1(x, relu=True, subsampled=shared)
-        om = self.conv2_offset(out)
+        co = self.conv2_offset
+        if out.is_cuda and co.stride == (1, 1) and co.dilation == (1, 1) and co.padding == (1, 1):
+            om = ops.conv3x3(out, co.weight, co.bias)
+        else:
+            om = co(out)
         c2 = self.conv2
         scale, shift = c2.norm.scale_shift()
         # modulated deformable convolution (DCNv2) [ref: configs/Distillation/RetinaNet/retinanet_R_101_dcnv2_*.yaml:7-8; d2-memory:
