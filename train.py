@@ -14,7 +14,9 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch  # noqa: E402
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
