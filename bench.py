@@ -170,15 +170,23 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LGD_BENCH_SHARE_GPU=1 + LGD_BENCH_BACKEND=gloo: every rank on cuda:0, exchange over gloo -- the N > 1 code path of this file
+    # (barriers, max over ranks, rank-0 record, DDP) on a 1-GPU box (tests/test_model_gpu.py); never a performance number
+    share = os.environ.get("LGD_BENCH_SHARE_GPU", "0") == "1"
+    gpu = 0 if share else local_rank
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     force_ddp = os.environ.get("LGD_FORCE_DDP", "0") == "1"  # exercise the RCCL/DDP path on a single GPU (tests)
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        backend = os.environ.get("LGD_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from lgd_amd import config, hip, ops
     from lgd_amd.data import synthetic_batch
@@ -190,7 +198,7 @@ def main():
     if args.library_convs:
         ops.conv3x3_backend(winograd=False)
 
-    cfg = config.setup_cfg(args.config, ["MODEL.DEVICE", "cuda:%d" % local_rank])
+    cfg = config.setup_cfg(args.config, ["MODEL.DEVICE", "cuda:%d" % gpu])
     torch.manual_seed(0)
     model = build_model(cfg)
     model.fused_head_pass = args.head_passes == 1

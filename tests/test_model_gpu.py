@@ -652,6 +652,33 @@ def test_bench_stdout_is_one_json_record():
     assert rec["config"]["workload"] and "model" not in rec["config"]
 
 
+@pytest.mark.timeout(1200)
+def test_bench_two_ranks_on_one_gpu():
+    """the driver's N > 1 launch of bench.py (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`) on the box there
+    is: both ranks on cuda:0, exchange over gloo (LGD_BENCH_SHARE_GPU / LGD_BENCH_BACKEND: test knobs, never a performance number).
+    The barriers, the max-over-ranks time, DDP and the rank-0 record: ONE JSON line, n_gpus 2, whole-job value = 2 ranks' images."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LGD_BENCH_SHARE_GPU="1", LGD_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch-per-gpu", "2", "--height", "256", "--width", "320"], env=env, capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 4
+    assert abs(rec["value"] - 4 * 1e3 / rec["ms_per_step"]) <= 1e-6 * rec["value"]      # whole-job images per second over the slowest rank's time
+    assert "cpu_baseline" not in rec                                                      # rank 0 at N = 1 only
+
+
 def test_trainer_fused_sgd_equals_torch_optimizers():
     """Trainer.step with the one-launch clip + SGD (csrc/optim.hip, the default) against the same trainer on torch's
     clamp_ / SGD(foreach) path (Trainer(fused_sgd=False)) from the same weights, three steps across both phase switches
