@@ -329,7 +329,8 @@ int lgd_wino_out_t_gn(const float* const* g_host, const float* const* y_host, co
                       int N, int C, int tile, float* dM, void* stream);
 /* Filter transforms:
  *   lgd_wino_filter_fwd: U[f][co][ci] = (G (scale[co] . g) G^T)[f] at U + f*u_plane + co*Ci + ci, and the same values transposed in
- *     (co, ci) at Ut + f*ut_plane + ci*ut_ld + co (the operand of dV = U^T dM); u_plane / ut_plane / ut_ld let several filters stack
+ *     (co, ci) at Ut + f*ut_plane + ci*ut_ld + co (the operand of dV = U^T dM; Ut may be NULL: a caller whose GEMM takes a transposed
+ *     operand needs U alone and the transform writes half the bytes); u_plane / ut_plane / ut_ld let several filters stack
  *     their slabs along C_out in one buffer (lgd_amd/ops.py::_Conv3x3K).  w: (Co, Ci, 3, 3) contiguous; scale: per-output-channel
  *     factor of a frozen affine that follows the convolution (detectron2 FrozenBatchNorm2d) or NULL.
  *   lgd_wino_filter_bwd: dw[co][ci] = scale[co] . G^T dU[:, co, ci] G, dU read at dU + f*du_plane + co*Ci + ci. */

@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256) void wino4_filter_fwd_kernel(FilterArgs a) {
         if (on) a.U[(size_t)f * a.u_plane + (size_t)co * a.Ci + ci] = v;
         tile[f][ol][cl] = v;
     }
+    if (!a.Ut) return;   // U alone: the caller's dV GEMM takes U^T as a transposed operand
     __syncthreads();
     const int co2 = blockIdx.y * 16 + cl, ci2 = blockIdx.x * 16 + ol;   // transposed roles: co fastest
     if (co2 < a.Co && ci2 < a.Ci) {
@@ -750,8 +751,8 @@ int lgd_wino_in_t(const float* dV, const int32_t* level_hw_host, int L, int N, i
 
 int lgd_wino_filter_fwd(const float* w, const float* scale, int Co, int Ci, int tile, float* U, long long u_plane, float* Ut,
                         long long ut_ld, long long ut_plane, void* stream) {
-    if (!w || !U || !Ut || Co < 1 || Ci < 1 || (tile != 4 && tile != 6) || u_plane < (long long)Co * Ci || ut_ld < Co
-        || ut_plane < (long long)Ci * ut_ld) return LGD_EINVAL;
+    if (!w || !U || Co < 1 || Ci < 1 || (tile != 4 && tile != 6) || u_plane < (long long)Co * Ci
+        || (Ut && (ut_ld < Co || ut_plane < (long long)Ci * ut_ld))) return LGD_EINVAL;
     lgd::FilterArgs a{};
     a.w = w; a.scale = scale; a.U = U; a.Ut = Ut; a.u_plane = u_plane; a.ut_plane = ut_plane; a.ut_ld = ut_ld; a.Co = Co; a.Ci = Ci;
     if (tile == 6) lgd::wino6_launch_filter_fwd(a, (hipStream_t)stream);

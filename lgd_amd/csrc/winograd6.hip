@@ -769,13 +769,14 @@ __global__ __launch_bounds__(256) void wino6_filter_fwd_kernel(FilterArgs a) {
     const int co2 = blockIdx.y * 16 + cl, ci2 = blockIdx.x * 16 + ol;   // transposed roles: co fastest
     #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();
+        if (half && a.Ut) __syncthreads();
         #pragma unroll
         for (int f = 0; f < 32; ++f) {
             const float v = u[(32 * half + f) / 8][(32 * half + f) % 8];
             if (on) a.U[(size_t)(32 * half + f) * a.u_plane + (size_t)co * a.Ci + ci] = v;
-            tile[f][ol][cl] = v;
+            if (a.Ut) tile[f][ol][cl] = v;
         }
+        if (!a.Ut) continue;   // U alone (wave-uniform): the caller's dV GEMM takes U^T as a transposed operand
         __syncthreads();
         if (co2 < a.Co && ci2 < a.Ci) {
             #pragma unroll

@@ -1024,20 +1024,21 @@ def _freq_buf(nf, C, T, device):
 
 
 def _wino_filters(lib, ws, scales, Ci, dev, tile):
-    """U (nf, sum Co, Ci) and U^T (nf, Ci, sum Co) of K filters stacked along C_out, one lgd_wino_filter_fwd launch per filter
-    (the frozen per-channel scale of a FrozenBN that follows the conv is folded in on the way: no scaled copy of the weights)."""
+    """U (nf, sum Co, Ci) of K filters stacked along C_out, one lgd_wino_filter_fwd launch per filter (the frozen per-channel scale of a
+    FrozenBN that follows the conv is folded in on the way: no scaled copy of the weights), and its (Co, Ci)-transposed VIEW: the dV GEMM
+    of the backward takes U^T as a transposed operand (tuned TN solutions are as fast as NN on a materialised U^T or faster --
+    tools/gemm_tn_probe.py: 720 x 256: 7.17 vs 7.57 ms -- and the transform writes half the bytes)."""
     Cos = [w.shape[0] for w in ws]
     Ct = sum(Cos)
     nf = (tile + 2) ** 2
     U = torch.empty((nf, Ct, Ci), dtype=torch.float32, device=dev)
-    Ut = torch.empty((nf, Ci, Ct), dtype=torch.float32, device=dev)
     c0 = 0
     for w, sc, Co in zip(ws, scales, Cos):
         hip.check(lib.lgd_wino_filter_fwd(hip.ptr(w), hip.ptr(sc) if sc is not None else None, Co, Ci, tile,
-                                          ctypes.c_void_p(U.data_ptr() + 4 * c0 * Ci), Ct * Ci,
-                                          ctypes.c_void_p(Ut.data_ptr() + 4 * c0), Ct, Ci * Ct, hip.stream_ptr()), "lgd_wino_filter_fwd")
+                                          ctypes.c_void_p(U.data_ptr() + 4 * c0 * Ci), Ct * Ci, None, 0, 0, hip.stream_ptr()),
+                  "lgd_wino_filter_fwd")
         c0 += Co
-    return U, Ut
+    return U, U.transpose(1, 2)
 
 
 def _wino_filter_grads(lib, dU, scales, Cos, need, Ci, tile):

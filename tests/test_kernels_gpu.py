@@ -916,7 +916,8 @@ def test_native_conv3x3_calls_match_the_composed_pipeline(wino_tile):
         else:
             Ct, T, Ci = a.shape[1], a.shape[2], b.shape[2]
             out = torch.empty((nf, Ct, Ci), dtype=torch.float32, device=a.device)
-        hip.check(lib.lgd_wino_gemm(kind, hip.ptr(a), hip.ptr(b), hip.ptr(out), Ct, Ci, T, wino_tile, 0, hip.stream_ptr()), "lgd_wino_gemm")
+        an = a.contiguous() if kind == 1 else a   # the product hands dV = U^T dM a transposed VIEW of U; the library's GEMM reads a stored U^T
+        hip.check(lib.lgd_wino_gemm(kind, hip.ptr(an), hip.ptr(b), hip.ptr(out), Ct, Ci, T, wino_tile, 0, hip.stream_ptr()), "lgd_wino_gemm")
         ref = torch.bmm(a, b)
         gemm_err.append(float((out - ref).abs().max() / (ref.abs().max() + 1e-30)))
         return out
