@@ -1898,8 +1898,9 @@ def test_deform_conv3x3_dx_gather_full_lists_and_determinism(pull):
     assert float((runs[0] - x.grad).abs().max()) <= 2e-4 * float(x.grad.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("gather", [True, False])
 @pytest.mark.parametrize("N,C,O,H,W,stride", [(2, 10, 4, 17, 21, 1), (1, 64, 16, 24, 40, 1), (2, 16, 8, 19, 23, 2)])
-def test_deform_conv3x3_packed_offsets_and_mask_logits(N, C, O, H, W, stride):
+def test_deform_conv3x3_packed_offsets_and_mask_logits(N, C, O, H, W, stride, gather):
     """ops.deform_conv3x3_packed (the kernels read the offset convolution's (N, 27, Ho, Wo) output in place: channels 0..17 offsets,
     18..26 mask logits, sigmoid and its derivative inside the kernels) against the reference's composition chunk(3) -> cat(o1, o2),
     sigmoid(m) -> modulated deformable convolution [d2-memory: DeformBottleneckBlock] in fp64 on the per-tap restatement: output and the
@@ -1911,8 +1912,13 @@ def test_deform_conv3x3_packed_offsets_and_mask_logits(N, C, O, H, W, stride):
     om = (torch.randn(N, 27, Ho, Wo, device=DEV) * 1.5).requires_grad_(True)
     w = (torch.randn(O, C, 3, 3, device=DEV) * (2.0 / (9 * C)) ** 0.5).requires_grad_(True)
     gy = torch.randn(N, O, Ho, Wo, device=DEV)
-    y = ops.deform_conv3x3_packed(x, om, w, None, stride, 1, 1)
-    y.backward(gy)
+    was = ops._DCN_GATHER
+    ops._DCN_GATHER = gather          # False: dx by atomic scatter (a NULL workspace)
+    try:
+        y = ops.deform_conv3x3_packed(x, om, w, None, stride, 1, 1)
+        y.backward(gy)
+    finally:
+        ops._DCN_GATHER = was
     x64, om64, w64 = (t.detach().double().requires_grad_(True) for t in (x, om, w))
     o1, o2, m = torch.chunk(om64, 3, dim=1)
     ref = SO.modulated_deform_conv2d(x64, torch.cat((o1, o2), 1), m.sigmoid(), w64, None, stride, 1, 1)
