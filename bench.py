@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Benchmark of the LGD training step (BASELINE.json metric: images/sec, RetinaNet R-50 + LGD, fwd+bwd).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: re-executes itself as N ranks, lgd_amd/launch.py)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W         (the driver's form: runs as the rank it is)
 
 One step = student forward -> dynamic teacher -> head re-run on teacher features -> distillation loss
 -> backward -> clip -> both SGD optimizers -> both LR schedulers, on a synthetic COCO-shaped batch
@@ -34,6 +34,24 @@ sys.path.insert(0, ROOT)
 
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); exported on the boxes already
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def _gpus_requested(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__":
+    # `python bench.py --gpus N` started plainly: become N ranks of one node (one process per GPU, env rendezvous on 127.0.0.1) BEFORE
+    # the runtime is imported; under a launcher (the driver's torch.distributed.run form) this process already is one of the ranks
+    from lgd_amd import launch as _launch
+    if _gpus_requested(sys.argv[1:]) > 1 and not _launch.launched():
+        raise SystemExit(_launch.self_launch(__file__, _gpus_requested(sys.argv[1:]), sys.argv[1:]))
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -168,8 +186,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if args.gpus > 1 and world == 1:   # only reachable when main() is called with a hand-made environment: the __main__ block self-launches
+        raise SystemExit("--gpus %d needs %d ranks: run `python bench.py --gpus %d` (self-launching) or torch.distributed.run" % ((args.gpus,) * 3))
     # LGD_BENCH_SHARE_GPU=1 + LGD_BENCH_BACKEND=gloo: every rank on cuda:0, exchange over gloo -- the N > 1 code path of this file
     # (barriers, max over ranks, rank-0 record, DDP) on a 1-GPU box (tests/test_model_gpu.py); never a performance number
     share = os.environ.get("LGD_BENCH_SHARE_GPU", "0") == "1"
@@ -177,6 +195,18 @@ def main():
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
     force_ddp = os.environ.get("LGD_FORCE_DDP", "0") == "1"  # exercise the RCCL/DDP path on a single GPU (tests)
+    pinned_cpus = None
+    if world > 1:
+        # one slice of the node's CPUs per rank, near its GPU when sysfs tells (lgd_amd/launch.py); LGD_PIN=0 disables
+        from lgd_amd import launch
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        try:
+            props = [torch.cuda.get_device_properties(0 if share else i) for i in range(local_world)]
+            bus = ["%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id) for p in props]
+        except Exception:  # noqa: BLE001 -- attribute names differ across torch builds: fall back to equal slices by local rank
+            bus = None
+        pinned_cpus = launch.pin_host_threads(local_rank, local_world, bus)
+    rccl_ranks = None
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -187,6 +217,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+        # the communicator really spans `world` ranks: an all-reduce of ones over the process group, read back (also warms the ring up
+        # outside the timed region)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(round(float(ones.item())))
+        assert rccl_ranks == dist.get_world_size() == max(world, 1), (rccl_ranks, dist.get_world_size(), world)
 
     from lgd_amd import config, hip, ops
     from lgd_amd.data import synthetic_batch
@@ -368,6 +404,9 @@ def main():
             "value": world * Bg * args.steps / dt,
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "rccl_ranks": rccl_ranks,   # sum of ones over the process group after init (None: no process group at N = 1)
+            "collective_backend": (dist.get_backend() if (world > 1 or force_ddp) else None),
+            "host_threads_pinned": None if pinned_cpus is None else "%d CPUs per rank (rank 0: %d-%d)" % (len(pinned_cpus), pinned_cpus[0], pinned_cpus[-1]),
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
@@ -384,6 +423,11 @@ def main():
                                       ", multi-scale: short side per image from %s" % (list(cfg.INPUT.MIN_SIZE_TRAIN),) if args.multiscale else ""),
                        "yaml": os.path.relpath(args.config, ROOT), "global_batch": world * Bg, "parallelism": "dp%d" % world},
             "losses": {k: round(v, 6) for k, v in metrics.items()},
+            "losses_parity": {"loss_distill": "pinned: reference golden fixtures (tests/golden, generated from the reference), teacher features <= 1e-4",
+                              "detection_losses": ("FCOS head + target assignment pinned to the reference's in-tree code; focal / GIoU: restated (cvpods absent)"
+                                                   if arch == "FCOS" else
+                                                   "unpinned (detectron2 0.3 / fvcore absent from the reference tree and the image): "
+                                                   "kernels are held to oracle/student_oracle.py, a restatement of the public definitions")},
             "gemm_solution_table_loaded": bool(trainer.tuned_gemms), "conv3x3": "winograd F(%dx%d,3x3)" % (ops._WINO_TILE, ops._WINO_TILE) if ops._WINO_ON else "library",
             "hbm_peak_alloc_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,

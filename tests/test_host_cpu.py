@@ -556,3 +556,61 @@ def test_winograd_adjoint_input_transform_as_a_gather():
                 y[3] += 4 * tr[r]
                 out[4 * ty + r, 4 * tx:4 * tx + 4] = y
     assert np.abs(out[:H, :W] - ref).max() < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ one process per GPU: launch + host-thread slices
+def test_host_thread_slices_partition_the_allowed_cpus():
+    """lgd_amd/launch.py: eight ranks of one node get disjoint, equal, contiguous slices of the allowed CPUs; with topology, the ranks whose GPUs
+    hang off one NUMA node share THAT node's CPUs [ref: train.py:296-310 one process per GPU]."""
+    from lgd_amd import launch
+    allowed = set(range(256))
+    got = [launch.plan_affinity(r, 8, allowed) for r in range(8)]
+    assert all(len(g) == 32 for g in got) and sorted(c for g in got for c in g) == list(range(256))
+    assert got[3] == list(range(96, 128))
+    # two sockets: CPUs 0-63 + 128-191 on node 0, 64-127 + 192-255 on node 1; GPUs 0-3 on node 0, 4-7 on node 1
+    cpus_of_node = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    node_of_rank = {r: r // 4 for r in range(8)}
+    got = [launch.plan_affinity(r, 8, allowed, node_of_rank, cpus_of_node) for r in range(8)]
+    assert all(len(g) == 32 for g in got) and sorted(c for g in got for c in g) == list(range(256))
+    assert all(set(got[r]) <= set(cpus_of_node[r // 4]) for r in range(8))
+    # a cgroup that allows fewer CPUs than ranks: every rank keeps the whole set instead of an empty one
+    assert launch.plan_affinity(5, 8, {3, 4}) == [3, 4]
+    # unknown topology for this rank: equal slices
+    assert launch.plan_affinity(1, 2, set(range(8)), {0: None, 1: None}, {}) == [4, 5, 6, 7]
+    assert launch._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_bench_and_train_self_launch_command(monkeypatch):
+    """`python bench.py --gpus 4` / `python train.py --num-gpus 4` started without a launcher re-execute as 4 ranks of one node on 127.0.0.1;
+    under a launcher (RANK / WORLD_SIZE present) they do not."""
+    import importlib.util
+    import subprocess
+    from lgd_amd import launch
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    for k in ("RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert not launch.launched()
+    rc = launch.self_launch("/x/bench.py", 4, ["--gpus", "4", "--steps", "3"])
+    assert rc == 7
+    c = seen["cmd"]
+    assert c[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and c[c.index("--nproc-per-node") + 1] == "4"
+    assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert launch.launched()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, fn, flag in (("bench.py", "_gpus_requested", "--gpus"), ("train.py", "_num_gpus", "--num-gpus")):
+        spec = importlib.util.spec_from_file_location("m_" + name[:-3], os.path.join(root, name))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)     # not __main__: importing must not launch anything
+        f = getattr(mod, fn)
+        assert f([flag, "8", "--x"]) == 8 and f([flag + "=2"]) == 2 and f(["--steps", "3"]) == 1

@@ -150,7 +150,7 @@ def test_distill_loss_and_grads_match_reference(run):
     errs = {k: cm.rel_err(cm.sample(feats[k].grad, run["stride"])[0], g["gfeat_s_" + k]) for k in O.LEVELS}
     print("feature-gradient parity vs reference [%s]: %s" % (run["backend"], "; ".join(
         "%s product %.1e / torch-ops-on-this-GPU %.1e" % (k, errs[k], cm.rel_err(cm.sample(dev_feat[k], run["stride"])[0], g["gfeat_s_" + k])) for k in O.LEVELS)))
-    assert all(e <= 2e-2 for e in errs.values()), errs
+    assert all(e <= 5e-3 for e in errs.values()), errs   # measured <= 1.6e-3 (p3) .. 4e-3 (p5): trips on regressions, not on flips
     named = list(teacher.named_parameters()) + [("adapter." + n, p) for n, p in d.adapter["distill"].named_parameters()]
     worst = (0.0, 0.0, "")
     for n, prm in named:
@@ -166,7 +166,7 @@ def test_distill_loss_and_grads_match_reference(run):
         e_dev = float(np.abs(cm.sample(dev_w[n])[0][:64] - ref_s).max()) / scale
         e_prod = float(np.abs(cm.sample(prm.grad)[0][:64] - ref_s).max()) / scale
         worst = max(worst, (e_prod, e_dev, n))
-        assert e_prod <= 2e-2, (n, e_prod, e_dev)
+        assert e_prod <= 5e-3, (n, e_prod, e_dev)
         assert abs(cm.sample(prm.grad)[2] - ref_sq) <= 4e-2 * ref_sq, n
     print("weight-gradient parity: worst sampled deviation %.1e (torch ops on this GPU: %.1e) at %s" % worst)
 
@@ -288,12 +288,13 @@ def test_teacher_edge_batch_vs_oracle():
         assert all(e <= 2e-2 for e in errs.values()), (ctx, errs)
 
 
-def test_full_size_properties():
-    """size-independent properties at BASELINE config-2 size (B=8, 800x1344, C=256) where the oracle is too slow:
-    distill(a, a) == 0 and is invariant to per-plane affine maps; GN(1) output has zero mean / unit variance per
-    sample; box_sum is linear; the focal loss of a shifted-class relabelling is unchanged for symmetric logits."""
+@pytest.mark.parametrize("B,ctx", [(8, True), (16, False)], ids=["config2-b8-ctx", "config3-b16-noctx"])
+def test_full_size_properties(B, ctx):
+    """size-independent properties at BASELINE config-2 size (B=8, 800x1344, C=256, context box) and at config 3's (B=16, no context
+    box, T=160) where the oracle is too slow: distill(a, a) == 0 and is invariant to per-plane affine maps; GN(1) output has zero
+    mean / unit variance per sample; box_sum is linear; the box sum of ones is the pixel count of the bit-exact rectangle."""
     from lgd_amd import ops
-    B, H, W, C = 8, 800, 1344, 256
+    H, W, C = 800, 1344, 256
     level_hw = synth.pyramid_shapes(H, W)
     g = torch.Generator(device=DEV).manual_seed(0)
     a = [torch.randn(B, C, h, w, device=DEV, generator=g) * 2 + 0.5 for h, w in level_hw]
@@ -309,8 +310,9 @@ def test_full_size_properties():
         v = y.double().var(dim=(1, 2, 3), unbiased=False)
         assert float(m.abs().max()) < 1e-5 and float((v - 1).abs().max()) < 1e-4
     gt = synth.synth_gt(B, H, W, 10, seed=0)
-    _, boxlists, _ = O.encode_box_descriptors([(torch.from_numpy(x), torch.from_numpy(c)) for x, c in gt], H, W, True)
+    _, boxlists, _ = O.encode_box_descriptors([(torch.from_numpy(x), torch.from_numpy(c)) for x, c in gt], H, W, ctx)
     boxes = torch.tensor([r for bl in boxlists for r in bl], dtype=torch.float32).to(DEV)
+    assert len(boxes) == B * (11 if ctx else 10)
     geom = ops.BoxGeometry(boxes, [len(bl) for bl in boxlists], (H, W), level_hw)
     s1, s2 = ops._box_sum(geom, a, False, False), ops._box_sum(geom, b, False, False)
     s12 = ops._box_sum(geom, [x * 2.0 - y for x, y in zip(a, b)], False, False)
@@ -320,6 +322,55 @@ def test_full_size_properties():
     cnt = torch.where(r[..., 1] >= r[..., 0], (r[..., 1] - r[..., 0] + 1) * (r[..., 3] - r[..., 2] + 1), torch.zeros_like(r[..., 0]))
     assert torch.equal(ones[..., 0], cnt.float())              # box sum of ones == pixel count of the bit-exact rectangle
 
+
+
+@pytest.mark.timeout(900)
+def test_config3_batch16_equals_two_batches_of_8():
+    """BASELINE config 3 at ITS batch size: 16 images of 800x1344, no context box, 10 boxes each (T = 160) through the product
+    DynamicTeacher + adapter + distill loss on the shipped Winograd path.  Nothing on the path mixes images (label-encoder pooling,
+    block-diagonal attention, mask pooling / rendering, GroupNorm(1), InstanceNorm are all per image: SURVEY.md section 8e), so the
+    teacher features of the batch of 16 must equal those of its two halves of 8 run on their own, the distill loss must be the mean
+    of the halves' losses, and so must the gradients w.r.t. the student features (x 1/2: the loss is a mean over the batch)
+    [ref: dynamic_teacher.py:209-283, base_distillator.py:34-64, configs/Distillation/FCOS/fcos_R_50...yaml:24]."""
+    from lgd_amd import ops
+    from lgd_amd.adapters import SequentialConvs
+    from lgd_amd.dynamic_teacher import DynamicTeacher
+    from lgd_amd.structures import ImageList
+    B, H, W = 16, 800, 1344
+    t = DynamicTeacher(_cfg(False, "stuGuided", "x1y1x2y2", student="FCOSCT", meta="FCOS"))
+    t.load_state_dict(cm.teacher_params(), strict=True)
+    t.to(DEV).train()
+    ad = SequentialConvs(None)
+    ad.load_state_dict(cm.adapter_params(), strict=True)
+    ad.to(DEV).train()
+    feats = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synth_features(B, H, W, seed=5).items()}
+    gt = [(torch.from_numpy(b), torch.from_numpy(c)) for b, c in synth.synth_gt(B, H, W, 10, seed=4)]
+    keys = sorted(feats)
+
+    def run(lo, hi):
+        n = hi - lo
+        f = {k: v[lo:hi].clone().requires_grad_(True) for k, v in feats.items()}
+        images = ImageList(torch.zeros(n, 3, H, W, device=DEV), [(H, W)] * n)
+        tea, labels, geom = t((_batched_inputs(gt[lo:hi], H, W), images, None, f))
+        assert geom.counts == [10] * n and len(labels) == n
+        loss = ops.distill_in_mse(ad.levels([f[k] for k in keys]), [tea[k] for k in keys], 1.0)
+        loss.backward()
+        return {k: v.detach() for k, v in tea.items()}, float(loss), {k: f[k].grad for k in keys}
+    assert ops._WINO_ON and ops._WINO_TILE == 6
+    tea16, loss16, g16 = run(0, 16)
+    assert 0.5 < loss16 < 4.0 and loss16 == loss16
+    halves = [run(0, 8), run(8, 16)]
+    for h, (tea8, _, g8) in enumerate(halves):
+        for k in keys:
+            assert cm.rel_err(tea16[k][8 * h:8 * h + 8], tea8[k]) < 1e-5, (h, k)
+            # the gradient of a mean over 16 images w.r.t. one image's features is half that of the mean over its 8
+            assert cm.rel_err(2.0 * g16[k][8 * h:8 * h + 8], g8[k]) < 1e-4, (h, k)
+    mean_halves = 0.5 * (halves[0][1] + halves[1][1])
+    assert abs(loss16 - mean_halves) <= 1e-6 * abs(mean_halves), (loss16, mean_halves)
+    # GroupNorm(1, no affine) is the last op of the teacher: every sample of every level has zero mean / unit variance
+    for k in keys:
+        y = tea16[k].double()
+        assert float(y.mean(dim=(1, 2, 3)).abs().max()) < 1e-5 and float((y.var(dim=(1, 2, 3), unbiased=False) - 1).abs().max()) < 1e-4
 
 def test_full_size_conv3x3_properties():
     """the Winograd convolution at BASELINE config-2 size (B=8, whole pyramid, 256 -> 256): agrees with the library's direct
@@ -653,30 +704,35 @@ def test_bench_stdout_is_one_json_record():
 
 
 @pytest.mark.timeout(1200)
-def test_bench_two_ranks_on_one_gpu():
-    """the driver's N > 1 launch of bench.py (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`) on the box there
-    is: both ranks on cuda:0, exchange over gloo (LGD_BENCH_SHARE_GPU / LGD_BENCH_BACKEND: test knobs, never a performance number).
-    The barriers, the max-over-ranks time, DDP and the rank-0 record: ONE JSON line, n_gpus 2, whole-job value = 2 ranks' images."""
+@pytest.mark.parametrize("form", ["plain", "torchrun"])
+def test_bench_two_ranks_on_one_gpu(form):
+    """bench.py at N = 2 on the box there is, in both forms it can be started in: `python bench.py --gpus 2` PLAINLY (it re-executes itself
+    as 2 ranks, lgd_amd/launch.py) and the driver's `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`.  Both ranks
+    on cuda:0, exchange over gloo (LGD_BENCH_SHARE_GPU / LGD_BENCH_BACKEND: test knobs, never a performance number).  The barriers, the
+    max-over-ranks time, DDP, the host-thread slices and the rank-0 record: ONE JSON line on stdout, n_gpus 2, the communicator's size read
+    back from an all-reduce, whole-job value = 2 ranks' images [ref: train.py:296-310]."""
     import json
-    import socket
     import subprocess
     import sys
+    from lgd_amd import launch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, LGD_BENCH_SHARE_GPU="1", LGD_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch-per-gpu", "2", "--height", "256", "--width", "320"], env=env, capture_output=True, text=True, timeout=1100)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-per-gpu", "2", "--height", "256", "--width", "320"]
+    head = [sys.executable] if form == "plain" else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                      "--master-addr", "127.0.0.1", "--master-port", str(launch.free_port())]
+    r = subprocess.run(head + tail, env=env, capture_output=True, text=True, timeout=1100)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 4
+    assert rec["rccl_ranks"] == 2 and rec["collective_backend"] == "gloo"
     assert abs(rec["value"] - 4 * 1e3 / rec["ms_per_step"]) <= 1e-6 * rec["value"]      # whole-job images per second over the slowest rank's time
     assert "cpu_baseline" not in rec                                                      # rank 0 at N = 1 only
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert rec["host_threads_pinned"] and rec["host_threads_pinned"].startswith("%d CPUs per rank" % (len(os.sched_getaffinity(0)) // 2))
 
 
 def test_trainer_fused_sgd_equals_torch_optimizers():
@@ -787,13 +843,14 @@ def test_step_folds_equal_per_op_folds():
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("yaml_name", ["lgd_retinanet_r50.yaml", "lgd_fcos_r50.yaml"])   # (R-101-DCNv2 passes too: 3.5 min of library conv search)
+@pytest.mark.parametrize("yaml_name", ["lgd_retinanet_r50.yaml", "lgd_fcos_r50.yaml", "lgd_retinanet_r101.yaml"])   # (R-101-DCNv2 passes too: 3.5 min of library conv search)
 def test_full_size_step_shipped_path_vs_library_convolutions(yaml_name):
-    """Two training steps of the distillator meta-arch (BASELINE configs 2 / 3) at the BASELINE image size (2 x 800 x 1333, 10 boxes; every 3x3 convolution of the
-    backbone, FPN, head and teacher is above the Winograd threshold) on the shipped path -- F(4x4,3x3) transforms with the folded
-    pre-activations, conv1 + shortcut nodes with beta = 1 accumulation, FPN laterals as GEMMs, fused stem epilogue, one-launch clip +
-    SGD -- against the same model on the library's convolutions and torch's optimizers: same losses (the loss of step 2 goes through
-    every gradient and the parameter update) [ref: train.py:184-207]."""
+    """Two training steps of the distillator meta-arch (BASELINE configs 2 / 3, and config 4's exact per-rank workload: R-101 at 2 images) at the
+    BASELINE image size (2 x 800 x 1333, 10 boxes; every 3x3 convolution of the backbone, FPN, head and teacher is above the Winograd
+    threshold) on the SHIPPED path -- whatever `ops` ships as its default tile (F(6x6,3x3) transforms with the folded pre-activations), conv1 +
+    shortcut nodes with beta = 1 accumulation, FPN laterals as GEMMs, fused stem epilogue, one-launch clip + SGD -- against the same model
+    on the library's convolutions and torch's optimizers: same losses (the loss of step 2 goes through every gradient and the parameter
+    update) [ref: train.py:184-207]."""
     import copy
     from lgd_amd import config, ops
     from lgd_amd.data import synthetic_batch
@@ -807,7 +864,8 @@ def test_full_size_step_shipped_path_vs_library_convolutions(yaml_name):
     data = synthetic_batch(2, 800, 1333, 10, seed=3)
     d = cfg.MODEL.DISTILLATOR
     it0 = max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS)
-    prev = ops.conv3x3_backend(winograd=True, tile=4)
+    prev = ops.conv3x3_backend(winograd=True)           # the shipped tile, whatever it is: no `tile=` here
+    assert ops._WINO_TILE == 6                          # ... and today that is F(6x6,3x3)
     try:
         a = Trainer(cfg, base, distributed=False)
         assert a._fused_sgd is not None
@@ -863,11 +921,11 @@ def test_fcos_head_matches_reference_golden(tile):
     worst = 0.0
     for i, f in enumerate(feats):
         e = cm.rel_err(f.grad.reshape(-1)[::7], g["gfeat_s_%d" % i])
-        assert e < 2e-2, (i, e)
+        assert e < 5e-3 + (5e-3 if tile == 6 else 0.0), (i, e)   # measured 2..4e-3 with F(4x4), twice that with F(6x6)
         worst = max(worst, e)
     for n, prm in head.named_parameters():
         e = cm.rel_err(prm.grad.reshape(-1)[::cm.SAMPLE_STRIDE][:64], g["gw_s_" + n])
-        assert e < 2e-2, (n, e)
+        assert e < 5e-3 + (5e-3 if tile == 6 else 0.0), (n, e)
         worst = max(worst, e)
     print("FCOS head vs reference: worst gradient deviation %.2e (tile %d)" % (worst, tile))
 

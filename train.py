@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Training entry with the reference's command line
     python train.py --config-file CFG --num-gpus N [--resume] [--eval-only] [KEY VALUE ...]
-[ref: train.py:237-310; README.md:97-126].  N > 1: launch one process per GPU with
+[ref: train.py:237-310; README.md:97-126].  N > 1: the command above re-executes itself as one process per GPU (lgd_amd/launch.py), or
+start the ranks yourself with
     python -m torch.distributed.run --nproc-per-node N train.py --config-file CFG --num-gpus N ...
 (RCCL over xGMI; the reference's detectron2 `launch` + tcp rendezvous is replaced by the env rendezvous).
 Data: synthetic COCO-shaped batches (lgd_amd/data.py) -- real-image IO/evaluation are out of scope.
@@ -16,11 +17,27 @@ import time
 
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-import torch  # noqa: E402
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _num_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--num-gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--num-gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__":
+    # the reference's `launch(main, args.num_gpus, ...)` (train.py:303-310): started plainly with --num-gpus N, become N ranks of this node
+    from lgd_amd import launch as _launch
+    if _num_gpus(sys.argv[1:]) > 1 and not _launch.launched():
+        raise SystemExit(_launch.self_launch(__file__, _num_gpus(sys.argv[1:]), sys.argv[1:]))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def parse():
@@ -53,10 +70,18 @@ def main():
     args = parse()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     if args.num_gpus > 1 and world != args.num_gpus:
-        raise SystemExit("use: python -m torch.distributed.run --nproc-per-node %d train.py --num-gpus %d ..." % (args.num_gpus, args.num_gpus))
+        raise SystemExit("--num-gpus %d but WORLD_SIZE=%d" % (args.num_gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        from lgd_amd import launch
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        try:
+            props = [torch.cuda.get_device_properties(i) for i in range(local_world)]
+            bus = ["%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id) for p in props]
+        except Exception:  # noqa: BLE001
+            bus = None
+        launch.pin_host_threads(local_rank, local_world, bus)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     from lgd_amd import config
