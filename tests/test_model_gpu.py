@@ -150,7 +150,11 @@ def test_distill_loss_and_grads_match_reference(run):
     errs = {k: cm.rel_err(cm.sample(feats[k].grad, run["stride"])[0], g["gfeat_s_" + k]) for k in O.LEVELS}
     print("feature-gradient parity vs reference [%s]: %s" % (run["backend"], "; ".join(
         "%s product %.1e / torch-ops-on-this-GPU %.1e" % (k, errs[k], cm.rel_err(cm.sample(dev_feat[k], run["stride"])[0], g["gfeat_s_" + k])) for k in O.LEVELS)))
-    assert all(e <= 5e-3 for e in errs.values()), errs   # measured <= 1.6e-3 (p3) .. 4e-3 (p5): trips on regressions, not on flips
+    # measured: <= 1.6e-3 (p3) .. 4e-3 (p5) on the 512 x 512 cases; the 800 x 1344 cases have dozens of near-zero units per level
+    # (8.4e-3 at p3).  Bounds at ~2x the measured flip noise: they trip on regressions, not on flips
+    bound = 5e-3 if run["name"] in cm.SMALL_CASES else 1.5e-2
+    assert all(e <= bound for e in errs.values()), errs
+    bound = max(bound, 1e-2)   # parameter gradients sum the flips of all levels: torch's own ops on this GPU leave the reference by 7.5e-3
     named = list(teacher.named_parameters()) + [("adapter." + n, p) for n, p in d.adapter["distill"].named_parameters()]
     worst = (0.0, 0.0, "")
     for n, prm in named:
@@ -166,7 +170,7 @@ def test_distill_loss_and_grads_match_reference(run):
         e_dev = float(np.abs(cm.sample(dev_w[n])[0][:64] - ref_s).max()) / scale
         e_prod = float(np.abs(cm.sample(prm.grad)[0][:64] - ref_s).max()) / scale
         worst = max(worst, (e_prod, e_dev, n))
-        assert e_prod <= 5e-3, (n, e_prod, e_dev)
+        assert e_prod <= bound, (n, e_prod, e_dev)
         assert abs(cm.sample(prm.grad)[2] - ref_sq) <= 4e-2 * ref_sq, n
     print("weight-gradient parity: worst sampled deviation %.1e (torch ops on this GPU: %.1e) at %s" % worst)
 
@@ -356,10 +360,14 @@ def test_config3_batch16_equals_two_batches_of_8():
         loss = ops.distill_in_mse(ad.levels([f[k] for k in keys]), [tea[k] for k in keys], 1.0)
         loss.backward()
         return {k: v.detach() for k, v in tea.items()}, float(loss), {k: f[k].grad for k in keys}
-    assert ops._WINO_ON and ops._WINO_TILE == 6
-    tea16, loss16, g16 = run(0, 16)
-    assert 0.5 < loss16 < 4.0 and loss16 == loss16
-    halves = [run(0, 8), run(8, 16)]
+    prev = ops.conv3x3_backend(winograd=True)    # (a module-scoped golden fixture may still hold the library back-end)
+    try:
+        assert ops._WINO_TILE == 6
+        tea16, loss16, g16 = run(0, 16)
+        assert 0.5 < loss16 < 4.0 and loss16 == loss16
+        halves = [run(0, 8), run(8, 16)]
+    finally:
+        ops.conv3x3_backend(*prev)
     for h, (tea8, _, g8) in enumerate(halves):
         for k in keys:
             assert cm.rel_err(tea16[k][8 * h:8 * h + 8], tea8[k]) < 1e-5, (h, k)
@@ -731,8 +739,9 @@ def test_bench_two_ranks_on_one_gpu(form):
     assert rec["rccl_ranks"] == 2 and rec["collective_backend"] == "gloo"
     assert abs(rec["value"] - 4 * 1e3 / rec["ms_per_step"]) <= 1e-6 * rec["value"]      # whole-job images per second over the slowest rank's time
     assert "cpu_baseline" not in rec                                                      # rank 0 at N = 1 only
-    if len(os.sched_getaffinity(0)) >= 2:
-        assert rec["host_threads_pinned"] and rec["host_threads_pinned"].startswith("%d CPUs per rank" % (len(os.sched_getaffinity(0)) // 2))
+    if len(os.sched_getaffinity(0)) >= 2:   # equal slices of the CPUs of the GPU's NUMA node (or of all allowed CPUs when sysfs does not tell)
+        n_cpus = int(rec["host_threads_pinned"].split()[0])
+        assert 1 <= n_cpus <= len(os.sched_getaffinity(0)) // 2 and "CPUs per rank" in rec["host_threads_pinned"]
 
 
 def test_trainer_fused_sgd_equals_torch_optimizers():

@@ -1,0 +1,237 @@
+// LAB: strided-batched fp32 GEMM on the bf16 MFMA pipe with three-way split operands.
+//   C[b] (M x N) = A[b] (M x K) . B[b] (K x N),  fp32 in HBM on both sides and in the result.
+// Every fp32 operand element x is split while it is STAGED into LDS:  x = h + m + l,  h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
+// (round to nearest: |x - h - m - l| <= 2^-24 |x| up to bf16 underflow), and 6 of the 9 cross products are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16:   a.b ~= ah.bh + (ah.bm + am.bh) + (ah.bl + am.bm + al.bh)      (dropped: am.bl + al.bm + al.bl <= ~2^-23 |a||b|)
+// The frequency buffers stay fp32 [C][64][T] (no extra HBM bytes, the Winograd transforms are untouched); the split costs ~5.5 VALU
+// operations per staged element, issued beside the MFMAs.
+//
+// Tile: 128 x 128 x 32 per 256-thread workgroup (2 x 2 waves, 64 x 64 per wave = 2 x 2 MFMA blocks of 32 x 32), one LDS buffer of
+// 48 KB (3 pieces x (128 + 128) rows x 32 k x 2 B) so that three workgroups share a CU and one's staging hides under the others' MFMAs;
+// the next k-tile's global loads are in flight (registers) during the MFMA phase.
+// LDS image: per piece and 32-row block, per 16-deep k-step, the 64 lanes' 16-byte fragments in lane order (a wave's ds_read_b128 covers
+// 1 KB linearly), the 16-byte slot XOR-ed with the (k-group, k-step) bits so that the staging stores are conflict-free as well.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int PIECE_BYTES = 128 * BK * 2;          // one piece of one operand: 8 KB
+constexpr int OPER_BYTES = 3 * PIECE_BYTES;        // 24 KB
+constexpr int LDS_BYTES = 2 * OPER_BYTES;          // 48 KB
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const bf16x2 v = __builtin_convertvector((f32x2){a, b}, bf16x2);   // v_cvt_pk_bf16_f32 (RNE), a in the low half
+    return __builtin_bit_cast(uint32_t, v);
+}
+// two floats -> three packed bf16 pairs
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = pack_bf16(x0, x1);
+    float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = pack_bf16(r0, r1);
+    r0 -= __builtin_bit_cast(float, m << 16);
+    r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
+    l = pack_bf16(r0, r1);
+}
+// byte offset of the 16-byte fragment (row r of 128, 8-deep k-group kg of 4) inside one piece
+__device__ __forceinline__ int frag_off(int r, int kg) {
+    const int rb = r >> 5, rr = r & 31, ks = kg >> 1, g = kg & 1;
+    return ((rb * 2 + ks) << 10) + (g << 9) + ((rr << 4) ^ (g << 6) ^ (ks << 5));
+}
+
+// ---- staging, operand whose k axis is contiguous in memory: X(row, k) at X[row * ld + k].  Thread <-> (row, k-group) pairs q = t, t + 256.
+struct StageK {
+    float4 v[2][2];
+    __device__ __forceinline__ void load(const float* __restrict__ X, long ld, int row0, int rows, int k0, int K, int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = t + NT * j, r = q >> 2, kg = q & 3;
+            const int row = row0 + r, k = k0 + kg * 8;
+            const bool ok = row < rows && k < K;            // K % 8 == 0 (host-checked): a k-group is all in or all out
+            const float* p = X + (long)(ok ? row : 0) * ld + (ok ? k : 0);
+            float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+            if (!ok) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+            v[j][0] = a; v[j][1] = b;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int t) const {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = t + NT * j, r = q >> 2, kg = q & 3;
+            uint32_t h[4], m[4], l[4];
+            split2(v[j][0].x, v[j][0].y, h[0], m[0], l[0]);
+            split2(v[j][0].z, v[j][0].w, h[1], m[1], l[1]);
+            split2(v[j][1].x, v[j][1].y, h[2], m[2], l[2]);
+            split2(v[j][1].z, v[j][1].w, h[3], m[3], l[3]);
+            const int o = frag_off(r, kg);
+            *reinterpret_cast<u32x4*>(lds + o) = (u32x4){h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4*>(lds + PIECE_BYTES + o) = (u32x4){m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<u32x4*>(lds + 2 * PIECE_BYTES + o) = (u32x4){l[0], l[1], l[2], l[3]};
+        }
+    }
+};
+// ---- staging, operand whose row (m or n) axis is contiguous: X(row, k) at X[k * ld + row].  Thread <-> (k-group = wave, rows 2*lane, 2*lane+1).
+struct StageR {
+    float2 v[8];
+    __device__ __forceinline__ void load(const float* __restrict__ X, long ld, int row0, int rows, int k0, int K, int t) {
+        const int kg = t >> 6, r = (t & 63) * 2;
+        const int row = row0 + r;
+        const bool rok = row < rows;                        // rows % 2 == 0 (host-checked)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + kg * 8 + e;
+            const bool ok = rok && k < K;
+            const float* p = X + (long)(ok ? k : 0) * ld + (ok ? row : 0);
+            float2 a = *reinterpret_cast<const float2*>(p);
+            if (!ok) a = make_float2(0.f, 0.f);
+            v[e] = a;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int t) const {
+        const int kg = t >> 6, r = (t & 63) * 2;
+        uint32_t h0[4], m0[4], l0[4], h1[4], m1[4], l1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            split2(v[2 * e].x, v[2 * e + 1].x, h0[e], m0[e], l0[e]);
+            split2(v[2 * e].y, v[2 * e + 1].y, h1[e], m1[e], l1[e]);
+        }
+        const int o0 = frag_off(r, kg), o1 = frag_off(r + 1, kg);
+        *reinterpret_cast<u32x4*>(lds + o0) = (u32x4){h0[0], h0[1], h0[2], h0[3]};
+        *reinterpret_cast<u32x4*>(lds + o1) = (u32x4){h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<u32x4*>(lds + PIECE_BYTES + o0) = (u32x4){m0[0], m0[1], m0[2], m0[3]};
+        *reinterpret_cast<u32x4*>(lds + PIECE_BYTES + o1) = (u32x4){m1[0], m1[1], m1[2], m1[3]};
+        *reinterpret_cast<u32x4*>(lds + 2 * PIECE_BYTES + o0) = (u32x4){l0[0], l0[1], l0[2], l0[3]};
+        *reinterpret_cast<u32x4*>(lds + 2 * PIECE_BYTES + o1) = (u32x4){l1[0], l1[1], l1[2], l1[3]};
+    }
+};
+
+struct Params {
+    const float* A; long a_sb, a_ld;      // A(m, k): AK ? A[m * a_ld + k] : A[k * a_ld + m]
+    const float* B; long b_sb, b_ld;      // B(k, n): BK_ ? B[n * b_ld + k] : B[k * b_ld + n]
+    float* C; long c_sb, c_ld;            // C(m, n) at C[m * c_ld + n]
+    int nb, M, N, K, mt, nt;              // mt / nt: tiles along M / N
+    int ksplit; long c_ss;                // split-K: slice s of batch b writes C + s * c_ss (partials summed by the caller)
+};
+
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+    // workgroup -> (batch, n-tile, m-tile, k-slice): ids that differ by 8 share an XCD (round-robin dispatch), so the m-tiles that
+    // read the same B tile, then the n-tiles of one batch (same A), are neighbours on ONE XCD's L2
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int per = p.mt * p.ksplit;
+    const int sub = j % per, rest = (j / per) * 8 + xcd;
+    if (rest >= p.nb * p.nt) return;
+    const int tm = sub % p.mt, ksl = sub / p.mt;
+    const int b = rest / p.nt, tn = rest % p.nt;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int ktiles = (p.K + BK - 1) / BK;
+    const int kt0 = (int)((long)ktiles * ksl / p.ksplit), kt1 = (int)((long)ktiles * (ksl + 1) / p.ksplit);
+    const float* A = p.A + (long)b * p.a_sb;
+    const float* B = p.B + (long)b * p.b_sb;
+    char* ldsA = lds;
+    char* ldsB = lds + OPER_BYTES;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    typename std::conditional<AK, StageK, StageR>::type sa;
+    typename std::conditional<BKC, StageK, StageR>::type sb;
+    if (kt0 < kt1) {
+        sa.load(A, p.a_ld, m0, p.M, kt0 * BK, p.K, t);
+        sb.load(B, p.b_ld, n0, p.N, kt0 * BK, p.K, t);
+    }
+    // this lane's fragment slot inside a (32-row block, k-step) sub-block: row lane & 31, k-group lane >> 5
+    const int g = lane >> 5, rr = lane & 31;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        sa.store(ldsA, t);
+        sb.store(ldsB, t);
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            sa.load(A, p.a_ld, m0, p.M, (kt + 1) * BK, p.K, t);
+            sb.load(B, p.b_ld, n0, p.N, (kt + 1) * BK, p.K, t);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = (g << 9) + ((rr << 4) ^ (g << 6) ^ (ks << 5));
+            bf16x8 fb[3][2];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn)
+                    fb[pc][jn] = *reinterpret_cast<const bf16x8*>(ldsB + pc * PIECE_BYTES + (((wn * 2 + jn) * 2 + ks) << 10) + slot);
+#pragma unroll
+            for (int pa = 2; pa >= 0; --pa) {            // smallest pieces first
+                bf16x8 fa[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8*>(ldsA + pa * PIECE_BYTES + (((wm * 2 + i) * 2 + ks) << 10) + slot);
+#pragma unroll
+                for (int pb = 2 - pa; pb >= 0; --pb)     // pa + pb <= 2: the six kept products
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[pb][jn], acc[i][jn], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    float* C = p.C + (long)b * p.c_sb + (long)ksl * p.c_ss;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int n = n0 + (wn * 2 + jn) * 32 + rr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+                if (m < p.M && n < p.N) C[(long)m * p.c_ld + n] = acc[i][jn][e];
+            }
+        }
+}
+
+}  // namespace
+
+// A(m,k): a_sk == 1 (k contiguous, a_sm = leading dimension) or a_sm == 1 (m contiguous, a_sk = leading dimension); B(k,n) alike;
+// C(m,n) with n contiguous.  Strides in elements.  ksplit > 1: slice s writes its partial product to C + s * c_ss.
+extern "C" int gemm3_lab(const float* A, long a_sb, long a_sm, long a_sk, const float* B, long b_sb, long b_sk, long b_sn,
+                         float* C, long c_sb, long c_sm, int nb, int M, int N, int K, int ksplit, long c_ss, void* stream) {
+    const bool ak = a_sk == 1, bk = b_sk == 1 && b_sn != 1;
+    if (!ak && a_sm != 1) return -1;
+    if (!bk && b_sn != 1) return -1;
+    Params p;
+    p.A = A; p.a_sb = a_sb; p.a_ld = ak ? a_sm : a_sk;
+    p.B = B; p.b_sb = b_sb; p.b_ld = bk ? b_sn : b_sk;
+    p.C = C; p.c_sb = c_sb; p.c_ld = c_sm;
+    p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + BM - 1) / BM; p.nt = (N + BN - 1) / BN;
+    p.ksplit = ksplit < 1 ? 1 : ksplit; p.c_ss = c_ss;
+    // alignment the vector loads need
+    if (ak && ((K & 7) || (p.a_ld & 3) || (a_sb & 3) || ((uintptr_t)A & 15))) return -2;
+    if (!ak && ((M & 1) || (p.a_ld & 1) || (a_sb & 1) || ((uintptr_t)A & 7))) return -2;
+    if (bk && ((K & 7) || (p.b_ld & 3) || (b_sb & 3) || ((uintptr_t)B & 15))) return -2;
+    if (!bk && ((N & 1) || (p.b_ld & 1) || (b_sb & 1) || ((uintptr_t)B & 7))) return -2;
+    const long groups = ((long)nb * p.nt + 7) / 8;
+    const long grid = groups * 8 * p.mt * p.ksplit;
+    hipStream_t s = (hipStream_t)stream;
+    if (ak && !bk) hipLaunchKernelGGL((gemm3_kernel<true, false>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, s, p);
+    else if (!ak && !bk) hipLaunchKernelGGL((gemm3_kernel<false, false>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, s, p);
+    else if (ak && bk) hipLaunchKernelGGL((gemm3_kernel<true, true>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((gemm3_kernel<false, true>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
