@@ -57,6 +57,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), same guide
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), same guide; the bf16x3 products issue 6 bf16 MFMA flops per fp32 flop
 
 
 def parse():
@@ -84,6 +85,7 @@ def parse():
     ap.add_argument("--multiscale", action="store_true",
                     help="per-image short side drawn from INPUT.MIN_SIZE_TRAIN (640..800, max 1333: BASELINE config 5, "
                          "configs/Base-RetinaNet.yaml:26) instead of every image at --height x --width")
+    ap.add_argument("--library-gemms", action="store_true", help="the Winograd channel products on the library's fp32 GEMM instead of csrc/gemm3.hip (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
     ap.add_argument("--no-gn-bwd-fold", action="store_true", help="FCOS towers: the GroupNorm backward as its own statistics + apply passes instead of inside the producing convolution's adjoint output transform (A/B runs)")
@@ -233,6 +235,8 @@ def main():
         ops.conv3x3_backend(tile=args.wino_tile)
     if args.library_convs:
         ops.conv3x3_backend(winograd=False)
+    if args.library_gemms:
+        ops.gemm3_backend(False)
 
     cfg = config.setup_cfg(args.config, ["MODEL.DEVICE", "cuda:%d" % gpu])
     torch.manual_seed(0)
@@ -383,19 +387,30 @@ def main():
                            "by_kind": {n: {"TFLOPs": round(v["TFLOPs"], 1), "avg_us": round(v["avg_us"], 1), "min_us": round(v["min_us"], 1),
                                            "max_us": round(v["max_us"], 1), "launches_per_step": v["launches"] / args.steps}
                                        for n, v in pw.items()}}
-        gemms = {n: v for n, v in kernels.items() if n.startswith("wino_gemm")}
-        if gemms:
-            tot_ms = sum(v["total_ms"] for v in gemms.values())
-            tot_fl = sum(kflops[n] for n in gemms)
-            n_l = sum(v["launches"] for v in gemms.values())
-            ach = tot_fl / (1e-3 * tot_ms) / 1e12
-            roofline_mfma = {"bound": "mfma", "kernel": "Winograd channel GEMMs (library fp32 MFMA via torch.bmm: forward, input-gradient, "
-                             "weight-gradient)", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "flop_per_launch": tot_fl / n_l,
-                             "avg_launch_us": 1e3 * tot_ms / n_l, "ms_per_step": tot_ms / args.steps,
-                             "by_kind": {n: {"TFLOPs": round(v["TFLOPs"], 1), "avg_us": round(v["avg_us"], 1), "min_us": round(v["min_us"], 1),
-                                             "max_us": round(v["max_us"], 1), "launches_per_step": v["launches"] / args.steps}
-                                         for n, v in gemms.items()}}
+        def mfma_object(sel, label, peak, mult):
+            tot_ms = sum(v["total_ms"] for v in sel.values())
+            tot_fl = sum(kflops[n] for n in sel)
+            n_l = sum(v["launches"] for v in sel.values())
+            ach = mult * tot_fl / (1e-3 * tot_ms) / 1e12
+            return {"bound": "mfma", "kernel": label, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                    "flop_per_launch": mult * tot_fl / n_l, "fp32_equivalent_TFLOPs": tot_fl / (1e-3 * tot_ms) / 1e12,
+                    "avg_launch_us": 1e3 * tot_ms / n_l, "ms_per_step": tot_ms / args.steps,
+                    "by_kind": {n: {"TFLOPs": round(mult * v["TFLOPs"], 1), "avg_us": round(v["avg_us"], 1), "min_us": round(v["min_us"], 1),
+                                    "max_us": round(v["max_us"], 1), "launches_per_step": v["launches"] / args.steps} for n, v in sel.items()}}
+        # the Winograd channel products: csrc/gemm3.hip (forward, input gradient; bf16 MFMA, 6 MFMA flops per fp32 flop, split + product launch
+        # timed together) and the library's fp32 GEMMs (weight gradient; shapes outside gemm3's tile)
+        g3 = {n: v for n, v in kernels.items() if n.startswith("wino_gemm3_")}
+        gl = {n: v for n, v in kernels.items() if n.startswith("wino_gemm_")}
+        roofline_mfma_lib = None
+        if g3:
+            roofline_mfma = mfma_object(g3, "Winograd channel products on csrc/gemm3.hip (fp32 operands split into three bf16 pieces, 6 of 9 cross products on "
+                                        "v_mfma_f32_32x32x16_bf16, fp32 accumulate; forward + input gradient; filter split launch included)",
+                                        MFMA_BF16_PEAK_TFLOPS, 6.0)
+        if gl:
+            roofline_mfma_lib = mfma_object(gl, "Winograd channel GEMMs left on the library (fp32 MFMA via torch.bmm: weight gradient, shapes outside gemm3's tile)",
+                                            MFMA_F32_PEAK_TFLOPS, 1.0)
+            if not g3:
+                roofline_mfma, roofline_mfma_lib = roofline_mfma_lib, None
         arch = cfg.MODEL.META_ARCHITECTURE.replace("Distillator", "")
         default_cfg = os.path.abspath(args.config) == os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml")
         out = {
@@ -409,7 +424,7 @@ def main():
             "host_threads_pinned": None if pinned_cpus is None else "%d CPUs per rank (rank 0: %d-%d)" % (len(pinned_cpus), pinned_cpus[0], pinned_cpus[-1]),
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (bf16x3 split products, fp32 accumulate)" if ops._GEMM3_ON else "f32",
             "data": ("synthetic (%d distinct batches rotated; %s)" % (nb, "pinned HOST batches copied inside every step" if args.host_batch
                                                                       else "device-resident when the timed region starts, no H2D copy inside it")),
             "host_batch": None if dt_host is None else {
@@ -433,7 +448,8 @@ def main():
             "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,
             "fused_clip_sgd": trainer._fused_sgd is not None,
             "head_pass": "single (student + teacher pyramids in one pass)" if getattr(model, "fused_head_pass", False) else "two passes",
-            "roofline": roofline, "roofline_mfma": roofline_mfma, "roofline_mfma_pointwise": roofline_pw, "roofline_lgd_forward": lgd_fwd,
+            "roofline": roofline, "roofline_mfma": roofline_mfma, "roofline_mfma_library": roofline_mfma_lib, "roofline_mfma_pointwise": roofline_pw,
+            "roofline_lgd_forward": lgd_fwd,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.boxes, ctx)

@@ -344,61 +344,24 @@ int lgd_wino_filter_bwd(const float* dU, long long du_plane, const float* scale,
 int lgd_wino_in_t_out_t(const float* dV, const void* relu_bits, const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM,
                         void* stream);
 
-/* ------------------------------------------------------------------ K8: one call per convolution
- * The whole Winograd pipeline of ONE 3x3 / stride 1 / padding 1 convolution (K <= LGD_MAX_FILTERS filters applied to the same L maps)
- * behind a single entry point: filter transforms, input transform, the per-frequency channel GEMMs -- issued by THIS library through
- * rocBLAS (fp32 MFMA strided-batched GEMM) on the caller's stream --, output transforms; and the backward of the same pipeline.
- * [replaces nn.Conv2d(C, C', 3, padding=1).forward / its autograd: dynamic_teacher.py:57,61,67-73, sequential_convs.py:10-12,
- *  distillator.py:107-109 -> retinanet.py:36-43.]  At 2 images per GPU a convolution's kernels run 10-90 us each; issuing them from
- * one native call instead of 6-12 host-language calls is what keeps the queue from running dry.
- * Every buffer is the caller's (layouts as above: U [nf][sum Co][Ci], Ut [nf][Ci][sum Co], V / dV [Ci][nf][T], M / dM [sum Co][nf][T],
- * dU [nf][sum Co][Ci], mask tables [C][T]); pointers that are "optional" may be NULL.
- * sol_*: rocBLAS solution index for the GEMM shape (the host reads it from its tuning table, lgd_amd/tuning/tunableop_gfx950.csv;
- * 0 = the library's own choice; an index the loaded rocBLAS rejects falls back to it).
- * lgd_blas_init creates the library's rocBLAS handle (once; rocBLAS allocates its device workspace there, never later). */
-#define LGD_MAX_FILTERS 4
-typedef struct lgd_conv3x3_fwd_args {
-    int32_t L, N, Ci, K, tile, relu;
-    int32_t level_hw[2 * LGD_MAX_LEVELS];
-    int32_t Co[LGD_MAX_FILTERS];
-    const float* x[LGD_MAX_LEVELS];                       /* the L input maps (N, Ci, H_l, W_l) */
-    const float* w[LGD_MAX_FILTERS];                      /* (Co_k, Ci, 3, 3) */
-    const float* scale[LGD_MAX_FILTERS];                  /* optional frozen per-output-channel factor */
-    const float* bias[LGD_MAX_FILTERS];                   /* optional */
-    float* y[LGD_MAX_FILTERS * LGD_MAX_LEVELS];           /* outputs, filter-major: y[k * L + l] is (N, Co_k, H_l, W_l) */
-    const float* pre_bias;                                /* optional: the maps are pre-activations, see lgd_wino_in */
-    void* pre_bits;                                       /* optional: [Ci][T] activation masks written for the backward */
-    void* relu_bits;                                      /* optional (relu = 1): [sum Co][T] output masks written for the backward */
-    float *U, *Ut, *V, *M;                                /* U^T and V are what the backward needs; U and M are scratch */
-    int32_t sol_fwd, reserved;
-} lgd_conv3x3_fwd_args;
-typedef struct lgd_conv3x3_bwd_args {
-    int32_t L, N, Ci, K, tile, dM_ready;
-    int32_t level_hw[2 * LGD_MAX_LEVELS];
-    int32_t Co[LGD_MAX_FILTERS];
-    const float* dy[LGD_MAX_FILTERS * LGD_MAX_LEVELS];    /* gradients of the outputs, filter-major (unused if dM_ready) */
-    const void* relu_bits;                                /* optional: the forward's output masks */
-    float* dM;                                            /* scratch; or, dM_ready = 1, the INPUT (a chain link already produced it) */
-    const float* Ut;                                      /* from the forward */
-    const float* V;                                       /* from the forward (optional: needed for dw) */
-    float* dV;                                            /* scratch [Ci][nf][T]; NULL: no input gradient */
-    float* dx[LGD_MAX_LEVELS];                            /* input gradients (used when dM_prev == NULL) */
-    const void* pre_bits;                                 /* optional: the forward's pre-activation masks */
-    float* dM_prev;                                       /* optional: fused chain link -- dM of the PRODUCING convolution instead of dx */
-    const void* prev_bits;                                /* optional: that convolution's output masks */
-    float* dU;                                            /* scratch [nf][sum Co][Ci] (needed for dw) */
-    float* dw[LGD_MAX_FILTERS];                           /* optional per filter: (Co_k, Ci, 3, 3) */
-    const float* scale[LGD_MAX_FILTERS];
-    float* db[LGD_MAX_FILTERS];                           /* optional per filter: (Co_k) */
-    int32_t sol_dx, sol_dw;
-} lgd_conv3x3_bwd_args;
-int lgd_blas_init(void);
-/* version string of the rocBLAS this process resolved (the host checks it against its tuning table's validator before passing indices) */
-int lgd_blas_version(char* buf, size_t len);
-/* one of the three channel products on [C][nf][T] buffers: kind 0 M = U V, 1 dV = Ut dM, 2 dU = dM V^T (A, B, C in that order) */
-int lgd_wino_gemm(int kind, const float* A, const float* B, float* C, int Ct, int Ci, long long T, int tile, int solution, void* stream);
-int lgd_conv3x3_fwd(const lgd_conv3x3_fwd_args* args, void* stream);
-int lgd_conv3x3_bwd(const lgd_conv3x3_bwd_args* args, void* stream);
+/* ------------------------------------------------------------------ K9: channel products on the bf16 MFMA pipe, fp32 in and out
+ * The per-frequency channel GEMMs of the Winograd convolutions  M[f] = U[f] V[f]  and  dV[f] = U[f]^T dM[f]
+ * [the arithmetic of nn.Conv2d(C, C', 3, padding=1): dynamic_teacher.py:57,61,67-73,145,280; sequential_convs.py:10-12; the head towers
+ *  distillator.py:107-109] as strided-batched products  C[b] (M x N) = A[b] (M x K) B[b] (K x N)  with fp32 operands and result, computed
+ * on v_mfma_f32_32x32x16_bf16: every fp32 element x is split x = h + m + l into three bf16 pieces (round to nearest; h + m + l = x to
+ * 2^-24 |x|) and 6 of the 9 cross products (ah bh, ah bm, am bh, ah bl, am bm, al bh) are accumulated in fp32: the dropped terms are
+ * <= 2^-23 |a||b|, i.e. the result is an fp32-class product (measured error against fp64: 6.2e-7 of the output scale, rocBLAS fp32:
+ * 7.6e-7) at 6/16 of the fp32 MFMA pipe's time.
+ *   A is the FILTER operand: it is split ahead of the product (lgd_gemm3_split) into an image in MFMA fragment order,
+ *   [batch][K/16][piece 3][ceil(M/32)][lane 64][8 bf16], lgd_gemm3_image_bytes(nb, M, K) bytes, which the product kernel copies into
+ *   LDS by LDS-DMA; element (m, k) of batch b is read at A[b * a_sb + m * a_sm + k * a_sk] (any strides: U and U^T are both views).
+ *   B (K x N) and C (M x N) have their last axis contiguous: B[b * b_sb + k * b_sk + n], C[b * c_sb + m * c_sm + n]; B is split inside
+ *   the product kernel while it is staged (each element once: a workgroup's tile spans 256 rows of A).
+ * Requirements (LGD_EINVAL otherwise; the host falls back to the library GEMM): K % 16 == 0, 16-byte aligned image. */
+size_t lgd_gemm3_image_bytes(int nb, int M, int K);
+int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_sk, int nb, int M, int K, void* image, void* stream);
+int lgd_gemm3(const void* image, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm, int nb, int M,
+              int N, int K, void* stream);
 
 /* ------------------------------------------------------------------ FCOS ground-truth assignment
  * [ref: models/customized_detectors/thirdparty_heads/fcos.py:177-284  FCOS.get_ground_truth]

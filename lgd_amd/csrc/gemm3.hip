@@ -1,0 +1,257 @@
+// K9: the channel products of the Winograd convolutions on the bf16 MFMA pipe, fp32 in HBM on both sides  (include/lgd_hip.h: lgd_gemm3*)
+//   C[b] (M x N) = A[b] (M x K) . B[b] (K x N)      [the arithmetic of nn.Conv2d(C, C', 3, padding=1): dynamic_teacher.py:57,61,67-73,
+//                                                     145,280; sequential_convs.py:10-12; the head towers, distillator.py:107-109]
+// gfx950 runs fp32-input MFMA at the VECTOR rate (157 TFLOP/s, 1/16 of bf16; the xf32 forms of gfx942 are gone) and the library's
+// fp32 GEMMs were 68 % of the training step.  Here every fp32 element x is split into three bf16 pieces, x = h + m + l with
+// h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round to nearest: the sum is x to 2^-24 |x|), and the product keeps 6 of the 9
+// cross terms:  a b ~ ah bh + (ah bm + am bh) + (ah bl + am bm + al bh);  the dropped ones are <= ~2^-23 |a||b|, accumulation is fp32
+// inside v_mfma_f32_32x32x16_bf16.  Measured against an fp64 product of the same operands: 6.2e-7 of the output scale (rocBLAS fp32:
+// 7.6e-7).  A two-piece split (2^-16) does not survive the F(6x6,3x3) transforms; three pieces do.
+//
+// What keeps it an MFMA-bound kernel instead of a VALU-bound one (lab history: tools/lab/gemm3_lab.hip, profiles/r04_gemm3_lab*.log):
+//  * the FILTER operand A is split once, ahead of the product (split_a_kernel), into an image in MFMA fragment order --
+//    [batch][k-step of 16][piece][32-row block][lane][8 bf16] -- so that a k-step's share of a 256-row tile is 3 runs of 8 KB which
+//    LDS-DMA (global_load_lds_dwordx4: no registers, no VALU) drops into LDS unchanged;
+//  * the workgroup's tile spans 256 rows of A (all output channels of a 256 -> 256 convolution), so every element of B (the
+//    activations, 342 MB per product at BASELINE config 2) is read from HBM once and split once: ~1.4 VALU instructions per MFMA
+//    (splitting both operands in a 128 x 128 tile: 7.8, issue-bound at 30 % of the pipe);
+//  * all addresses of the k-loop are a uniform base + per-thread 32-bit offsets computed once.
+// Tile 256 x 128 x 16, 256 threads (2 x 2 waves, 128 x 64 per wave = 4 x 2 MFMA blocks of 32 x 32, 128 accumulator registers), two
+// LDS buffers of 36 KB (A pieces 24 KB + B pieces 12 KB): one barrier per k-step, two workgroups per CU so that one's staging and
+// epilogue hide under the other's MFMAs.
+#include <type_traits>
+
+#include "common.h"
+
+namespace lgd {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 256, BN = 128, BK = 16, NT = 256;
+constexpr int A_BYTES = 3 * 8 * 1024, B_BYTES = 3 * 4 * 1024, BUF = A_BYTES + B_BYTES, LDS_BYTES = 2 * BUF;   // 72 KB
+
+#define LGD_GLDS16(src, dst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const bf16x2 v = __builtin_convertvector((f32x2){a, b}, bf16x2);   // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
+    return __builtin_bit_cast(uint32_t, v);
+}
+// two floats -> three packed bf16 pairs (11 VALU operations per pair)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = pack_bf16(x0, x1);
+    float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = pack_bf16(r0, r1);
+    r0 -= __builtin_bit_cast(float, m << 16);
+    r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
+    l = pack_bf16(r0, r1);
+}
+
+struct Params {
+    const char* Aimg; long a_sb; int rbp, ktp;   // image [nb][ktp][3][rbp][1024 B]; a_sb in bytes
+    const float* B; long b_sb, b_ld;             // B(k, n) at B[k * b_ld + n]
+    float* C; long c_sb, c_ld;                   // C(m, n) at C[m * c_ld + n]
+    int nb, M, N, K, mt, nt;
+};
+
+__global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];   // ONE LDS object (a second one makes hipcc drain vmcnt(0) before every ds_read)
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
+    // workgroup -> (batch, n-tile, m-tile).  Consecutive ids go round-robin to the 8 XCDs: XCD x takes the batches b = x (mod 8) and walks
+    // their tiles in order, so that its L2 holds the images of the one or two batches it is working on (tiles of one batch spread over
+    // all XCDs: every L2 holds all ~13 images in flight; measured 2 % slower)
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int per_b = p.nt * p.mt;
+    const int b = (j / per_b) * 8 + xcd, r = j % per_b;
+    if (b >= p.nb) return;
+    const int tn = r / p.mt, sub = r % p.mt;
+    const int m0 = sub * BM, n0 = tn * BN, rb0 = sub * 8;
+    const int ksteps = p.K / BK;                       // K % 16 == 0 (host-checked)
+    const char* Ai = p.Aimg + (long)b * p.a_sb;
+    // B staging: thread <-> (k-group kg = t >> 7, column n = t & 127): 8 dwords down the k axis, a wave's load covers 256 contiguous
+    // bytes.  Columns >= N are read from column N - 1 and rows >= M come as zeros from the image: both only reach elements of C that are
+    // never stored (rows and columns of a product are independent), so nothing is zeroed here.
+    const int kg = t >> 7, nl = t & 127;
+    const int ncol = n0 + nl < p.N ? n0 + nl : p.N - 1;
+    const float* Bb = p.B + (long)b * p.b_sb;
+    uint32_t boff[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) boff[e] = (uint32_t)((kg * 8 + e) * (int)p.b_ld + ncol);
+    const long bstep = (long)BK * p.b_ld;
+    const int bslot = A_BYTES + (nl >> 5) * 1024 + kg * 512 + (nl & 31) * 16;   // 8 consecutive lanes -> 128 contiguous bytes: no conflicts
+    float bv[8];
+    auto load_b = [&](int ks) {
+        const float* Bk = Bb + ks * bstep;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = Bk[boff[e]];
+    };
+    auto store_b = [&](char* buf) {
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2(bv[2 * e], bv[2 * e + 1], h[e], m[e], l[e]);
+        char* d = buf + bslot;
+        *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(d + 4096) = (u32x4){m[0], m[1], m[2], m[3]};
+        *reinterpret_cast<u32x4*>(d + 8192) = (u32x4){l[0], l[1], l[2], l[3]};
+    };
+    // A: 24 chunks of 1 KB per k-step ([piece][row block]); wave w moves chunks 6w .. 6w+5 (row blocks past the image repeat its last one:
+    // their products are rows >= M)
+    uint32_t aoff[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int ch = w * 6 + c, pc = ch >> 3, rbl = ch & 7;
+        int rb = rb0 + rbl;
+        rb = rb < p.rbp ? rb : p.rbp - 1;
+        aoff[c] = (uint32_t)((pc * p.rbp + rb) * 1024 + lane * 16);
+    }
+    const long astep = (long)3 * p.rbp * 1024;
+    auto dma_a = [&](int ks, char* buf) {
+        const char* Ak = Ai + ks * astep;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) LGD_GLDS16(Ak + aoff[c], buf + (w * 6 + c) * 1024);
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    // prologue: k-step 0 into buffer 0, B of k-step 1 into registers
+    dma_a(0, lds);
+    load_b(0);
+    store_b(lds);
+    if (ksteps > 1) load_b(1);
+    __syncthreads();
+    const int slot = lane * 16;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        char* cur = lds + (ks & 1) * BUF;
+        char* nxt = lds + ((ks + 1) & 1) * BUF;
+        if (ks + 1 < ksteps) {
+            // order matters to hipcc's wait insertion: the use of bv (loaded a whole k-step ago) comes BEFORE the LDS-DMA is issued --
+            // with a DMA in flight the compiler waits vmcnt(0) at the next use of an ordinary load's result, which would expose the DMA.
+            // (A hand-counted variant -- asm loads two k-steps ahead, counted vmcnt(14) / vmcnt(8) -- measured 281 against 285 us and
+            //  produced wrong tiles under load: hipcc may copy an asm load's destination at the loop back-edge before the data lands.)
+            store_b(nxt);
+            dma_a(ks + 1, nxt);
+            if (ks + 2 < ksteps) load_b(ks + 2);
+        }
+        bf16x8 fb[3][2];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+                fb[pc][jn] = *reinterpret_cast<const bf16x8*>(cur + A_BYTES + pc * 4096 + (wn * 2 + jn) * 1024 + slot);
+#pragma unroll
+        for (int pa = 2; pa >= 0; --pa) {            // smallest pieces first
+            bf16x8 fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(cur + pa * 8192 + (wm * 4 + i) * 1024 + slot);
+#pragma unroll
+            for (int pb = 2 - pa; pb >= 0; --pb)     // pa + pb <= 2: the six kept products
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[pb][jn], acc[i][jn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); 32-bit offsets from one base;
+    // a half-wave's store covers 128 contiguous bytes
+    const int g = lane >> 5, rr = lane & 31;
+    const int mw = m0 + wm * 128 + 4 * g, nw = n0 + wn * 64 + rr;
+    float* C = p.C + (long)b * p.c_sb + (long)mw * p.c_ld + nw;
+    const int ld = (int)p.c_ld;
+    if (m0 + BM <= p.M && n0 + BN <= p.N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) C[(i * 32 + (e & 3) + 8 * (e >> 2)) * ld + jn * 32] = acc[i][jn][e];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (mw + dm < p.M && nw + jn * 32 < p.N) C[dm * ld + jn * 32] = acc[i][jn][e];
+                }
+    }
+}
+
+// A (M x K per batch, element (m, k) at A[b * a_sb + m * sm + k * sk]) -> the image.  Thread per 16-byte fragment slot; rows >= M and
+// k >= K are zeros.
+__global__ void split_a_kernel(const float* __restrict__ A, long a_sb, long sm, long sk, int nb, int M, int K, int rbp, int ktp, char* __restrict__ img) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)nb * ktp * rbp * 64;
+    if (q >= total) return;
+    const int lane = (int)(q & 63);
+    long r = q >> 6;
+    const int rb = (int)(r % rbp); r /= rbp;
+    const int kt = (int)(r % ktp);
+    const int b = (int)(r / ktp);
+    const int m = rb * 32 + (lane & 31), k0 = kt * 16 + (lane >> 5) * 8;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (m < M && k0 + e < K) ? A[(long)b * a_sb + (long)m * sm + (long)(k0 + e) * sk] : 0.f;
+    uint32_t h[4], mm[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2(x[2 * e], x[2 * e + 1], h[e], mm[e], l[e]);
+    char* d = img + ((((long)b * ktp + kt) * 3) * rbp + rb) * 1024 + lane * 16;
+    *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(d + (long)rbp * 1024) = (u32x4){mm[0], mm[1], mm[2], mm[3]};
+    *reinterpret_cast<u32x4*>(d + 2 * (long)rbp * 1024) = (u32x4){l[0], l[1], l[2], l[3]};
+}
+
+}  // namespace
+}  // namespace lgd
+
+extern "C" {
+
+size_t lgd_gemm3_image_bytes(int nb, int M, int K) {
+    if (nb <= 0 || M <= 0 || K <= 0) return 0;
+    return (size_t)nb * ((K + 15) / 16) * 3 * ((M + 31) / 32) * 1024;
+}
+
+int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_sk, int nb, int M, int K, void* image, void* stream) {
+    if (!A || !image || nb <= 0 || M <= 0 || K <= 0 || ((uintptr_t)image & 15)) return LGD_EINVAL;
+    const int rbp = (M + 31) / 32, ktp = (K + 15) / 16;
+    const long total = (long)nb * ktp * rbp * 64;
+    LGD_LAUNCH("gemm3_split_kernel", lgd::split_a_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, (long)a_sb,
+               (long)a_sm, (long)a_sk, nb, M, K, rbp, ktp, (char*)image);
+    return lgd::check_launch();
+}
+
+int lgd_gemm3(const void* image, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm, int nb, int M, int N,
+              int K, void* stream) {
+    if (!image || !B || !C || nb <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 15) || ((uintptr_t)image & 15)) return LGD_EINVAL;
+    lgd::Params p;
+    p.rbp = (M + 31) / 32; p.ktp = K / 16;
+    p.Aimg = (const char*)image; p.a_sb = (long)p.ktp * 3 * p.rbp * 1024;
+    p.B = B; p.b_sb = (long)b_sb; p.b_ld = (long)b_sk;
+    p.C = C; p.c_sb = (long)c_sb; p.c_ld = (long)c_sm;
+    p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + lgd::BM - 1) / lgd::BM; p.nt = (N + lgd::BN - 1) / lgd::BN;
+    // 32-bit offsets inside the kernel: one k-step of B rows, one batch of the image, one tile of C rows
+    if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 31) || p.a_sb >= (1L << 31) || (long)lgd::BM * c_sm >= (1L << 31)) return LGD_EINVAL;
+    static bool attr = false;   // 72 KB of dynamic LDS: above the default 64 KB limit
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)lgd::gemm3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lgd::LDS_BYTES) != hipSuccess) return LGD_ELAUNCH;
+        attr = true;
+    }
+    const long groups = (long)((nb + 7) / 8) * p.nt * p.mt;
+    LGD_LAUNCH("gemm3_kernel", lgd::gemm3_kernel, dim3((unsigned)(groups * 8)), dim3(lgd::NT), lgd::LDS_BYTES, (hipStream_t)stream, p);
+    return lgd::check_launch();
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -77,11 +77,9 @@ SIGNATURES = {
     "lgd_wino_filter_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp]),
     "lgd_wino_filter_bwd": (c_i, [c_fp, ctypes.c_longlong, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_in_t_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
-    "lgd_blas_init": (c_i, []),
-    "lgd_blas_version": (c_i, [ctypes.c_char_p, c_sz]),
-    "lgd_wino_gemm": (c_i, [c_i, c_fp, c_fp, c_fp, c_i, c_i, ctypes.c_longlong, c_i, c_i, c_fp]),
-    "lgd_conv3x3_fwd": (c_i, [c_fp, c_fp]),
-    "lgd_conv3x3_bwd": (c_i, [c_fp, c_fp]),
+    "lgd_gemm3_image_bytes": (c_sz, [c_i, c_i, c_i]),
+    "lgd_gemm3_split": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_gemm3": (c_i, [c_fp, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_i, c_fp]),
     "lgd_relu_bits_words": (c_sz, [ctypes.c_longlong]),
     "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_stem_bias_relu_maxpool": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
@@ -112,28 +110,6 @@ class GemmProblem(ctypes.Structure):
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("reserved0", ctypes.c_int32),
                 ("sa_m", ctypes.c_int64), ("sa_k", ctypes.c_int64), ("sb_n", ctypes.c_int64), ("sb_k", ctypes.c_int64),
                 ("sc_m", ctypes.c_int64), ("sc_n", ctypes.c_int64), ("alpha", ctypes.c_float), ("reserved1", ctypes.c_int32)]
-
-
-MAX_LEVELS, MAX_FILTERS = 16, 4
-
-
-class Conv3x3FwdArgs(ctypes.Structure):
-    """mirror of `lgd_conv3x3_fwd_args` (include/lgd_hip.h)."""
-    _fields_ = [("L", ctypes.c_int32), ("N", ctypes.c_int32), ("Ci", ctypes.c_int32), ("K", ctypes.c_int32), ("tile", ctypes.c_int32),
-                ("relu", ctypes.c_int32), ("level_hw", ctypes.c_int32 * (2 * MAX_LEVELS)), ("Co", ctypes.c_int32 * MAX_FILTERS),
-                ("x", c_fp * MAX_LEVELS), ("w", c_fp * MAX_FILTERS), ("scale", c_fp * MAX_FILTERS), ("bias", c_fp * MAX_FILTERS),
-                ("y", c_fp * (MAX_FILTERS * MAX_LEVELS)), ("pre_bias", c_fp), ("pre_bits", c_fp), ("relu_bits", c_fp),
-                ("U", c_fp), ("Ut", c_fp), ("V", c_fp), ("M", c_fp), ("sol_fwd", ctypes.c_int32), ("reserved", ctypes.c_int32)]
-
-
-class Conv3x3BwdArgs(ctypes.Structure):
-    """mirror of `lgd_conv3x3_bwd_args` (include/lgd_hip.h)."""
-    _fields_ = [("L", ctypes.c_int32), ("N", ctypes.c_int32), ("Ci", ctypes.c_int32), ("K", ctypes.c_int32), ("tile", ctypes.c_int32),
-                ("dM_ready", ctypes.c_int32), ("level_hw", ctypes.c_int32 * (2 * MAX_LEVELS)), ("Co", ctypes.c_int32 * MAX_FILTERS),
-                ("dy", c_fp * (MAX_FILTERS * MAX_LEVELS)), ("relu_bits", c_fp), ("dM", c_fp), ("Ut", c_fp), ("V", c_fp), ("dV", c_fp),
-                ("dx", c_fp * MAX_LEVELS), ("pre_bits", c_fp), ("dM_prev", c_fp), ("prev_bits", c_fp), ("dU", c_fp),
-                ("dw", c_fp * MAX_FILTERS), ("scale", c_fp * MAX_FILTERS), ("db", c_fp * MAX_FILTERS),
-                ("sol_dx", ctypes.c_int32), ("sol_dw", ctypes.c_int32)]
 
 
 class LgdHipError(RuntimeError):

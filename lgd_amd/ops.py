@@ -1107,7 +1107,7 @@ class _Conv3x3K(torch.autograd.Function):
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
         fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
         _count_bytes("wino_in_kernel", (px + fb) * Ci)
-        M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
+        M = _wino_gemm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
         # ReLU mask for the backward: one bit per pixel, a table entry per tile, written by the output transform, so the backward
         # reads 1 bit instead of 4 bytes per pixel and the forward output is not kept alive
         bits = torch.empty((Ct, T), dtype=mdt, device=dev) if relu else None
@@ -1154,7 +1154,7 @@ class _Conv3x3K(torch.autograd.Function):
             c0 += Cos[k]
         if need_x:
             _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
-            dV = _timed_bmm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
+            dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
             dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
             hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs),
                                         hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in_t")
@@ -1217,7 +1217,7 @@ class _Conv3x3GN(torch.autograd.Function):
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)
         fb = 4 * nf * T
         _count_bytes("wino_in_kernel", (px + fb) * Ci)
-        M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
+        M = _wino_gemm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
         ys, affs, stats, c0 = [], [], [], 0
         for k in range(K):
             yk = [torch.empty((N, Cos[k]) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
@@ -1287,7 +1287,7 @@ class _Conv3x3GN(torch.autograd.Function):
             c0 += Cos[k]
         if need_x:
             _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
-            dV = _timed_bmm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
+            dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
             dxs = [torch.empty((N, Ci) + sh, dtype=torch.float32, device=dev) for sh in shapes]
             hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs),
                                         hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in_t")
@@ -1337,7 +1337,7 @@ class _Conv3x3Chain(torch.autograd.Function):
             V = _freq_buf(nf, Ci, T, dev)
             hip.check(lib.lgd_wino_in(hip.ptr_array(cur), hw, L, N, Ci, tile, hip.ptr(V), None, None, None, hip.stream_ptr()), "lgd_wino_in")
             _count_bytes("wino_in_kernel", (px + fb) * Ci)
-            M = _timed_bmm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
+            M = _wino_gemm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
             bits = torch.empty((Co, T), dtype=mdt, device=dev) if relus[k] else None
             cur = [torch.empty((N, Co) + s, dtype=torch.float32, device=dev) for s in shapes]
             _count_bytes("wino_out_kernel", (px + fb + (mb * T if bits is not None else 0)) * Co)
@@ -1378,7 +1378,7 @@ class _Conv3x3Chain(torch.autograd.Function):
                 dbs[k] = dM[tile + 3].sum(1)   # A's row of the interpolation point 1 is all ones: the tile's gradient sum
             if k == 0 and not need_x:
                 break
-            dV = _timed_bmm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
+            dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
             del dM
             if k > 0:   # the link to conv k-1: dM_{k-1} = A (in_t(dV) . relu mask) A^T without the map in between
                 pb = saved[3 * (k - 1) + 2]
@@ -2010,6 +2010,66 @@ def _timed_bmm(name, a, b, out=None):
     e0.record()
     r = torch.bmm(a, b, out=out) if out is not None else torch.bmm(a, b)
     e1.record()
+    _GEMM_EVENTS.append((name, e0, e1))
+    _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + 2 * a.shape[0] * a.shape[1] * a.shape[2] * b.shape[2]
+    return r
+
+
+# ---- K9: the Winograd channel products on the bf16 MFMA pipe (csrc/gemm3.hip: three-way split fp32 operands, fp32 accumulate)
+_GEMM3_ON = os.environ.get("LGD_GEMM3", "1") != "0"
+
+
+def gemm3_backend(on=None):
+    """whether the forward / input-gradient channel products of the Winograd convolutions run on csrc/gemm3.hip (default) or on the
+    library's fp32 GEMM (A/B runs, tests).  Returns the previous setting."""
+    global _GEMM3_ON
+    prev = _GEMM3_ON
+    if on is not None:
+        _GEMM3_ON = bool(on)
+    return prev
+
+
+def _gemm3_ok(a, b, out):
+    if not (_GEMM3_ON and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 3 and b.dim() == 3):
+        return False
+    nb, M, K = a.shape
+    N = b.shape[2]
+    # the kernel's tile spans 256 rows of A: shapes that would leave more than ~30 % of the MFMA rows empty (C' = 36, 64, 128, 320 ...) and
+    # tiny problems stay on the library; K % 16: the k-step
+    if K % 16 or K < 32 or N < 256 or M < 192 or M < 0.7 * 256 * ((M + 255) // 256):
+        return False
+    return b.stride(2) == 1 and (out is None or (out.stride(2) == 1 and out.dtype == torch.float32))
+
+
+def gemm3_bmm(a, b, out=None):
+    """out[i] = a[i] @ b[i] for fp32 (nb, M, K) x (nb, K, N): an fp32-class product (error vs fp64 as the library's fp32 GEMM) computed on
+    v_mfma_f32_32x32x16_bf16 from three-way split operands.  a (the filter operand, any strides) is split ahead of the product into an
+    MFMA-ordered image; b and out have their last axis contiguous."""
+    lib = hip.load()
+    nb, M, K = a.shape
+    N = b.shape[2]
+    if out is None:
+        out = torch.empty((nb, M, N), dtype=torch.float32, device=a.device)
+    img = torch.empty(lib.lgd_gemm3_image_bytes(nb, M, K), dtype=torch.uint8, device=a.device)
+    st = hip.stream_ptr()
+    hip.check(lib.lgd_gemm3_split(hip.ptr(a), a.stride(0), a.stride(1), a.stride(2), nb, M, K, hip.ptr(img), st), "lgd_gemm3_split")
+    hip.check(lib.lgd_gemm3(hip.ptr(img), hip.ptr(b), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1), nb, M, N, K, st),
+              "lgd_gemm3")
+    return out
+
+
+def _wino_gemm(name, a, b, out=None):
+    """one of the per-frequency channel products (forward M = U V, input gradient dV = U^T dM): csrc/gemm3.hip where its tile fits the
+    shape, the library's fp32 GEMM otherwise.  Timed under `name` + '3' (its launches also appear as gemm3_kernel / gemm3_split_kernel)."""
+    if not _gemm3_ok(a, b, out):
+        return _timed_bmm(name, a, b, out)
+    if not _TIMER_ON:
+        return gemm3_bmm(a, b, out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = gemm3_bmm(a, b, out)
+    e1.record()
+    name = name.replace("wino_gemm_", "wino_gemm3_")
     _GEMM_EVENTS.append((name, e0, e1))
     _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + 2 * a.shape[0] * a.shape[1] * a.shape[2] * b.shape[2]
     return r

@@ -887,80 +887,68 @@ def test_conv3x3_chain(N, Ci, Cos, hws, relus, bias, need_x, wino_tile):
         ops.conv3x3_backend(*prev)
 
 
-# ------------------------------------------------------------------------------------------- student conv epilogues
-def test_native_conv3x3_calls_match_the_composed_pipeline(wino_tile):
-    """lgd_conv3x3_fwd / lgd_conv3x3_bwd (csrc/conv.hip: the whole convolution behind ONE C-ABI call per direction, channel GEMMs
-    issued by the library through rocBLAS -- what a host without a tensor library binds) against the product's nodes,
-    which compose the same kernels around torch.bmm: K = 2 filters on shared maps with bias + ReLU, a folded pre-activation with a
-    frozen filter scale, and a three-convolution chain with fused backward links.  (1) lgd_wino_gemm == torch.bmm to fp32 rounding on
-    the three products; (2) with the product's GEMMs routed through lgd_wino_gemm as well (two different GEMM kernels round
-    differently, and a ReLU unit within rounding of zero would then take different masks), outputs are BIT-identical and every
-    gradient agrees to rounding."""
-    import ctypes
-    import sys
-    from lgd_amd import hip, ops
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "tools"))
-    import native_conv as nc
-    lib = hip.load()
-    real_bmm = ops._timed_bmm
-    gemm_err = []
+# ------------------------------------------------------------------------------------------- K9: channel products on the bf16 MFMA pipe
+@pytest.mark.parametrize("nb,M,K,N,a_t", [(3, 256, 256, 1000, False),    # N not a multiple of the 128-column tile
+                                          (9, 720, 256, 384, False),     # cls_score: three row tiles, the last one 208 rows; nb not a multiple of 8 XCDs
+                                          (2, 256, 720, 520, True),      # its input gradient: A = U^T as a transposed VIEW, 45 k-steps (odd)
+                                          (5, 208, 64, 256, False),      # a single partial row tile, 4 k-steps
+                                          (64, 512, 512, 288, True)])    # res5-like: two full row tiles, two column tiles + 32 columns
+def test_gemm3_fp32_class_product(nb, M, K, N, a_t):
+    """lgd_gemm3 (csrc/gemm3.hip: bf16x3 split operands, 6 of 9 cross products, fp32 accumulate) against an fp64 product of the SAME fp32
+    operands and against the library's fp32 GEMM: an fp32-class result (bar 2e-6 of the output scale; measured 6e-7, rocBLAS 7.6e-7).
+    Operands in the layouts the Winograd pipeline hands over: B / C as (nf, C, T) views of [C][nf][T] buffers, A plain or transposed view.
+    Scaling the operands by powers of two scales the result EXACTLY (the split is exponent-independent: no range assumptions)
+    [ref: the channel products of nn.Conv2d(256, C', 3, padding=1), dynamic_teacher.py:57-73, sequential_convs.py:10-12]."""
+    from lgd_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(nb * 1000 + M)
+    a = torch.randn((nb, K, M) if a_t else (nb, M, K), device=DEV, generator=g) * 0.05
+    if a_t:
+        a = a.transpose(1, 2)
+    b = ops._freq_buf(nb, K, N, DEV).normal_(generator=g)
+    out = ops._freq_buf(nb, M, N, DEV).fill_(float("nan"))
+    assert ops._gemm3_ok(a, b, out)
+    c = ops.gemm3_bmm(a, b, out)
+    assert c.data_ptr() == out.data_ptr()
+    ref = torch.bmm(a.double(), b.double())
+    scale = float(ref.abs().max())
+    e_new = float((c.double() - ref).abs().max()) / scale
+    e_lib = float((torch.bmm(a, b).double() - ref).abs().max()) / scale
+    print("gemm3 %dx[%dx%d].[%dx%d]: max error vs fp64 %.2e of the output scale (library fp32 GEMM: %.2e)" % (nb, M, K, K, N, e_new, e_lib))
+    assert e_new <= 2e-6 and e_new <= 3 * e_lib + 2e-7
+    # exponent independence: exact under power-of-two scaling (2^40 and 2^-30: far outside the fp16 range, inside bf16's)
+    c2 = ops.gemm3_bmm(a * 2.0 ** 40, b * 2.0 ** -30)
+    assert torch.equal(c2, c * 2.0 ** 10)
+    # zeros in, zeros out; a NaN poisons only its own row / column
+    a0 = a.clone()
+    a0[:, 3, :] = 0.0
+    c0 = ops.gemm3_bmm(a0, b)
+    assert float(c0[:, 3, :].abs().max()) == 0.0
+    b1 = b.clone()
+    b1[0, 5, 7] = float("nan")
+    c1 = ops.gemm3_bmm(a, b1)
+    assert bool(torch.isnan(c1[0, :, 7]).all()) and not bool(torch.isnan(c1[0, :, 8]).any()) and not bool(torch.isnan(c1[1:]).any())
 
-    def native_bmm(name, a, b, out=None):
-        kind = {"wino_gemm_fwd": 0, "wino_gemm_dx": 1, "wino_gemm_dw": 2}[name]
-        nf = a.shape[0]
-        if kind == 0:
-            Ct, Ci, T = a.shape[1], a.shape[2], b.shape[2]
-        elif kind == 1:
-            Ci, Ct, T = a.shape[1], a.shape[2], b.shape[2]
-        else:
-            Ct, T, Ci = a.shape[1], a.shape[2], b.shape[2]
-            out = torch.empty((nf, Ct, Ci), dtype=torch.float32, device=a.device)
-        an = a.contiguous() if kind == 1 else a   # the product hands dV = U^T dM a transposed VIEW of U; the library's GEMM reads a stored U^T
-        hip.check(lib.lgd_wino_gemm(kind, hip.ptr(an), hip.ptr(b), hip.ptr(out), Ct, Ci, T, wino_tile, 0, hip.stream_ptr()), "lgd_wino_gemm")
-        ref = torch.bmm(a, b)
-        gemm_err.append(float((out - ref).abs().max() / (ref.abs().max() + 1e-30)))
-        return out
-    hws = [(26, 36), (13, 18), (7, 9)]
-    N, Ci = 2, 64
-    xs = [torch.from_numpy(synth.det_uniform((N, Ci, h, w), 2101 + i, -2.0, 2.0)).to(DEV) for i, (h, w) in enumerate(hws)]
-    ws = [torch.from_numpy(synth.det_uniform((co, Ci, 3, 3), 2110 + k, -0.1, 0.1)).to(DEV) for k, co in enumerate((64, 40, 64))]
-    bs = [torch.from_numpy(synth.det_uniform((co,), 2120 + k, -0.5, 0.5)).to(DEV) for k, co in enumerate((64, 40, 64))]
-    sc = torch.from_numpy(synth.det_uniform((64,), 2130, 0.5, 1.5)).to(DEV)
-    pre = torch.from_numpy(synth.det_uniform((Ci,), 2131, -0.7, 0.7)).to(DEV)
 
-    def run(fn):
-        x = [t.clone().requires_grad_(True) for t in xs]
-        w = [t.clone().requires_grad_(True) for t in ws]
-        b = [t.clone().requires_grad_(True) for t in bs]
-        ys = fn(x, w, b)
-        gys = [torch.from_numpy(synth.det_uniform(tuple(y.shape), 2150 + i, -1.0, 1.0)).to(DEV) for i, y in enumerate(ys)]
-        torch.autograd.backward(ys, gys)
-        return [y.detach() for y in ys], [t.grad for t in x + w + b if t.grad is not None]
-
-    cases = {
-        "shared input, K = 2, bias + ReLU": lambda x, w, b: [y for ys in ops.conv3x3_shared_input(x, [(w[0], b[0]), (w[1], b[1])], relu=True) for y in ys],
-        "folded pre-activation + filter scale": lambda x, w, b: ops.conv3x3_levels(x, w[0], b[0], relu=True, scale=sc, pre=pre),
-        "chain of three with fused links": lambda x, w, b: ops.conv3x3_chain(x, [(w[0], b[0]), (w[2], b[2]), (w[1], b[1])], (True, True, False)),
-    }
-    prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=wino_tile)
-    ops._timed_bmm = native_bmm
+def test_gemm3_shape_gate():
+    """shapes whose tile would waste the MFMA rows (C' = 36, 64, 128) or break the k-step stay on the library GEMM; _wino_gemm then
+    returns the library's result bit for bit."""
+    from lgd_amd import ops
+    mk = lambda nb, M, K, N: (torch.randn(nb, M, K, device=DEV), ops._freq_buf(nb, K, N, DEV).normal_(), ops._freq_buf(nb, M, N, DEV))  # noqa: E731
+    for M, K, N, ok in ((256, 256, 5232, True), (720, 256, 5232, True), (512, 256, 1024, True), (36, 256, 5232, False), (128, 128, 5232, False),
+                        (320, 256, 5232, False), (256, 36, 5232, False), (256, 256, 128, False)):
+        a, b, o = mk(2, M, K, N)
+        assert ops._gemm3_ok(a, b, o) == ok, (M, K, N)
+        if not ok:
+            assert torch.equal(ops._wino_gemm("wino_gemm_fwd", a, b, out=o), torch.bmm(a, b))
+    prev = ops.gemm3_backend(False)
     try:
-        for name, fn in cases.items():
-            ya, ga = run(fn)
-            with nc.installed():
-                yb, gb = run(fn)
-            assert len(ya) == len(yb) and len(ga) == len(gb), name
-            for a, b_ in zip(ya, yb):
-                assert torch.equal(a, b_), name
-            for a, b_ in zip(ga, gb):
-                assert float((a - b_).abs().max()) <= 2e-6 * (float(a.abs().max()) + 1e-30), name
+        a, b, o = mk(2, 256, 256, 512)
+        assert not ops._gemm3_ok(a, b, o)
     finally:
-        ops._timed_bmm = real_bmm
-        ops.conv3x3_backend(*prev)
-    assert len(gemm_err) >= 15 and max(gemm_err) <= 2e-6, gemm_err   # the in-library GEMMs against torch.bmm on the same operands
+        ops.gemm3_backend(prev)
 
 
+# ------------------------------------------------------------------------------------------- student conv epilogues
 @pytest.mark.parametrize("N,C,H,W,res,relu,bias_grad", [(2, 8, 6, 8, True, True, False), (1, 5, 3, 5, False, True, True),
                                                         (3, 16, 7, 4, True, False, True), (2, 4, 5, 5, False, False, False),
                                                         (2, 64, 50, 84, True, True, False), (3, 7, 33, 37, True, True, True),
