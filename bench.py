@@ -374,7 +374,7 @@ def main():
             lgd_fwd = {"bound": "hbm", "kernels": list(names), "alg_bytes": 4 * P, "us": us, "achieved": 4 * P / us / 1e3, "peak": HBM_PEAK_GBPS,
                        "unit": "GB/s", "frac": 4 * P / us / 1e3 / HBM_PEAK_GBPS}
         roofline_pw = None
-        pw = {n: v for n, v in kernels.items() if n.startswith("pw_gemm")}
+        pw = {n: v for n, v in kernels.items() if n.startswith("pw_gemm_")}
         if pw:
             tot_ms = sum(v["total_ms"] for v in pw.values())
             tot_fl = sum(kflops[n] for n in pw)
@@ -399,12 +399,12 @@ def main():
                                     "max_us": round(v["max_us"], 1), "launches_per_step": v["launches"] / args.steps} for n, v in sel.items()}}
         # the Winograd channel products: csrc/gemm3.hip (forward, input gradient; bf16 MFMA, 6 MFMA flops per fp32 flop, split + product launch
         # timed together) and the library's fp32 GEMMs (weight gradient; shapes outside gemm3's tile)
-        g3 = {n: v for n, v in kernels.items() if n.startswith("wino_gemm3_")}
+        g3 = {n: v for n, v in kernels.items() if n.startswith("wino_gemm3_") or n.startswith("pw_gemm3_")}
         gl = {n: v for n, v in kernels.items() if n.startswith("wino_gemm_")}
         roofline_mfma_lib = None
         if g3:
-            roofline_mfma = mfma_object(g3, "Winograd channel products on csrc/gemm3.hip (fp32 operands split into three bf16 pieces, 6 of 9 cross products on "
-                                        "v_mfma_f32_32x32x16_bf16, fp32 accumulate; forward + input gradient; filter split launch included)",
+            roofline_mfma = mfma_object(g3, "csrc/gemm3.hip: Winograd channel products and the student's 1x1 convolutions, forward + input gradient (fp32 operands "
+                                        "split into three bf16 pieces, 6 of 9 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; filter split launch included)",
                                         MFMA_BF16_PEAK_TFLOPS, 6.0)
         if gl:
             roofline_mfma_lib = mfma_object(gl, "Winograd channel GEMMs left on the library (fp32 MFMA via torch.bmm: weight gradient, shapes outside gemm3's tile)",

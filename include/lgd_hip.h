@@ -357,11 +357,14 @@ int lgd_wino_in_t_out_t(const float* dV, const void* relu_bits, const int32_t* l
  *   LDS by LDS-DMA; element (m, k) of batch b is read at A[b * a_sb + m * a_sm + k * a_sk] (any strides: U and U^T are both views).
  *   B (K x N) and C (M x N) have their last axis contiguous: B[b * b_sb + k * b_sk + n], C[b * c_sb + m * c_sm + n]; B is split inside
  *   the product kernel while it is staged (each element once: a workgroup's tile spans 256 rows of A).
+ *   image_shared: ONE image (split with nb = 1) serves every batch -- the student's 1x1 convolutions, W (C' x C) against a batch of
+ *   (C x HW) maps [d2-memory: BottleneckBlock conv1 / conv3, FPN laterals; SURVEY.md appendix A].  accumulate: C += A B (the input
+ *   gradient of a block's first 1x1 convolution lands on the shortcut's gradient).  Tiles of 256 x 128 (C' = 128: 128 x 128).
  * Requirements (LGD_EINVAL otherwise; the host falls back to the library GEMM): K % 16 == 0, 16-byte aligned image. */
 size_t lgd_gemm3_image_bytes(int nb, int M, int K);
 int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_sk, int nb, int M, int K, void* image, void* stream);
-int lgd_gemm3(const void* image, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm, int nb, int M,
-              int N, int K, void* stream);
+int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm,
+              int accumulate, int nb, int M, int N, int K, void* stream);
 
 /* ------------------------------------------------------------------ FCOS ground-truth assignment
  * [ref: models/customized_detectors/thirdparty_heads/fcos.py:177-284  FCOS.get_ground_truth]

@@ -18,7 +18,8 @@
 //  * all addresses of the k-loop are a uniform base + per-thread 32-bit offsets computed once.
 // Tile 256 x 128 x 16, 256 threads (2 x 2 waves, 128 x 64 per wave = 4 x 2 MFMA blocks of 32 x 32, 128 accumulator registers), two
 // LDS buffers of 36 KB (A pieces 24 KB + B pieces 12 KB): one barrier per k-step, two workgroups per CU so that one's staging and
-// epilogue hide under the other's MFMAs.
+// epilogue hide under the other's MFMAs.  A 128-row variant of the same kernel serves C' = 128 layers.  The image may be shared by all
+// batches (the student's 1x1 convolutions: one filter, a batch of images) and the result may be accumulated onto C.
 #include <type_traits>
 
 #include "common.h"
@@ -32,8 +33,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 256, BN = 128, BK = 16, NT = 256;
-constexpr int A_BYTES = 3 * 8 * 1024, B_BYTES = 3 * 4 * 1024, BUF = A_BYTES + B_BYTES, LDS_BYTES = 2 * BUF;   // 72 KB
+constexpr int BN = 128, BK = 16, NT = 256;
+// tile rows BM = 256 (4 x 2 MFMA blocks per wave, 2 workgroups per CU) or 128 (2 x 2 blocks, 64 accumulator registers, 3 workgroups per
+// CU: C' = 128 layers, whose 256-row tile would idle half of every MFMA)
+template <int BM> struct Tile {
+    static constexpr int RB = BM / 32, MI = BM / 64;                      // 32-row blocks per tile / per wave
+    static constexpr int A_BYTES = 3 * RB * 1024, B_BYTES = 3 * 4 * 1024, BUF = A_BYTES + B_BYTES, LDS_BYTES = 2 * BUF;   // 72 / 48 KB
+    static constexpr int CHUNKS = 3 * RB / 4;                             // 1 KB LDS-DMA pieces per wave and k-step
+};
 
 #define LGD_GLDS16(src, dst) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
@@ -59,18 +66,30 @@ struct Params {
     int nb, M, N, K, mt, nt;
 };
 
+template <int BM, bool ACC>
 __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
+    typedef Tile<BM> TL;
+    constexpr int A_BYTES = TL::A_BYTES, BUF = TL::BUF, MI = TL::MI, RB = TL::RB, CH = TL::CHUNKS;
     extern __shared__ __attribute__((aligned(1024))) char lds[];   // ONE LDS object (a second one makes hipcc drain vmcnt(0) before every ds_read)
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
     // workgroup -> (batch, n-tile, m-tile).  Consecutive ids go round-robin to the 8 XCDs: XCD x takes the batches b = x (mod 8) and walks
     // their tiles in order, so that its L2 holds the images of the one or two batches it is working on (tiles of one batch spread over
     // all XCDs: every L2 holds all ~13 images in flight; measured 2 % slower)
     const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
-    const int per_b = p.nt * p.mt;
-    const int b = (j / per_b) * 8 + xcd, r = j % per_b;
-    if (b >= p.nb) return;
-    const int tn = r / p.mt, sub = r % p.mt;
-    const int m0 = sub * BM, n0 = tn * BN, rb0 = sub * 8;
+    int b, tn, sub;
+    if (p.a_sb != 0) {
+        const int per_b = p.nt * p.mt;
+        b = (j / per_b) * 8 + xcd;
+        const int r = j % per_b;
+        if (b >= p.nb) return;
+        tn = r / p.mt; sub = r % p.mt;
+    } else {   // ONE image for all batches: nothing ties a batch to an XCD; the m-tiles that read the same B tile stay neighbours on one L2
+        sub = j % p.mt;
+        const int rest = (j / p.mt) * 8 + xcd;
+        if (rest >= p.nb * p.nt) return;
+        b = rest / p.nt; tn = rest % p.nt;
+    }
+    const int m0 = sub * BM, n0 = tn * BN, rb0 = sub * RB;
     const int ksteps = p.K / BK;                       // K % 16 == 0 (host-checked)
     const char* Ai = p.Aimg + (long)b * p.a_sb;
     // B staging: thread <-> (k-group kg = t >> 7, column n = t & 127): 8 dwords down the k axis, a wave's load covers 256 contiguous
@@ -99,12 +118,12 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
         *reinterpret_cast<u32x4*>(d + 4096) = (u32x4){m[0], m[1], m[2], m[3]};
         *reinterpret_cast<u32x4*>(d + 8192) = (u32x4){l[0], l[1], l[2], l[3]};
     };
-    // A: 24 chunks of 1 KB per k-step ([piece][row block]); wave w moves chunks 6w .. 6w+5 (row blocks past the image repeat its last one:
-    // their products are rows >= M)
-    uint32_t aoff[6];
+    // A: 3 * RB chunks of 1 KB per k-step ([piece][row block]); wave w moves chunks CH w .. CH w + CH - 1 (row blocks past the image repeat
+    // its last one: their products are rows >= M)
+    uint32_t aoff[CH];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const int ch = w * 6 + c, pc = ch >> 3, rbl = ch & 7;
+    for (int c = 0; c < CH; ++c) {
+        const int ch = w * CH + c, pc = ch / RB, rbl = ch % RB;
         int rb = rb0 + rbl;
         rb = rb < p.rbp ? rb : p.rbp - 1;
         aoff[c] = (uint32_t)((pc * p.rbp + rb) * 1024 + lane * 16);
@@ -113,15 +132,41 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     auto dma_a = [&](int ks, char* buf) {
         const char* Ak = Ai + ks * astep;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) LGD_GLDS16(Ak + aoff[c], buf + (w * 6 + c) * 1024);
+        for (int c = 0; c < CH; ++c) LGD_GLDS16(Ak + aoff[c], buf + (w * CH + c) * 1024);
     };
-    f32x16 acc[4][2];
+    // the accumulators start from zero, or (ACC: C += A B) from C itself: the MFMA chain adds the product on top and the epilogue is the
+    // plain store (an epilogue that re-reads C needs the 128 accumulators in VGPRs at once: one resident workgroup instead of two)
+    const int g = lane >> 5, rr = lane & 31;
+    const int mw = m0 + wm * (BM / 2) + 4 * g, nw = n0 + wn * 64 + rr;
+    float* C = p.C + (long)b * p.c_sb + (long)mw * p.c_ld + nw;
+    const int ld = (int)p.c_ld;
+    f32x16 acc[MI][2];
+    if constexpr (ACC) {
+        const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+            for (int jn = 0; jn < 2; ++jn) {
+                if (full) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) acc[i][jn][e] = C[(i * 32 + (e & 3) + 8 * (e >> 2)) * ld + jn * 32];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
+                        acc[i][jn][e] = (mw + dm < p.M && nw + jn * 32 < p.N) ? C[dm * ld + jn * 32] : 0.f;
+                    }
+                }
+                asm volatile("" : "+a"(acc[i][jn]) :: "memory");   // one 32 x 32 block of loads in flight at a time (16 VGPRs, not 128)
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+    }
 
     // prologue: k-step 0 into buffer 0, B of k-step 1 into registers
     dma_a(0, lds);
@@ -150,14 +195,14 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
                 fb[pc][jn] = *reinterpret_cast<const bf16x8*>(cur + A_BYTES + pc * 4096 + (wn * 2 + jn) * 1024 + slot);
 #pragma unroll
         for (int pa = 2; pa >= 0; --pa) {            // smallest pieces first
-            bf16x8 fa[4];
+            bf16x8 fa[MI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(cur + pa * 8192 + (wm * 4 + i) * 1024 + slot);
+            for (int i = 0; i < MI; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(cur + pa * (RB * 1024) + (wm * MI + i) * 1024 + slot);
 #pragma unroll
             for (int pb = 2 - pa; pb >= 0; --pb)     // pa + pb <= 2: the six kept products
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[pb][jn], acc[i][jn], 0, 0, 0);
@@ -166,20 +211,16 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     }
     // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); 32-bit offsets from one base;
     // a half-wave's store covers 128 contiguous bytes
-    const int g = lane >> 5, rr = lane & 31;
-    const int mw = m0 + wm * 128 + 4 * g, nw = n0 + wn * 64 + rr;
-    float* C = p.C + (long)b * p.c_sb + (long)mw * p.c_ld + nw;
-    const int ld = (int)p.c_ld;
     if (m0 + BM <= p.M && n0 + BN <= p.N) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) C[(i * 32 + (e & 3) + 8 * (e >> 2)) * ld + jn * 32] = acc[i][jn][e];
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
@@ -233,24 +274,33 @@ int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_
     return lgd::check_launch();
 }
 
-int lgd_gemm3(const void* image, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm, int nb, int M, int N,
-              int K, void* stream) {
+int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm,
+              int accumulate, int nb, int M, int N, int K, void* stream) {
     if (!image || !B || !C || nb <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 15) || ((uintptr_t)image & 15)) return LGD_EINVAL;
+    // 256-row tiles unless that leaves more than a quarter of the rows of the last tile empty and 128-row tiles do not
+    // (accumulate: the 128-row tile as well -- initialising 128 accumulators per lane from C costs the 256-row kernel its second resident
+    //  workgroup: 138 VGPRs + 128 AGPRs)
+    const bool small = accumulate || ((M + 255) / 256 * 256 - M >= 64 && (M + 127) / 128 * 128 - M < 64);
+    const int bm = small ? 128 : 256;
     lgd::Params p;
     p.rbp = (M + 31) / 32; p.ktp = K / 16;
-    p.Aimg = (const char*)image; p.a_sb = (long)p.ktp * 3 * p.rbp * 1024;
+    p.Aimg = (const char*)image; p.a_sb = image_shared ? 0 : (long)p.ktp * 3 * p.rbp * 1024;
     p.B = B; p.b_sb = (long)b_sb; p.b_ld = (long)b_sk;
     p.C = C; p.c_sb = (long)c_sb; p.c_ld = (long)c_sm;
-    p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + lgd::BM - 1) / lgd::BM; p.nt = (N + lgd::BN - 1) / lgd::BN;
+    p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + bm - 1) / bm; p.nt = (N + lgd::BN - 1) / lgd::BN;
     // 32-bit offsets inside the kernel: one k-step of B rows, one batch of the image, one tile of C rows
-    if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 31) || p.a_sb >= (1L << 31) || (long)lgd::BM * c_sm >= (1L << 31)) return LGD_EINVAL;
+    if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 31) || (long)p.ktp * 3 * p.rbp * 1024 >= (1L << 31) || 256L * c_sm >= (1L << 31)) return LGD_EINVAL;
     static bool attr = false;   // 72 KB of dynamic LDS: above the default 64 KB limit
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)lgd::gemm3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lgd::LDS_BYTES) != hipSuccess) return LGD_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)lgd::gemm3_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lgd::Tile<256>::LDS_BYTES) != hipSuccess)
+            return LGD_ELAUNCH;
         attr = true;
     }
-    const long groups = (long)((nb + 7) / 8) * p.nt * p.mt;
-    LGD_LAUNCH("gemm3_kernel", lgd::gemm3_kernel, dim3((unsigned)(groups * 8)), dim3(lgd::NT), lgd::LDS_BYTES, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)((image_shared ? ((long)nb * p.nt + 7) / 8 : (long)((nb + 7) / 8) * p.nt) * p.mt * 8)), block(lgd::NT);
+    hipStream_t st = (hipStream_t)stream;
+    if (small && accumulate) { LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<128, true>), grid, block, lgd::Tile<128>::LDS_BYTES, st, p); }
+    else if (small) { LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<128, false>), grid, block, lgd::Tile<128>::LDS_BYTES, st, p); }
+    else { LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<256, false>), grid, block, lgd::Tile<256>::LDS_BYTES, st, p); }
     return lgd::check_launch();
 }
 

@@ -79,7 +79,7 @@ SIGNATURES = {
     "lgd_wino_in_t_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_gemm3_image_bytes": (c_sz, [c_i, c_i, c_i]),
     "lgd_gemm3_split": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_fp, c_fp]),
-    "lgd_gemm3": (c_i, [c_fp, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_i, c_fp]),
+    "lgd_gemm3": (c_i, [c_fp, c_i, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "lgd_relu_bits_words": (c_sz, [ctypes.c_longlong]),
     "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_stem_bias_relu_maxpool": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),

@@ -1895,8 +1895,11 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
                 acc = hip.dense_f32(dskip)
                 own = getattr(dskip, "_lgd_exclusive", False) and acc is dskip
                 a3 = acc.view(N, Ci, -1)
-                dx = _timed_gemm("pw_gemm_dx", _pw_flops(x, Co), torch.baddbmm, a3, wf.view(Co, Ci).t().unsqueeze(0).expand(N, Ci, Co),
-                                 dz.view(N, Co, -1), **({"out": a3} if own else {})).view_as(x)
+                wt, dz3 = wf.view(Co, Ci).t().unsqueeze(0).expand(N, Ci, Co), dz.view(N, Co, -1)
+                if own and _gemm3_ok(wt, dz3, a3, accumulate=True):   # csrc/gemm3.hip with its accumulators initialised from the gradient
+                    dx = _timed_gemm3("pw_gemm3_dx", wt, dz3, a3, accumulate=True).view_as(x)
+                else:
+                    dx = _timed_gemm("pw_gemm_dx", _pw_flops(x, Co), torch.baddbmm, a3, wt, dz3, **({"out": a3} if own else {})).view_as(x)
         if ctx.needs_input_grad[1] and dz is not None:
             dw = _pointwise_dw(dz, x, scale)
         return dx, dw, None, None, None, None
@@ -2029,33 +2032,67 @@ def gemm3_backend(on=None):
     return prev
 
 
-def _gemm3_ok(a, b, out):
+_CU_COUNT = {}
+
+
+def _cu_count(device):
+    i = device.index if device.index is not None else torch.cuda.current_device()
+    if i not in _CU_COUNT:
+        _CU_COUNT[i] = torch.cuda.get_device_properties(i).multi_processor_count
+    return _CU_COUNT[i]
+
+
+def _gemm3_ok(a, b, out, accumulate=False):
     if not (_GEMM3_ON and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 3 and b.dim() == 3):
         return False
     nb, M, K = a.shape
     N = b.shape[2]
-    # the kernel's tile spans 256 rows of A: shapes that would leave more than ~30 % of the MFMA rows empty (C' = 36, 64, 128, 320 ...) and
-    # tiny problems stay on the library; K % 16: the k-step
-    if K % 16 or K < 32 or N < 256 or M < 192 or M < 0.7 * 256 * ((M + 255) // 256):
+    # the kernel's tile spans 256 (or 128) rows of A: shapes that would leave more than ~30 % of the MFMA rows empty (C' = 36, 64, 320 ...) and
+    # tiny problems stay on the library; K % 16: the k-step.  (Tile choice as in csrc/gemm3.hip::lgd_gemm3.)
+    small = accumulate or ((M + 255) // 256 * 256 - M >= 64 and (M + 127) // 128 * 128 - M < 64)
+    bm = 128 if small else 256
+    if K % 16 or K < 32 or N < 256 or M < 0.7 * bm * ((M + bm - 1) // bm):
+        return False
+    # at least one full round of workgroups (2 per CU with 256-row tiles, 3 with 128-row ones): below that a tile's prologue, its short
+    # k-loop without a co-resident partner and the filter split are the whole launch and the library's smaller tiles win
+    # (tools/gemm3_probe.py, profiles/r04_gemm3_probe.log: res5's 288 tiles x0.61, the 2048 -> 256 lateral x0.55; from one round up x1.05-1.6)
+    if nb * ((N + 127) // 128) * ((M + bm - 1) // bm) < _cu_count(a.device) * (3 if small else 2):
         return False
     return b.stride(2) == 1 and (out is None or (out.stride(2) == 1 and out.dtype == torch.float32))
 
 
-def gemm3_bmm(a, b, out=None):
-    """out[i] = a[i] @ b[i] for fp32 (nb, M, K) x (nb, K, N): an fp32-class product (error vs fp64 as the library's fp32 GEMM) computed on
-    v_mfma_f32_32x32x16_bf16 from three-way split operands.  a (the filter operand, any strides) is split ahead of the product into an
-    MFMA-ordered image; b and out have their last axis contiguous."""
+def gemm3_bmm(a, b, out=None, accumulate=False):
+    """out[i] = a[i] @ b[i] (accumulate: out[i] += ...) for fp32 (nb, M, K) x (nb, K, N): an fp32-class product (error vs fp64 as the
+    library's fp32 GEMM) computed on v_mfma_f32_32x32x16_bf16 from three-way split operands.  a (the filter operand, any strides) is split
+    ahead of the product into an MFMA-ordered image -- ONE image when a is the same matrix for every batch (stride 0: the student's 1x1
+    convolutions); b and out have their last axis contiguous."""
     lib = hip.load()
     nb, M, K = a.shape
     N = b.shape[2]
     if out is None:
+        if accumulate:
+            raise hip.LgdHipError("accumulate needs the tensor to accumulate onto")
         out = torch.empty((nb, M, N), dtype=torch.float32, device=a.device)
-    img = torch.empty(lib.lgd_gemm3_image_bytes(nb, M, K), dtype=torch.uint8, device=a.device)
+    shared = a.stride(0) == 0 and nb > 1
+    ni = 1 if shared else nb
+    img = torch.empty(lib.lgd_gemm3_image_bytes(ni, M, K), dtype=torch.uint8, device=a.device)
     st = hip.stream_ptr()
-    hip.check(lib.lgd_gemm3_split(hip.ptr(a), a.stride(0), a.stride(1), a.stride(2), nb, M, K, hip.ptr(img), st), "lgd_gemm3_split")
-    hip.check(lib.lgd_gemm3(hip.ptr(img), hip.ptr(b), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1), nb, M, N, K, st),
-              "lgd_gemm3")
+    hip.check(lib.lgd_gemm3_split(hip.ptr(a), a.stride(0), a.stride(1), a.stride(2), ni, M, K, hip.ptr(img), st), "lgd_gemm3_split")
+    hip.check(lib.lgd_gemm3(hip.ptr(img), 1 if shared else 0, hip.ptr(b), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1),
+                            1 if accumulate else 0, nb, M, N, K, st), "lgd_gemm3")
     return out
+
+
+def _timed_gemm3(name, a, b, out=None, accumulate=False):
+    if not _TIMER_ON:
+        return gemm3_bmm(a, b, out, accumulate)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = gemm3_bmm(a, b, out, accumulate)
+    e1.record()
+    _GEMM_EVENTS.append((name, e0, e1))
+    _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + 2 * a.shape[0] * a.shape[1] * a.shape[2] * b.shape[2]
+    return r
 
 
 def _wino_gemm(name, a, b, out=None):
@@ -2063,16 +2100,7 @@ def _wino_gemm(name, a, b, out=None):
     shape, the library's fp32 GEMM otherwise.  Timed under `name` + '3' (its launches also appear as gemm3_kernel / gemm3_split_kernel)."""
     if not _gemm3_ok(a, b, out):
         return _timed_bmm(name, a, b, out)
-    if not _TIMER_ON:
-        return gemm3_bmm(a, b, out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = gemm3_bmm(a, b, out)
-    e1.record()
-    name = name.replace("wino_gemm_", "wino_gemm3_")
-    _GEMM_EVENTS.append((name, e0, e1))
-    _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + 2 * a.shape[0] * a.shape[1] * a.shape[2] * b.shape[2]
-    return r
+    return _timed_gemm3(name.replace("wino_gemm_", "wino_gemm3_"), a, b, out)
 
 
 def _timed_gemm(name, flops, fn, *args, **kw):
@@ -2100,15 +2128,20 @@ def _conv1x1_fwd(x, wf):
     MIOpen's own 1x1 kernels: 100 TFLOP/s at config 2 against 125-140 for the table's GEMMs."""
     N, Ci, H, W = x.shape
     Co = wf.shape[0]
-    return _timed_gemm("pw_gemm_fwd", _pw_flops(x, Co), torch.bmm, wf.view(1, Co, Ci).expand(N, Co, Ci), x.view(N, Ci, H * W)).view(N, Co, H, W)
+    a, b = wf.view(1, Co, Ci).expand(N, Co, Ci), x.view(N, Ci, H * W)
+    if _gemm3_ok(a, b, None):   # csrc/gemm3.hip: one bf16x3 image of the filter for the whole batch
+        return _timed_gemm3("pw_gemm3_fwd", a, b).view(N, Co, H, W)
+    return _timed_gemm("pw_gemm_fwd", _pw_flops(x, Co), torch.bmm, a, b).view(N, Co, H, W)
 
 
 def _conv1x1_dx(dz, x, wf):
     """input gradient of the pointwise convolution: W^T [Ci x Co] . dz [Co x HW] per image (same form as the forward)"""
     N, Ci, H, W = x.shape
     Co = wf.shape[0]
-    return _timed_gemm("pw_gemm_dx", _pw_flops(x, Co), torch.bmm, wf.view(1, Co, Ci).transpose(1, 2).expand(N, Ci, Co),
-                       dz.view(N, Co, H * W)).view(N, Ci, H, W)
+    a, b = wf.view(1, Co, Ci).transpose(1, 2).expand(N, Ci, Co), dz.view(N, Co, H * W)
+    if _gemm3_ok(a, b, None):
+        return _timed_gemm3("pw_gemm3_dx", a, b).view(N, Ci, H, W)
+    return _timed_gemm("pw_gemm_dx", _pw_flops(x, Co), torch.bmm, a, b).view(N, Ci, H, W)
 
 
 def kernel_gemm_flops():

@@ -906,8 +906,7 @@ def test_gemm3_fp32_class_product(nb, M, K, N, a_t):
         a = a.transpose(1, 2)
     b = ops._freq_buf(nb, K, N, DEV).normal_(generator=g)
     out = ops._freq_buf(nb, M, N, DEV).fill_(float("nan"))
-    assert ops._gemm3_ok(a, b, out)
-    c = ops.gemm3_bmm(a, b, out)
+    c = ops.gemm3_bmm(a, b, out)      # (called directly: ops._gemm3_ok is a speed policy, the kernel takes any M, N and K % 16 == 0)
     assert c.data_ptr() == out.data_ptr()
     ref = torch.bmm(a.double(), b.double())
     scale = float(ref.abs().max())
@@ -929,20 +928,51 @@ def test_gemm3_fp32_class_product(nb, M, K, N, a_t):
     assert bool(torch.isnan(c1[0, :, 7]).all()) and not bool(torch.isnan(c1[0, :, 8]).any()) and not bool(torch.isnan(c1[1:]).any())
 
 
+@pytest.mark.parametrize("Co,Ci,HW", [(128, 256, 1300), (512, 128, 700), (1024, 256, 4200), (256, 2048, 1050)])
+def test_gemm3_pointwise_shared_image_and_accumulate(Co, Ci, HW):
+    """the student's 1x1 convolutions on csrc/gemm3.hip: ONE bf16x3 image of the filter serves the whole batch (stride-0 batch axis), the
+    128-row tile serves C' = 128, and the input gradient of a block's first convolution lands ON the shortcut's gradient (accumulators
+    initialised from it) -- against fp64 and against torch.bmm / torch.baddbmm [d2-memory: BottleneckBlock; SURVEY.md appendix A]."""
+    from lgd_amd import ops
+    N = 3
+    g = torch.Generator(device=DEV).manual_seed(Co + Ci)
+    w = torch.randn(Co, Ci, device=DEV, generator=g) * 0.05
+    x = torch.randn(N, Ci, HW, device=DEV, generator=g)
+    a = w.view(1, Co, Ci).expand(N, Co, Ci)
+    y = ops.gemm3_bmm(a, x)
+    ref = torch.matmul(w.double(), x.double())
+    e = float((y.double() - ref).abs().max() / ref.abs().max())
+    e_lib = float((torch.bmm(a, x).double() - ref).abs().max() / ref.abs().max())
+    assert e <= 2e-6 and e <= 3 * e_lib + 2e-7, (e, e_lib)
+    # input gradient accumulated onto an existing gradient: dx = W^T dz + d_skip
+    dz = torch.randn(N, Co, HW, device=DEV, generator=g)
+    skip = torch.randn(N, Ci, HW, device=DEV, generator=g)
+    at = w.t().unsqueeze(0).expand(N, Ci, Co)
+    want = skip.double() + torch.matmul(w.t().double(), dz.double())
+    acc = skip.clone()
+    got = ops.gemm3_bmm(at, dz, acc, accumulate=True)
+    assert got.data_ptr() == acc.data_ptr()
+    e2 = float((got.double() - want).abs().max() / want.abs().max())
+    e2_lib = float((torch.baddbmm(skip, at, dz).double() - want).abs().max() / want.abs().max())
+    print("gemm3 1x1 %d -> %d over %d px: forward %.2e (library %.2e), accumulated input gradient %.2e (library %.2e)" % (Ci, Co, HW, e, e_lib, e2, e2_lib))
+    assert e2 <= 2e-6 and e2 <= 3 * e2_lib + 4e-7, (e2, e2_lib)
+
+
 def test_gemm3_shape_gate():
     """shapes whose tile would waste the MFMA rows (C' = 36, 64, 128) or break the k-step stay on the library GEMM; _wino_gemm then
     returns the library's result bit for bit."""
     from lgd_amd import ops
     mk = lambda nb, M, K, N: (torch.randn(nb, M, K, device=DEV), ops._freq_buf(nb, K, N, DEV).normal_(), ops._freq_buf(nb, M, N, DEV))  # noqa: E731
-    for M, K, N, ok in ((256, 256, 5232, True), (720, 256, 5232, True), (512, 256, 1024, True), (36, 256, 5232, False), (128, 128, 5232, False),
-                        (320, 256, 5232, False), (256, 36, 5232, False), (256, 256, 128, False)):
-        a, b, o = mk(2, M, K, N)
+    for M, K, N, ok in ((256, 256, 5232, True), (720, 256, 5232, True), (512, 256, 1024, True), (36, 256, 5232, False), (128, 128, 5232, True),
+                        (64, 256, 5232, False), (320, 256, 5232, False), (384, 64, 5232, True), (256, 36, 5232, False), (256, 256, 128, False),
+                        (512, 512, 288, False)):    # res5 at config 2: 64 x 3 x 2 workgroups, less than one round
+        a, b, o = mk(64, M, K, N)
         assert ops._gemm3_ok(a, b, o) == ok, (M, K, N)
         if not ok:
             assert torch.equal(ops._wino_gemm("wino_gemm_fwd", a, b, out=o), torch.bmm(a, b))
     prev = ops.gemm3_backend(False)
     try:
-        a, b, o = mk(2, 256, 256, 512)
+        a, b, o = mk(64, 256, 256, 1024)
         assert not ops._gemm3_ok(a, b, o)
     finally:
         ops.gemm3_backend(prev)
@@ -1601,12 +1631,17 @@ def test_identity_bottleneck_skip_node_vs_fp64():
     # the in-place accumulation must be taken (the residual gradient of conv3's node is tagged) and must not touch foreign tensors
     from lgd_amd import ops as _ops
     calls = []
-    orig = torch.baddbmm
+    orig, orig3 = torch.baddbmm, _ops.gemm3_bmm
 
     def spy(inp, b1, b2, **kw):
         calls.append("out" in kw)
         return orig(inp, b1, b2, **kw)
-    torch.baddbmm = spy
+
+    def spy3(a, b, out=None, accumulate=False):   # csrc/gemm3.hip takes the in-place accumulation where its tile fits the shape
+        if accumulate:
+            calls.append(True)
+        return orig3(a, b, out, accumulate)
+    torch.baddbmm, _ops.gemm3_bmm = spy, spy3
     try:
         x4 = x.to(DEV).requires_grad_(True)
         blk(x4).backward(gy.to(DEV))
@@ -1619,7 +1654,7 @@ def test_identity_bottleneck_skip_node_vs_fp64():
         torch.autograd.backward([o5, s5], [torch.ones_like(o5), gs])
         assert calls == [False] and torch.equal(gs, keep)   # a caller's gradient buffer is not accumulated into
     finally:
-        torch.baddbmm = orig
+        torch.baddbmm, _ops.gemm3_bmm = orig, orig3
     # partial gradients through the node itself
     w, scale, shift = blk.conv1.weight.detach(), *blk.conv1.norm.scale_shift()
     x2 = x.to(DEV).requires_grad_(True)
