@@ -425,6 +425,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (bf16x3 split products, fp32 accumulate)" if ops._GEMM3_ON else "f32",
+            "filter_images_from_transform": bool(ops._GEMM3_ON and ops._FILTER_IMAGES),
             "data": ("synthetic (%d distinct batches rotated; %s)" % (nb, "pinned HOST batches copied inside every step" if args.host_batch
                                                                       else "device-resident when the timed region starts, no H2D copy inside it")),
             "host_batch": None if dt_host is None else {

@@ -336,6 +336,11 @@ int lgd_wino_out_t_gn(const float* const* g_host, const float* const* y_host, co
  *   lgd_wino_filter_bwd: dw[co][ci] = scale[co] . G^T dU[:, co, ci] G, dU read at dU + f*du_plane + co*Ci + ci. */
 int lgd_wino_filter_fwd(const float* w, const float* scale, int Co, int Ci, int tile, float* U, long long u_plane, float* Ut,
                         long long ut_ld, long long ut_plane, void* stream);
+/* lgd_wino_filter_images (tile 6): the same transform written as the bf16x3 operand images of lgd_gemm3 instead of fp32 U -- img_fwd: image
+ *   of U (64 batches, M = Ct rows, K = Ci) for M = U V; img_bwd: image of U^T (M = Ci, K = Ct) for dV = U^T dM; either may be NULL.  The
+ *   filter's rows are row0 .. row0 + Co of a stack of Ct output channels (K filters on shared maps).  Co, Ci, row0, Ct multiples of 16. */
+int lgd_wino_filter_images(const float* w, const float* scale, int Co, int Ci, int tile, int row0, int Ct, void* img_fwd, void* img_bwd,
+                           void* stream);
 int lgd_wino_filter_bwd(const float* dU, long long du_plane, const float* scale, int Co, int Ci, int tile, float* dw, void* stream);
 /* lgd_wino_in_t followed by lgd_wino_out_t of the convolution that PRODUCED these maps, in one kernel: the backward link of a
  * conv -> [ReLU] -> conv chain whose intermediate maps have no other consumer (the head towers, the adapter: distillator.py:107-109,

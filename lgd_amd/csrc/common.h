@@ -92,6 +92,37 @@ __device__ __forceinline__ void vstore(float* p, const Vec<VW>& r) {
     else { *p = r.v[0]; }
 }
 
+// ---- bf16x3 split of fp32 values (csrc/gemm3.hip and the filter transforms that emit its operand image): x = h + m + l with
+// h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round to nearest even; packed two elements per dword, the first in the low half
+typedef float lgd_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 lgd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t lgd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const lgd_bf16x2 v = __builtin_convertvector((lgd_f32x2){a, b}, lgd_bf16x2);   // v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {   // 11 VALU operations per pair
+    h = pack_bf16(x0, x1);
+    float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = pack_bf16(r0, r1);
+    r0 -= __builtin_bit_cast(float, m << 16);
+    r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
+    l = pack_bf16(r0, r1);
+}
+// eight consecutive-k values of one row -> the three 16-byte fragments of the gemm3 operand image
+// [batch][k-step of 16][piece][32-row block][lane = (k % 16 / 8) * 32 + row % 32][8 bf16]; d: the h fragment, piece stride rbp KB
+__device__ __forceinline__ void store_split8(const float* x, char* d, long rbp) {
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2(x[2 * e], x[2 * e + 1], h[e], m[e], l[e]);
+    *reinterpret_cast<lgd_u32x4*>(d) = (lgd_u32x4){h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<lgd_u32x4*>(d + rbp * 1024) = (lgd_u32x4){m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<lgd_u32x4*>(d + 2 * rbp * 1024) = (lgd_u32x4){l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ long gemm3_image_off(long b, int ktp, int rbp, int m, int k) {   // byte offset of the h fragment holding (m, k)
+    return ((((b * ktp + (k >> 4)) * 3) * rbp + (m >> 5)) << 10) + ((((k >> 3) & 1) * 32 + (m & 31)) << 4);
+}
+
 // ---- geometry workspace layout (int32 units): rects [L][B][max_n][4] | nbp [L][B] | bands [L][B][maxbp]
 // (rectangles are padded per image so that a wave's start-up loads -- counts, band table, its box -- depend only on
 //  (level, image) and issue together: one memory latency instead of a chain of three)

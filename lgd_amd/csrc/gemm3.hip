@@ -28,10 +28,8 @@ namespace lgd {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef lgd_u32x4 u32x4;
 
 constexpr int BN = 128, BK = 16, NT = 256;
 // tile rows BM = 256 (4 x 2 MFMA blocks per wave, 2 workgroups per CU) or 128 (2 x 2 blocks, 64 accumulator registers, 3 workgroups per
@@ -44,20 +42,6 @@ template <int BM> struct Tile {
 
 #define LGD_GLDS16(src, dst) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    const bf16x2 v = __builtin_convertvector((f32x2){a, b}, bf16x2);   // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
-    return __builtin_bit_cast(uint32_t, v);
-}
-// two floats -> three packed bf16 pairs (11 VALU operations per pair)
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = pack_bf16(x0, x1);
-    float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
-    m = pack_bf16(r0, r1);
-    r0 -= __builtin_bit_cast(float, m << 16);
-    r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
-    l = pack_bf16(r0, r1);
-}
 
 struct Params {
     const char* Aimg; long a_sb; int rbp, ktp;   // image [nb][ktp][3][rbp][1024 B]; a_sb in bytes
@@ -246,13 +230,7 @@ __global__ void split_a_kernel(const float* __restrict__ A, long a_sb, long sm, 
     float x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = (m < M && k0 + e < K) ? A[(long)b * a_sb + (long)m * sm + (long)(k0 + e) * sk] : 0.f;
-    uint32_t h[4], mm[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split2(x[2 * e], x[2 * e + 1], h[e], mm[e], l[e]);
-    char* d = img + ((((long)b * ktp + kt) * 3) * rbp + rb) * 1024 + lane * 16;
-    *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
-    *reinterpret_cast<u32x4*>(d + (long)rbp * 1024) = (u32x4){mm[0], mm[1], mm[2], mm[3]};
-    *reinterpret_cast<u32x4*>(d + 2 * (long)rbp * 1024) = (u32x4){l[0], l[1], l[2], l[3]};
+    store_split8(x, img + gemm3_image_off(b, ktp, rbp, m, k0), rbp);
 }
 
 }  // namespace

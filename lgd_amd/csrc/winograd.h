@@ -81,8 +81,10 @@ struct FilterArgs {
     float* U; float* Ut; float* dw;
     long long u_plane, ut_plane, ut_ld;
     int Co, Ci;
+    char* img_fwd; char* img_bwd; int row0, Ct;   // wino6_filter_img_kernel: gemm3 operand images of the stacked filter (rows row0 .. row0 + Co of Ct)
 };
 void wino6_launch_filter_fwd(const FilterArgs& a, hipStream_t st);
+void wino6_launch_filter_img(const FilterArgs& a, hipStream_t st);
 void wino6_launch_filter_bwd(const FilterArgs& a, hipStream_t st);
 
 }  // namespace lgd

@@ -760,6 +760,16 @@ int lgd_wino_filter_fwd(const float* w, const float* scale, int Co, int Ci, int 
     return lgd::check_launch();
 }
 
+int lgd_wino_filter_images(const float* w, const float* scale, int Co, int Ci, int tile, int row0, int Ct, void* img_fwd, void* img_bwd,
+                           void* stream) {
+    if (!w || (!img_fwd && !img_bwd) || tile != 6 || Co < 16 || Ci < 16 || (Co & 15) || (Ci & 15) || (row0 & 15) || (Ct & 15) || row0 < 0 ||
+        row0 + Co > Ct || ((uintptr_t)img_fwd & 15) || ((uintptr_t)img_bwd & 15)) return LGD_EINVAL;
+    lgd::FilterArgs a{};
+    a.w = w; a.scale = scale; a.Co = Co; a.Ci = Ci; a.img_fwd = (char*)img_fwd; a.img_bwd = (char*)img_bwd; a.row0 = row0; a.Ct = Ct;
+    lgd::wino6_launch_filter_img(a, (hipStream_t)stream);
+    return lgd::check_launch();
+}
+
 int lgd_wino_filter_bwd(const float* dU, long long du_plane, const float* scale, int Co, int Ci, int tile, float* dw, void* stream) {
     if (!dU || !dw || Co < 1 || Ci < 1 || (tile != 4 && tile != 6) || du_plane < (long long)Co * Ci) return LGD_EINVAL;
     lgd::FilterArgs a{};

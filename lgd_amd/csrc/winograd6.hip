@@ -785,6 +785,59 @@ __global__ __launch_bounds__(256) void wino6_filter_fwd_kernel(FilterArgs a) {
     }
 }
 
+// The same transform written as the bf16x3 operand IMAGES of csrc/gemm3.hip instead of fp32 U: image of U (rows co, k = ci) for the forward
+// product M = U V, image of U^T (rows ci, k = co) for dV = U^T dM -- the filter is split where it is produced, not by a pass that
+// re-reads U (58 launches of ~20 us per step at BASELINE config 2).  Co % 16 == Ci % 16 == row0 % 16 == 0 (host-checked): every
+// workgroup owns whole 16-deep k-steps of both images, nothing is guarded.  32 frequencies at a time through the LDS tile.
+__global__ __launch_bounds__(256) void wino6_filter_img_kernel(FilterArgs a) {
+    __shared__ float tile[32][16][17];
+    const int cl = threadIdx.x & 15, ol = threadIdx.x >> 4;
+    const int ci = blockIdx.x * 16 + cl, co = blockIdx.y * 16 + ol;
+    float u[8][8];
+    {
+        float g[9];
+        const float sc = a.scale ? a.scale[co] : 1.f;
+        #pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = a.w[((size_t)co * a.Ci + ci) * 9 + i] * sc;
+        float r[8][3];
+        #pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float o[8];
+            g8(g[j], g[3 + j], g[6 + j], o);
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) r[i][j] = o[i];
+        }
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) g8(r[i][0], r[i][1], r[i][2], u[i]);
+    }
+    const int ktp_f = a.Ci >> 4, rbp_f = (a.Ct + 31) >> 5;     // image of U:   M = Ct, K = Ci
+    const int ktp_b = a.Ct >> 4, rbp_b = (a.Ci + 31) >> 5;     // image of U^T: M = Ci, K = Ct
+    const int co0 = a.row0 + blockIdx.y * 16, ci0 = blockIdx.x * 16;
+    #pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        #pragma unroll
+        for (int f = 0; f < 32; ++f) tile[f][ol][cl] = u[(32 * half + f) / 8][(32 * half + f) % 8];
+        __syncthreads();
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {   // 32 frequencies x 32 fragments (16 rows x 2 k-groups) per image: 4 per thread
+            const int q = threadIdx.x + 256 * j, fl = q >> 5, x = q & 15, g = (q >> 4) & 1;
+            const long f = 32 * half + fl;
+            float v[8];
+            if (a.img_fwd) {
+                #pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[fl][x][g * 8 + e];
+                store_split8(v, a.img_fwd + gemm3_image_off(f, ktp_f, rbp_f, co0 + x, ci0 + g * 8), rbp_f);
+            }
+            if (a.img_bwd) {
+                #pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[fl][g * 8 + e][x];
+                store_split8(v, a.img_bwd + gemm3_image_off(f, ktp_b, rbp_b, ci0 + x, co0 + g * 8), rbp_b);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void wino6_filter_bwd_kernel(FilterArgs a) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)a.Co * a.Ci) return;
@@ -828,6 +881,9 @@ void wino6_launch_in_t(const WinoArgs& a, unsigned blocks, bool fuse, hipStream_
 }
 void wino6_launch_filter_fwd(const FilterArgs& a, hipStream_t st) {
     LGD_LAUNCH("wino_filter_kernel", wino6_filter_fwd_kernel, dim3((a.Ci + 15) / 16, (a.Co + 15) / 16), dim3(256), 0, st, a);
+}
+void wino6_launch_filter_img(const FilterArgs& a, hipStream_t st) {
+    LGD_LAUNCH("wino_filter_img_kernel", wino6_filter_img_kernel, dim3(a.Ci / 16, a.Co / 16), dim3(256), 0, st, a);
 }
 void wino6_launch_filter_bwd(const FilterArgs& a, hipStream_t st) {
     const long long n = (long long)a.Co * a.Ci;

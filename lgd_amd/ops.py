@@ -1023,22 +1023,59 @@ def _freq_buf(nf, C, T, device):
     return torch.empty((C, nf, T), dtype=torch.float32, device=device).permute(1, 0, 2)
 
 
-def _wino_filters(lib, ws, scales, Ci, dev, tile):
-    """U (nf, sum Co, Ci) of K filters stacked along C_out, one lgd_wino_filter_fwd launch per filter (the frozen per-channel scale of a
-    FrozenBN that follows the conv is folded in on the way: no scaled copy of the weights), and its (Co, Ci)-transposed VIEW: the dV GEMM
-    of the backward takes U^T as a transposed operand (tuned TN solutions are as fast as NN on a materialised U^T or faster --
-    tools/gemm_tn_probe.py: 720 x 256: 7.17 vs 7.57 ms -- and the transform writes half the bytes)."""
+class _FilterImage:
+    """the filter operand of one channel product as csrc/gemm3.hip takes it: the bf16x3 image (a uint8 tensor) of an (nf, M, K) fp32 operand"""
+    __slots__ = ("t", "shape")
+
+    def __init__(self, t, shape):
+        self.t, self.shape = t, tuple(shape)
+
+    @property
+    def device(self):
+        return self.t.device
+
+
+def _pack_filter(a):
+    """(tensor for ctx.save_for_backward, shape or None) of a filter operand that is an fp32 tensor or a _FilterImage"""
+    return (a.t, a.shape) if isinstance(a, _FilterImage) else (a, None)
+
+
+def _unpack_filter(t, shape):
+    return _FilterImage(t, shape) if shape is not None else t
+
+
+def _wino_filters(lib, ws, scales, Ci, dev, tile, T=None, need_dx=True):
+    """The transformed filter of K convolutions stacked along C_out, as the two channel products take it:
+         A_fwd for M = U V            -- U (nf, sum Co, Ci) fp32, or its gemm3 image,
+         A_dx  for dV = U^T dM        -- the (Co, Ci)-transposed VIEW of U (tuned TN library solutions are as fast as NN on a materialised
+                                         U^T, tools/gemm_tn_probe.py), or the gemm3 image of U^T; None when no input gradient is needed.
+    Where csrc/gemm3.hip will run the product (T given, shape gate as in _gemm3_ok) lgd_wino_filter_images writes the bf16x3 image straight
+    from the filter transform: fp32 U is neither written nor re-read by a split pass.  The frozen per-channel scale of a FrozenBN that
+    follows the conv is folded in on the way (no scaled copy of the weights)."""
     Cos = [w.shape[0] for w in ws]
     Ct = sum(Cos)
     nf = (tile + 2) ** 2
-    U = torch.empty((nf, Ct, Ci), dtype=torch.float32, device=dev)
+    img_ok = (tile == 6 and T is not None and _GEMM3_ON and _FILTER_IMAGES and Ci % 16 == 0 and all(c % 16 == 0 for c in Cos) and ws[0].is_cuda)
+    fwd_img = img_ok and _gemm3_shape_ok(nf, Ct, Ci, T, dev)
+    dx_img = img_ok and need_dx and _gemm3_shape_ok(nf, Ci, Ct, T, dev)
+    need_u = (not fwd_img) or (need_dx and not dx_img)
+    U = torch.empty((nf, Ct, Ci), dtype=torch.float32, device=dev) if need_u else None
+    imf = torch.empty(lib.lgd_gemm3_image_bytes(nf, Ct, Ci), dtype=torch.uint8, device=dev) if fwd_img else None
+    imb = torch.empty(lib.lgd_gemm3_image_bytes(nf, Ci, Ct), dtype=torch.uint8, device=dev) if dx_img else None
     c0 = 0
     for w, sc, Co in zip(ws, scales, Cos):
-        hip.check(lib.lgd_wino_filter_fwd(hip.ptr(w), hip.ptr(sc) if sc is not None else None, Co, Ci, tile,
-                                          ctypes.c_void_p(U.data_ptr() + 4 * c0 * Ci), Ct * Ci, None, 0, 0, hip.stream_ptr()),
-                  "lgd_wino_filter_fwd")
+        if need_u:
+            hip.check(lib.lgd_wino_filter_fwd(hip.ptr(w), hip.ptr(sc) if sc is not None else None, Co, Ci, tile,
+                                              ctypes.c_void_p(U.data_ptr() + 4 * c0 * Ci), Ct * Ci, None, 0, 0, hip.stream_ptr()),
+                      "lgd_wino_filter_fwd")
+        if fwd_img or dx_img:
+            hip.check(lib.lgd_wino_filter_images(hip.ptr(w), hip.ptr(sc) if sc is not None else None, Co, Ci, tile, c0, Ct,
+                                                 hip.ptr(imf) if fwd_img else None, hip.ptr(imb) if dx_img else None, hip.stream_ptr()),
+                      "lgd_wino_filter_images")
         c0 += Co
-    return U, U.transpose(1, 2)
+    a_fwd = _FilterImage(imf, (nf, Ct, Ci)) if fwd_img else U
+    a_dx = (_FilterImage(imb, (nf, Ci, Ct)) if dx_img else U.transpose(1, 2)) if need_dx else None
+    return a_fwd, a_dx
 
 
 def _wino_filter_grads(lib, dU, scales, Cos, need, Ci, tile):
@@ -1093,7 +1130,7 @@ class _Conv3x3K(torch.autograd.Function):
         mdt, mb = _WINO_MASK_DTYPE[tile], _WINO_MASK_DTYPE[tile].itemsize
         hw = hip.int_array([d for x in xs for d in x.shape[2:]])
         T = lib.lgd_wino_tiles(hw, L, N, tile)
-        U, Ut = _wino_filters(lib, ws, scales, Ci, dev, tile)
+        U, Ut = _wino_filters(lib, ws, scales, Ci, dev, tile, T, any(ctx.needs_input_grad[5 + 2 * K:]))
         V = _freq_buf(nf, Ci, T, dev)
         pre = hip.dense_f32(pre) if pre is not None else None
         affine = pre is not None and pre.dim() == 3   # (L*N, Ci, 2) scale / shift per (map, sample, channel): a folded GroupNorm + ReLU
@@ -1120,7 +1157,9 @@ class _Conv3x3K(torch.autograd.Function):
             ys += yk
             c0 += Cos[k]
         need_w = any(ctx.needs_input_grad[5:5 + 2 * K:2])
-        ctx.save_for_backward(Ut, V if need_w else None, bits, pre_bits)   # the backward needs U^T (dV = U^T dM)
+        ut_t, ctx.ut_shape = _pack_filter(Ut)
+        ctx.dev = dev
+        ctx.save_for_backward(ut_t, V if need_w else None, bits, pre_bits)   # the backward needs U^T (dV = U^T dM)
         ctx.scales = scales
         ctx.meta = (K, L, N, Ci, Cos, hw, T, [b is not None for b in bs], [tuple(x.shape[2:]) for x in xs], tile, px, fb)
         return tuple(ys)
@@ -1128,10 +1167,11 @@ class _Conv3x3K(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dys):
         Ut, V, bits, pre_bits = ctx.saved_tensors
+        Ut = _unpack_filter(Ut, ctx.ut_shape)
         K, L, N, Ci, Cos, hw, T, has_bias, shapes, tile, px, fb = ctx.meta
         Ct = sum(Cos)
         lib = hip.load()
-        dev = Ut.device
+        dev = ctx.dev
         nf = (tile + 2) ** 2
         mb = _WINO_MASK_DTYPE[tile].itemsize
         # an output nothing downstream used arrives as None
@@ -1204,7 +1244,7 @@ class _Conv3x3GN(torch.autograd.Function):
         mdt = _WINO_MASK_DTYPE[tile]
         hw = hip.int_array([d for x in xs for d in x.shape[2:]])
         T = lib.lgd_wino_tiles(hw, L, N, tile)
-        U, Ut = _wino_filters(lib, ws, [None] * K, Ci, dev, tile)
+        U, Ut = _wino_filters(lib, ws, [None] * K, Ci, dev, tile, T, any(ctx.needs_input_grad[4 + 4 * K:]))
         V = _freq_buf(nf, Ci, T, dev)
         pre = hip.dense_f32(pre) if pre is not None else None
         affine_in = pre is not None and pre.dim() == 3
@@ -1239,7 +1279,9 @@ class _Conv3x3GN(torch.autograd.Function):
             stats.append(st)
             c0 += Cos[k]
         need_w = any(ctx.needs_input_grad[4:4 + 4 * K:4])
-        ctx.save_for_backward(Ut, V if need_w else None, pre_bits, *stats, *gammas, *ys)
+        ut_t, ctx.ut_shape = _pack_filter(Ut)
+        ctx.dev = dev
+        ctx.save_for_backward(ut_t, V if need_w else None, pre_bits, *stats, *gammas, *ys)
         ctx.meta = (K, L, N, Ci, Cos, hw, T, [b is not None for b in bs], [b is not None for b in betas],
                     [tuple(x.shape[2:]) for x in xs], tile, groups, px, fb)
         ctx.mark_non_differentiable(*affs)
@@ -1249,13 +1291,14 @@ class _Conv3x3GN(torch.autograd.Function):
     def backward(ctx, *grads):
         K, L, N, Ci, Cos, hw, T, has_bias, has_beta, shapes, tile, groups, px, fb = ctx.meta
         Ut, V, pre_bits = ctx.saved_tensors[:3]
+        Ut = _unpack_filter(Ut, ctx.ut_shape)
         stats = ctx.saved_tensors[3:3 + K]
         gammas = ctx.saved_tensors[3 + K:3 + 2 * K]
         ys = ctx.saved_tensors[3 + 2 * K:]
         gs = grads[K:]
         Ct = sum(Cos)
         lib = hip.load()
-        dev = Ut.device
+        dev = ctx.dev
         nf = (tile + 2) ** 2
         gs = [hip.dense_f32(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
               for i, g in enumerate(gs)]
@@ -1330,10 +1373,10 @@ class _Conv3x3Chain(torch.autograd.Function):
         px = 4 * N * sum(h * w_ for h, w_ in shapes)   # bytes of one channel of the maps
         fb = 4 * nf * T                                # bytes of one channel of a frequency buffer
         need_ws = list(ctx.needs_input_grad[3:3 + 2 * K:2])
-        saved, cur = [], xs
+        saved, cur, ut_shapes, dims = [], xs, [], []
         for k in range(K):
             Co, Ci = ws[k].shape[0], ws[k].shape[1]
-            U, Ut = _wino_filters(lib, [ws[k]], [None], Ci, dev, tile)
+            U, Ut = _wino_filters(lib, [ws[k]], [None], Ci, dev, tile, T, k > 0 or any(ctx.needs_input_grad[3 + 2 * K:]))
             V = _freq_buf(nf, Ci, T, dev)
             hip.check(lib.lgd_wino_in(hip.ptr_array(cur), hw, L, N, Ci, tile, hip.ptr(V), None, None, None, hip.stream_ptr()), "lgd_wino_in")
             _count_bytes("wino_in_kernel", (px + fb) * Ci)
@@ -1344,7 +1387,11 @@ class _Conv3x3Chain(torch.autograd.Function):
             hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Co, tile, int(relus[k]),
                                        hip.ptr_array(cur), hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
             del M
-            saved += [Ut, V if need_ws[k] else None, bits]
+            ut_t, ut_shape = _pack_filter(Ut)
+            ut_shapes.append(ut_shape)
+            dims.append((Ci, Co))
+            saved += [ut_t, V if need_ws[k] else None, bits]
+        ctx.ut_shapes, ctx.dims, ctx.dev = ut_shapes, dims, dev
         ctx.save_for_backward(*saved)
         ctx.meta = (K, L, N, hw, T, shapes, [b is not None for b in bs], px, fb, tile)
         return tuple(cur)
@@ -1356,12 +1403,12 @@ class _Conv3x3Chain(torch.autograd.Function):
         lib = hip.load()
         nf = (tile + 2) ** 2
         mb = _WINO_MASK_DTYPE[tile].itemsize
-        dev = saved[0].device
+        dev = ctx.dev
         need_ws = list(ctx.needs_input_grad[3:3 + 2 * K:2])
         need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[4:4 + 2 * K:2])]
         need_x = any(ctx.needs_input_grad[3 + 2 * K:])
         dws, dbs, dxs = [None] * K, [None] * K, [None] * L
-        Co = saved[3 * (K - 1)].shape[2]
+        Co = ctx.dims[K - 1][1]
         dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Co) + shapes[i], dtype=torch.float32, device=dev) for i, g in enumerate(dys)]
         bits = saved[3 * (K - 1) + 2]
         dM = _freq_buf(nf, Co, T, dev)
@@ -1369,8 +1416,8 @@ class _Conv3x3Chain(torch.autograd.Function):
         hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), hip.ptr(bits) if bits is not None else None, hw, L, N, Co, tile, hip.ptr(dM),
                                      hip.stream_ptr()), "lgd_wino_out_t")
         for k in range(K - 1, -1, -1):
-            Ut, V = saved[3 * k], saved[3 * k + 1]
-            Ci, Co = Ut.shape[1], Ut.shape[2]
+            Ut, V = _unpack_filter(saved[3 * k], ctx.ut_shapes[k]), saved[3 * k + 1]
+            Ci, Co = ctx.dims[k]
             if need_ws[k]:
                 dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
                 dws[k] = _wino_filter_grads(lib, dU, [None], [Co], [True], Ci, tile)[0]
@@ -2020,15 +2067,22 @@ def _timed_bmm(name, a, b, out=None):
 
 # ---- K9: the Winograd channel products on the bf16 MFMA pipe (csrc/gemm3.hip: three-way split fp32 operands, fp32 accumulate)
 _GEMM3_ON = os.environ.get("LGD_GEMM3", "1") != "0"
+_FILTER_IMAGES = os.environ.get("LGD_FILTER_IMAGES", "1") != "0"   # 0: fp32 U + the split pass of gemm3_bmm (A/B runs)
 
 
-def gemm3_backend(on=None):
-    """whether the forward / input-gradient channel products of the Winograd convolutions run on csrc/gemm3.hip (default) or on the
-    library's fp32 GEMM (A/B runs, tests).  Returns the previous setting."""
-    global _GEMM3_ON
-    prev = _GEMM3_ON
+_GEMM3_FORCE = False   # tests: take csrc/gemm3.hip wherever the kernel CAN run (K % 16 == 0), whatever the speed policy says
+
+
+def gemm3_backend(on=None, force=None):
+    """whether the forward / input-gradient channel products of the Winograd convolutions (and the student's 1x1 convolutions) run on
+    csrc/gemm3.hip (default) or on the library's fp32 GEMM (A/B runs, tests); force: bypass the speed policy so that small test problems
+    take the kernel too.  Returns the previous (on, force)."""
+    global _GEMM3_ON, _GEMM3_FORCE
+    prev = (_GEMM3_ON, _GEMM3_FORCE)
     if on is not None:
         _GEMM3_ON = bool(on)
+    if force is not None:
+        _GEMM3_FORCE = bool(force)
     return prev
 
 
@@ -2042,13 +2096,14 @@ def _cu_count(device):
     return _CU_COUNT[i]
 
 
-def _gemm3_ok(a, b, out, accumulate=False):
-    if not (_GEMM3_ON and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 3 and b.dim() == 3):
+def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False):
+    """the speed policy of csrc/gemm3.hip on plain sizes (tile choice as in lgd_gemm3)"""
+    if not _GEMM3_ON:
         return False
-    nb, M, K = a.shape
-    N = b.shape[2]
+    if _GEMM3_FORCE:
+        return K % 16 == 0
     # the kernel's tile spans 256 (or 128) rows of A: shapes that would leave more than ~30 % of the MFMA rows empty (C' = 36, 64, 320 ...) and
-    # tiny problems stay on the library; K % 16: the k-step.  (Tile choice as in csrc/gemm3.hip::lgd_gemm3.)
+    # tiny problems stay on the library; K % 16: the k-step
     small = accumulate or ((M + 255) // 256 * 256 - M >= 64 and (M + 127) // 128 * 128 - M < 64)
     bm = 128 if small else 256
     if K % 16 or K < 32 or N < 256 or M < 0.7 * bm * ((M + bm - 1) // bm):
@@ -2056,7 +2111,13 @@ def _gemm3_ok(a, b, out, accumulate=False):
     # at least one full round of workgroups (2 per CU with 256-row tiles, 3 with 128-row ones): below that a tile's prologue, its short
     # k-loop without a co-resident partner and the filter split are the whole launch and the library's smaller tiles win
     # (tools/gemm3_probe.py, profiles/r04_gemm3_probe.log: res5's 288 tiles x0.61, the 2048 -> 256 lateral x0.55; from one round up x1.05-1.6)
-    if nb * ((N + 127) // 128) * ((M + bm - 1) // bm) < _cu_count(a.device) * (3 if small else 2):
+    return nb * ((N + 127) // 128) * ((M + bm - 1) // bm) >= _cu_count(device) * (3 if small else 2)
+
+
+def _gemm3_ok(a, b, out, accumulate=False):
+    if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 3 and b.dim() == 3):
+        return False
+    if not _gemm3_shape_ok(a.shape[0], a.shape[1], a.shape[2], b.shape[2], a.device, accumulate):
         return False
     return b.stride(2) == 1 and (out is None or (out.stride(2) == 1 and out.dtype == torch.float32))
 
@@ -2083,12 +2144,23 @@ def gemm3_bmm(a, b, out=None, accumulate=False):
     return out
 
 
+def gemm3_image_bmm(img, b, out):
+    """out[i] = A[i] @ b[i] with A given as its gemm3 image (_FilterImage of an (nb, M, K) operand)"""
+    nb, M, K = img.shape
+    if b.shape[0] != nb or b.shape[1] != K or out.shape[1] != M or b.stride(2) != 1 or out.stride(2) != 1:
+        raise hip.LgdHipError("gemm3 image %s does not match B %s / C %s" % (img.shape, tuple(b.shape), tuple(out.shape)))
+    hip.check(hip.load().lgd_gemm3(hip.ptr(img.t), 0, hip.ptr(b), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1), 0, nb, M,
+                                   b.shape[2], K, hip.stream_ptr()), "lgd_gemm3")
+    return out
+
+
 def _timed_gemm3(name, a, b, out=None, accumulate=False):
+    fn = (lambda: gemm3_image_bmm(a, b, out)) if isinstance(a, _FilterImage) else (lambda: gemm3_bmm(a, b, out, accumulate))
     if not _TIMER_ON:
-        return gemm3_bmm(a, b, out, accumulate)
+        return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    r = gemm3_bmm(a, b, out, accumulate)
+    r = fn()
     e1.record()
     _GEMM_EVENTS.append((name, e0, e1))
     _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + 2 * a.shape[0] * a.shape[1] * a.shape[2] * b.shape[2]
@@ -2098,6 +2170,8 @@ def _timed_gemm3(name, a, b, out=None, accumulate=False):
 def _wino_gemm(name, a, b, out=None):
     """one of the per-frequency channel products (forward M = U V, input gradient dV = U^T dM): csrc/gemm3.hip where its tile fits the
     shape, the library's fp32 GEMM otherwise.  Timed under `name` + '3' (its launches also appear as gemm3_kernel / gemm3_split_kernel)."""
+    if isinstance(a, _FilterImage):   # decided (same gate) where the filter was transformed: its image came straight from the transform
+        return _timed_gemm3(name.replace("wino_gemm_", "wino_gemm3_"), a, b, out)
     if not _gemm3_ok(a, b, out):
         return _timed_bmm(name, a, b, out)
     return _timed_gemm3(name.replace("wino_gemm_", "wino_gemm3_"), a, b, out)

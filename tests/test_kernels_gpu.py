@@ -958,6 +958,80 @@ def test_gemm3_pointwise_shared_image_and_accumulate(Co, Ci, HW):
     assert e2 <= 2e-6 and e2 <= 3 * e2_lib + 4e-7, (e2, e2_lib)
 
 
+def test_wino_filter_images_equal_the_split_of_U():
+    """lgd_wino_filter_images (the F(6x6,3x3) filter transform written straight as the bf16x3 operand images of csrc/gemm3.hip) against
+    lgd_wino_filter_fwd followed by lgd_gemm3_split: the image of U (forward product) and of U^T (input gradient), two filters stacked
+    along C_out, one with a frozen per-channel scale."""
+    from lgd_amd import hip, ops
+    lib = hip.load()
+    Ci, Cos = 48, (32, 64)
+    ws = [torch.from_numpy(synth.det_uniform((co, Ci, 3, 3), 3100 + k, -0.1, 0.1)).to(DEV) for k, co in enumerate(Cos)]
+    scales = [None, torch.from_numpy(synth.det_uniform((Cos[1],), 3110, 0.5, 1.5)).to(DEV)]
+    prev = ops.gemm3_backend(True, force=True)
+    try:
+        a_fwd, a_dx = ops._wino_filters(lib, ws, scales, Ci, torch.device(DEV), 6, T=64, need_dx=True)
+        assert isinstance(a_fwd, ops._FilterImage) and isinstance(a_dx, ops._FilterImage)
+        assert a_fwd.shape == (64, sum(Cos), Ci) and a_dx.shape == (64, Ci, sum(Cos))
+        ops.gemm3_backend(False)
+        U, Ut = ops._wino_filters(lib, ws, scales, Ci, torch.device(DEV), 6, T=64, need_dx=True)
+    finally:
+        ops.gemm3_backend(*prev)
+    # the two kernels contract the transform's multiply-adds differently (1 ulp in some U values), so the images are compared through the
+    # product they feed: gemm3 on the image == gemm3 on the split of the fp32 U, to fp32 rounding; rows >= M of the last 32-row block are
+    # padding the transform leaves unwritten (their products are rows of C that are never stored)
+    for img, a in ((a_fwd, U), (a_dx, Ut)):
+        nb, M, K = a.shape
+        b = torch.from_numpy(synth.det_uniform((nb, K, 96), 3120 + M, -1.0, 1.0)).to(DEV)
+        got = ops.gemm3_image_bmm(img, b, torch.full((nb, M, 96), float("nan"), device=DEV))
+        want = ops.gemm3_bmm(a, b)
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("case", ["levels-scale", "shared-input", "chain"])
+def test_conv3x3_on_gemm3_equals_library_gemms(case):
+    """the three Winograd convolution nodes with their channel products forced onto csrc/gemm3.hip (filter images straight from the filter
+    transform, forward and input gradient) against the same nodes on the library's fp32 GEMMs: two fp32-class products of the same
+    operands -- outputs and every gradient agree to 2e-5 of their scale [ref: dynamic_teacher.py:57-73, sequential_convs.py:10-12]."""
+    from lgd_amd import ops
+    hws = [(26, 36), (13, 18), (7, 9)]
+    N, Ci = 2, 64
+    xs = [torch.from_numpy(synth.det_uniform((N, Ci, h, w), 3201 + i, -2.0, 2.0)).to(DEV) for i, (h, w) in enumerate(hws)]
+    ws = [torch.from_numpy(synth.det_uniform((co, Ci, 3, 3), 3210 + k, -0.1, 0.1)).to(DEV) for k, co in enumerate((64, 48, 64))]
+    bs = [torch.from_numpy(synth.det_uniform((co,), 3220 + k, -0.5, 0.5)).to(DEV) for k, co in enumerate((64, 48, 64))]
+    sc = torch.from_numpy(synth.det_uniform((64,), 3230, 0.5, 1.5)).to(DEV)
+    # (no ReLU anywhere: a unit within rounding of zero would take its backward mask from whichever GEMM computed it, and one flipped unit
+    #  is a 0.1-sized difference in dx -- the mask plumbing does not depend on the GEMM back-end and has its own tests)
+    fns = {"levels-scale": lambda x, w, b: ops.conv3x3_levels(x, w[0], b[0], relu=False, scale=sc),
+           "shared-input": lambda x, w, b: [y for ys in ops.conv3x3_shared_input(x, [(w[0], b[0]), (w[1], b[1])], relu=False) for y in ys],
+           "chain": lambda x, w, b: ops.conv3x3_chain(x, [(w[0], b[0]), (w[2], b[2]), (w[1], b[1])], (False, False, False))}
+
+    def run():
+        x = [t.clone().requires_grad_(True) for t in xs]
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        ys = fns[case](x, w, b)
+        gys = [torch.from_numpy(synth.det_uniform(tuple(y.shape), 3250 + i, -1.0, 1.0)).to(DEV) for i, y in enumerate(ys)]
+        torch.autograd.backward(ys, gys)
+        return [y.detach() for y in ys], [t.grad for t in x + w + b if t.grad is not None]
+    pw = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=6)
+    pg = ops.gemm3_backend(True, force=True)
+    seen = []
+    real = ops._timed_gemm3
+    ops._timed_gemm3 = lambda name, a, *r, **k: (seen.append((name, isinstance(a, ops._FilterImage))), real(name, a, *r, **k))[1]
+    try:
+        ya, ga = run()
+        assert seen and all(img for _, img in seen) and {n for n, _ in seen} == {"wino_gemm3_fwd", "wino_gemm3_dx"}, seen
+        ops.gemm3_backend(False)
+        yb, gb = run()
+    finally:
+        ops._timed_gemm3 = real
+        ops.gemm3_backend(*pg)
+        ops.conv3x3_backend(*pw)
+    assert len(ya) == len(yb) and len(ga) == len(gb)
+    for a, b_ in zip(ya + ga, yb + gb):
+        assert float((a - b_).abs().max()) <= 2e-5 * (float(b_.abs().max()) + 1e-30)
+
+
 def test_gemm3_shape_gate():
     """shapes whose tile would waste the MFMA rows (C' = 36, 64, 128) or break the k-step stay on the library GEMM; _wino_gemm then
     returns the library's result bit for bit."""
@@ -975,7 +1049,7 @@ def test_gemm3_shape_gate():
         a, b, o = mk(64, 256, 256, 1024)
         assert not ops._gemm3_ok(a, b, o)
     finally:
-        ops.gemm3_backend(prev)
+        ops.gemm3_backend(*prev)
 
 
 # ------------------------------------------------------------------------------------------- student conv epilogues

@@ -39,7 +39,7 @@ def ab(tag, a, b, o, flop, accumulate=False):
     ok = ops._gemm3_ok(a[0], b[0], o[0], accumulate)
     t_lib = bench((lambda i: torch.baddbmm(o[i % NSET], a[i % NSET], b[i % NSET], out=o[i % NSET])) if accumulate else
                   (lambda i: torch.bmm(a[i % NSET], b[i % NSET], out=o[i % NSET])))
-    prev = ops.gemm3_backend(True)
+    prev = ops.gemm3_backend(True)[0]
     t_new = bench(lambda i: ops.gemm3_bmm(a[i % NSET], b[i % NSET], o[i % NSET], accumulate)) if a[0].shape[2] % 16 == 0 else float("nan")
     ops.gemm3_backend(prev)
     print("%-58s library %7.1f us %6.1f TF | gemm3 %7.1f us %6.1f TF-eq | x%.2f %s" % (tag, t_lib, flop / t_lib / 1e6, t_new, flop / t_new / 1e6, t_lib / t_new,
