@@ -20,6 +20,8 @@
 // LDS buffers of 36 KB (A pieces 24 KB + B pieces 12 KB): one barrier per k-step, two workgroups per CU so that one's staging and
 // epilogue hide under the other's MFMAs.  A 128-row variant of the same kernel serves C' = 128 layers.  The image may be shared by all
 // batches (the student's 1x1 convolutions: one filter, a batch of images) and the result may be accumulated onto C.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -48,6 +50,7 @@ struct Params {
     const float* B; long b_sb, b_ld;             // B(k, n) at B[k * b_ld + n]
     float* C; long c_sb, c_ld;                   // C(m, n) at C[m * c_ld + n]
     int nb, M, N, K, mt, nt;
+    int total;                                   // workgroup ids to walk (tiles, rounded up to a multiple of 8)
 };
 
 template <int BM, bool ACC>
@@ -59,18 +62,22 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     // workgroup -> (batch, n-tile, m-tile).  Consecutive ids go round-robin to the 8 XCDs: XCD x takes the batches b = x (mod 8) and walks
     // their tiles in order, so that its L2 holds the images of the one or two batches it is working on (tiles of one batch spread over
     // all XCDs: every L2 holds all ~13 images in flight; measured 2 % slower)
-    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    // A workgroup walks the tiles id, id + gridDim, ... (gridDim a multiple of 8: all on one XCD): launched with one workgroup per tile
+    // it runs the body once; launched PERSISTENT (as many workgroups as fit the chip at once) the next tile's prologue is issued while
+    // the last tile's stores drain, and no slot waits for a workgroup to retire and another to be dispatched.
+    for (int id = blockIdx.x; id < p.total; id += gridDim.x) {
+    const int xcd = id & 7, j = id >> 3;
     int b, tn, sub;
     if (p.a_sb != 0) {
         const int per_b = p.nt * p.mt;
         b = (j / per_b) * 8 + xcd;
         const int r = j % per_b;
-        if (b >= p.nb) return;
+        if (b >= p.nb) continue;
         tn = r / p.mt; sub = r % p.mt;
     } else {   // ONE image for all batches: nothing ties a batch to an XCD; the m-tiles that read the same B tile stay neighbours on one L2
         sub = j % p.mt;
         const int rest = (j / p.mt) * 8 + xcd;
-        if (rest >= p.nb * p.nt) return;
+        if (rest >= p.nb * p.nt) continue;
         b = rest / p.nt; tn = rest % p.nt;
     }
     const int m0 = sub * BM, n0 = tn * BN, rb0 = sub * RB;
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
                     if (mw + dm < p.M && nw + jn * 32 < p.N) C[dm * ld + jn * 32] = acc[i][jn][e];
                 }
     }
+    }   // tiles of this workgroup
 }
 
 // A (M x K per batch, element (m, k) at A[b * a_sb + m * sm + k * sk]) -> the image.  Thread per 16-byte fragment slot; rows >= M and
@@ -274,7 +282,21 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
             return LGD_ELAUNCH;
         attr = true;
     }
-    const dim3 grid((unsigned)((image_shared ? ((long)nb * p.nt + 7) / 8 : (long)((nb + 7) / 8) * p.nt) * p.mt * 8)), block(lgd::NT);
+    p.total = (int)((image_shared ? ((long)nb * p.nt + 7) / 8 : (long)((nb + 7) / 8) * p.nt) * p.mt * 8);
+    // persistent launch: as many workgroups as are resident at once (2 per CU with the 256-row tile, 3 with the 128-row one); each walks
+    // tiles id, id + grid, ...  Measured equal to one workgroup per tile on every shape of tools/gemm3_probe.py (dispatch is not what
+    // the kernel waits for), so the default stays one workgroup per tile (the hardware balances edge tiles); LGD_GEMM3_PERSIST=1 selects it
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LGD_ELAUNCH;
+        cus = prop.multiProcessorCount;
+    }
+    const char* pe = getenv("LGD_GEMM3_PERSIST");
+    const int slots = (cus * (small ? 3 : 2)) & ~7;
+    const int gridn = (pe && pe[0] == '1') && p.total > slots ? slots : p.total;
+    const dim3 grid((unsigned)gridn), block(lgd::NT);
     hipStream_t st = (hipStream_t)stream;
     if (small && accumulate) { LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<128, true>), grid, block, lgd::Tile<128>::LDS_BYTES, st, p); }
     else if (small) { LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<128, false>), grid, block, lgd::Tile<128>::LDS_BYTES, st, p); }

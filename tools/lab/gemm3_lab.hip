@@ -246,7 +246,7 @@ struct Params {
 //  produced wrong tiles under load: hipcc may copy an asm load's destination register at the loop back-edge before the data lands
 //  (guide 5.7 item 1).  Not kept.)
 #ifndef ABL
-#define ABL 0     // lab ablations: 1 no staging in the loop, 2 no staging + no barriers, 3 no MFMA, 4 no epilogue stores
+#define ABL 0     // lab ablations: 1 no staging in the loop, 2 no staging + no barriers, 3 no MFMA, 4 no epilogue stores, 5 no split + ds_write of B, 6 no image DMA, 7 no B loads
 #endif
 __global__ __launch_bounds__(NT) void gemm3s_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -333,6 +333,59 @@ __global__ __launch_bounds__(NT) void gemm3s_kernel(const Params p) {
     if (ksteps > 1) load_b(1);
     __syncthreads();
     const int slot = lane * 16;
+#if ABL == 8 || ABL == 9
+    // variant: the DMA is issued first, the split of B(ks+1) sits INSIDE the MFMA phase (after the first 8 MFMAs; ABL 9: paired 1:1 with
+    // MFMAs by sched_group_barrier), its three LDS stores and the loads of B(ks+2) follow the last MFMA
+    for (int ks = 0; ks < ksteps; ++ks) {
+        char* cur = lds + (ks & 1) * BUF;
+        char* nxt = lds + ((ks + 1) & 1) * BUF;
+        // one basic block per k-step (nothing conditional: past the end the DMA and the loads repeat the last k-step into the unused buffer),
+        // so that the scheduler may place the split's VALU work between the MFMAs
+        const int k1 = ks + 1 < ksteps ? ks + 1 : ksteps - 1, k2 = ks + 2 < ksteps ? ks + 2 : ksteps - 1;
+        dma_a(k1, nxt);
+        bf16x8 fb[3][2];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+                fb[pc][jn] = *reinterpret_cast<const bf16x8*>(cur + A_BYTES + pc * 4096 + (wn * 2 + jn) * 1024 + slot);
+        uint32_t sh[4], sm[4], sl[4];
+#pragma unroll
+        for (int pa = 2; pa >= 0; --pa) {
+            bf16x8 fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(cur + pa * 8192 + (wm * 4 + i) * 1024 + slot);
+#pragma unroll
+            for (int pb = 2 - pa; pb >= 0; --pb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[pb][jn], acc[i][jn], 0, 0, 0);
+            if (pa == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(bv[2 * e], bv[2 * e + 1], sh[e], sm[e], sl[e]);
+            }
+        }
+#if ABL == 9
+        // 48 MFMAs, ~40 VALU: one VALU behind each MFMA
+#pragma unroll
+        for (int q = 0; q < 40; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+#endif
+        {
+            char* d = nxt + bslot;
+            *reinterpret_cast<u32x4*>(d) = (u32x4){sh[0], sh[1], sh[2], sh[3]};
+            *reinterpret_cast<u32x4*>(d + 4096) = (u32x4){sm[0], sm[1], sm[2], sm[3]};
+            *reinterpret_cast<u32x4*>(d + 8192) = (u32x4){sl[0], sl[1], sl[2], sl[3]};
+            load_b(k2);
+        }
+        __syncthreads();
+    }
+#else
     for (int ks = 0; ks < ksteps; ++ks) {
         char* cur = lds + (ks & 1) * BUF;
         char* nxt = lds + ((ks + 1) & 1) * BUF;
@@ -340,9 +393,17 @@ __global__ __launch_bounds__(NT) void gemm3s_kernel(const Params p) {
         if (ks + 1 < ksteps) {
             // order matters to hipcc's wait insertion: the use of bv (loaded a whole k-step ago) comes BEFORE the LDS-DMA is issued --
             // with a DMA in flight the compiler waits vmcnt(0) at the next use of an ordinary load's result, which would expose the DMA
+#if ABL != 5
             store_b(nxt);
+#endif
+#if ABL != 6
             dma_a(ks + 1, nxt);
+#endif
+#if ABL != 7
             if (ks + 2 < ksteps) load_b(ks + 2);
+#else
+            asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]));
+#endif
         }
 #endif
         bf16x8 fb[3][2];
@@ -376,6 +437,7 @@ __global__ __launch_bounds__(NT) void gemm3s_kernel(const Params p) {
         __syncthreads();
 #endif
     }
+#endif
     const int g = lane >> 5, rr = lane & 31;
     const int mw = m0 + wm * 128 + 4 * g, nw = n0 + wn * 64 + rr;
     float* C = p.C + (long)b * p.c_sb + (long)mw * p.c_ld + nw;
