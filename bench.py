@@ -86,6 +86,7 @@ def parse():
                     help="per-image short side drawn from INPUT.MIN_SIZE_TRAIN (640..800, max 1333: BASELINE config 5, "
                          "configs/Base-RetinaNet.yaml:26) instead of every image at --height x --width")
     ap.add_argument("--library-gemms", action="store_true", help="the Winograd channel products on the library's fp32 GEMM instead of csrc/gemm3.hip (A/B runs)")
+    ap.add_argument("--no-teacher-fold", action="store_true", help="DynamicTeacher: rendering's + ctx / ReLU and the refinement GroupNorm(1) + ReLU pairs as their own passes instead of inside the next convolution's input transform (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
     ap.add_argument("--no-gn-bwd-fold", action="store_true", help="FCOS towers: the GroupNorm backward as its own statistics + apply passes instead of inside the producing convolution's adjoint output transform (A/B runs)")
@@ -242,6 +243,8 @@ def main():
     torch.manual_seed(0)
     model = build_model(cfg)
     model.fused_head_pass = args.head_passes == 1
+    if args.no_teacher_fold:
+        model.teacher.fold_activations = False
     if args.no_fcos_fused_loss and hasattr(model.student, "fused_reg_loss"):
         model.student.fused_reg_loss = False
     if args.no_gn_fold and hasattr(model.student.head, "fold_group_norm"):

@@ -102,56 +102,66 @@ __global__ __launch_bounds__(256) void gg_stats_kernel(GgArgs a) {
     if (lane == 0) { a.ws[2 * (size_t)w] = s0; a.ws[2 * (size_t)w + 1] = s1; }
 }
 
-// one workgroup (one wave) per (level, sample, group): its C/G planes x cpp chunks are contiguous in ws
+// one workgroup per (level, sample, group): its C/G planes x cpp chunks are contiguous in ws.  A THREAD owns a channel plane (its cpp
+// chunk partials summed in order: the plane sums the backward emits), the planes are combined by a fixed-order wave / workgroup
+// reduction, and every thread writes its own channel's folded coefficients.  (Round 3's form -- one wave walking the group's planes
+// one after the other, a wave-wide fp64 reduction per plane -- took 155 us for GroupNorm(1)'s 256-plane groups against 6 us for
+// GroupNorm(32)'s 8-plane ones; this one serves both.)
 template <int MODE>
-__global__ __launch_bounds__(64) void gg_finalize_kernel(GgArgs a) {
+__global__ __launch_bounds__(256) void gg_finalize_kernel(GgArgs a) {
+    __shared__ double red[4][2];
+    __shared__ float bc[2];
     const int seg = blockIdx.x, g = seg % a.G, lb = seg / a.G, l = lb / a.B, b = lb % a.B;
     const int cg = a.C / a.G, cpp = a.cpp[l];
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const double n = (double)cg * (double)a.HW[l];
     double t0 = 0, t1 = 0;
-    for (int j = 0; j < cg; ++j) {
+    for (int j = t; j < cg; j += 256) {
         const int c = g * cg + j, plane = b * a.C + c;
         const double* p = a.ws + 2 * ((size_t)a.wave0[l] + (size_t)plane * cpp);
         double s0 = 0, s1 = 0;
-        for (int k = lane; k < cpp; k += 64) { s0 += p[2 * k]; s1 += p[2 * k + 1]; }
-        s0 = wave_sum(s0); s1 = wave_sum(s1);
+        for (int k = 0; k < cpp; ++k) { s0 += p[2 * k]; s1 += p[2 * k + 1]; }
         if (MODE == 0) { t0 += s0; t1 += s1; }
         else {
             const double ga = a.gamma ? (double)a.gamma[c] : 1.0;
             t0 += ga * s0; t1 += ga * s1;
-            if (lane == 0) {
-                a.plane_sums[2 * ((size_t)l * a.B * a.C + plane)] = (float)s0;
-                a.plane_sums[2 * ((size_t)l * a.B * a.C + plane) + 1] = (float)s1;
-            }
+            a.plane_sums[2 * ((size_t)l * a.B * a.C + plane)] = (float)s0;
+            a.plane_sums[2 * ((size_t)l * a.B * a.C + plane) + 1] = (float)s1;
         }
     }
-    if (lane == 0) {
+    t0 = wave_sum(t0); t1 = wave_sum(t1);
+    if (lane == 0) { red[wv][0] = t0; red[wv][1] = t1; }
+    __syncthreads();
+    if (t == 0) {
+        const double u0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]), u1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
         if (MODE == 0) {
-            const double m = t0 / n, var = fmax(t1 / n - m * m, 0.0);
-            const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)kGgEps));
-            a.stats[2 * seg] = mf;
-            a.stats[2 * seg + 1] = rf;
-            if (a.affine) {   // y = gamma * (x - mean) * rstd + beta as x * scale + shift: what the next convolution's input transform applies
-                for (int j = 0; j < cg; ++j) {
-                    const int c = g * cg + j;
-                    const float sc = rf * (a.gamma ? a.gamma[c] : 1.f);
-                    a.affine[2 * ((size_t)lb * a.C + c)] = sc;
-                    a.affine[2 * ((size_t)lb * a.C + c) + 1] = (a.beta ? a.beta[c] : 0.f) - mf * sc;
-                }
-            }
+            const double m = u0 / n, var = fmax(u1 / n - m * m, 0.0);
+            bc[0] = (float)m; bc[1] = (float)(1.0 / sqrt(var + (double)kGgEps));
+            a.stats[2 * seg] = bc[0];
+            a.stats[2 * seg + 1] = bc[1];
         } else {
-            const float m1 = (float)(t0 / n), m2 = (float)(t1 / n);
-            a.bstats[2 * seg] = m1;
-            a.bstats[2 * seg + 1] = m2;
-            if (a.coef) {
-                const float mu = a.stats[2 * seg], r = a.stats[2 * seg + 1];
-                for (int j = 0; j < cg; ++j) {
-                    const int c = g * cg + j;
-                    float* k = a.coef + 4 * ((size_t)lb * a.C + c);
-                    k[0] = r * (a.gamma ? a.gamma[c] : 1.f); k[1] = r * m1; k[2] = mu; k[3] = r * r * m2;
-                }
-            }
+            bc[0] = (float)(u0 / n); bc[1] = (float)(u1 / n);
+            a.bstats[2 * seg] = bc[0];
+            a.bstats[2 * seg + 1] = bc[1];
+        }
+    }
+    __syncthreads();
+    if (MODE == 0 && a.affine) {   // y = gamma * (x - mean) * rstd + beta as x * scale + shift: what the next convolution's input transform applies
+        const float mf = bc[0], rf = bc[1];
+        for (int j = t; j < cg; j += 256) {
+            const int c = g * cg + j;
+            const float sc = rf * (a.gamma ? a.gamma[c] : 1.f);
+            a.affine[2 * ((size_t)lb * a.C + c)] = sc;
+            a.affine[2 * ((size_t)lb * a.C + c) + 1] = (a.beta ? a.beta[c] : 0.f) - mf * sc;
+        }
+    }
+    if (MODE == 1 && a.coef) {
+        const float m1 = bc[0], m2 = bc[1];
+        const float mu = a.stats[2 * seg], r = a.stats[2 * seg + 1];
+        for (int j = t; j < cg; j += 256) {
+            const int c = g * cg + j;
+            float* k = a.coef + 4 * ((size_t)lb * a.C + c);
+            k[0] = r * (a.gamma ? a.gamma[c] : 1.f); k[1] = r * m1; k[2] = mu; k[3] = r * r * m2;
         }
     }
 }
@@ -248,7 +258,7 @@ int lgd_gn_group_fwd(const float* const* x_host, const int32_t* level_hw_host, i
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((a.nwaves + 3) / 4);
     LGD_LAUNCH("gn_group_stats_kernel", lgd::gg_stats_kernel<0>, grid, dim3(256), 0, s, a);
-    LGD_LAUNCH("gn_group_finalize_kernel", lgd::gg_finalize_kernel<0>, dim3(L * B * G), dim3(64), 0, s, a);
+    LGD_LAUNCH("gn_group_finalize_kernel", lgd::gg_finalize_kernel<0>, dim3(L * B * G), dim3(256), 0, s, a);
     LGD_LAUNCH("gn_group_apply_kernel", lgd::gg_apply_kernel<0>, grid, dim3(256), 0, s, a);
     return lgd::check_launch();
 }
@@ -260,7 +270,7 @@ int lgd_gn_group_stats_affine(const float* const* x_host, const int32_t* level_h
     a.gamma = gamma; a.beta = beta; a.ws = ws; a.stats = stats; a.affine = affine;
     hipStream_t s = (hipStream_t)stream;
     LGD_LAUNCH("gn_group_stats_kernel", lgd::gg_stats_kernel<0>, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
-    LGD_LAUNCH("gn_group_finalize_kernel", lgd::gg_finalize_kernel<0>, dim3(L * B * G), dim3(64), 0, s, a);
+    LGD_LAUNCH("gn_group_finalize_kernel", lgd::gg_finalize_kernel<0>, dim3(L * B * G), dim3(256), 0, s, a);
     return lgd::check_launch();
 }
 
@@ -279,7 +289,7 @@ int lgd_gn_group_bwd(const float* const* x_host, const float* const* dy_host, co
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((a.nwaves + 3) / 4);
     LGD_LAUNCH("gn_group_bwd_stats_kernel", lgd::gg_stats_kernel<1>, grid, dim3(256), 0, s, a);
-    LGD_LAUNCH("gn_group_bwd_finalize_kernel", lgd::gg_finalize_kernel<1>, dim3(L * B * G), dim3(64), 0, s, a);
+    LGD_LAUNCH("gn_group_bwd_finalize_kernel", lgd::gg_finalize_kernel<1>, dim3(L * B * G), dim3(256), 0, s, a);
     LGD_LAUNCH("gn_group_bwd_apply_kernel", lgd::gg_apply_kernel<1>, grid, dim3(256), 0, s, a);
     return lgd::check_launch();
 }
@@ -297,7 +307,7 @@ int lgd_gn_group_bwd_coef(const float* const* x_host, const float* const* dy_hos
     a.gamma = gamma; a.ws = ws; a.stats = const_cast<float*>(stats); a.bstats = bstats; a.plane_sums = plane_sums; a.coef = coef;
     hipStream_t s = (hipStream_t)stream;
     LGD_LAUNCH("gn_group_bwd_stats_kernel", lgd::gg_stats_kernel<1>, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
-    LGD_LAUNCH("gn_group_bwd_finalize_kernel", lgd::gg_finalize_kernel<1>, dim3(L * B * G), dim3(64), 0, s, a);
+    LGD_LAUNCH("gn_group_bwd_finalize_kernel", lgd::gg_finalize_kernel<1>, dim3(L * B * G), dim3(256), 0, s, a);
     return lgd::check_launch();
 }
 

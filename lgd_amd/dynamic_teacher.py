@@ -181,9 +181,16 @@ class DynamicTeacher(nn.Module):
         self.nr_transformer_heads = d.TEACHER.NR_TRANSFORMER_HEADS
         self.multi_head_attn = nn.MultiheadAttention(C, self.nr_transformer_heads)
 
+    # rendering's "+ ctx, ReLU" and the GroupNorm(1) + ReLU pairs of the refinement module run INSIDE the next convolution's input transform
+    # (ops.ctx_shift_fold / ops.conv3x3_gn -> the `pre` affine of the Winograd input transform, its adjoint applies the activation bits):
+    # the activated / normalised maps are never written or re-read -- 2 + 2 x 2 map transfers forward, 3 + 2 x 3 backward per level.
+    # False: every activation as its own pass (ops.bias_ctx_relu, ops.gn1), what the folded form is tested against.
+    fold_activations = True
+
     # -- a-8: per-box projected embeddings painted back through the box rectangles, conv, +ctx, ReLU
     def rendering(self, attn_out, geom):
-        """attn_out (L,T,C) -> list of L maps.  [ref: dynamic_teacher.py:106-190]
+        """attn_out (L,T,C) -> (list of L maps, pre): pre is None (the maps are final) or the affine whose ReLU(scale x + shift) the next
+        convolution applies while it loads.  [ref: dynamic_teacher.py:106-190]
         The context row of every image is projected too (one GEMM for all rows) but never painted."""
         proj = ops.linear(attn_out, self.local_inst_proj_1D.weight, self.local_inst_proj_1D.bias)
         painted = ops.render_paint(geom, proj, skip_last=self.add_context_box)
@@ -191,14 +198,22 @@ class DynamicTeacher(nn.Module):
         if self.add_context_box:
             last = hip.to_device([o - 1 for o in _offsets(geom.counts)[1:]], torch.int64, attn_out.device)
             ctx = ops.linear(attn_out[:, last], self.global_ctx_proj_1D.weight, self.global_ctx_proj_1D.bias)  # (L,B,C)
-            return ops.bias_ctx_relu(conv.levels(painted), ctx)
-        return conv.levels(painted, relu=True)
+            if self.fold_activations:
+                pre, maps = ops.ctx_shift_fold(conv.levels(painted), ctx)
+                return maps, pre
+            return ops.bias_ctx_relu(conv.levels(painted), ctx), None
+        return conv.levels(painted, relu=True), None
 
-    def refine(self, xs):
-        """[ref: dynamic_teacher.py:67-73,280-281] on all levels: one Winograd conv over all levels, GN(1)[+ReLU] in one HIP call."""
+    def refine(self, xs, pre=None):
+        """[ref: dynamic_teacher.py:67-73,280-281] on all levels: conv -> GN(1) -> ReLU -> conv -> GN(1) -> ReLU -> conv -> GN(1); each
+        convolution one Winograd pass over the concatenated levels."""
         m = self.refinement_module
+        if self.fold_activations:
+            (a0, r0), = ops.conv3x3_gn(xs, [(m[0].weight, m[0].bias, None, None)], 1, pre=pre)
+            (a1, r1), = ops.conv3x3_gn(r0, [(m[3].weight, m[3].bias, None, None)], 1, pre=a0)
+            return ops.gn1(m[6].levels(r1, pre=a1), relu=False)   # the last GroupNorm has no ReLU behind it and its output IS the teacher feature
         for idx, relu in ((0, True), (3, True), (6, False)):
-            xs = ops.gn1(m[idx].levels(xs), relu=relu)
+            xs = ops.gn1(m[idx].levels(xs, pre=pre if idx == 0 else None), relu=relu)
         return xs
 
     def interactive_remapping(self, label_embed, boxes, counts, feats, img_size_dict):
@@ -224,7 +239,7 @@ class DynamicTeacher(nn.Module):
         else:  # labelGuided: Q = label embeddings, K = V = appearance
             att = ops.mha_blockdiag(canoni.unsqueeze(0), app, counts, a.in_proj_weight, a.in_proj_bias,
                                     a.out_proj.weight, a.out_proj.bias, self.nr_transformer_heads, geom.img_off)
-        tea = dict(zip(keys, self.refine(self.rendering(att, geom))))
+        tea = dict(zip(keys, self.refine(*self.rendering(att, geom))))
         return tea, geom
 
     def forward(self, info_list):

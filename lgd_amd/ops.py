@@ -439,6 +439,51 @@ def bias_ctx_relu(xs, ctx):
     return list(_CtxRelu.apply(ctx, *xs))
 
 
+class _CtxShiftFold(torch.autograd.Function):
+    """ReLU(x_l + ctx[l][:, :, None, None]) [ref: dynamic_teacher.py:151] handed to the NEXT 3x3 convolution as a per-(map, sample, channel)
+    scale 1 / shift ctx that its input transform applies while it loads (the `pre` affine of conv3x3_levels / conv3x3_gn): the activated maps
+    are neither written nor re-read.  That convolution returns, for its input maps, the gradient w.r.t. the affine OUTPUT with the ReLU
+    mask applied -- which for scale 1 is the gradient of x itself, and whose per-plane sum is the gradient of ctx."""
+
+    @staticmethod
+    def forward(ctx, cvec, *xs):
+        L = len(xs)
+        B, C, hw = _levels_meta(xs)
+        if tuple(cvec.shape) != (L, B, C):
+            raise hip.LgdHipError("ctx must be (L,B,C)=(%d,%d,%d), got %s" % (L, B, C, tuple(cvec.shape)))
+        aff = torch.stack((torch.ones_like(cvec), cvec), -1).view(L * B, C, 2)
+        ctx.mark_non_differentiable(aff)
+        ctx.meta = (L, B, C, hw)
+        return (aff, *[x.view_as(x) for x in xs])
+
+    @staticmethod
+    def backward(ctx, _daff, *dxs):
+        if not ctx.needs_input_grad[0]:
+            return (None, *dxs)
+        # d ctx[l, b, c] = the plane sum of the gradient: per-plane means in ONE pass over all levels (the GroupNorm statistics kernel with one
+        # group per channel, fp64 partials) times the plane sizes
+        lib = hip.load()
+        L, B, C, hw = ctx.meta
+        gs = [hip.dense_f32(d) for d in dxs]
+        dev = gs[0].device
+        ws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)
+        stats = torch.empty((L * B * C, 2), dtype=torch.float32, device=dev)
+        aff = torch.empty((L * B, C, 2), dtype=torch.float32, device=dev)
+        _count_bytes("gn_group_stats_kernel", 4 * sum(g.numel() for g in gs))
+        hip.check(lib.lgd_gn_group_stats_affine(hip.ptr_array(gs), hw, L, B, C, C, None, None, hip.ptr(ws), hip.ptr(stats), hip.ptr(aff),
+                                                hip.stream_ptr()), "lgd_gn_group_stats_affine")
+        sizes = hip.to_device([float(g.shape[2] * g.shape[3]) for g in gs], torch.float32, dev)
+        dctx = stats[:, 0].view(L, B, C) * sizes.view(L, 1, 1)
+        return (dctx, *dxs)
+
+
+def ctx_shift_fold(xs, cvec):
+    """(affine, maps): ReLU(x_l + ctx[l]) to be applied by the next convolution -- conv3x3_levels(maps, w, b, pre=affine) /
+    conv3x3_gn(maps, filters, groups, pre=affine).  cvec (L,B,C)."""
+    out = _CtxShiftFold.apply(cvec, *xs)
+    return out[0], list(out[1:])
+
+
 def _gemm(A, sa, B, sb, C, sc, M, N, K, bias=None, alpha=1.0, rowsum=None):
     """one lgd_gemm_problem: C[m,n] = alpha*(sum_k A(m,k)B(n,k) + bias[n]); strides in elements; A/B/C are (tensor, offset)."""
     def addr(t):

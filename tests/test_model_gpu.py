@@ -974,7 +974,8 @@ def _run_product_capturing_masks(name, coef):
     from lgd_amd.structures import ImageList
     B, H, W, ctx, interact, fmt, _, _ = cm.CASES[name]
     rec = {"ln": [], "proj": None, "render": None, "gn": [], "adapter": []}
-    real = {k: getattr(ops, k) for k in ("row_ln", "gn_relu_mask_pool", "bias_ctx_relu", "gn1", "conv3x3_chain", "conv3x3_levels")}
+    real = {k: getattr(ops, k) for k in ("row_ln", "gn_relu_mask_pool", "bias_ctx_relu", "gn1", "conv3x3_chain", "conv3x3_levels", "ctx_shift_fold",
+                                         "conv3x3_gn")}
     on = lambda ys: [(y.detach() > 0).cpu() for y in ys]  # noqa: E731
 
     def row_ln(x, relu):
@@ -999,6 +1000,26 @@ def _run_product_capturing_masks(name, coef):
             rec["gn"].append(on(ys))
         return ys
 
+    # the folded activations (DynamicTeacher.fold_activations): the next convolution's input transform applies relu(fma(x, scale, shift)) with
+    # the raw maps x and the per-(map, sample, channel) affine these calls return; the sign of an fp32 fma is the sign of the exact value,
+    # which fp64 holds (the product of two floats is exact)
+    def folded(aff, xs):
+        n = xs[0].shape[0]
+        a64 = aff.double()
+        return [((x.detach().double() * a64[lv * n:(lv + 1) * n, :, 0, None, None] + a64[lv * n:(lv + 1) * n, :, 1, None, None]) > 0).cpu()
+                for lv, x in enumerate(xs)]
+
+    def ctx_shift_fold(xs, c):
+        aff, ys = real["ctx_shift_fold"](xs, c)
+        rec["render"] = folded(aff, ys)
+        return aff, ys
+
+    def conv_gn(xs, *a, **k):
+        out = real["conv3x3_gn"](xs, *a, **k)
+        for aff, ys in out:
+            rec["gn"].append(folded(aff, ys))
+        return out
+
     def levels(xs, w, b=None, relu=False, **kw):
         ys = real["conv3x3_levels"](xs, w, b, relu, **kw)
         if relu:   # the rendering conv of the configurations without a context box
@@ -1019,7 +1040,7 @@ def _run_product_capturing_masks(name, coef):
             self.adapter = torch.nn.ModuleDict({"distill": SequentialConvs(None)})
     prev = ops.conv3x3_backend(winograd=True, min_tiles=0)
     patched = {"row_ln": row_ln, "gn_relu_mask_pool": pool, "bias_ctx_relu": ctx_relu, "gn1": gn1, "conv3x3_chain": chain,
-               "conv3x3_levels": levels}
+               "conv3x3_levels": levels, "ctx_shift_fold": ctx_shift_fold, "conv3x3_gn": conv_gn}
     try:
         for k, f in patched.items():
             setattr(ops, k, f)
