@@ -33,7 +33,7 @@ fi
 if [[ $what == all || $what == profile ]]; then
   (cd /tmp && export TMPDIR=/tmp
    for n in 5 25; do rm -rf /tmp/prof_$n
-     timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$n -- python $R/bench.py --steps $n --warmup 3 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+     timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$n -- python $R/bench.py --steps $n --warmup 3 --no-cpu-baseline --no-kernel-timing --no-host-pass > /dev/null 2>&1
      cp $(ls /tmp/prof_$n/*/*kernel_stats.csv | head -1) $R/$O/kernel_stats_steps$n.csv
    done)
   python tools/prof_diff.py $O/kernel_stats_steps5.csv $O/kernel_stats_steps25.csv 20 $O/bench_rocprofv3_steady_state.csv

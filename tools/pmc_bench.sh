@@ -11,5 +11,5 @@ done
 F=$(ls /tmp/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1)
 W=$(ls /tmp/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
 mkdir -p $R/gpurun_out
-python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r03_bench_pmc_fetch_write.csv $R/gpurun_out/r03_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing --no-host-pass (BASELINE configs[1], B=8 800x1333; round 3 launch mix: F(6x6,3x3))"
-cat $R/gpurun_out/r03_bench_pmc_fetch_write.csv
+python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r04_bench_pmc_fetch_write.csv $R/gpurun_out/r04_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing --no-host-pass (BASELINE configs[1], B=8 800x1333; round 4 launch mix: F(6x6,3x3), channel products on gemm3.hip)"
+cat $R/gpurun_out/r04_bench_pmc_fetch_write.csv

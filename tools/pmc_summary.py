@@ -20,8 +20,10 @@ def load(path, counter):
             name = r["Kernel_Name"]
             if "lgd::" not in name:
                 continue
-            name = re.sub(r"^void ", "", name)
+            name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
             name = re.sub(r"\(.*$", "", name)
+            name = re.sub(r"^gemm3_kernel<.*", "gemm3_kernel", name.replace("lgd::", ""))
+            name = name if name.startswith("lgd::") else "lgd::" + name
             acc[name][0] += 1
             acc[name][1] += float(r["Counter_Value"])
     return acc
