@@ -354,13 +354,13 @@ def main():
         roofline = roofline_mfma = None
         if dom:
             traffic = None
-            tf = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+            tf = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
             if os.path.exists(tf) and is_cfg1:  # the counters were collected on configs[1]
                 traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
             k = kernels[dom]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
-                        "traffic_source": "static profile: profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                        "traffic_source": "static profile: profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                           "over this command, not re-measured in this run)" if traffic is not None else None,
                         "alg_bytes_per_launch": alg[dom], "avg_launch_us": k["avg_us"], "min_launch_us": k["min_us"],
                         "max_launch_us": k["max_us"],
