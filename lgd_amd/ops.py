@@ -2203,6 +2203,9 @@ def _timed_gemm3(name, a, b, out=None, accumulate=False):
     fn = (lambda: gemm3_image_bmm(a, b, out)) if isinstance(a, _FilterImage) else (lambda: gemm3_bmm(a, b, out, accumulate))
     if not _TIMER_ON:
         return fn()
+    nb_, M_, K_ = a.shape
+    # algorithmic bytes of the product: B read once, C written once (read as well when accumulating), the filter image once per batch
+    _count_bytes("gemm3_kernel", 4 * nb_ * b.shape[2] * (K_ + M_ * (2 if accumulate else 1)) + 6 * M_ * K_ * (1 if not isinstance(a, _FilterImage) and a.stride(0) == 0 else nb_))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
