@@ -395,12 +395,29 @@ class _GroupNormFold(torch.autograd.Function):
         return (None, dw, db, *dxs)
 
 
+def _tag_folded(affine, maps):
+    """the raw maps of a folded activation are only meaningful together with their affine: their autograd gradient is the gradient w.r.t.
+    the activation's OUTPUT, which only a convolution called with pre=affine returns.  The tag lets this library's consumers refuse a
+    mismatch; a foreign consumer (a hook, an auxiliary loss on tower features) must apply the affine itself."""
+    for m in maps:
+        m._lgd_needs_pre = affine
+    return affine, maps
+
+
+def _check_pre(xs, pre):
+    for x in xs:
+        need = getattr(x, "_lgd_needs_pre", None)
+        if need is not None and need is not pre:
+            raise hip.LgdHipError("these maps are the RAW outputs of a folded activation (group_norm_fold / conv3x3_gn / ctx_shift_fold): pass the "
+                                  "affine returned with them as pre=")
+
+
 def group_norm_fold(xs, groups, weight=None, bias=None):
     """GroupNorm(groups, C) + ReLU of a list of maps, to be applied by the NEXT 3x3 convolution's input transform: returns (affine, maps);
     pass both on: conv3x3_levels(maps, w, b, pre=affine) / conv3x3_shared_input(maps, filters, pre=affine)
     [ref: thirdparty_heads/fcos.py:455-470 tower layers conv -> GroupNorm(32) -> ReLU -> conv]."""
     out = _GroupNormFold.apply(int(groups), weight, bias, *xs)
-    return out[0], list(out[1:])
+    return _tag_folded(out[0], list(out[1:]))
 
 
 class _CtxRelu(torch.autograd.Function):
@@ -481,7 +498,7 @@ def ctx_shift_fold(xs, cvec):
     """(affine, maps): ReLU(x_l + ctx[l]) to be applied by the next convolution -- conv3x3_levels(maps, w, b, pre=affine) /
     conv3x3_gn(maps, filters, groups, pre=affine).  cvec (L,B,C)."""
     out = _CtxShiftFold.apply(cvec, *xs)
-    return out[0], list(out[1:])
+    return _tag_folded(out[0], list(out[1:]))
 
 
 def _gemm(A, sa, B, sb, C, sc, M, N, K, bias=None, alpha=1.0, rowsum=None):
@@ -904,8 +921,10 @@ class _FocalSumNorm(torch.autograd.Function):
         return loss * inv
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         lib = hip.load()
+        _consume_once(ctx, "focal_loss_sum")
         grads = list(ctx.saved_tensors)
         g = g.contiguous().to(torch.float32)
         hip.check(lib.lgd_scale_unless_one(hip.ptr_array(grads), ctx.sizes, len(grads), hip.ptr(g), hip.stream_ptr()), "lgd_scale_unless_one")
@@ -922,6 +941,16 @@ def focal_loss_sum(raw_logits, label_planes, A, K, alpha, gamma, normalizer=None
         return _FocalSumNorm.apply(int(A), int(K), float(alpha), float(gamma), len(raw_logits), normalizer, *raw_logits, *label_planes)
     out = _FocalSum.apply(int(A), int(K), float(alpha), float(gamma), len(raw_logits), *raw_logits, *label_planes)
     return out if normalizer is None else out / normalizer
+
+
+def _consume_once(ctx, what):
+    """the one-pass losses write their gradient buffers in the forward pass and rescale them IN PLACE by the upstream scalar: a second
+    backward over the same graph (retain_graph, a per-loss torch.autograd.grad) would scale them again and alias what the first one
+    returned -- refuse it instead of returning g^2-scaled gradients silently."""
+    if getattr(ctx, "_lgd_consumed", False):
+        raise RuntimeError("%s: its gradient buffers were consumed by a previous backward pass (they are written by the forward pass and "
+                           "scaled in place); run the forward again instead of backpropagating twice through the same graph" % what)
+    ctx._lgd_consumed = True
 
 
 class _FcosRegCtrLoss(torch.autograd.Function):
@@ -967,8 +996,10 @@ class _FcosRegCtrLoss(torch.autograd.Function):
         return out[0], out[1]
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_box, g_c):
         lib = hip.load()
+        _consume_once(ctx, "fcos_reg_ctr_loss")
         L = ctx.L
         out, *g = ctx.saved_tensors
         g_reg, g_ctr = list(g[:L]), list(g[L:])
@@ -1557,6 +1588,7 @@ def conv3x3_levels(xs, w, b=None, relu=False, scale=None, pre=None):
     bias of a bias + ReLU that precedes the convolution (the maps are its pre-activations), folded into the input transform on the
     Winograd path (see _Conv3x3K); elsewhere applied as its own pass."""
     xs = list(xs)
+    _check_pre(xs, pre)
     if _wino_ok(xs, w):
         return list(_Conv3x3.apply(w, b, bool(relu), _WINO_TILE, *xs, scale=scale, pre=pre))
     if pre is not None:
@@ -1586,6 +1618,7 @@ def conv3x3_shared_input(xs, filters, relu=False, pre=None):
     """several 3x3 / stride 1 / padding 1 filters [(w, b), ...] [+ ReLU] on the SAME list of maps: one input transform, one
     stacked GEMM, one adjoint input transform for the summed input gradient (see _Conv3x3K).  Returns one list of maps per filter."""
     xs = list(xs)
+    _check_pre(xs, pre)
     if len(filters) > 1 and all(_wino_ok(xs, w) for w, _ in filters):
         ys = _Conv3x3K.apply(len(filters), bool(relu), _WINO_TILE, None, pre, *[t for wb in filters for t in wb], *xs)
         return [list(ys[k * len(xs):(k + 1) * len(xs)]) for k in range(len(filters))]
@@ -1603,11 +1636,12 @@ def conv3x3_gn(xs, filters, groups, pre=None):
     ..., pre=affine).  One autograd node per call on the F(6x6,3x3) path (_Conv3x3GN: no GroupNorm apply pass in either direction);
     elsewhere conv3x3_levels / conv3x3_shared_input + group_norm_fold."""
     xs = list(xs)
+    _check_pre(xs, pre)
     L = len(xs)
     if _GN_FUSED_BWD and _WINO_TILE == 6 and all(_wino_ok(xs, f[0]) for f in filters):
         K = len(filters)
         out = _Conv3x3GN.apply(K, _WINO_TILE, int(groups), pre, *[t for f in filters for t in f], *xs)
-        return [(out[k], list(out[K + k * L:K + (k + 1) * L])) for k in range(K)]
+        return [_tag_folded(out[k], list(out[K + k * L:K + (k + 1) * L])) for k in range(K)]
     if len(filters) > 1:
         ys = conv3x3_shared_input(xs, [(f[0], f[1]) for f in filters], pre=pre)
     else:

@@ -28,6 +28,11 @@ class Scale(nn.Module):
         return x * self.scale
 
 
+class RawRegMaps(list):
+    """the head's bbox_pred maps BEFORE the per-level Scale / ReLU / stride epilogue (FCOSHead.forward(raw_reg=True)): FCOSCT.losses applies the
+    epilogue inside the fused loss kernel for these, and expects decoded distances for a plain list."""
+
+
 class FCOSHead(nn.Module):
     """towers of conv3x3 + GN(32) + ReLU; per-level Scale; ReLU(.)*stride regression
     [ref: thirdparty_heads/fcos.py:433-546]"""
@@ -94,7 +99,7 @@ class FCOSHead(nn.Module):
             regs = self.bbox_pred.levels(b, pre=pb)
             logits, ctr = ops.conv3x3_shared_input(c, [(self.cls_score.weight, self.cls_score.bias), (self.centerness.weight, self.centerness.bias)], pre=pc)
         if raw_reg:
-            return logits, list(regs), ctr
+            return logits, RawRegMaps(regs), ctr
         reg = []
         for i, r in enumerate(regs):
             lvl = i % nl
@@ -211,7 +216,9 @@ class FCOSCT(nn.Module):
         """[ref: thirdparty_heads/fcos.py:107-175] without boolean-index gathers / host syncs; the focal loss is the fused
         HIP kernel on the raw (N, K, H, W) logits."""
         fg = (gt_classes >= 0) & (gt_classes != self.num_classes)
-        if self.training and self.fused_reg_loss:   # pred_shift_deltas: the RAW bbox_pred maps (head(..., raw_reg=True))
+        # which representation the regression maps are in travels WITH them (RawRegMaps: the raw bbox_pred maps of head(..., raw_reg=True);
+        # a plain list: decoded distances, the reference's losses() contract) -- not re-derived from module state at a different time
+        if isinstance(pred_shift_deltas, RawRegMaps):
             gt_ctr = torch.where(fg, gt_centerness, torch.zeros_like(gt_centerness))
             counts = self.reduce_counts(torch.stack((fg.sum().to(torch.float32), gt_ctr.sum())))
             num_fg, num_targets = counts[0].clamp(min=1.0), counts[1].clamp(min=1.0)
@@ -255,7 +262,9 @@ class FCOSCT(nn.Module):
         shifts, (cls_a, delta_a, center_a), (cls_b, delta_b, center_b)."""
         L = len(feats_a)
         cls, reg, ctr = self.head(list(feats_a) + list(feats_b), raw_reg=self.training and self.fused_reg_loss)
-        return self.shift_generator(feats_a), (cls[:L], reg[:L], ctr[:L]), (cls[L:], reg[L:], ctr[L:])
+        raw = isinstance(reg, RawRegMaps)
+        ra, rb = (RawRegMaps(reg[:L]), RawRegMaps(reg[L:])) if raw else (reg[:L], reg[L:])
+        return self.shift_generator(feats_a), (cls[:L], ra, ctr[:L]), (cls[L:], rb, ctr[L:])
 
     def forward(self, batched_inputs):
         """[ref: customized_detectors/fcos.py:36-63]"""

@@ -259,6 +259,7 @@ class StepFolds:
     def __init__(self, model):
         self.model = model
         self._key = None
+        self._candidates = None
 
     def _build(self, mods):
         import numpy as np
@@ -290,8 +291,9 @@ class StepFolds:
     @torch.no_grad()
     def prepare(self):
         from .. import hip
-        mods = [m for m in self.model.modules()
-                if isinstance(m, ConvBN) and (m._pointwise or m._pointwise_s2) and m.weight.requires_grad and m.weight.is_cuda]
+        if self._candidates is None:   # the module tree does not change after construction: walk it once, not every step
+            self._candidates = [m for m in self.model.modules() if isinstance(m, ConvBN) and (m._pointwise or m._pointwise_s2)]
+        mods = [m for m in self._candidates if m.weight.requires_grad and m.weight.is_cuda]
         if not mods:
             return
         key = tuple((id(m), m.weight.data_ptr(), id(m.norm.scale_shift()[0])) for m in mods)
@@ -301,5 +303,10 @@ class StepFolds:
         lib = hip.load()
         hip.check(lib.lgd_scale_rows_multi(hip.ptr(self.tab), hip.ptr(self.blk0), len(self.mods), self.nblk, hip.stream_ptr()),
                   "lgd_scale_rows_multi")
+        # the views were rewritten behind autograd's back (a raw kernel on their storage): bump their version counters, so that a graph that
+        # saved LAST step's folds (gradient accumulation, an evaluation forward between step and backward) raises instead of running its
+        # backward with this step's filters
+        for v in self.views:
+            torch.autograd.graph.increment_version(v)
         for m, v, sc in zip(self.mods, self.views, self.scales):
             m._step_fold = ((m.weight._version, id(sc)), v)

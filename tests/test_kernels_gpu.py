@@ -434,6 +434,32 @@ def test_focal_loss_normalised_one_pass(N, A, K, level_hw, gamma, upstream):
         assert cm.rel_err(a.grad, b.grad) < 1e-6
 
 
+def test_one_pass_losses_refuse_a_second_backward():
+    """the one-pass focal loss writes the logits' gradient in its forward pass and rescales it in place by the upstream scalar: a second
+    backward over the same graph would scale it again (g^2) and alias what the first returned -- it raises instead."""
+    from lgd_amd import ops
+    level_hw = [(6, 8), (3, 4)]
+    labels = torch.from_numpy(np.random.default_rng(9).integers(-1, 5, size=(2, sum(h * w * 3 for h, w in level_hw))))
+    rg = [(torch.from_numpy(synth.det_uniform((2, 12, h, w), 730 + i)) * 4).to(DEV).requires_grad_(True) for i, (h, w) in enumerate(level_hw)]
+    loss = ops.focal_loss_sum(rg, ops.label_planes(labels.to(DEV), level_hw, 3), 3, 4, 0.25, 2.0, normalizer=torch.tensor(7.0, device=DEV))
+    (loss * 0.5).backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="consumed by a previous backward"):
+        (loss * 0.5).backward()
+
+
+def test_folded_maps_refuse_a_consumer_without_their_affine():
+    """the raw maps of a folded GroupNorm + ReLU carry their affine as a tag: this library's convolutions refuse them without pre=affine
+    (their autograd gradient is the gradient w.r.t. the activation OUTPUT, which only that call returns)."""
+    from lgd_amd import hip, ops
+    xs = [torch.from_numpy(synth.det_uniform((2, 16, h, w), 740 + i, -1.0, 1.0)).to(DEV).requires_grad_(True) for i, (h, w) in enumerate([(10, 12), (5, 6)])]
+    w = torch.from_numpy(synth.det_uniform((16, 16, 3, 3), 745, -0.1, 0.1)).to(DEV)
+    aff, maps = ops.group_norm_fold(xs, 4)
+    with pytest.raises(hip.LgdHipError, match="pass the affine"):
+        ops.conv3x3_levels(maps, w)
+    ys = ops.conv3x3_levels(maps, w, pre=aff)
+    assert len(ys) == 2 and all(torch.isfinite(y).all() for y in ys)
+
+
 def test_mlp_ladder_equals_layers():
     """ops.mlp_ln_relu (the label encoder's Linear -> LayerNorm -> ReLU ladders as ONE autograd node) issues the same launches as
     row_ln(linear(.)) layer by layer: outputs and every gradient bit-identical, with and without the last plain layer, incl. the wide
