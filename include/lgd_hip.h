@@ -363,13 +363,21 @@ int lgd_wino_in_t_out_t(const float* dV, const void* relu_bits, const int32_t* l
  *   B (K x N) and C (M x N) have their last axis contiguous: B[b * b_sb + k * b_sk + n], C[b * c_sb + m * c_sm + n]; B is split inside
  *   the product kernel while it is staged (each element once: a workgroup's tile spans 256 rows of A).
  *   image_shared: ONE image (split with nb = 1) serves every batch -- the student's 1x1 convolutions, W (C' x C) against a batch of
- *   (C x HW) maps [d2-memory: BottleneckBlock conv1 / conv3, FPN laterals; SURVEY.md appendix A].  accumulate: C += A B (the input
- *   gradient of a block's first 1x1 convolution lands on the shortcut's gradient).  Tiles of 256 x 128 (C' = 128: 128 x 128).
+ *   (C x HW) maps [d2-memory: BottleneckBlock conv1 / conv3, FPN laterals; SURVEY.md appendix A].  Tiles of 256 x 128 (C' = 128: 128 x 128).
+ *   Epilogue (each part optional, NULL / 0 = absent; runs on the 128-row tile): C = relu?(A B + R + shift[m]) -- R (M x N, R[b * r_sb + m * r_sm
+ *   + n]) the residual map, R == C with C's strides: C += A B (the input gradient of a block's first 1x1 convolution lands on the
+ *   shortcut's gradient); shift[m] the frozen affine's per-channel shift; relu_bits: the ReLU mask, bit n % 32 of word
+ *   (b * M + m) * ceil(N / 32) + n / 32 set <=> C(m, n) > 0 (lgd_relu_rowbits_words(nb * M, N) words; consumed by lgd_relu_rowbits_bwd)
+ *   [d2-memory: BottleneckBlock.forward -- out = conv3(out); out += shortcut; out = relu(out)].
  * Requirements (LGD_EINVAL otherwise; the host falls back to the library GEMM): K % 16 == 0, 16-byte aligned image. */
 size_t lgd_gemm3_image_bytes(int nb, int M, int K);
 int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_sk, int nb, int M, int K, void* image, void* stream);
 int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm,
-              int accumulate, int nb, int M, int N, int K, void* stream);
+              const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits, int nb, int M, int N, int K,
+              void* stream);
+/* dx = dy where the bit is set, for rows of HW elements with ceil(HW / 32) mask words each */
+size_t lgd_relu_rowbits_words(long long rows, int HW);
+int lgd_relu_rowbits_bwd(const uint32_t* relu_bits, const float* dy, long long rows, int HW, float* dx, void* stream);
 
 /* ------------------------------------------------------------------ FCOS ground-truth assignment
  * [ref: models/customized_detectors/thirdparty_heads/fcos.py:177-284  FCOS.get_ground_truth]

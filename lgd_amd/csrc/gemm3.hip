@@ -19,7 +19,10 @@
 // Tile 256 x 128 x 16, 256 threads (2 x 2 waves, 128 x 64 per wave = 4 x 2 MFMA blocks of 32 x 32, 128 accumulator registers), two
 // LDS buffers of 36 KB (A pieces 24 KB + B pieces 12 KB): one barrier per k-step, two workgroups per CU so that one's staging and
 // epilogue hide under the other's MFMAs.  A 128-row variant of the same kernel serves C' = 128 layers.  The image may be shared by all
-// batches (the student's 1x1 convolutions: one filter, a batch of images) and the result may be accumulated onto C.
+// batches (the student's 1x1 convolutions: one filter, a batch of images).  The 128-row kernel also carries the bottleneck blocks'
+// epilogue: C = relu?(A B + R + shift[m]) with the accumulators INITIALISED from the residual map R and the per-row shift (R = C: the
+// accumulating form C += A B), the ReLU applied on the way out and its 1-bit mask written from wave ballots (one word per 32 columns of
+// a row) -- the pre-activation map is neither written nor re-read by a bias / residual / ReLU pass.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -34,6 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef lgd_u32x4 u32x4;
 
 constexpr int BN = 128, BK = 16, NT = 256;
+
 // tile rows BM = 256 (4 x 2 MFMA blocks per wave, 2 workgroups per CU) or 128 (2 x 2 blocks, 64 accumulator registers, 3 workgroups per
 // CU: C' = 128 layers, whose 256-row tile would idle half of every MFMA)
 template <int BM> struct Tile {
@@ -51,9 +55,15 @@ struct Params {
     float* C; long c_sb, c_ld;                   // C(m, n) at C[m * c_ld + n]
     int nb, M, N, K, mt, nt;
     int total;                                   // workgroup ids to walk (tiles, rounded up to a multiple of 8)
+    // EPI kernels: C = relu?(A B + R + shift[m]); R (may be C itself), shift and bits may each be NULL
+    const float* R; long r_sb, r_ld, r_bytes;    // r_bytes: extent of R from its first element (the buffer descriptor's range)
+    const float* shift;
+    uint32_t* bits; int wpr;                     // ReLU mask: bit n % 32 of word (b * M + m) * wpr + n / 32 = (C(m, n) > 0)
+    int relu;
 };
 
-template <int BM, bool ACC>
+// EPI: 0 the plain product; otherwise the epilogue kernel with bit 0: R present, bit 1: shift present
+template <int BM, int EPI>
 __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     typedef Tile<BM> TL;
     constexpr int A_BYTES = TL::A_BYTES, BUF = TL::BUF, MI = TL::MI, RB = TL::RB, CH = TL::CHUNKS;
@@ -125,30 +135,43 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) LGD_GLDS16(Ak + aoff[c], buf + (w * CH + c) * 1024);
     };
-    // the accumulators start from zero, or (ACC: C += A B) from C itself: the MFMA chain adds the product on top and the epilogue is the
-    // plain store (an epilogue that re-reads C needs the 128 accumulators in VGPRs at once: one resident workgroup instead of two)
+    // the accumulators start from zero, or (EPI) from R + shift: the MFMA chain adds the product on top and the epilogue is the plain
+    // store (an epilogue that re-reads a map needs the 128 accumulators in VGPRs at once: one resident workgroup instead of two)
     const int g = lane >> 5, rr = lane & 31;
     const int mw = m0 + wm * (BM / 2) + 4 * g, nw = n0 + wn * 64 + rr;
-    float* C = p.C + (long)b * p.c_sb + (long)mw * p.c_ld + nw;
     const int ld = (int)p.c_ld;
+    const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
     f32x16 acc[MI][2];
-    if constexpr (ACC) {
-        const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
+    if constexpr (EPI != 0) {
+        // R by BUFFER loads straight into the accumulator registers, all of a lane's loads in flight at once: one per-lane 32-bit offset
+        // for the whole tile + a scalar offset per row (global loads took a 64-bit address pair per row: 32 VGPRs, the third resident
+        // workgroup), and the range check of the descriptor stands in for every branch -- rows past M and columns past N read other
+        // elements of the map or, past its end, zeros: values that only reach elements never stored.  The shift is added on the way out.
+        const int wrow = m0 + wm * (BM / 2), wcol = n0 + wn * 64;
+        const int rld = (int)p.r_ld;
+        __amdgpu_buffer_rsrc_t rr_src;
+        if constexpr ((EPI & 1) != 0) {
+            const long o = ((long)b * p.r_sb + (long)wrow * rld + wcol) * 4;
+            const long left = p.r_bytes - o;
+            rr_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)p.R + o), 0, (uint32_t)(left < 0 ? 0 : left > 0xffffffffL ? 0xffffffffL : left), 0x00020000);
+        }
+        // the row offset runs in ONE register (+ 1 or + 5 rows per step): as scalar offsets the compiler precomputes all 128 at kernel entry,
+        // spills them into VGPR lanes and pays v_readlane + s_nop 4 in front of every load
+        int ro = (4 * g * rld + rr) * 4;
+        const int r1 = rld * 4, r5 = rld * 20;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn) {
-                if (full) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][jn][e] = C[(i * 32 + (e & 3) + 8 * (e >> 2)) * ld + jn * 32];
+            for (int e = 0; e < 16; ++e) {
+                if constexpr ((EPI & 1) != 0) {
+                    acc[i][0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_src, ro, 0, 0));
+                    acc[i][1][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_src, ro + 128, 0, 0));
+                    ro += (e & 3) == 3 ? r5 : r1;
+                    asm volatile("" : "+v"(ro));
                 } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
-                        acc[i][jn][e] = (mw + dm < p.M && nw + jn * 32 < p.N) ? C[dm * ld + jn * 32] : 0.f;
-                    }
+                    acc[i][0][e] = 0.f;
+                    acc[i][1][e] = 0.f;
                 }
-                asm volatile("" : "+a"(acc[i][jn]) :: "memory");   // one 32 x 32 block of loads in flight at a time (16 VGPRs, not 128)
             }
     } else {
 #pragma unroll
@@ -201,24 +224,72 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
         __syncthreads();
     }
     // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); 32-bit offsets from one base;
-    // a half-wave's store covers 128 contiguous bytes
-    if (m0 + BM <= p.M && n0 + BN <= p.N) {
+    // a half-wave's store covers 128 contiguous bytes.  EPI: shift and ReLU on the way out, straight-line per (mask?, full tile?) variant
+    // (a condition per element splits the block into 16 basic blocks with a wait each).  The ReLU mask: a ballot per accumulator register
+    // is two words (the low one row m's 32 columns, the high one row m + 4's); the 32 words of a 32 x 32 block are dropped into lanes
+    // 0..31 of one register (v_writelane) and leave as ONE store per block -- lane j holds (e = j & 15, half = j >> 4).
+    {
+        const bool norelu = p.relu == 0;
+        const int wrow = m0 + wm * (BM / 2), wcol = n0 + wn * 64;
+        // the tile's shift values through LDS (free after the k-loop's last barrier): a global load per row here would queue behind the
+        // block's own stores (gfx9 counts loads and stores in one in-order vmcnt) and wait for their acknowledgements, block after block
+        const float* lsh = reinterpret_cast<const float*>(lds) + wm * (BM / 2) + 4 * g;
+        if constexpr ((EPI & 2) != 0) {
+            if (t < BM) reinterpret_cast<float*>(lds)[t] = m0 + t < p.M ? p.shift[m0 + t] : 0.f;
+            __syncthreads();
+        }
+        const int brow = ((lane & 3) + 8 * ((lane & 15) >> 2) + 4 * ((lane >> 4) & 1));   // the row (within a block) of the word lane j < 32 holds
+        uint32_t* bwl = p.bits + ((long)b * p.M + wrow + brow) * p.wpr + (wcol >> 5);
+        // C by buffer stores: the wave's origin in the descriptor, ONE running per-lane offset (+ 1 or + 5 rows per step; as scalar offsets
+        // hipcc precomputes all of them at kernel entry, spills them into VGPR lanes and pays a v_readlane per store)
+        const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(p.C + (long)b * p.c_sb + (long)wrow * ld + wcol, 0, 0xffffffffu, 0x00020000);
+        const int c1 = ld * 4, c5 = ld * 20, mrem = p.M - mw;
+        const bool colok[2] = {nw < p.N, nw + 32 < p.N};
+        auto epi = [&](auto HB, auto HF) {
+            constexpr bool hb = decltype(HB)::value, hf = decltype(HF)::value;
+            int cbase = (4 * g * ld + rr) * 4;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
+                for (int jn = 0; jn < 2; ++jn) {
+                    asm volatile("" : "+a"(acc[i][jn]) :: "memory");   // one block out of the accumulator file at a time (all at once: 64+ VGPRs)
+                    int words = 0, co = cbase;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) C[(i * 32 + (e & 3) + 8 * (e >> 2)) * ld + jn * 32] = acc[i][jn][e];
-    } else {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
-                    if (mw + dm < p.M && nw + jn * 32 < p.N) C[dm * ld + jn * 32] = acc[i][jn][e];
+                    for (int e = 0; e < 16; ++e) {
+                        const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
+                        float v = acc[i][jn][e];
+                        if constexpr ((EPI & 2) != 0) v += lsh[dm];
+                        if constexpr (EPI != 0) {
+                            const bool pos = v > 0.f;
+                            if constexpr (hb) {
+                                const unsigned long long bal = __ballot(pos);
+                                // s_nop: v_writelane reads a stale SGPR when it issues right behind the VALU compare that wrote it (measured: every
+                                // word held the previous register's ballot); the hazard recogniser does not look inside inline asm
+                                asm("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(words) : "s"((uint32_t)bal), "n"(e));
+                                asm("v_writelane_b32 %0, %1, %2" : "+v"(words) : "s"((uint32_t)(bal >> 32)), "n"(16 + e));
+                            }
+                            v = (pos | norelu) ? v : 0.f;
+                        }
+                        if (hf || (dm < mrem && colok[jn])) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
+                        co += (e & 3) == 3 ? c5 : c1;
+                        asm volatile("" : "+v"(co));
+                    }
+                    if constexpr (hb) {
+                        if (lane < 32 && wrow + i * 32 + brow < p.M && wcol + jn * 32 < p.N) bwl[(long)(i * 32) * p.wpr + jn] = (uint32_t)words;
+                    }
+                    if (jn == 1) cbase = co;
                 }
+            }
+        };
+        typedef std::true_type Y;
+        typedef std::false_type NO;
+        if constexpr (EPI != 0) {
+            if (p.bits) { if (full) epi(Y(), Y()); else epi(Y(), NO()); }
+            else { if (full) epi(NO(), Y()); else epi(NO(), NO()); }
+        } else {
+            if (full) epi(NO(), Y()); else epi(NO(), NO());
+        }
+        if constexpr ((EPI & 2) != 0) __syncthreads();   // the next tile's prologue writes the LDS the shift values were read from
     }
     }   // tiles of this workgroup
 }
@@ -261,25 +332,28 @@ int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_
 }
 
 int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm,
-              int accumulate, int nb, int M, int N, int K, void* stream) {
+              const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits, int nb, int M, int N, int K,
+              void* stream) {
     if (!image || !B || !C || nb <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 15) || ((uintptr_t)image & 15)) return LGD_EINVAL;
     // 256-row tiles unless that leaves more than a quarter of the rows of the last tile empty and 128-row tiles do not
-    // (accumulate: the 128-row tile as well -- initialising 128 accumulators per lane from C costs the 256-row kernel its second resident
-    //  workgroup: 138 VGPRs + 128 AGPRs)
-    const bool small = accumulate || ((M + 255) / 256 * 256 - M >= 64 && (M + 127) / 128 * 128 - M < 64);
+    const bool epi = R || shift || relu || relu_bits;
+    const bool small = ((M + 255) / 256 * 256 - M >= 64 && (M + 127) / 128 * 128 - M < 64);
     const int bm = small ? 128 : 256;
     lgd::Params p;
     p.rbp = (M + 31) / 32; p.ktp = K / 16;
     p.Aimg = (const char*)image; p.a_sb = image_shared ? 0 : (long)p.ktp * 3 * p.rbp * 1024;
     p.B = B; p.b_sb = (long)b_sb; p.b_ld = (long)b_sk;
     p.C = C; p.c_sb = (long)c_sb; p.c_ld = (long)c_sm;
+    p.R = R; p.r_sb = (long)r_sb; p.r_ld = (long)r_sm; p.r_bytes = (((long)nb - 1) * r_sb + ((long)M - 1) * r_sm + N) * 4; p.shift = shift; p.bits = relu_bits; p.wpr = (N + 31) / 32; p.relu = relu ? 1 : 0;
     p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + bm - 1) / bm; p.nt = (N + lgd::BN - 1) / lgd::BN;
     // 32-bit offsets inside the kernel: one k-step of B rows, one batch of the image, one tile of C rows
-    if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 31) || (long)p.ktp * 3 * p.rbp * 1024 >= (1L << 31) || 256L * c_sm >= (1L << 31)) return LGD_EINVAL;
+    if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 31) || (long)p.ktp * 3 * p.rbp * 1024 >= (1L << 31) || 256L * c_sm >= (1L << 31) || (R && (r_sb < 0 || r_sm < 0 || ((long)M + 256) * r_sm >= (1L << 29)))) return LGD_EINVAL;
     static bool attr = false;   // 72 KB of dynamic LDS: above the default 64 KB limit
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)lgd::gemm3_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lgd::Tile<256>::LDS_BYTES) != hipSuccess)
-            return LGD_ELAUNCH;
+        const void* big[5] = {(const void*)lgd::gemm3_kernel<256, 0>, (const void*)lgd::gemm3_kernel<256, 1>, (const void*)lgd::gemm3_kernel<256, 2>,
+                              (const void*)lgd::gemm3_kernel<256, 3>, (const void*)lgd::gemm3_kernel<256, 4>};
+        for (const void* f : big)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lgd::Tile<256>::LDS_BYTES) != hipSuccess) return LGD_ELAUNCH;
         attr = true;
     }
     p.total = (int)((image_shared ? ((long)nb * p.nt + 7) / 8 : (long)((nb + 7) / 8) * p.nt) * p.mt * 8);
@@ -298,9 +372,15 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
     const int gridn = (pe && pe[0] == '1') && p.total > slots ? slots : p.total;
     const dim3 grid((unsigned)gridn), block(lgd::NT);
     hipStream_t st = (hipStream_t)stream;
-    if (small && accumulate) { LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<128, true>), grid, block, lgd::Tile<128>::LDS_BYTES, st, p); }
-    else if (small) { LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<128, false>), grid, block, lgd::Tile<128>::LDS_BYTES, st, p); }
-    else { LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<256, false>), grid, block, lgd::Tile<256>::LDS_BYTES, st, p); }
+    const int kind = !epi ? 0 : (R ? 1 : 0) | (shift ? 2 : 0) ? (R ? 1 : 0) | (shift ? 2 : 0) : 4;
+#define LGD_GEMM3_CASE(BM_, E_) \
+    case E_: LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<BM_, E_>), grid, block, lgd::Tile<BM_>::LDS_BYTES, st, p); break;
+    if (small) {
+        switch (kind) { LGD_GEMM3_CASE(128, 0) LGD_GEMM3_CASE(128, 1) LGD_GEMM3_CASE(128, 2) LGD_GEMM3_CASE(128, 3) LGD_GEMM3_CASE(128, 4) }
+    } else {
+        switch (kind) { LGD_GEMM3_CASE(256, 0) LGD_GEMM3_CASE(256, 1) LGD_GEMM3_CASE(256, 2) LGD_GEMM3_CASE(256, 3) LGD_GEMM3_CASE(256, 4) }
+    }
+#undef LGD_GEMM3_CASE
     return lgd::check_launch();
 }
 

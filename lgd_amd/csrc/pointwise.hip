@@ -69,6 +69,23 @@ __global__ __launch_bounds__(256) void relu_bits_kernel(const uint32_t* __restri
     vstore<VW>(dx + i, r);
 }
 
+// the same from the row-padded bitmap the gemm3 epilogue writes (csrc/gemm3.hip: a word per 32 columns of a row, rows = (image, channel)
+// planes of HW elements): thread per VW consecutive columns of one row (VW | 32: one word)
+template <int VW>
+__global__ __launch_bounds__(256) void relu_rowbits_kernel(const uint32_t* __restrict__ bits, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int HW, int wpr) {
+    const int n = (blockIdx.y * 256 + threadIdx.x) * VW;
+    if (n >= HW) return;
+    const long long row = blockIdx.x;
+    const unsigned w = bits[row * wpr + (n >> 5)] >> (unsigned)(n & 31);
+    const long long i = row * HW + n;
+    const Vec<VW> g = vload<VW>(dy + i);
+    Vec<VW> r;
+    #pragma unroll
+    for (int k = 0; k < VW; ++k) r.v[k] = ((w >> k) & 1u) ? g.v[k] : 0.f;
+    vstore<VW>(dx + i, r);
+}
+
 template <int VW>
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                         float* __restrict__ dx, long long total) {
@@ -109,6 +126,21 @@ int lgd_relu_bits_bwd(const uint32_t* relu_bits, const float* dy, long long tota
         LGD_LAUNCH("relu_bits_kernel", lgd::relu_bits_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, relu_bits, dy, dx, total);
     } else {
         LGD_LAUNCH("relu_bits_kernel", lgd::relu_bits_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, relu_bits, dy, dx, total);
+    }
+    return lgd::check_launch();
+}
+
+size_t lgd_relu_rowbits_words(long long rows, int HW) { return rows < 1 || HW < 1 ? 0 : (size_t)rows * (size_t)((HW + 31) / 32); }
+
+int lgd_relu_rowbits_bwd(const uint32_t* relu_bits, const float* dy, long long rows, int HW, float* dx, void* stream) {
+    if (!relu_bits || !dy || !dx || rows < 1 || rows >= (1LL << 31) || HW < 1) return LGD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+    const int wpr = (HW + 31) / 32;
+    if (HW % 4 == 0 && al) {
+        LGD_LAUNCH("relu_rowbits_kernel", lgd::relu_rowbits_kernel<4>, dim3((unsigned)rows, (unsigned)((HW / 4 + 255) / 256)), dim3(256), 0, st, relu_bits, dy, dx, HW, wpr);
+    } else {
+        LGD_LAUNCH("relu_rowbits_kernel", lgd::relu_rowbits_kernel<1>, dim3((unsigned)rows, (unsigned)((HW + 255) / 256)), dim3(256), 0, st, relu_bits, dy, dx, HW, wpr);
     }
     return lgd::check_launch();
 }

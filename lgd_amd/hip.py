@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -80,7 +80,10 @@ SIGNATURES = {
     "lgd_wino_in_t_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_gemm3_image_bytes": (c_sz, [c_i, c_i, c_i]),
     "lgd_gemm3_split": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_fp, c_fp]),
-    "lgd_gemm3": (c_i, [c_fp, c_i, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "lgd_gemm3": (c_i, [c_fp, c_i, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong,
+                        c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "lgd_relu_rowbits_words": (c_sz, [ctypes.c_longlong, c_i]),
+    "lgd_relu_rowbits_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_i, c_fp, c_fp]),
     "lgd_relu_bits_words": (c_sz, [ctypes.c_longlong]),
     "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_stem_bias_relu_maxpool": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),

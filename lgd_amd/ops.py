@@ -1932,12 +1932,15 @@ class _PointwiseConvBN(torch.autograd.Function):
         x = hip.dense_f32(x)
         if wf is None:   # wf given: the folded filter of a FROZEN convolution, cached by the caller until the weight is written
             wf = w * scale.view(-1, 1, 1, 1)
-        y = _conv1x1_fwd(x, wf)
         if shift is None and residual is None and not relu:   # raw output: the consumer folds the bias + ReLU into its own load
             ctx.relu = False
             ctx.save_for_backward(x, wf, scale, None)
-            return y
+            return _conv1x1_fwd(x, wf)
         residual = hip.dense_f32(residual) if residual is not None else None
+        fused = _conv1x1_epilogue(ctx, x, wf, scale, shift, residual, relu)   # csrc/gemm3.hip with the epilogue inside the product kernel
+        if fused is not None:
+            return fused
+        y = _conv1x1_fwd(x, wf)
         N, C = y.shape[0], y.shape[1]
         out = torch.empty_like(y)
         bits = _relu_bits(lib, y.numel(), y.device) if relu and any(ctx.needs_input_grad) else None
@@ -1945,6 +1948,7 @@ class _PointwiseConvBN(torch.autograd.Function):
                                        y.numel() // (N * C), int(relu), hip.ptr(out), hip.ptr(bits) if bits is not None else None,
                                        hip.stream_ptr()), "lgd_bias_act_fwd")
         ctx.relu = bool(relu)
+        ctx.rowbits = False
         ctx.save_for_backward(x, wf, scale, bits)
         return out
 
@@ -1953,9 +1957,7 @@ class _PointwiseConvBN(torch.autograd.Function):
         x, wf, scale, bits = ctx.saved_tensors
         dy = hip.dense_f32(dy)
         if ctx.relu:
-            dz = torch.empty_like(dy)
-            hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
-                      "lgd_relu_bits_bwd")
+            dz = _relu_bits_bwd(ctx, bits, dy)
             dz._lgd_exclusive = True   # fresh; after the GEMMs below its only reader is whoever receives the residual gradient
         else:
             dz = dy
@@ -1965,6 +1967,42 @@ class _PointwiseConvBN(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = _pointwise_dw(dz, x, scale)
         return dx, dw, None, None, (dz if ctx.needs_input_grad[4] else None), None, None
+
+
+def _conv1x1_epilogue(ctx, x, wf, scale, shift, residual, relu):
+    """relu?(conv1x1(x, wf) + shift[c] + residual) as ONE launch of csrc/gemm3.hip (accumulators initialised from residual + shift, ReLU
+    and its row-padded 1-bit mask in the kernel's epilogue), where the shape gate lets the 128-row tile run; None otherwise (the caller
+    runs the product and the bias_act pass).  Saves (x, wf, scale, bits) on ctx like the unfused path."""
+    if not _GEMM3_EPILOGUE:
+        return None
+    N, Ci, H, W = x.shape
+    Co = wf.shape[0]
+    a, b = wf.view(1, Co, Ci).expand(N, Co, Ci), x.view(N, Ci, H * W)
+    if not _gemm3_ok(a, b, None, accumulate=True):
+        return None
+    if residual is not None and tuple(residual.shape) != (N, Co, H, W):
+        return None
+    lib = hip.load()
+    bits = None
+    if relu and any(ctx.needs_input_grad):
+        bits = torch.empty(int(lib.lgd_relu_rowbits_words(N * Co, H * W)), dtype=torch.int32, device=x.device)
+    out = _timed_gemm3("pw_gemm3_fwd", a, b, None, residual=residual.view(N, Co, H * W) if residual is not None else None,
+                       shift=hip.dense_f32(shift) if shift is not None else None, relu=bool(relu), relu_bits=bits).view(N, Co, H, W)
+    ctx.relu = bool(relu)
+    ctx.rowbits = True
+    ctx.save_for_backward(x, wf, scale, bits)
+    return out
+
+
+def _relu_bits_bwd(ctx, bits, dy):
+    """dy where the forward output was > 0, from the flat bitmap bias_act wrote or the row-padded one of the gemm3 epilogue"""
+    dz = torch.empty_like(dy)
+    if getattr(ctx, "rowbits", False):
+        hip.check(hip.load().lgd_relu_rowbits_bwd(hip.ptr(bits), hip.ptr(dy), dy.shape[0] * dy.shape[1], dy.shape[2] * dy.shape[3], hip.ptr(dz),
+                                                  hip.stream_ptr()), "lgd_relu_rowbits_bwd")
+    else:
+        hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()), "lgd_relu_bits_bwd")
+    return dz
 
 
 class _PointwiseConvBNSkip(torch.autograd.Function):
@@ -1982,16 +2020,20 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
         x = hip.dense_f32(x)
         if wf is None:   # wf given: this step's fold from StepFolds.prepare() (one launch for all trainable 1x1 convolutions)
             wf = w * scale.view(-1, 1, 1, 1)
-        y = _conv1x1_fwd(x, wf)
         ctx.raw = bool(raw)
         if raw:   # the 3x3 convolution that follows folds + shift and the ReLU into its input transform (and the mask into its adjoint)
             ctx.save_for_backward(x, wf, scale, None)
-            return y, x.view_as(x)
+            return _conv1x1_fwd(x, wf), x.view_as(x)
+        fused = _conv1x1_epilogue(ctx, x, wf, scale, shift, None, True)
+        if fused is not None:
+            return fused, x.view_as(x)
+        y = _conv1x1_fwd(x, wf)
         N, C = y.shape[0], y.shape[1]
         out = torch.empty_like(y)
         bits = _relu_bits(lib, y.numel(), y.device) if any(ctx.needs_input_grad) else None
         hip.check(lib.lgd_bias_act_fwd(hip.ptr(y), hip.ptr(shift), None, N, C, y.numel() // (N * C), 1, hip.ptr(out),
                                        hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_bias_act_fwd")
+        ctx.rowbits = False
         ctx.save_for_backward(x, wf, scale, bits)
         return out, x.view_as(x)
 
@@ -2004,10 +2046,7 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
         if dy is not None and ctx.raw:
             dz = hip.dense_f32(dy)
         elif dy is not None:
-            dy = hip.dense_f32(dy)
-            dz = torch.empty_like(dy)
-            hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()),
-                      "lgd_relu_bits_bwd")
+            dz = _relu_bits_bwd(ctx, bits, hip.dense_f32(dy))
         if ctx.needs_input_grad[0]:
             if dz is None:
                 dx = dskip
@@ -2147,6 +2186,7 @@ def _timed_bmm(name, a, b, out=None):
 # ---- K9: the Winograd channel products on the bf16 MFMA pipe (csrc/gemm3.hip: three-way split fp32 operands, fp32 accumulate)
 _GEMM3_ON = os.environ.get("LGD_GEMM3", "1") != "0"
 _FILTER_IMAGES = os.environ.get("LGD_FILTER_IMAGES", "1") != "0"   # 0: fp32 U + the split pass of gemm3_bmm (A/B runs)
+_GEMM3_EPILOGUE = os.environ.get("LGD_GEMM3_EPILOGUE", "1") != "0"   # 0: product + a bias_act pass (A/B runs)
 
 
 _GEMM3_FORCE = False   # tests: take csrc/gemm3.hip wherever the kernel CAN run (K % 16 == 0), whatever the speed policy says
@@ -2183,7 +2223,7 @@ def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False):
         return K % 16 == 0
     # the kernel's tile spans 256 (or 128) rows of A: shapes that would leave more than ~30 % of the MFMA rows empty (C' = 36, 64, 320 ...) and
     # tiny problems stay on the library; K % 16: the k-step
-    small = accumulate or ((M + 255) // 256 * 256 - M >= 64 and (M + 127) // 128 * 128 - M < 64)
+    small = (M + 255) // 256 * 256 - M >= 64 and (M + 127) // 128 * 128 - M < 64
     bm = 128 if small else 256
     if K % 16 or K < 32 or N < 256 or M < 0.7 * bm * ((M + bm - 1) // bm):
         return False
@@ -2201,11 +2241,12 @@ def _gemm3_ok(a, b, out, accumulate=False):
     return b.stride(2) == 1 and (out is None or (out.stride(2) == 1 and out.dtype == torch.float32))
 
 
-def gemm3_bmm(a, b, out=None, accumulate=False):
+def gemm3_bmm(a, b, out=None, accumulate=False, residual=None, shift=None, relu=False, relu_bits=None):
     """out[i] = a[i] @ b[i] (accumulate: out[i] += ...) for fp32 (nb, M, K) x (nb, K, N): an fp32-class product (error vs fp64 as the
     library's fp32 GEMM) computed on v_mfma_f32_32x32x16_bf16 from three-way split operands.  a (the filter operand, any strides) is split
     ahead of the product into an MFMA-ordered image -- ONE image when a is the same matrix for every batch (stride 0: the student's 1x1
-    convolutions); b and out have their last axis contiguous."""
+    convolutions); b and out have their last axis contiguous.  Epilogue inside the kernel: out = relu?(a @ b + residual + shift[:, None]),
+    relu_bits (int32, lgd_relu_rowbits_words(nb * M, N)) receives the ReLU mask for lgd_relu_rowbits_bwd."""
     lib = hip.load()
     nb, M, K = a.shape
     N = b.shape[2]
@@ -2213,13 +2254,23 @@ def gemm3_bmm(a, b, out=None, accumulate=False):
         if accumulate:
             raise hip.LgdHipError("accumulate needs the tensor to accumulate onto")
         out = torch.empty((nb, M, N), dtype=torch.float32, device=a.device)
+    if accumulate:
+        if residual is not None:
+            raise hip.LgdHipError("accumulate and residual are the same slot of the epilogue")
+        residual = out
+    if residual is not None and (tuple(residual.shape) != (nb, M, N) or residual.stride(2) != 1 or residual.dtype != torch.float32):
+        raise hip.LgdHipError("residual must be an fp32 (nb, M, N) map with its last axis contiguous")
+    if shift is not None and (shift.numel() != M or not shift.is_contiguous() or shift.dtype != torch.float32):
+        raise hip.LgdHipError("shift must be M contiguous fp32 values")
     shared = a.stride(0) == 0 and nb > 1
     ni = 1 if shared else nb
     img = torch.empty(lib.lgd_gemm3_image_bytes(ni, M, K), dtype=torch.uint8, device=a.device)
     st = hip.stream_ptr()
     hip.check(lib.lgd_gemm3_split(hip.ptr(a), a.stride(0), a.stride(1), a.stride(2), ni, M, K, hip.ptr(img), st), "lgd_gemm3_split")
     hip.check(lib.lgd_gemm3(hip.ptr(img), 1 if shared else 0, hip.ptr(b), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1),
-                            1 if accumulate else 0, nb, M, N, K, st), "lgd_gemm3")
+                            hip.ptr(residual) if residual is not None else None, residual.stride(0) if residual is not None else 0,
+                            residual.stride(1) if residual is not None else 0, hip.ptr(shift) if shift is not None else None, 1 if relu else 0,
+                            hip.ptr(relu_bits) if relu_bits is not None else None, nb, M, N, K, st), "lgd_gemm3")
     return out
 
 
@@ -2228,18 +2279,19 @@ def gemm3_image_bmm(img, b, out):
     nb, M, K = img.shape
     if b.shape[0] != nb or b.shape[1] != K or out.shape[1] != M or b.stride(2) != 1 or out.stride(2) != 1:
         raise hip.LgdHipError("gemm3 image %s does not match B %s / C %s" % (img.shape, tuple(b.shape), tuple(out.shape)))
-    hip.check(hip.load().lgd_gemm3(hip.ptr(img.t), 0, hip.ptr(b), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1), 0, nb, M,
-                                   b.shape[2], K, hip.stream_ptr()), "lgd_gemm3")
+    hip.check(hip.load().lgd_gemm3(hip.ptr(img.t), 0, hip.ptr(b), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1),
+                                   None, 0, 0, None, 0, None, nb, M, b.shape[2], K, hip.stream_ptr()), "lgd_gemm3")
     return out
 
 
-def _timed_gemm3(name, a, b, out=None, accumulate=False):
-    fn = (lambda: gemm3_image_bmm(a, b, out)) if isinstance(a, _FilterImage) else (lambda: gemm3_bmm(a, b, out, accumulate))
+def _timed_gemm3(name, a, b, out=None, accumulate=False, **epi):
+    fn = (lambda: gemm3_image_bmm(a, b, out)) if isinstance(a, _FilterImage) else (lambda: gemm3_bmm(a, b, out, accumulate, **epi))
     if not _TIMER_ON:
         return fn()
     nb_, M_, K_ = a.shape
-    # algorithmic bytes of the product: B read once, C written once (read as well when accumulating), the filter image once per batch
-    _count_bytes("gemm3_kernel", 4 * nb_ * b.shape[2] * (K_ + M_ * (2 if accumulate else 1)) + 6 * M_ * K_ * (1 if not isinstance(a, _FilterImage) and a.stride(0) == 0 else nb_))
+    # algorithmic bytes of the product: B read once, C written once (a residual / accumulated map read as well), the filter image once per batch
+    reads_c = accumulate or epi.get("residual") is not None
+    _count_bytes("gemm3_kernel", 4 * nb_ * b.shape[2] * (K_ + M_ * (2 if reads_c else 1)) + 6 * M_ * K_ * (1 if not isinstance(a, _FilterImage) and a.stride(0) == 0 else nb_))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()

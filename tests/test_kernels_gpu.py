@@ -984,6 +984,99 @@ def test_gemm3_pointwise_shared_image_and_accumulate(Co, Ci, HW):
     assert e2 <= 2e-6 and e2 <= 3 * e2_lib + 4e-7, (e2, e2_lib)
 
 
+@pytest.mark.parametrize("Co,Ci,HW,res,sh,relu", [(256, 64, 1000, True, True, True), (128, 32, 333, False, True, True),
+                                                  (200, 48, 130, True, False, True), (512, 128, 4200, True, True, False),
+                                                  (96, 16, 31, False, False, True)])
+def test_gemm3_epilogue_residual_shift_relu_and_mask(Co, Ci, HW, res, sh, relu):
+    """the bottleneck blocks' epilogue inside csrc/gemm3.hip: out = relu?(W x + R + shift[c]) with the accumulators initialised from the
+    residual map and the shift, the ReLU on the way out and its row-padded 1-bit mask from wave ballots; the mask consumed by
+    lgd_relu_rowbits_bwd.  Full and ragged tiles (rows % 128, columns % 128 / 32 / 4 != 0), each part of the epilogue present and absent
+    [d2-memory: BottleneckBlock.forward -- conv3 -> FrozenBN, += shortcut, relu; SURVEY.md appendix A]."""
+    from lgd_amd import hip, ops
+    lib = hip.load()
+    N = 3
+    g = torch.Generator(device=DEV).manual_seed(Co + Ci + HW)
+    w = torch.randn(Co, Ci, device=DEV, generator=g) * 0.1
+    x = torch.randn(N, Ci, HW, device=DEV, generator=g)
+    R = torch.randn(N, Co, HW, device=DEV, generator=g) if res else None
+    shift = torch.randn(Co, device=DEV, generator=g) if sh else None
+    a = w.view(1, Co, Ci).expand(N, Co, Ci)
+    bits = torch.full((int(lib.lgd_relu_rowbits_words(N * Co, HW)),), -1, dtype=torch.int32, device=DEV) if relu else None
+    keep = R.clone() if res else None
+    y = ops.gemm3_bmm(a, x, residual=R, shift=shift, relu=relu, relu_bits=bits)
+    if res:
+        assert torch.equal(R, keep)                                         # the residual is read, not written
+    pre = torch.matmul(w.double(), x.double())
+    if res:
+        pre = pre + R.double()
+    if sh:
+        pre = pre + shift.double().view(1, -1, 1)
+    want = pre.clamp_min(0) if relu else pre
+    e = float((y.double() - want).abs().max() / pre.abs().max())
+    assert e <= 2e-6, e
+    if relu:
+        assert float(y.min()) >= 0.0
+        # the mask is the sign of what was stored; against fp64 it may differ only where the pre-activation is within rounding of zero
+        wpr = (HW + 31) // 32
+        words = bits.view(N * Co, wpr).cpu().numpy().astype(np.uint32)
+        mask = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(N * Co, wpr * 32)[:, :HW].astype(bool)
+        got = torch.from_numpy(mask).to(DEV).view(N, Co, HW)
+        assert torch.equal(got, y > 0)
+        flips = (got != (pre > 0))
+        assert float(pre.abs()[flips].max() if flips.any() else 0.0) <= 1e-5 * float(pre.abs().max())
+        dy = torch.randn(N, Co, HW, device=DEV, generator=g)
+        dz = torch.empty_like(dy)
+        hip.check(lib.lgd_relu_rowbits_bwd(hip.ptr(bits), hip.ptr(dy), N * Co, HW, hip.ptr(dz), hip.stream_ptr()), "lgd_relu_rowbits_bwd")
+        assert torch.equal(dz, torch.where(got, dy, torch.zeros_like(dy)))
+    print("gemm3 epilogue %d -> %d over %d px (residual %s, shift %s, relu %s): %.2e" % (Ci, Co, HW, res, sh, relu, e))
+
+
+@pytest.mark.parametrize("residual,relu", [(True, True), (False, True), (True, False)])
+def test_pointwise_conv_bn_fused_epilogue_equals_product_plus_bias_act(residual, relu):
+    """ops.pointwise_conv_bn with the epilogue inside the product kernel (one launch) against the product + bias_act pass it replaces:
+    output, input gradient, weight gradient and the residual's gradient [d2-memory: BottleneckBlock conv3 + shortcut + relu]."""
+    from lgd_amd import ops
+    N, Ci, Co, H, W = 2, 64, 256, 20, 27
+    g = torch.Generator(device=DEV).manual_seed(77)
+    x0 = torch.randn(N, Ci, H, W, device=DEV, generator=g)
+    w0 = torch.randn(Co, Ci, 1, 1, device=DEV, generator=g) * 0.1
+    scale = torch.rand(Co, device=DEV, generator=g) + 0.5
+    shift = torch.randn(Co, device=DEV, generator=g) * 0.3
+    r0 = torch.randn(N, Co, H, W, device=DEV, generator=g) if residual else None
+    dy = torch.randn(N, Co, H, W, device=DEV, generator=g)
+    prev, prev_epi = ops.gemm3_backend(True, force=True), ops._GEMM3_EPILOGUE
+    out = {}
+    try:
+        for fused in (True, False):
+            ops._GEMM3_EPILOGUE = fused
+            x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+            r = r0.clone().requires_grad_(True) if residual else None
+            calls = []
+            real = ops.gemm3_bmm
+            ops.gemm3_bmm = lambda *a, **k: (calls.append(k), real(*a, **k))[1]
+            try:
+                y = ops.pointwise_conv_bn(x, w, scale, shift, residual=r, relu=relu)
+                y.backward(dy)
+            finally:
+                ops.gemm3_bmm = real
+            assert any(k.get("shift") is not None for k in calls) == fused     # the fused run carried the epilogue into the kernel
+            out[fused] = (y.detach(), x.grad, w.grad, r.grad if residual else None)
+    finally:
+        ops._GEMM3_EPILOGUE = prev_epi
+        ops.gemm3_backend(*prev)
+    e = float((out[True][0] - out[False][0]).abs().max() / out[False][0].abs().max())
+    assert e <= 2e-6, e    # the same products; R + shift enter the fp32 accumulation first instead of last
+    flips = int(((out[True][0] > 0) != (out[False][0] > 0)).sum()) if relu else 0
+    print("fused epilogue vs bias_act pass: out %.2e, %d ReLU kink flips" % (e, flips))
+    for a, b, name in zip(out[True][1:], out[False][1:], ("dx", "dw", "d residual")):
+        if a is None:
+            continue
+        if flips == 0:   # the same mask -> the same masked gradient through the same kernels
+            assert torch.equal(a, b), name
+        else:
+            assert float((a - b).abs().max() / b.abs().max()) <= 5e-2, name
+
+
 def test_wino_filter_images_equal_the_split_of_U():
     """lgd_wino_filter_images (the F(6x6,3x3) filter transform written straight as the bf16x3 operand images of csrc/gemm3.hip) against
     lgd_wino_filter_fwd followed by lgd_gemm3_split: the image of U (forward product) and of U^T (input gradient), two filters stacked
