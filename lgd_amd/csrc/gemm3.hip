@@ -101,14 +101,15 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     const float* Bb = p.B + (long)b * p.b_sb;
     uint32_t boff[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) boff[e] = (uint32_t)((kg * 8 + e) * (int)p.b_ld + ncol);
+    for (int e = 0; e < 8; ++e) boff[e] = (uint32_t)((kg * 8 + e) * (int)p.b_ld + ncol) * 4u;   // bytes
     const long bstep = (long)BK * p.b_ld;
     const int bslot = A_BYTES + (nl >> 5) * 1024 + kg * 512 + (nl & 31) * 16;   // 8 consecutive lanes -> 128 contiguous bytes: no conflicts
     float bv[8];
+    // buffer loads: the k-step's origin in the descriptor (scalar), the eight per-thread offsets as they are -- no 64-bit address per load
     auto load_b = [&](int ks) {
-        const float* Bk = Bb + ks * bstep;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb + ks * bstep), 0, 0xffffffffu, 0x00020000);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = Bk[boff[e]];
+        for (int e = 0; e < 8; ++e) bv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff[e], 0, 0));
     };
     auto store_b = [&](char* buf) {
         uint32_t h[4], m[4], l[4];
@@ -131,9 +132,10 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     }
     const long astep = (long)3 * p.rbp * 1024;
     auto dma_a = [&](int ks, char* buf) {
-        const char* Ak = Ai + ks * astep;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ai + ks * astep), 0, 0xffffffffu, 0x00020000);
 #pragma unroll
-        for (int c = 0; c < CH; ++c) LGD_GLDS16(Ak + aoff[c], buf + (w * CH + c) * 1024);
+        for (int c = 0; c < CH; ++c)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(buf + (w * CH + c) * 1024), 16, (int)aoff[c], 0, 0, 0);
     };
     // the accumulators start from zero, or (EPI) from R + shift: the MFMA chain adds the product on top and the epilogue is the plain
     // store (an epilogue that re-reads a map needs the 128 accumulators in VGPRs at once: one resident workgroup instead of two)
@@ -347,7 +349,7 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
     p.R = R; p.r_sb = (long)r_sb; p.r_ld = (long)r_sm; p.r_bytes = (((long)nb - 1) * r_sb + ((long)M - 1) * r_sm + N) * 4; p.shift = shift; p.bits = relu_bits; p.wpr = (N + 31) / 32; p.relu = relu ? 1 : 0;
     p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + bm - 1) / bm; p.nt = (N + lgd::BN - 1) / lgd::BN;
     // 32-bit offsets inside the kernel: one k-step of B rows, one batch of the image, one tile of C rows
-    if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 31) || (long)p.ktp * 3 * p.rbp * 1024 >= (1L << 31) || 256L * c_sm >= (1L << 31) || (R && (r_sb < 0 || r_sm < 0 || ((long)M + 256) * r_sm >= (1L << 29)))) return LGD_EINVAL;
+    if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 30) || (long)p.ktp * 3 * p.rbp * 1024 >= (1L << 31) || 256L * c_sm >= (1L << 31) || (R && (r_sb < 0 || r_sm < 0 || ((long)M + 256) * r_sm >= (1L << 29)))) return LGD_EINVAL;
     static bool attr = false;   // 72 KB of dynamic LDS: above the default 64 KB limit
     if (!attr) {
         const void* big[5] = {(const void*)lgd::gemm3_kernel<256, 0>, (const void*)lgd::gemm3_kernel<256, 1>, (const void*)lgd::gemm3_kernel<256, 2>,
