@@ -348,8 +348,9 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
     p.C = C; p.c_sb = (long)c_sb; p.c_ld = (long)c_sm;
     p.R = R; p.r_sb = (long)r_sb; p.r_ld = (long)r_sm; p.r_bytes = (((long)nb - 1) * r_sb + ((long)M - 1) * r_sm + N) * 4; p.shift = shift; p.bits = relu_bits; p.wpr = (N + 31) / 32; p.relu = relu ? 1 : 0;
     p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + bm - 1) / bm; p.nt = (N + lgd::BN - 1) / lgd::BN;
-    // 32-bit offsets inside the kernel: one k-step of B rows, one batch of the image, one tile of C rows
-    if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 30) || (long)p.ktp * 3 * p.rbp * 1024 >= (1L << 31) || 256L * c_sm >= (1L << 31) || (R && (r_sb < 0 || r_sm < 0 || ((long)M + 256) * r_sm >= (1L << 29)))) return LGD_EINVAL;
+    // 32-bit BYTE offsets from the descriptors' origins inside the kernel: one k-step of B rows, one tile of C / R rows
+    if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 30) || 256L * c_sm >= (1L << 30) || c_sm < 0 || (R && (r_sb < 0 || r_sm < 0 || 256L * r_sm >= (1L << 30))))
+        return LGD_EINVAL;
     static bool attr = false;   // 72 KB of dynamic LDS: above the default 64 KB limit
     if (!attr) {
         const void* big[5] = {(const void*)lgd::gemm3_kernel<256, 0>, (const void*)lgd::gemm3_kernel<256, 1>, (const void*)lgd::gemm3_kernel<256, 2>,

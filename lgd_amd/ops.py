@@ -2238,7 +2238,9 @@ def _gemm3_ok(a, b, out, accumulate=False):
         return False
     if not _gemm3_shape_ok(a.shape[0], a.shape[1], a.shape[2], b.shape[2], a.device, accumulate):
         return False
-    return b.stride(2) == 1 and (out is None or (out.stride(2) == 1 and out.dtype == torch.float32))
+    if b.stride(2) != 1 or 17 * b.stride(1) + b.shape[2] >= 1 << 30:   # the kernel's 32-bit byte offsets (lgd_gemm3 returns LGD_EINVAL beyond)
+        return False
+    return out is None or (out.stride(2) == 1 and out.dtype == torch.float32 and 0 <= 256 * out.stride(1) < 1 << 30)
 
 
 def gemm3_bmm(a, b, out=None, accumulate=False, residual=None, shift=None, relu=False, relu_bits=None):

@@ -5,7 +5,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lgd_amd import hip, ops
 
+
+def _warm_clocks(seconds=1.0):
+    """the first second of work on an idle GPU runs at ramping clocks: shapes measured first would read 10-20 % slow"""
+    import time
+    a = torch.randn(4096, 4096, device="cuda")
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        for _ in range(10):
+            a @ a
+        torch.cuda.synchronize()
+
+
 lib = hip.load()
+_warm_clocks()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 SH = [("res2 conv3 64->256", 64, 256, 200 * 336), ("res3 conv3 128->512", 128, 512, 100 * 168), ("res4 conv3 256->1024", 256, 1024, 50 * 84),
       ("res5 conv3 512->2048", 512, 2048, 25 * 42), ("res3 conv1 512->128", 512, 128, 100 * 168), ("res4 conv1 1024->256", 1024, 256, 50 * 84)]
