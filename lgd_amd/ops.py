@@ -2186,6 +2186,7 @@ def _timed_bmm(name, a, b, out=None):
 # ---- K9: the Winograd channel products on the bf16 MFMA pipe (csrc/gemm3.hip: three-way split fp32 operands, fp32 accumulate)
 _GEMM3_ON = os.environ.get("LGD_GEMM3", "1") != "0"
 _FILTER_IMAGES = os.environ.get("LGD_FILTER_IMAGES", "1") != "0"   # 0: fp32 U + the split pass of gemm3_bmm (A/B runs)
+_GEMM3_ONE_ROUND = os.environ.get("LGD_GEMM3_ONE_ROUND", "1") != "0"   # 0: two rounds of workgroups for every shape (A/B runs)
 _GEMM3_EPILOGUE = os.environ.get("LGD_GEMM3_EPILOGUE", "1") != "0"   # 0: product + a bias_act pass (A/B runs)
 
 
@@ -2230,7 +2231,12 @@ def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False):
     # at least one full round of workgroups (2 per CU with 256-row tiles, 3 with 128-row ones): below that a tile's prologue, its short
     # k-loop without a co-resident partner and the filter split are the whole launch and the library's smaller tiles win
     # (tools/gemm3_probe.py, profiles/r04_gemm3_probe.log: res5's 288 tiles x0.61, the 2048 -> 256 lateral x0.55; from one round up x1.05-1.6)
-    return nb * ((N + 127) // 128) * ((M + bm - 1) // bm) >= _cu_count(device) * (3 if small else 2)
+    wgs, cus = nb * ((N + 127) // 128) * ((M + bm - 1) // bm), _cu_count(device)
+    if wgs >= cus * (3 if small else 2):
+        return True
+    # one round of 256-row tiles is enough when the k-loop is long (64+ steps amortise a tile's prologue and epilogue): the 1024 -> 256
+    # convolutions of res4 and the 1024-channel lateral at 8 images, x1.05-1.10 (profiles/r04_gemm3_probe_buffer_addressing.log)
+    return _GEMM3_ONE_ROUND and (not small) and wgs >= cus and K >= 1024
 
 
 def _gemm3_ok(a, b, out, accumulate=False):

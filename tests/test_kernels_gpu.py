@@ -1158,7 +1158,8 @@ def test_gemm3_shape_gate():
     mk = lambda nb, M, K, N: (torch.randn(nb, M, K, device=DEV), ops._freq_buf(nb, K, N, DEV).normal_(), ops._freq_buf(nb, M, N, DEV))  # noqa: E731
     for M, K, N, ok in ((256, 256, 5232, True), (720, 256, 5232, True), (512, 256, 1024, True), (36, 256, 5232, False), (128, 128, 5232, True),
                         (64, 256, 5232, False), (320, 256, 5232, False), (384, 64, 5232, True), (256, 36, 5232, False), (256, 256, 128, False),
-                        (512, 512, 288, False)):    # res5 at config 2: 64 x 3 x 2 workgroups, less than one round
+                        (512, 512, 288, False),     # res5 at config 2: 64 x 3 x 2 workgroups: one round, a short k-loop
+                        (256, 1024, 512, True), (256, 512, 512, False)):   # exactly one round of 256-row tiles: enough with 64 k-steps, not with 32
         a, b, o = mk(64, M, K, N)
         assert ops._gemm3_ok(a, b, o) == ok, (M, K, N)
         if not ok:
