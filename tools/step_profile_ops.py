@@ -30,3 +30,7 @@ tot = sum(e.self_device_time_total for e in rows)
 print("non-GEMM/conv aten ops: %.2f ms" % (tot / 1e3))
 for e in sorted(rows, key=lambda e: -e.self_device_time_total)[:60]:
     print("%7.2f ms n=%3d %-40s %s" % (e.self_device_time_total / 1e3, e.count, e.key[:40], str(e.input_shapes)[:110]))
+aten = [e for e in rows if e.key.startswith("aten::")]
+print("aten:: ops (torch's own elementwise / reduction / copy kernels): %.2f ms" % (sum(e.self_device_time_total for e in aten) / 1e3))
+for e in sorted(aten, key=lambda e: -e.self_device_time_total)[:50]:
+    print("%7.3f ms n=%3d %-28s %s" % (e.self_device_time_total / 1e3, e.count, e.key[:28], str(e.input_shapes)[:150]))
