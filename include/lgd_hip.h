@@ -421,6 +421,11 @@ typedef struct lgd_rows_task { unsigned long long w, scale, out; int rows, cols;
 int lgd_scale_rows_multi(const void* tasks_dev, const int32_t* blk0_dev, int n, int nblocks, void* stream);
 int lgd_relu_bits_bwd(const uint32_t* relu_bits, const float* dy, long long total, float* dx, void* stream);
 int lgd_relu_mask_bwd(const float* y, const float* dy, long long total, float* dx, void* stream);
+/* y = x[..., ::2, ::2] of `planes` (image, channel) planes of H x W (the input of a 1x1 / stride 2 convolution: detectron2 BottleneckBlock with
+ * STRIDE_IN_1X1, projection shortcuts) as ceil(H/2) x ceil(W/2) planes, and its adjoint dx = g at the even (row, column) positions, 0 elsewhere:
+ * one pass each. */
+int lgd_subsample2_fwd(const float* x, long long planes, int H, int W, float* y, void* stream);
+int lgd_subsample2_bwd(const float* g, long long planes, int H, int W, float* dx, void* stream);
 
 /* ------------------------------------------------------------------ anchor <-> ground-truth matching of the student loss
  * [ref: distillator.py:96-112 -> student.losses on student AND teacher features; detectron2 RetinaNet.label_anchors /

@@ -98,9 +98,51 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
     vstore<VW>(dx + i, r);
 }
 
+// every other pixel of every other row (the input of a 1x1 / stride 2 convolution) and its adjoint: one pass each.  torch runs
+// x[:, :, ::2, ::2].contiguous() as a strided copy and its backward as two zero fills + two strided copies over the full-resolution map
+// (res3 -> res4 at BASELINE config 2: 170 us per step for the backward alone)
+__global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int H, int W, int Ho, int Wo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= planes * Ho * Wo) return;
+    const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+    const long long p = i / ((long long)Wo * Ho);
+    y[i] = x[(p * H + 2 * yo) * W + 2 * xo];
+}
+// thread per pair of input columns (x = 2 xo, 2 xo + 1) of one row: (g, 0) on even rows, (0, 0) on odd ones
+__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, long long planes, int H, int W, int Ho, int Wo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= planes * H * Wo) return;
+    const int xo = (int)(i % Wo), yy = (int)((i / Wo) % H);
+    const long long p = i / ((long long)Wo * H);
+    const float v = (yy & 1) ? 0.f : g[(p * Ho + (yy >> 1)) * Wo + xo];
+    float* o = dx + (p * H + yy) * W + 2 * xo;
+    if (2 * xo + 1 < W) {
+        if (((uintptr_t)o & 7) == 0) *reinterpret_cast<float2*>(o) = make_float2(v, 0.f);
+        else { o[0] = v; o[1] = 0.f; }
+    } else {
+        o[0] = v;
+    }
+}
+
 }  // namespace lgd
 
 extern "C" {
+
+int lgd_subsample2_fwd(const float* x, long long planes, int H, int W, float* y, void* stream) {
+    if (!x || !y || planes < 1 || H < 1 || W < 1) return LGD_EINVAL;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long total = planes * Ho * Wo;
+    LGD_LAUNCH("subsample2_kernel", lgd::subsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, planes, H, W, Ho, Wo);
+    return lgd::check_launch();
+}
+
+int lgd_subsample2_bwd(const float* g, long long planes, int H, int W, float* dx, void* stream) {
+    if (!g || !dx || planes < 1 || H < 1 || W < 1) return LGD_EINVAL;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long total = planes * H * Wo;
+    LGD_LAUNCH("subsample2_bwd_kernel", lgd::subsample2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, dx, planes, H, W, Ho, Wo);
+    return lgd::check_launch();
+}
 
 size_t lgd_relu_bits_words(long long total) { return total < 1 ? 0 : (size_t)((total + 63) / 64) * 2; }
 

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")
 _lib = None
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -91,6 +91,8 @@ SIGNATURES = {
     "lgd_scale_rows_multi": (c_i, [c_fp, c_fp, c_i, c_i, c_fp]),
     "lgd_relu_bits_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_relu_mask_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
+    "lgd_subsample2_fwd": (c_i, [c_fp, ctypes.c_longlong, c_i, c_i, c_fp, c_fp]),
+    "lgd_subsample2_bwd": (c_i, [c_fp, ctypes.c_longlong, c_i, c_i, c_fp, c_fp]),
     "lgd_anchor_match": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_box_reg_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i]),
     "lgd_box_reg_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),

@@ -1906,6 +1906,36 @@ def _pointwise_dw(dz, x, scale=None):
     return dw
 
 
+class _Subsample2(torch.autograd.Function):
+    """x[:, :, ::2, ::2] as a contiguous map, one pass forward and one backward (torch: a strided copy, and two zero fills + two strided
+    copies over the full-resolution gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        hip.require_gpu(x)
+        x = hip.dense_f32(x)
+        N, C, H, W = x.shape
+        ctx.dims = (N, C, H, W)
+        y = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device)
+        hip.check(hip.load().lgd_subsample2_fwd(hip.ptr(x), N * C, H, W, hip.ptr(y), hip.stream_ptr()), "lgd_subsample2_fwd")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.dims
+        g = hip.dense_f32(g)
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device)
+        hip.check(hip.load().lgd_subsample2_bwd(hip.ptr(g), N * C, H, W, hip.ptr(dx), hip.stream_ptr()), "lgd_subsample2_bwd")
+        return dx
+
+
+def subsample2(x):
+    """every other pixel of every other row of an NCHW map [d2-memory: the stride of a 1x1 / stride 2 convolution, applied ahead of it]"""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and os.environ.get("LGD_SUBSAMPLE2", "1") != "0":
+        return _Subsample2.apply(x)
+    return x[:, :, ::2, ::2].contiguous()
+
+
 def stem_bias_relu_maxpool(y, bias):
     """max_pool2d(relu(y + bias[c]), 3, 2, 1) of the frozen stem convolution's output in one pass (no autograd: the stem is frozen)."""
     hip.require_gpu(y, bias)

@@ -71,7 +71,7 @@ class ConvBN(nn.Conv2d):
 
     @staticmethod
     def subsample2(x):
-        return x[:, :, ::2, ::2].contiguous()
+        return ops.subsample2(x)
 
     def forward(self, x, relu=False, residual=None, subsampled=False, raw=False, pre=None):
         """conv -> FrozenBN [-> += residual] [-> ReLU]: the affine is folded into the filter; bias, residual and ReLU are ONE

@@ -1151,6 +1151,22 @@ def test_conv3x3_on_gemm3_equals_library_gemms(case):
         assert float((a - b_).abs().max()) <= 2e-5 * (float(b_.abs().max()) + 1e-30)
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 5, 10, 12), (1, 3, 7, 9), (3, 4, 100, 168), (2, 2, 25, 42), (1, 1, 1, 1)])
+def test_subsample2_and_its_adjoint(N, C, H, W):
+    """ops.subsample2 (the stride of a 1x1 / stride 2 convolution applied ahead of it, one pass forward and one backward) == x[:, :, ::2, ::2]
+    and its autograd, bit for bit, for even and odd map sizes [d2-memory: BottleneckBlock STRIDE_IN_1X1, projection shortcuts]."""
+    from lgd_amd import ops
+    x = torch.from_numpy(synth.det_uniform((N, C, H, W), 4100 + H, -1.0, 1.0)).to(DEV).requires_grad_(True)
+    y = ops.subsample2(x)
+    want = x.detach()[:, :, ::2, ::2]
+    assert y.is_contiguous() and torch.equal(y, want)
+    g = torch.from_numpy(synth.det_uniform(tuple(y.shape), 4200 + W, -1.0, 1.0)).to(DEV)
+    y.backward(g)
+    ref = torch.zeros_like(x)
+    ref[:, :, ::2, ::2] = g
+    assert torch.equal(x.grad, ref)
+
+
 def test_gemm3_shape_gate():
     """shapes whose tile would waste the MFMA rows (C' = 36, 64, 128) or break the k-step stay on the library GEMM; _wino_gemm then
     returns the library's result bit for bit."""
