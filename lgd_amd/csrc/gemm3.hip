@@ -37,6 +37,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef lgd_u32x4 u32x4;
 
 constexpr int BN = 128, BK = 16, NT = 256;
+#ifndef LGD_GEMM3_PIPE
+#define LGD_GEMM3_PIPE 1   // 1: staging behind the k-step's barrier (shipped); 0: at the top of the k-step (lab: the form until the end of round 4)
+#endif
+#ifndef LGD_GEMM3_ABL
+#define LGD_GEMM3_ABL 0   // lab ablations of the staging parts (tools/gpu_checks.sh ablate; results are garbage): 1 no split arithmetic, 2 no B at
+#endif                    // all, 3 no image DMA, 4 no C stores, 5 none of them (MFMA phase, fragment reads and barriers only)
 
 // tile rows BM = 256 (4 x 2 MFMA blocks per wave, 2 workgroups per CU) or 128 (2 x 2 blocks, 64 accumulator registers, 3 workgroups per
 // CU: C' = 128 layers, whose 256-row tile would idle half of every MFMA)
@@ -76,6 +82,9 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     // it runs the body once; launched PERSISTENT (as many workgroups as fit the chip at once) the next tile's prologue is issued while
     // the last tile's stores drain, and no slot waits for a workgroup to retire and another to be dispatched.
     for (int id = blockIdx.x; id < p.total; id += gridDim.x) {
+    // (persistent launch only) the previous tile's stores may be acknowledged out of order with the loads below: the k-loop's counted
+    // waits need an empty memory pipe in front of the first load of a tile
+    if (id != (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int xcd = id & 7, j = id >> 3;
     int b, tn, sub;
     if (p.a_sb != 0) {
@@ -107,14 +116,25 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     float bv[8];
     // buffer loads: the k-step's origin in the descriptor (scalar), the eight per-thread offsets as they are -- no 64-bit address per load
     auto load_b = [&](int ks) {
+#if LGD_GEMM3_ABL == 2 || LGD_GEMM3_ABL == 5
+        return;
+#endif
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb + ks * bstep), 0, 0xffffffffu, 0x00020000);
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff[e], 0, 0));
     };
     auto store_b = [&](char* buf) {
+#if LGD_GEMM3_ABL == 2 || LGD_GEMM3_ABL == 5
+        return;
+#endif
         uint32_t h[4], m[4], l[4];
+#if LGD_GEMM3_ABL == 1   // lab: the LDS store without the split's arithmetic
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = m[e] = l[e] = __builtin_bit_cast(uint32_t, bv[2 * e]) ^ __builtin_bit_cast(uint32_t, bv[2 * e + 1]);
+#else
 #pragma unroll
         for (int e = 0; e < 4; ++e) split2(bv[2 * e], bv[2 * e + 1], h[e], m[e], l[e]);
+#endif
         char* d = buf + bslot;
         *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
         *reinterpret_cast<u32x4*>(d + 4096) = (u32x4){m[0], m[1], m[2], m[3]};
@@ -132,6 +152,9 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     }
     const long astep = (long)3 * p.rbp * 1024;
     auto dma_a = [&](int ks, char* buf) {
+#if LGD_GEMM3_ABL == 3 || LGD_GEMM3_ABL == 5
+        return;
+#endif
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ai + ks * astep), 0, 0xffffffffu, 0x00020000);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
@@ -184,13 +207,81 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
                 for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
     }
 
+    // the accumulators live in the accumulator file from here on (zero-initialised ones left to the compiler: it folds the zeros into the
+    // first MFMAs, peels the k-loop's first step and, in the paired loop, holds 100 more VGPRs)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) asm volatile("" : "+a"(acc[i][jn]));
+    const int slot = lane * 16;
+#if LGD_GEMM3_PIPE == 1
+    // Staging shifted by half a k-step.  hipcc hoists the k-step's barrier (with its s_waitcnt vmcnt(0): the LDS-DMA must have landed) to
+    // the point where the last fragment reads are issued -- in front of the last 24 MFMAs.  Staged at the TOP of the k-step, the image
+    // DMA and the B loads had half a k-step (~0.35 us) to come back from L2 / HBM before that wait; staged right BEHIND the barrier --
+    // into the buffer whose fragments every wave has just taken, for the k-step after next -- they have a whole one: -2.7 % on the
+    // two-pyramid products (508 -> 494 us, profiles/r04_gemm3_pipe.log).  B a SECOND k-step ahead (two register sets, the loop in pairs)
+    // measured the same as this: memory latency is not what the waves wait for any more.
+    dma_a(0, lds);
+    load_b(0);
+    store_b(lds);
+    if (ksteps > 1) {
+        load_b(1);
+        dma_a(1, lds + BUF);
+        store_b(lds + BUF);
+    }
+    load_b(ksteps > 2 ? 2 : ksteps - 1);   // always 8 loads behind the youngest DMA: the counted wait below
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        char* cur = lds + (ks & 1) * BUF;
+        bf16x8 fb[3][2], fa[MI];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+                fb[pc][jn] = *reinterpret_cast<const bf16x8*>(cur + A_BYTES + pc * 4096 + (wn * 2 + jn) * 1024 + slot);
+#pragma unroll
+        for (int pa = 2; pa >= 1; --pa) {            // smallest pieces first
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(cur + pa * (RB * 1024) + (wm * MI + i) * 1024 + slot);
+#pragma unroll
+            for (int pb = 2 - pa; pb >= 0; --pb)     // pa + pb <= 2: the six kept products
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[pb][jn], acc[i][jn], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            fa[i] = *reinterpret_cast<const bf16x8*>(cur + (wm * MI + i) * 1024 + slot);
+        // the image DMA of k-step ks + 1 (issued behind the previous barrier) must have LANDED before anybody passes this one; hipcc's own
+        // wait insertion loses an LDS-DMA across the loop's back-edge (it emitted no vmcnt wait here at all), and vmcnt(0) would also
+        // drain the 8 B loads issued behind that DMA, which nobody needs before store_b.  The memory pipe returns in order: vmcnt(8).
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();   // every wave holds its last fragments of cur; k-step ks + 1 is complete in the other buffer
+        if (ks + 2 < ksteps) {
+            store_b(cur);                            // bv: B of k-step ks + 2, loaded behind the previous barrier
+            dma_a(ks + 2, cur);
+        }
+        if (ks + 1 < ksteps) load_b(ks + 3 < ksteps ? ks + 3 : ksteps - 1);   // (the last ones re-read a valid k-step: the count stays 8)
+#pragma unroll
+        for (int pb = 2; pb >= 0; --pb)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[pb][jn], acc[i][jn], 0, 0, 0);
+    }
+    __syncthreads();       // (the epilogue and the next tile's prologue reuse the buffers)
+#else
     // prologue: k-step 0 into buffer 0, B of k-step 1 into registers
     dma_a(0, lds);
     load_b(0);
     store_b(lds);
     if (ksteps > 1) load_b(1);
     __syncthreads();
-    const int slot = lane * 16;
     for (int ks = 0; ks < ksteps; ++ks) {
         char* cur = lds + (ks & 1) * BUF;
         char* nxt = lds + ((ks + 1) & 1) * BUF;
@@ -225,6 +316,7 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
         }
         __syncthreads();
     }
+#endif
     // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); 32-bit offsets from one base;
     // a half-wave's store covers 128 contiguous bytes.  EPI: shift and ReLU on the way out, straight-line per (mask?, full tile?) variant
     // (a condition per element splits the block into 16 basic blocks with a wait each).  The ReLU mask: a ballot per accumulator register
@@ -272,6 +364,9 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
                             }
                             v = (pos | norelu) ? v : 0.f;
                         }
+#if LGD_GEMM3_ABL == 4 || LGD_GEMM3_ABL == 5   // lab: no C stores (one conditional store keeps the accumulators alive)
+                        if (v == 123456.f)
+#endif
                         if (hf || (dm < mrem && colok[jn])) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
                         co += (e & 3) == 3 ? c5 : c1;
                         asm volatile("" : "+v"(co));

@@ -3,7 +3,12 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lgd_amd import ops
+from lgd_amd import hip, ops
+
+if "--lib" in sys.argv:   # a lab build of the kernel library (tools/gemm3_ablate.sh)
+    i = sys.argv.index("--lib")
+    hip._LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 
 
 def _warm_clocks(seconds=1.0):
@@ -22,6 +27,7 @@ _warm_clocks()
 g = torch.Generator(device="cuda").manual_seed(0)
 U = torch.randn(64, 256, 256, device="cuda", generator=g) * 0.05
 NSET = 3
+print("library:", hip.lib_path())
 for T in (int(a) for a in (sys.argv[1:] or "2560 3840 5120 5232 5248 5376 5632 6144 10240 10464 11264".split())):
     V = [ops._freq_buf(64, 256, T, "cuda").normal_(generator=g) for _ in range(NSET)]
     M = [ops._freq_buf(64, 256, T, "cuda") for _ in range(NSET)]
