@@ -1,0 +1,491 @@
+// LAB (round 5): the Winograd channel products on the f16 MFMA pipe from TWO-piece split operands that are already split in HBM.
+//   x * 2^e = h + m,  h = f16(x 2^e), m = f16(x 2^e - h)   (round to nearest: |x 2^e - h - m| <= 2^-23 |x 2^e|, 11 + 11 bits + sign)
+//   a b ~ ah bh + ah bm + am bh   (dropped: am bm <= 2^-22 |a||b|), fp32 accumulation inside v_mfma_f32_32x32x16_f16
+// Three MFMAs per k-step instead of the six of the bf16x3 form (csrc/gemm3.hip), and 4 bytes per element in HBM -- the same as fp32 --
+// so the data transforms can write the operands split (no VALU split and no register staging in the product kernels: both operands come
+// by LDS-DMA).  f16 has 5 exponent bits: every operand carries one power-of-two scale per batch (frequency), chosen from a bound of
+// its magnitude; the products are rescaled by 2^-(ea + eb) on the way out.  Numerics first: tools/lab/split_numerics.py (CPU).
+//
+// Operand formats
+//   split rows  (activations: V, dM):  row r of batch b at  base + r * rs + b * sb  (bytes);  k (tile) index t inside the row:
+//        (t >> 4) * 64 + piece * 32 + (t & 15) * 2        -- blocks of 16 tiles: 32 B of h then 32 B of m
+//   image       (filters: U, U^T):  [batch][k-step of 16][piece][32-row block][lane = (k % 16 / 8) * 32 + row % 32][8 f16]
+// Kernels
+//   h2_fwd_kernel :  C[b] (M x N) = A[b] (image, M x K) . B[b] (split rows = k, N contiguous)      M = U V,  dV = U^T dM
+//        B is k-strided / n-contiguous: its LDS image is [piece][k][256 B] with every row rotated by 64 B x (k % 4) and the fragments
+//        are taken with ds_read_b64_tr_b16 (conflict-free: a half-wave's 4 rows x 2 column groups tile one 256-byte bank row)
+//   h2_dw_kernel  :  P[s][b] (M x N) = sum over the k-range of split s of A[b][m][k] B[b][n][k]     dU = dM V^T   (split-K, fixed order)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long bytes_left) {
+    const uint32_t n = bytes_left <= 0 ? 0u : bytes_left > 0xffffffffL ? 0xffffffffu : (uint32_t)bytes_left;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+
+// 16 bytes per lane, global -> LDS (lane-linear: LDS byte address lds_addr + 16 lane), as inline asm: hipcc's wait insertion drains
+// vmcnt(0) in front of every LDS read and every barrier that follows a builtin LDS-DMA, which would serialise the pipeline; the kernels
+// count their own waits (the memory pipe returns loads in order)
+__device__ __forceinline__ void glds16(const __amdgpu_buffer_rsrc_t rs, uint32_t lds_addr, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+
+// two elements -> packed h pair, packed m pair
+__device__ __forceinline__ void split2h(float x0, float x1, float s, uint32_t& h, uint32_t& m) {
+    const float t0 = x0 * s, t1 = x1 * s;
+    const f16x2 hh = __builtin_convertvector((f32x2){t0, t1}, f16x2);
+    const float r0 = t0 - (float)hh[0], r1 = t1 - (float)hh[1];
+    const f16x2 mm = __builtin_convertvector((f32x2){r0, r1}, f16x2);
+    h = __builtin_bit_cast(uint32_t, hh);
+    m = __builtin_bit_cast(uint32_t, mm);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ forward / dx product
+struct FwdP {
+    const char* Aimg; long a_sb; int rbp;            // image; a_sb bytes per batch
+    const char* B; long b_sb, b_ld, b_bytes;         // split rows: batch stride, k-row stride, extent (bytes)
+    float* C; long c_sb, c_ld;                       // floats
+    const float* a_inv; const float* b_inv;          // per batch 2^-e
+    unsigned* amax_out;                              // optional: per batch max |C| (float bits)
+    int nb, M, N, K, mt, nt, total;
+};
+
+template <int BM, bool AMAX>
+__global__ __launch_bounds__(256) void h2_fwd_kernel(const FwdP p) {
+    constexpr int RB = BM / 32, MI = BM / 64, BN = 128;
+    constexpr int A_BYTES = 2 * RB * 1024, B_BYTES = 8192, BUF = A_BYTES + B_BYTES, ST = 3;
+    constexpr int ACH = 2 * RB / 4, DPW = ACH + 2;   // LDS-DMA instructions per wave and k-step
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int per_b = p.nt * p.mt;
+    const int b = (j / per_b) * 8 + xcd;
+    const int r = j % per_b;
+    if (b >= p.nb) return;
+    const int tn = r / p.mt, sub = r % p.mt;
+    const int m0 = sub * BM, n0 = tn * BN, rb0 = sub * RB;
+    const int ksteps = p.K / 16;
+    const char* Ai = p.Aimg + (long)b * p.a_sb;
+    const char* Bb = p.B + (long)b * p.b_sb;
+    uint32_t aoff[ACH];
+#pragma unroll
+    for (int c = 0; c < ACH; ++c) {
+        const int ch = w * ACH + c, pc = ch / RB, rbl = ch % RB;
+        int rb = rb0 + rbl;
+        rb = rb < p.rbp ? rb : p.rbp - 1;
+        aoff[c] = (uint32_t)((pc * p.rbp + rb) * 1024 + lane * 16);
+    }
+    const long astep = (long)2 * p.rbp * 1024;
+    // B: instruction jb = 2 w + jj moves piece jb >> 2, rows 4 (jb & 3) .. + 3; lane -> (row = lane >> 4, LDS chunk q = lane & 15), which holds
+    // the row's chunk (q - 4 row) & 15: the rotation by 64 bytes per row that makes the transposing reads conflict-free
+    uint32_t boff[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int jb = 2 * w + jj, pc = jb >> 2, rg = jb & 3, rl = lane >> 4, q = lane & 15;
+        const int sc = (q - 4 * rl) & 15, rr = 4 * rg + rl;
+        boff[jj] = (uint32_t)(rr * (int)p.b_ld + ((n0 >> 4) + (sc >> 1)) * 64 + pc * 32 + (sc & 1) * 16);
+    }
+    const long bstep = 16 * p.b_ld;
+    const long b_left0 = p.b_bytes - (long)b * p.b_sb;
+    auto dma = [&](int ks, int buf) {
+        char* dst = lds + buf * BUF;
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ai + ks * astep, 0x7fffffff);
+#pragma unroll
+        for (int c = 0; c < ACH; ++c) glds16(ra, lds_addr_of(dst + (w * ACH + c) * 1024), aoff[c]);
+        const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(Bb + ks * bstep, b_left0 - ks * bstep);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            glds16(rb_, lds_addr_of(dst + A_BYTES + (2 * w + jj) * 1024), boff[jj]);
+    };
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) asm volatile("" : "+a"(acc[i][jn]));
+    // transposing reads of B: lane -> 16-lane group cg = (lane >> 4) & 1 (columns cg 16 ..), k-group g = lane >> 5 (k = 8 g ..), i = lane & 15:
+    // source row 8 g + 4 h + (i >> 2), 4 columns at (i & 3) 4; position inside the rotated 256-byte row: (2 col + 64 (i >> 2)) & 255
+    const int g = lane >> 5, cg = (lane >> 4) & 1, i16 = lane & 15;
+    int btr[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int col = wn * 64 + jn * 32 + cg * 16 + (i16 & 3) * 4;
+        btr[jn] = A_BYTES + (8 * g + (i16 >> 2)) * 256 + ((2 * col + 64 * (i16 >> 2)) & 255);
+    }
+    const int slot = lane * 16;
+    // Pipeline: three buffers; the k-step's barrier sits at the END of the iteration (with a counted wait: the youngest group of DPW
+    // LDS-DMAs may still be in flight), the fragment reads open the next one and the DMA for k-step ks + 2 is issued right behind them into
+    // the buffer everybody left before the previous barrier.  (hipcc drains vmcnt(0) in front of the first LDS read that follows an
+    // LDS-DMA in program order; placed like this that happens once, in front of the loop, not per k-step.)
+    dma(0, 0);
+    dma(ksteps > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const char* cur = lds + (ks % ST) * BUF;
+        f16x8 fa[2][MI], fb[2][2];
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(cur + btr[jn] + pc * 4096));
+                const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(cur + btr[jn] + pc * 4096 + 1024));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                fb[pc][jn] = __builtin_bit_cast(f16x8, (u32x4){l2[0], l2[1], h2[0], h2[1]});
+            }
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[pc][i] = *reinterpret_cast<const f16x8*>(cur + pc * (RB * 1024) + (wm * MI + i) * 1024 + slot);
+        {
+            const int nx = ks + 2 < ksteps ? ks + 2 : ksteps - 1;
+            dma(nx, (ks + 2) % ST);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][jn], acc[i][jn], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    const float inv = p.a_inv[b] * p.b_inv[b];
+    const int rr = lane & 31;
+    const int wrow = m0 + wm * (BM / 2), wcol = n0 + wn * 64;
+    const int mw = wrow + 4 * g, nw = wcol + rr;
+    const int ld = (int)p.c_ld;
+    const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
+    const __amdgpu_buffer_rsrc_t cs = make_rsrc(p.C + (long)b * p.c_sb + (long)wrow * ld + wcol, 0x7fffffff);
+    const int c1 = ld * 4, c5 = ld * 20, mrem = p.M - mw;
+    const bool colok[2] = {nw < p.N, nw + 32 < p.N};
+    float amax = 0.f;
+    auto epi = [&](auto HF) {
+        constexpr bool hf = decltype(HF)::value;
+        int cbase = (4 * g * ld + rr) * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                asm volatile("" : "+a"(acc[i][jn])::"memory");
+                int co = cbase;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
+                    const float v = acc[i][jn][e] * inv;
+                    const bool ok = hf || (dm < mrem && colok[jn]);
+                    if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
+                    if constexpr (AMAX) amax = fmaxf(amax, ok ? fabsf(v) : 0.f);
+                    co += (e & 3) == 3 ? c5 : c1;
+                    asm volatile("" : "+v"(co));
+                }
+                if (jn == 1) cbase = co;
+            }
+        }
+    };
+    if (full) epi(std::true_type()); else epi(std::false_type());
+    if constexpr (AMAX) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if (lane == 0) atomicMax(p.amax_out + b, __builtin_bit_cast(unsigned, amax));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ weight-gradient product
+struct DwP {
+    const char* A; long a_rs, a_sb, a_bytes;       // split rows (m): row stride, batch stride, extent (bytes)
+    const char* B; long b_rs, b_sb, b_bytes;       // split rows (n)
+    float* P;                                      // partials [S][nb][M][N]
+    const float* a_inv; const float* b_inv;
+    int nb, M, N, nstage, S, per, mt, nt;          // nstage: k-stages in total; per: stages per split
+};
+
+// KC: 16-byte chunks per row and stage (4: 16 tiles, 8: 32 tiles); ST stages of 2 x 256 x KC x 16 bytes
+template <int KC, int ST>
+__global__ __launch_bounds__(512) void h2_dw_kernel(const DwP p) {
+    constexpr int ROWB = KC * 16, OPB = 256 * ROWB, BUF = 2 * OPB;
+    constexpr int RPI = 64 / KC, IPW = (256 / RPI) / 8;          // rows per DMA instruction, instructions per wave and operand
+    constexpr int DPW = 2 * IPW;
+    constexpr int SUB = KC / 4;                                  // 16-deep MFMA k-steps per stage
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 2, wn = w & 3;
+    int id = blockIdx.x;
+    const int tn = id % p.nt; id /= p.nt;
+    const int tm = id % p.mt; id /= p.mt;
+    const int s = id % p.S;
+    const int b = id / p.S;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int st0 = s * p.per, st1 = min(st0 + p.per, p.nstage), nst = st1 - st0;
+    // DMA: instruction jj of wave w covers rows (w IPW + jj) RPI .. of the tile; lane -> (row = lane / KC, LDS chunk q = lane % KC) which holds the
+    // row's chunk q ^ swz(row) (the fragment reads of a 16-lane group then touch 16 distinct 16-byte slots of a 256-byte bank row)
+    const int rl = lane / KC, q = lane % KC;
+    uint32_t offA[IPW], offB[IPW];
+#pragma unroll
+    for (int jj = 0; jj < IPW; ++jj) {
+        const int row = jj * RPI + rl;   // relative to the wave's first row (a multiple of 32: the swizzle sees the same bits)
+        const int sw = KC == 4 ? (row >> 2) & 3 : (row >> 1) & 7;
+        offA[jj] = (uint32_t)((long)row * p.a_rs + (q ^ sw) * 16);
+        offB[jj] = (uint32_t)((long)row * p.b_rs + (q ^ sw) * 16);
+    }
+    const long a0 = (long)b * p.a_sb + (long)(m0 + w * IPW * RPI) * p.a_rs, b0 = (long)b * p.b_sb + (long)(n0 + w * IPW * RPI) * p.b_rs;
+    auto dma = [&](int stg, int buf) {
+        char* dst = lds + buf * BUF;
+        const long ko = (long)stg * ROWB;
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + a0 + ko, p.a_bytes - a0 - ko);
+#pragma unroll
+        for (int jj = 0; jj < IPW; ++jj)
+            glds16(ra, lds_addr_of(dst + (w * IPW + jj) * 1024), offA[jj]);
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + b0 + ko, p.b_bytes - b0 - ko);
+#pragma unroll
+        for (int jj = 0; jj < IPW; ++jj)
+            glds16(rb, lds_addr_of(dst + OPB + (w * IPW + jj) * 1024), offB[jj]);
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) asm volatile("" : "+a"(acc[i][jn]));
+    // fragment reads: lane -> (row in block rib = lane & 31, k-group g = lane >> 5); chunk (sub 4 + piece 2 + g) ^ swz(rib)
+    const int rib = lane & 31, g = lane >> 5;
+    const int sw = KC == 4 ? (rib >> 2) & 3 : (rib >> 1) & 7;
+    const int abase = (wm * 128 + rib) * ROWB, bbase = OPB + (wn * 64 + rib) * ROWB;
+    int xo[SUB][2];
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) xo[sb][pc] = ((sb * 4 + pc * 2 + g) ^ sw) * 16;
+#pragma unroll
+    for (int i = 0; i < ST - 1; ++i) dma(st0 + (i < nst ? i : nst - 1), i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * DPW) : "memory");
+    __syncthreads();
+    for (int it = 0; it < nst; ++it) {
+        const char* cur = lds + (it % ST) * BUF;
+        f16x8 fa[SUB][2][4], fb[SUB][2][2];
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[sb][pc][i] = *reinterpret_cast<const f16x8*>(cur + abase + i * 32 * ROWB + xo[sb][pc]);
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) fb[sb][pc][jn] = *reinterpret_cast<const f16x8*>(cur + bbase + jn * 32 * ROWB + xo[sb][pc]);
+            }
+        if constexpr (ST == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }   // two buffers: the next stage lands in the one just read
+        {
+            const int nx = it + ST - 1 < nst ? it + ST - 1 : nst - 1;
+            dma(st0 + nx, (it + ST - 1) % ST);
+        }
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sb][1][i], fb[sb][0][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sb][0][i], fb[sb][1][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sb][0][i], fb[sb][0][jn], acc[i][jn], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * DPW) : "memory");
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float inv = p.a_inv[b] * p.b_inv[b];
+    float* P = p.P + ((long)s * p.nb + b) * p.M * p.N;
+    const int rr = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            asm volatile("" : "+a"(acc[i][jn])::"memory");
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * g, n = n0 + wn * 64 + jn * 32 + rr;
+                if (m < p.M && n < p.N) P[(long)m * p.N + n] = acc[i][jn][e] * inv;
+            }
+        }
+}
+
+__global__ void h2_reduce_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int S) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = P[i];
+    for (int s = 1; s < S; ++s) a += P[(long)s * n + i];
+    out[i] = a;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ lab-side splits
+// X (rows, nb, T) fp32, element (r, b, t) at X[(r * nb + b) * T + t]  ->  split rows with row stride nb * T * 4, batch stride T * 4
+__global__ void h2_split_rows_kernel(const float* __restrict__ X, const float* __restrict__ scale, char* __restrict__ out, long rows, int nb, int T) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-tile octet
+    const int oct = T / 8;
+    if (q >= rows * nb * oct) return;
+    const int o = (int)(q % oct);
+    const long pl = q / oct;
+    const int b = (int)(pl % nb);
+    const float s = scale[b];
+    const float* x = X + pl * T + o * 8;
+    uint32_t h[4], m[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2h(x[2 * e], x[2 * e + 1], s, h[e], m[e]);
+    char* d = out + pl * T * 4 + (o >> 1) * 64 + (o & 1) * 16;
+    *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(d + 32) = (u32x4){m[0], m[1], m[2], m[3]};
+}
+
+// A (nb, M, K) fp32 with strides -> image
+__global__ void h2_split_image_kernel(const float* __restrict__ A, long a_sb, long sm, long sk, const float* __restrict__ scale, int nb, int M, int K, int rbp,
+                                      int ktp, char* __restrict__ img) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)nb * ktp * rbp * 64) return;
+    const int lane = (int)(q & 63);
+    long r = q >> 6;
+    const int rb = (int)(r % rbp); r /= rbp;
+    const int kt = (int)(r % ktp);
+    const int b = (int)(r / ktp);
+    const int m = rb * 32 + (lane & 31), k0 = kt * 16 + (lane >> 5) * 8;
+    const float s = scale[b];
+    uint32_t h[4], mm[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = (m < M && k0 + 2 * e < K) ? A[(long)b * a_sb + (long)m * sm + (long)(k0 + 2 * e) * sk] : 0.f;
+        const float x1 = (m < M && k0 + 2 * e + 1 < K) ? A[(long)b * a_sb + (long)m * sm + (long)(k0 + 2 * e + 1) * sk] : 0.f;
+        split2h(x0, x1, s, h[e], mm[e]);
+    }
+    char* d = img + ((((long)b * ktp + kt) * 2) * rbp + rb) * 1024 + lane * 16;
+    *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(d + (long)rbp * 1024) = (u32x4){mm[0], mm[1], mm[2], mm[3]};
+}
+
+extern "C" {
+
+long h2_image_bytes(int nb, int M, int K) { return (long)nb * ((K + 15) / 16) * 2 * ((M + 31) / 32) * 1024; }
+
+int h2_split_rows(const float* X, const float* scale, void* out, long rows, int nb, int T, void* stream) {
+    const long n = rows * nb * (T / 8);
+    hipLaunchKernelGGL(h2_split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, scale, (char*)out, rows, nb, T);
+    return (int)hipGetLastError();
+}
+
+int h2_split_image(const float* A, long a_sb, long sm, long sk, const float* scale, int nb, int M, int K, void* img, void* stream) {
+    const int rbp = (M + 31) / 32, ktp = (K + 15) / 16;
+    const long n = (long)nb * ktp * rbp * 64;
+    hipLaunchKernelGGL(h2_split_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, a_sb, sm, sk, scale, nb, M, K, rbp, ktp,
+                       (char*)img);
+    return (int)hipGetLastError();
+}
+
+// C[b] (M x N) = A[b] . B[b];  B split rows: k-row stride b_ld bytes, batch stride b_sb bytes, extent b_bytes; C floats
+int h2_fwd(const void* img, const void* B, long b_sb, long b_ld, long b_bytes, float* C, long c_sb, long c_ld, const float* a_inv, const float* b_inv,
+           unsigned* amax_out, int nb, int M, int N, int K, void* stream) {
+    if (K & 15) return -1;
+    FwdP p;
+    p.rbp = (M + 31) / 32;
+    p.Aimg = (const char*)img; p.a_sb = (long)(K / 16) * 2 * p.rbp * 1024;
+    p.B = (const char*)B; p.b_sb = b_sb; p.b_ld = b_ld; p.b_bytes = b_bytes;
+    p.C = C; p.c_sb = c_sb; p.c_ld = c_ld; p.a_inv = a_inv; p.b_inv = b_inv; p.amax_out = amax_out;
+    const bool small = ((M + 255) / 256 * 256 - M >= 64 && (M + 127) / 128 * 128 - M < 64);
+    const int bm = small ? 128 : 256;
+    p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + bm - 1) / bm; p.nt = (N + 127) / 128;
+    p.total = ((nb + 7) / 8) * p.nt * p.mt * 8;
+    if (small) {
+        constexpr int L = 3 * (2 * 4 * 1024 + 8192);
+        if (amax_out) {
+            (void)hipFuncSetAttribute((const void*)h2_fwd_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L);
+            hipLaunchKernelGGL((h2_fwd_kernel<128, true>), dim3(p.total), dim3(256), L, (hipStream_t)stream, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)h2_fwd_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L);
+            hipLaunchKernelGGL((h2_fwd_kernel<128, false>), dim3(p.total), dim3(256), L, (hipStream_t)stream, p);
+        }
+    } else {
+        constexpr int L = 3 * (2 * 8 * 1024 + 8192);
+        if (amax_out) {
+            (void)hipFuncSetAttribute((const void*)h2_fwd_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L);
+            hipLaunchKernelGGL((h2_fwd_kernel<256, true>), dim3(p.total), dim3(256), L, (hipStream_t)stream, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)h2_fwd_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L);
+            hipLaunchKernelGGL((h2_fwd_kernel<256, false>), dim3(p.total), dim3(256), L, (hipStream_t)stream, p);
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+// out[b] (M x N) = sum_t A[b][m][t] B[b][n][t], t = 0 .. T-1; both split rows.  variant 0: 16 tiles per stage x 4 stages, 1: 32 tiles x 2 stages
+int h2_dw(const void* A, long a_rs, long a_sb, long a_bytes, const void* B, long b_rs, long b_sb, long b_bytes, float* partials, float* out,
+          const float* a_inv, const float* b_inv, int nb, int M, int N, int T, int S, int variant, void* stream) {
+    DwP p;
+    const int tiles_per_stage = variant == 0 ? 16 : 32;
+    if (T % tiles_per_stage) return -1;
+    p.A = (const char*)A; p.a_rs = a_rs; p.a_sb = a_sb; p.a_bytes = a_bytes;
+    p.B = (const char*)B; p.b_rs = b_rs; p.b_sb = b_sb; p.b_bytes = b_bytes;
+    p.P = S > 1 ? partials : out; p.a_inv = a_inv; p.b_inv = b_inv;
+    p.nb = nb; p.M = M; p.N = N; p.nstage = T / tiles_per_stage; p.S = S; p.per = (p.nstage + S - 1) / S;
+    p.mt = (M + 255) / 256; p.nt = (N + 255) / 256;
+    const unsigned grid = (unsigned)(nb * S * p.mt * p.nt);
+    if (variant == 0) {
+        constexpr int L = 4 * 2 * 256 * 64;
+        (void)hipFuncSetAttribute((const void*)h2_dw_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, L);
+        hipLaunchKernelGGL((h2_dw_kernel<4, 4>), dim3(grid), dim3(512), L, (hipStream_t)stream, p);
+    } else {
+        constexpr int L = 2 * 2 * 256 * 128;
+        (void)hipFuncSetAttribute((const void*)h2_dw_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, L);
+        hipLaunchKernelGGL((h2_dw_kernel<8, 2>), dim3(grid), dim3(512), L, (hipStream_t)stream, p);
+    }
+    if (S > 1) {
+        const long n = (long)nb * M * N;
+        hipLaunchKernelGGL(h2_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, out, n, S);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+// probe of ds_read_b64_tr_b16: LDS holds the f16 values 0, 1, 2, ...; lane l reads at byte address 8 l (+ base); out[l][0..3]
+__global__ void h2_tr_probe_kernel(float* out) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = (_Float16)(float)i;
+    __syncthreads();
+    const fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(lds + 4 * threadIdx.x));
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (float)v[j];
+}
+extern "C" int h2_tr_probe(float* out, void* stream) {
+    hipLaunchKernelGGL(h2_tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+    return (int)hipGetLastError();
+}
