@@ -62,6 +62,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
 }
 
+// ---- running maximum of non-negative floats, kept as their bit pattern in ONE device word (the magnitude bounds of csrc/h2.hip).  Tens of
+// thousands of waves report to the same word: an atomic each serialises in the L2 (measured: 530 us for a 25 us pass over the maps).  Nearly
+// all of them lose against the value already there, which a relaxed load settles; a stale (smaller) value only costs an unnecessary atomic.
+__device__ __forceinline__ void atomic_max_bits(unsigned* addr, unsigned v) {
+    if (v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, v);
+}
+
 // ---- streaming (non-temporal) 16-byte load: data that is read exactly once should not displace L2 lines.
 // Measured on MI355X (tools/lab/bw_lab.hip): +11 % read bandwidth over plain loads for one-pass reductions.
 typedef float lgd_vf4 __attribute__((ext_vector_type(4)));

@@ -626,6 +626,7 @@ int wino_fill(WinoArgs& a, const int32_t* level_hw, int L, int N, int C, int til
     if (!level_hw || L < 1 || L > LGD_MAX_LEVELS || N < 1 || C < 1 || C > 65535 || (tile != 4 && tile != 6)) return LGD_EINVAL;
     a.L = L; a.N = N; a.C = C; a.relu = 0;
     a.bias = nullptr; a.pre_affine = nullptr; a.gn_coef = nullptr; a.buf_in = nullptr; a.buf_out = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
+    a.amax_in = nullptr; a.scale_out = nullptr; a.amax_out = nullptr; a.h2 = 0;
     long long off = 0;
     unsigned blk = 0;
     for (int l = 0; l < LGD_MAX_LEVELS; ++l) {
@@ -788,6 +789,92 @@ int lgd_wino_in_t_out_t(const float* dV, const void* relu_bits, const int32_t* l
     a.buf_in = dV; a.buf_out = dM; a.bits_in = relu_bits;
     if (tile == 6) lgd::wino6_launch_in_t(a, blocks, true, (hipStream_t)stream);
     else { LGD_LAUNCH("wino_in_t_out_t_kernel", lgd::wino4_in_t_kernel<true>, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, a); }
+    return lgd::check_launch();
+}
+
+// ---- F(6x6,3x3) transforms around the f16x2 products of csrc/h2.hip: the frequency buffers they WRITE are split rows (winograd.h)
+int lgd_wino_in_h2(const float* const* x_host, const int32_t* level_hw_host, int L, int N, int C, void* V, const float* pre_bias,
+                   const float* pre_affine, void* pre_bits, const uint32_t* amax_in, float* inv_out, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!x_host || !V || !amax_in || !inv_out || lgd::wino_fill(a, level_hw_host, L, N, C, 6, &blocks) != LGD_OK) return LGD_EINVAL;
+    if ((pre_bits && !pre_bias && !pre_affine) || (pre_bias && pre_affine) || ((uintptr_t)V & 15)) return LGD_EINVAL;
+    a.bias = pre_bias; a.pre_affine = pre_affine; a.bits_out = pre_bits;
+    for (int l = 0; l < L; ++l) {
+        if (!x_host[l]) return LGD_EINVAL;
+        a.maps_in[l] = x_host[l];
+    }
+    a.buf_out = (float*)V; a.h2 = 1; a.amax_in = amax_in; a.scale_out = inv_out;
+    lgd::wino6_launch_in(a, blocks, pre_bias != nullptr || pre_affine != nullptr, (hipStream_t)stream);
+    return lgd::check_launch();
+}
+
+int lgd_wino_out_t_h2(const float* const* dy_host, const void* relu_bits, const int32_t* level_hw_host, int L, int N, int C, void* dM,
+                      const uint32_t* amax_in, float* inv_out64, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!dy_host || !dM || !amax_in || !inv_out64 || ((uintptr_t)dM & 15) || lgd::wino_fill(a, level_hw_host, L, N, C, 6, &blocks) != LGD_OK) return LGD_EINVAL;
+    a.bits_in = relu_bits;
+    for (int l = 0; l < L; ++l) {
+        if (!dy_host[l]) return LGD_EINVAL;
+        a.maps_in[l] = dy_host[l];
+    }
+    a.buf_out = (float*)dM; a.h2 = 1; a.amax_in = amax_in; a.scale_out = inv_out64;
+    lgd::wino6_launch_out_t(a, blocks, (hipStream_t)stream);
+    return lgd::check_launch();
+}
+
+int lgd_wino_in_t_out_t_h2(const float* dV, const void* relu_bits, const int32_t* level_hw_host, int L, int N, int C, void* dM,
+                           const uint32_t* bound_in, float* inv_out64, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!dV || !dM || !bound_in || !inv_out64 || ((uintptr_t)dM & 15) || lgd::wino_fill(a, level_hw_host, L, N, C, 6, &blocks) != LGD_OK) return LGD_EINVAL;
+    a.buf_in = dV; a.buf_out = (float*)dM; a.bits_in = relu_bits; a.h2 = 1; a.amax_in = bound_in; a.scale_out = inv_out64;
+    lgd::wino6_launch_in_t(a, blocks, true, (hipStream_t)stream);
+    return lgd::check_launch();
+}
+
+// lgd_wino_out / lgd_wino_in_t (tile 6) that also leave max |output| (float bits) in *amax_out: the bound the consumer's f16 scale needs
+int lgd_wino_out_amax(const float* M, const float* bias, const int32_t* level_hw_host, int L, int N, int C, int relu, float* const* y_host,
+                      void* relu_bits, uint32_t* amax_out, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!M || !y_host || !amax_out || lgd::wino_fill(a, level_hw_host, L, N, C, 6, &blocks) != LGD_OK) return LGD_EINVAL;
+    a.bits_out = relu_bits;
+    for (int l = 0; l < L; ++l) {
+        if (!y_host[l]) return LGD_EINVAL;
+        a.maps_out[l] = y_host[l];
+    }
+    a.buf_in = M; a.bias = bias; a.relu = relu ? 1 : 0; a.amax_out = amax_out;
+    if (hipMemsetAsync(amax_out, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return LGD_ELAUNCH;
+    lgd::wino6_launch_out(a, blocks, (hipStream_t)stream);
+    return lgd::check_launch();
+}
+
+int lgd_wino_in_t_amax(const float* dV, const int32_t* level_hw_host, int L, int N, int C, float* const* dx_host, const void* pre_bits,
+                       uint32_t* amax_out, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!dV || !dx_host || !amax_out || lgd::wino_fill(a, level_hw_host, L, N, C, 6, &blocks) != LGD_OK) return LGD_EINVAL;
+    a.bits_in = pre_bits;
+    for (int l = 0; l < L; ++l) {
+        if (!dx_host[l]) return LGD_EINVAL;
+        a.maps_out[l] = dx_host[l];
+    }
+    a.buf_in = dV; a.amax_out = amax_out;
+    if (hipMemsetAsync(amax_out, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return LGD_ELAUNCH;
+    lgd::wino6_launch_in_t(a, blocks, false, (hipStream_t)stream);
+    return lgd::check_launch();
+}
+
+int lgd_wino_filter_images_h2(const float* w, const float* scale, int Co, int Ci, int row0, int Ct, void* img_fwd, void* img_bwd,
+                              const uint32_t* amax_in, float* inv_out64, void* stream) {
+    if (!w || (!img_fwd && !img_bwd) || !amax_in || Co < 16 || Ci < 16 || (Co & 15) || (Ci & 15) || (row0 & 15) || (Ct & 15) || row0 < 0 ||
+        row0 + Co > Ct || ((uintptr_t)img_fwd & 15) || ((uintptr_t)img_bwd & 15)) return LGD_EINVAL;
+    lgd::FilterArgs a{};
+    a.w = w; a.scale = scale; a.Co = Co; a.Ci = Ci; a.img_fwd = (char*)img_fwd; a.img_bwd = (char*)img_bwd; a.row0 = row0; a.Ct = Ct;
+    a.amax_in = amax_in; a.inv_out = inv_out64;
+    lgd::wino6_launch_filter_img(a, (hipStream_t)stream);
     return lgd::check_launch();
 }
 

@@ -143,7 +143,8 @@ __device__ __forceinline__ void split6(bool odd, float y0, float y1, float y2, f
 
 // PRE: the maps are PRE-activations -- the transform reads relu(x + bias[c]) (the bias + ReLU epilogue of the producing 1x1 convolution
 // folded into this load) and writes the tile's 36-bit activation mask for the adjoint transform of the backward (wino6_in_t).
-template <bool VEC, bool PRE>
+// H2: V is written as f16x2 split rows of V * 2^e (winograd.h), e from the bound *amax_in of the (activated) input: |V| <= 15 * 15 * bound
+template <bool VEC, bool PRE, bool H2>
 __device__ __forceinline__ void wino6_in_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
     const long long units = (long long)a.N * TH * TW, padded = (units + kTilePad - 1) & ~(long long)(kTilePad - 1);
@@ -162,6 +163,13 @@ __device__ __forceinline__ void wino6_in_body(const WinoArgs& a, int l, float* l
     if constexpr (PRE) {
         if (a.pre_affine) { const float2 sa = reinterpret_cast<const float2*>(a.pre_affine)[((size_t)l * a.N + n) * a.C + c]; prs = sa.x; prb = sa.y; }
         else prb = a.bias[c];
+    }
+    float h2s = 1.f;              // H2: the power-of-two scale; with PRE it rides on the affine (relu(z) * s = relu(z * s), s > 0), else on the loaded values
+    if constexpr (H2) {
+        const int e = h2_exponent(*a.amax_in, 2 * kH2LgBt);
+        h2s = h2_pow2(e);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.scale_out[0] = h2_pow2(-e);
+        if constexpr (PRE) { prs *= h2s; prb *= h2s; }
     }
     float d[8][8];
     if constexpr (VEC) {
@@ -247,6 +255,12 @@ __device__ __forceinline__ void wino6_in_body(const WinoArgs& a, int l, float* l
             }
         }
     }
+    if constexpr (H2 && !PRE) {
+        #pragma unroll
+        for (int i = 0; i < 8; ++i)
+            #pragma unroll
+            for (int j = 0; j < 8; ++j) d[i][j] *= h2s;
+    }
     const size_t base = (size_t)c * a.cs + (size_t)a.tile_off[l] + t0;
     const long long tend = padded - t0;  // tiles of this workgroup that exist (incl. zero pad tiles), relative to t0
     if constexpr (PRE) {
@@ -272,19 +286,24 @@ __device__ __forceinline__ void wino6_in_body(const WinoArgs& a, int l, float* l
             float w[8];
             bt8(d[2 * ph + ii], w);
             #pragma unroll
-            for (int j = 0; j < 8; ++j) lds[(8 * ii + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (H2) reinterpret_cast<uint32_t*>(lds)[(8 * ii + j) * 256 + threadIdx.x] = on ? h2_pack(w[j]) : 0u;
+                else lds[(8 * ii + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
+            }
         }
         __syncthreads();
-        stage_store<16>(lds, a.buf_out + base, plane, 16 * ph, tend);
+        if constexpr (H2) stage_store_h2<16>(reinterpret_cast<const uint32_t*>(lds), reinterpret_cast<uint32_t*>(a.buf_out) + base, plane, 16 * ph, tend,
+                                             a.tile_off[l] + t0);
+        else stage_store<16>(lds, a.buf_out + base, plane, 16 * ph, tend);
     }
 }
 
-template <bool PRE>
+template <bool PRE, bool H2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_IN_WAVES, 8))) void wino6_in_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
-    if (a.pair[l]) wino6_in_body<true, PRE>(a, l, lds);
-    else wino6_in_body<false, PRE>(a, l, lds);
+    if (a.pair[l]) wino6_in_body<true, PRE, H2>(a, l, lds);
+    else wino6_in_body<false, PRE, H2>(a, l, lds);
 }
 
 // two frequency rows (16 planes x 256 tiles) of M / dV as 1 KB runs: issued into registers (slab_issue) and parked in LDS later
@@ -356,37 +375,48 @@ __device__ __forceinline__ void wino6_out_body(const WinoArgs& a, int l, float* 
             }
         }
     }
-    if (u >= units) return;
-    int tx, ty, n;
-    tile_coords(u, TW, TH, tx, ty, n);
-    const float b = a.bias ? a.bias[c] : 0.f;
-    float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
-    const int oy = 6 * ty, ox = 6 * tx;
-    const bool odd = tx & 1;
-    const bool relu = a.relu != 0;
-    Bits36 bits{0u, 0u};
-    for6([&](auto R) {   // row by row: transform, bias / ReLU, mask bits, store
-        constexpr int i = R.value;
-        float y[6];
-        at8(r[i], y);
-        #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            y[j] += b;
-            if (relu) y[j] = fmaxf(y[j], 0.f);
-        }
-        set36<6 * i + 0>(bits, y[0] > 0.f); set36<6 * i + 1>(bits, y[1] > 0.f); set36<6 * i + 2>(bits, y[2] > 0.f);
-        set36<6 * i + 3>(bits, y[3] > 0.f); set36<6 * i + 4>(bits, y[4] > 0.f); set36<6 * i + 5>(bits, y[5] > 0.f);
-        if (oy + i < H) {
-            float* row = p + (size_t)(oy + i) * W;
-            if constexpr (VEC) {
-                store_row6(row, ox, W, odd, y[0], y[1], y[2], y[3], y[4], y[5]);
-            } else {
-                #pragma unroll
-                for (int j = 0; j < 6; ++j) if (ox + j < W) row[ox + j] = y[j];
+    float am = 0.f;   // max |y| over the pixels this thread stores (a.amax_out: the next convolution's f16 scale comes from it)
+    if (u < units) {
+        int tx, ty, n;
+        tile_coords(u, TW, TH, tx, ty, n);
+        const float b = a.bias ? a.bias[c] : 0.f;
+        float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
+        const int oy = 6 * ty, ox = 6 * tx;
+        const bool odd = tx & 1;
+        const bool relu = a.relu != 0;
+        const bool want_max = a.amax_out != nullptr;
+        Bits36 bits{0u, 0u};
+        for6([&](auto R) {   // row by row: transform, bias / ReLU, mask bits, store
+            constexpr int i = R.value;
+            float y[6];
+            at8(r[i], y);
+            #pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                y[j] += b;
+                if (relu) y[j] = fmaxf(y[j], 0.f);
             }
-        }
-    });
-    if (a.bits_out) store_bits36(a.bits_out, (size_t)c * plane + (size_t)a.tile_off[l] + u, bits);
+            set36<6 * i + 0>(bits, y[0] > 0.f); set36<6 * i + 1>(bits, y[1] > 0.f); set36<6 * i + 2>(bits, y[2] > 0.f);
+            set36<6 * i + 3>(bits, y[3] > 0.f); set36<6 * i + 4>(bits, y[4] > 0.f); set36<6 * i + 5>(bits, y[5] > 0.f);
+            if (oy + i < H) {
+                float* row = p + (size_t)(oy + i) * W;
+                if constexpr (VEC) {
+                    store_row6(row, ox, W, odd, y[0], y[1], y[2], y[3], y[4], y[5]);
+                } else {
+                    #pragma unroll
+                    for (int j = 0; j < 6; ++j) if (ox + j < W) row[ox + j] = y[j];
+                }
+                if (want_max) {
+                    #pragma unroll
+                    for (int j = 0; j < 6; ++j) am = fmaxf(am, ox + j < W ? fabsf(y[j]) : 0.f);
+                }
+            }
+        });
+        if (a.bits_out) store_bits36(a.bits_out, (size_t)c * plane + (size_t)a.tile_off[l] + u, bits);
+    }
+    if (a.amax_out) {
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) atomic_max_bits(a.amax_out, __builtin_bit_cast(unsigned, am));
+    }
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_OUT_WAVES, 8))) void wino6_out_kernel(WinoArgs a) {
@@ -396,8 +426,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_OUT_
     else wino6_out_body<false>(a, l, lds);
 }
 
-// g (6x6, masked) -> dM = A g A^T staged two frequency rows at a time
-__device__ __forceinline__ void expand_block6(const float (&g)[6][6], bool on, float* lds, float* dst, size_t plane, long long tend, bool sync_first) {
+// g (6x6, masked) -> dM = A g A^T staged two frequency rows at a time.  H2: written as f16x2 split rows; frequency (i, j) carries the scale
+// 2^(e0 - lgA(i) - lgA(j)) -- |dM[i][j]| <= rowsum_i(A) rowsum_j(A) max|g| -- with 2^e0 already on g (h2_block_scale) and the per-index powers of
+// two applied here, after each pass
+__device__ __forceinline__ float h2_block_scale(const WinoArgs& a) {
+    const int e = h2_exponent(*a.amax_in, 0);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) a.scale_out[threadIdx.x] = h2_pow2(-e + h2_lg_a(threadIdx.x >> 3) + h2_lg_a(threadIdx.x & 7));
+    return h2_pow2(e);
+}
+template <bool H2>
+__device__ __forceinline__ void expand_block6(const float (&g)[6][6], bool on, float* lds, float* dst, size_t plane, long long tend, bool sync_first,
+                                              long long t0) {
+    constexpr float kA[8] = {1.f, 0.125f, 0.125f, 0.015625f, 0.015625f, 0.5f, 0.5f, 1.f};   // 2^-lgA
     float r[8][6];
     #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -405,7 +445,7 @@ __device__ __forceinline__ void expand_block6(const float (&g)[6][6], bool on, f
         float w[8];
         a8(col, w);
         #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i][j] = w[i];
+        for (int i = 0; i < 8; ++i) r[i][j] = H2 ? w[i] * kA[i] : w[i];
     }
     #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
@@ -415,15 +455,19 @@ __device__ __forceinline__ void expand_block6(const float (&g)[6][6], bool on, f
             float w[8];
             a8(r[2 * ph + ii], w);
             #pragma unroll
-            for (int j = 0; j < 8; ++j) lds[(8 * ii + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (H2) reinterpret_cast<uint32_t*>(lds)[(8 * ii + j) * 256 + threadIdx.x] = on ? h2_pack(w[j] * kA[j]) : 0u;
+                else lds[(8 * ii + j) * 256 + threadIdx.x] = on ? w[j] : 0.f;
+            }
         }
         __syncthreads();
-        stage_store<16>(lds, dst, plane, 16 * ph, tend);
+        if constexpr (H2) stage_store_h2<16>(reinterpret_cast<const uint32_t*>(lds), reinterpret_cast<uint32_t*>(dst), plane, 16 * ph, tend, t0);
+        else stage_store<16>(lds, dst, plane, 16 * ph, tend);
     }
 }
 
 // dM = A (dy . mask) A^T: the ONE transform of dy the backward pass needs (dU[f] = dM[f] V[f]^T, dV[f] = U[f]^T dM[f])
-template <bool VEC, bool GN>
+template <bool VEC, bool GN, bool H2>
 __device__ __forceinline__ void wino6_out_t_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
     const long long units = (long long)a.N * TH * TW, padded = (units + kTilePad - 1) & ~(long long)(kTilePad - 1);
@@ -507,23 +551,29 @@ __device__ __forceinline__ void wino6_out_t_body(const WinoArgs& a, int l, float
             }
         }
     }
-    for36([&](auto I, auto J) { g[I.value][J.value] = bit36<6 * I.value + J.value>(mb) ? g[I.value][J.value] : 0.f; });
-    expand_block6(g, on, lds, a.buf_out + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0, plane, padded - t0, false);
+    if constexpr (H2) {
+        const float s0 = h2_block_scale(a);
+        for36([&](auto I, auto J) { g[I.value][J.value] = bit36<6 * I.value + J.value>(mb) ? g[I.value][J.value] * s0 : 0.f; });
+    } else {
+        for36([&](auto I, auto J) { g[I.value][J.value] = bit36<6 * I.value + J.value>(mb) ? g[I.value][J.value] : 0.f; });
+    }
+    expand_block6<H2>(g, on, lds, a.buf_out + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0, plane, padded - t0, false, a.tile_off[l] + t0);
 }
 
+template <bool H2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_OUTT_WAVES, 8))) void wino6_out_t_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
-    if (a.pair[l]) wino6_out_t_body<true, false>(a, l, lds);
-    else wino6_out_t_body<false, false>(a, l, lds);
+    if (a.pair[l]) wino6_out_t_body<true, false, H2>(a, l, lds);
+    else wino6_out_t_body<false, false, H2>(a, l, lds);
 }
 
 // the same with the backward apply of a GroupNorm that follows the convolution folded into the load (WinoArgs::gn_coef)
 __global__ __launch_bounds__(256) void wino6_out_t_gn_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
-    if (a.pair[l]) wino6_out_t_body<true, true>(a, l, lds);
-    else wino6_out_t_body<false, true>(a, l, lds);
+    if (a.pair[l]) wino6_out_t_body<true, true, false>(a, l, lds);
+    else wino6_out_t_body<false, true, false>(a, l, lds);
 }
 
 // dx = adjoint of wino6_in: the 8x8 windows Z_t = B G_t B^T (G = dV) of neighbouring tiles overlap by two pixels and are summed
@@ -647,7 +697,7 @@ __device__ __forceinline__ void wino6_in_t_consume(const InTLoads& ld, const flo
 
 // FUSE: instead of storing the block, apply the producing convolution's ReLU mask and transform it straight into dM = A (dx . mask) A^T
 // of THAT convolution -- the backward link between two convolutions of a conv -> ReLU -> conv chain
-template <bool VEC, bool FUSE>
+template <bool VEC, bool FUSE, bool H2>
 __device__ __forceinline__ void wino6_in_t_body(const WinoArgs& a, int l, float* lds) {
     const int H = a.H[l], W = a.W[l], TH = a.TH[l], TW = a.TW[l];
     const long long units = (long long)a.N * TH * TW, padded = (units + kTilePad - 1) & ~(long long)(kTilePad - 1);
@@ -694,6 +744,15 @@ __device__ __forceinline__ void wino6_in_t_body(const WinoArgs& a, int l, float*
     if (a.bits_in) mb = load_bits36(a.bits_in, (size_t)c * plane + (size_t)a.tile_off[l] + uu);
     for36([&](auto I, auto J) { z[I.value][J.value] = bit36<6 * I.value + J.value>(mb) ? z[I.value][J.value] : 0.f; });
     if constexpr (!FUSE) {
+        if (a.amax_out) {   // max |dx| over the map (pixels of overhanging tiles beyond it excluded), for the consumer's f16 scale
+            float am = 0.f;
+            #pragma unroll
+            for (int r = 0; r < 6; ++r)
+                #pragma unroll
+                for (int j = 0; j < 6; ++j) am = fmaxf(am, (on && oy + r < H && ox + j < W) ? fabsf(z[r][j]) : 0.f);
+            am = wave_max(am);
+            if ((threadIdx.x & 63) == 0) atomic_max_bits(a.amax_out, __builtin_bit_cast(unsigned, am));
+        }
         if (!on) return;
         float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
         const bool odd = tx & 1;
@@ -714,17 +773,24 @@ __device__ __forceinline__ void wino6_in_t_body(const WinoArgs& a, int l, float*
         for (int r = 0; r < 6; ++r)
             #pragma unroll
             for (int j = 0; j < 6; ++j) z[r][j] = (oy + r < H && ox + j < W) ? z[r][j] : 0.f;
+        if constexpr (H2) {   // *amax_in bounds |dx| (lgd_h2_link_bound from the per-frequency maxima of dV)
+            const float s0 = h2_block_scale(a);
+            #pragma unroll
+            for (int r = 0; r < 6; ++r)
+                #pragma unroll
+                for (int j = 0; j < 6; ++j) z[r][j] *= s0;
+        }
         // (the slab is still being read by the last gather phase: expand_block6 syncs before its first LDS write)
-        expand_block6(z, on, lds, a.buf_out + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0, plane, padded - t0, true);
+        expand_block6<H2>(z, on, lds, a.buf_out + (size_t)c * a.cs + (size_t)a.tile_off[l] + t0, plane, padded - t0, true, a.tile_off[l] + t0);
     }
 }
 
-template <bool FUSE>
+template <bool FUSE, bool H2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_INT_WAVES, 8))) void wino6_in_t_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
-    if (a.pair[l]) wino6_in_t_body<true, FUSE>(a, l, lds);
-    else wino6_in_t_body<false, FUSE>(a, l, lds);
+    if (a.pair[l]) wino6_in_t_body<true, FUSE, H2>(a, l, lds);
+    else wino6_in_t_body<false, FUSE, H2>(a, l, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -789,6 +855,26 @@ __global__ __launch_bounds__(256) void wino6_filter_fwd_kernel(FilterArgs a) {
 // product M = U V, image of U^T (rows ci, k = co) for dV = U^T dM -- the filter is split where it is produced, not by a pass that
 // re-reads U (58 launches of ~20 us per step at BASELINE config 2).  Co % 16 == Ci % 16 == row0 % 16 == 0 (host-checked): every
 // workgroup owns whole 16-deep k-steps of both images, nothing is guarded.  32 frequencies at a time through the LDS tile.
+// H2: the f16x2 images of csrc/h2.hip -- [batch][k-step of 16][2 pieces][32-row block][1 KB] of U[f] * 2^e(f), e(f) from the bound
+// max|w . scale| * rowsum_i(|G|) rowsum_j(|G|) (*a.amax_in; row sums 1, 2/3, 2/3, 7/90, 7/90, 56/45, 56/45, 1 <= 2^(0, 0, 0, -3, -3, 1, 1, 0));
+// workgroup (0, 0) records the 64 inverse scales in a.inv_out
+__host__ __device__ constexpr int h2_lg_g(int i) { return i == 3 || i == 4 ? -3 : (i == 5 || i == 6 ? 1 : 0); }
+__device__ __forceinline__ long h2_image_off(long b, int ktp, int rbp, int m, int k) {   // byte offset of the h fragment holding (m, k)
+    return ((((b * ktp + (k >> 4)) * 2) * rbp + (m >> 5)) << 10) + ((((k >> 3) & 1) * 32 + (m & 31)) << 4);
+}
+__device__ __forceinline__ void store_split8_h2(const float* x, float s, char* d, long rbp) {
+    uint32_t h[4], m[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t p0 = h2_pack(x[2 * e] * s), p1 = h2_pack(x[2 * e + 1] * s);
+        h[e] = __builtin_amdgcn_perm(p1, p0, 0x05040100u);
+        m[e] = __builtin_amdgcn_perm(p1, p0, 0x07060302u);
+    }
+    *reinterpret_cast<lgd_u32x4*>(d) = (lgd_u32x4){h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<lgd_u32x4*>(d + rbp * 1024) = (lgd_u32x4){m[0], m[1], m[2], m[3]};
+}
+
+template <bool H2>
 __global__ __launch_bounds__(256) void wino6_filter_img_kernel(FilterArgs a) {
     __shared__ float tile[32][16][17];
     const int cl = threadIdx.x & 15, ol = threadIdx.x >> 4;
@@ -810,6 +896,12 @@ __global__ __launch_bounds__(256) void wino6_filter_img_kernel(FilterArgs a) {
         #pragma unroll
         for (int i = 0; i < 8; ++i) g8(r[i][0], r[i][1], r[i][2], u[i]);
     }
+    int e0 = 0;
+    if constexpr (H2) {
+        e0 = h2_exponent(*a.amax_in, 0);
+        if (a.inv_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64)
+            a.inv_out[threadIdx.x] = h2_pow2(-(e0 - h2_lg_g(threadIdx.x >> 3) - h2_lg_g(threadIdx.x & 7)));
+    }
     const int ktp_f = a.Ci >> 4, rbp_f = (a.Ct + 31) >> 5;     // image of U:   M = Ct, K = Ci
     const int ktp_b = a.Ct >> 4, rbp_b = (a.Ci + 31) >> 5;     // image of U^T: M = Ci, K = Ct
     const int co0 = a.row0 + blockIdx.y * 16, ci0 = blockIdx.x * 16;
@@ -823,16 +915,20 @@ __global__ __launch_bounds__(256) void wino6_filter_img_kernel(FilterArgs a) {
         for (int j = 0; j < 4; ++j) {   // 32 frequencies x 32 fragments (16 rows x 2 k-groups) per image: 4 per thread
             const int q = threadIdx.x + 256 * j, fl = q >> 5, x = q & 15, g = (q >> 4) & 1;
             const long f = 32 * half + fl;
+            float s = 1.f;
+            if constexpr (H2) s = h2_pow2(e0 - h2_lg_g((int)f >> 3) - h2_lg_g((int)f & 7));
             float v[8];
             if (a.img_fwd) {
                 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = tile[fl][x][g * 8 + e];
-                store_split8(v, a.img_fwd + gemm3_image_off(f, ktp_f, rbp_f, co0 + x, ci0 + g * 8), rbp_f);
+                if constexpr (H2) store_split8_h2(v, s, a.img_fwd + h2_image_off(f, ktp_f, rbp_f, co0 + x, ci0 + g * 8), rbp_f);
+                else store_split8(v, a.img_fwd + gemm3_image_off(f, ktp_f, rbp_f, co0 + x, ci0 + g * 8), rbp_f);
             }
             if (a.img_bwd) {
                 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = tile[fl][g * 8 + e][x];
-                store_split8(v, a.img_bwd + gemm3_image_off(f, ktp_b, rbp_b, ci0 + x, co0 + g * 8), rbp_b);
+                if constexpr (H2) store_split8_h2(v, s, a.img_bwd + h2_image_off(f, ktp_b, rbp_b, ci0 + x, co0 + g * 8), rbp_b);
+                else store_split8(v, a.img_bwd + gemm3_image_off(f, ktp_b, rbp_b, ci0 + x, co0 + g * 8), rbp_b);
             }
         }
     }
@@ -864,26 +960,32 @@ __global__ __launch_bounds__(256) void wino6_filter_bwd_kernel(FilterArgs a) {
 
 void wino6_launch_in(const WinoArgs& a, unsigned blocks, bool pre, hipStream_t st) {
     const dim3 grid(blocks, a.C), block(256);
-    if (pre) { LGD_LAUNCH("wino_in_kernel", (wino6_in_kernel<true>), grid, block, 0, st, a); }
-    else { LGD_LAUNCH("wino_in_kernel", (wino6_in_kernel<false>), grid, block, 0, st, a); }
+    if (a.h2) {
+        if (pre) { LGD_LAUNCH("wino_in_kernel", (wino6_in_kernel<true, true>), grid, block, 0, st, a); }
+        else { LGD_LAUNCH("wino_in_kernel", (wino6_in_kernel<false, true>), grid, block, 0, st, a); }
+    } else if (pre) { LGD_LAUNCH("wino_in_kernel", (wino6_in_kernel<true, false>), grid, block, 0, st, a); }
+    else { LGD_LAUNCH("wino_in_kernel", (wino6_in_kernel<false, false>), grid, block, 0, st, a); }
 }
 void wino6_launch_out(const WinoArgs& a, unsigned blocks, hipStream_t st) {
     LGD_LAUNCH("wino_out_kernel", wino6_out_kernel, dim3(blocks, a.C), dim3(256), 0, st, a);
 }
 void wino6_launch_out_t(const WinoArgs& a, unsigned blocks, hipStream_t st) {
     if (a.gn_coef) { LGD_LAUNCH("wino_out_t_gn_kernel", wino6_out_t_gn_kernel, dim3(blocks, a.C), dim3(256), 0, st, a); }
-    else { LGD_LAUNCH("wino_out_t_kernel", wino6_out_t_kernel, dim3(blocks, a.C), dim3(256), 0, st, a); }
+    else if (a.h2) { LGD_LAUNCH("wino_out_t_kernel", wino6_out_t_kernel<true>, dim3(blocks, a.C), dim3(256), 0, st, a); }
+    else { LGD_LAUNCH("wino_out_t_kernel", wino6_out_t_kernel<false>, dim3(blocks, a.C), dim3(256), 0, st, a); }
 }
 void wino6_launch_in_t(const WinoArgs& a, unsigned blocks, bool fuse, hipStream_t st) {
     const dim3 grid(blocks, a.C), block(256);
-    if (fuse) { LGD_LAUNCH("wino_in_t_out_t_kernel", (wino6_in_t_kernel<true>), grid, block, 0, st, a); }
-    else { LGD_LAUNCH("wino_in_t_kernel", (wino6_in_t_kernel<false>), grid, block, 0, st, a); }
+    if (fuse && a.h2) { LGD_LAUNCH("wino_in_t_out_t_kernel", (wino6_in_t_kernel<true, true>), grid, block, 0, st, a); }
+    else if (fuse) { LGD_LAUNCH("wino_in_t_out_t_kernel", (wino6_in_t_kernel<true, false>), grid, block, 0, st, a); }
+    else { LGD_LAUNCH("wino_in_t_kernel", (wino6_in_t_kernel<false, false>), grid, block, 0, st, a); }
 }
 void wino6_launch_filter_fwd(const FilterArgs& a, hipStream_t st) {
     LGD_LAUNCH("wino_filter_kernel", wino6_filter_fwd_kernel, dim3((a.Ci + 15) / 16, (a.Co + 15) / 16), dim3(256), 0, st, a);
 }
 void wino6_launch_filter_img(const FilterArgs& a, hipStream_t st) {
-    LGD_LAUNCH("wino_filter_img_kernel", wino6_filter_img_kernel, dim3(a.Ci / 16, a.Co / 16), dim3(256), 0, st, a);
+    if (a.amax_in) { LGD_LAUNCH("wino_filter_img_kernel", wino6_filter_img_kernel<true>, dim3(a.Ci / 16, a.Co / 16), dim3(256), 0, st, a); }
+    else { LGD_LAUNCH("wino_filter_img_kernel", wino6_filter_img_kernel<false>, dim3(a.Ci / 16, a.Co / 16), dim3(256), 0, st, a); }
 }
 void wino6_launch_filter_bwd(const FilterArgs& a, hipStream_t st) {
     const long long n = (long long)a.Co * a.Ci;

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.environ.get("LGD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")   # LGD_HIP_LIB: a lab build
 _lib = None
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -82,6 +82,19 @@ SIGNATURES = {
     "lgd_gemm3_split": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_gemm3": (c_i, [c_fp, c_i, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong,
                         c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "lgd_h2_image_bytes": (c_sz, [c_i, c_i, c_i]),
+    "lgd_h2_fwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "lgd_h2_dw_splits": (c_i, [c_i, c_i, c_i, c_i]),
+    "lgd_h2_dw": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "lgd_h2_amax_maps": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp]),
+    "lgd_h2_amax_filters": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
+    "lgd_h2_link_bound": (c_i, [c_fp, c_fp, c_fp]),
+    "lgd_wino_in_h2": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_wino_out_t_h2": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_wino_in_t_out_t_h2": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_wino_out_amax": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_wino_in_t_amax": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_wino_filter_images_h2": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_relu_rowbits_words": (c_sz, [ctypes.c_longlong, c_i]),
     "lgd_relu_rowbits_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_i, c_fp, c_fp]),
     "lgd_relu_bits_words": (c_sz, [ctypes.c_longlong]),

@@ -1169,6 +1169,31 @@ def _wino_filter_grads(lib, dU, scales, Cos, need, Ci, tile):
     return out
 
 
+def _wino_out(lib, Mk, bias, hw, L, N, Co, tile, relu, ys, bits):
+    """output transform of Co channels of M (+ bias, ReLU, mask bits); with the f16x2 pipeline on (tile 6) it also leaves max |y| for the
+    next convolution's scale and tags the maps with it"""
+    if tile == 6 and _H2_ON and _H2_TAGS:
+        amax = torch.empty(1, dtype=torch.int32, device=ys[0].device)
+        hip.check(lib.lgd_wino_out_amax(hip.ptr(Mk), hip.ptr(bias) if bias is not None else None, hw, L, N, Co, int(relu), hip.ptr_array(ys),
+                                        hip.ptr(bits) if bits is not None else None, hip.ptr(amax), hip.stream_ptr()), "lgd_wino_out_amax")
+        _amax_tag(ys, amax)
+    else:
+        hip.check(lib.lgd_wino_out(hip.ptr(Mk), hip.ptr(bias) if bias is not None else None, hw, L, N, Co, tile, int(relu), hip.ptr_array(ys),
+                                   hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
+
+
+def _wino_in_t(lib, dV, hw, L, N, Ci, tile, dxs, pre_bits):
+    """adjoint input transform (+ activation mask); tile 6 with the f16x2 pipeline on: also max |dx|, tagged on the gradient maps"""
+    if tile == 6 and _H2_ON and _H2_TAGS:
+        amax = torch.empty(1, dtype=torch.int32, device=dxs[0].device)
+        hip.check(lib.lgd_wino_in_t_amax(hip.ptr(dV), hw, L, N, Ci, hip.ptr_array(dxs), hip.ptr(pre_bits) if pre_bits is not None else None,
+                                         hip.ptr(amax), hip.stream_ptr()), "lgd_wino_in_t_amax")
+        _amax_tag(dxs, amax)
+    else:
+        hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), hip.ptr(pre_bits) if pre_bits is not None else None,
+                                    hip.stream_ptr()), "lgd_wino_in_t")
+
+
 class _Conv3x3K(torch.autograd.Function):
     """K filters nn.Conv2d(Ci, Co_k, 3, stride 1, padding 1) [+ ReLU] applied to the SAME L maps (the pyramid levels; K = 1: one
     conv, K = 2: e.g. the first convs of the cls / bbox towers, which read the same features) in the minimal-filtering form
@@ -1206,21 +1231,34 @@ class _Conv3x3K(torch.autograd.Function):
         mdt, mb = _WINO_MASK_DTYPE[tile], _WINO_MASK_DTYPE[tile].itemsize
         hw = hip.int_array([d for x in xs for d in x.shape[2:]])
         T = lib.lgd_wino_tiles(hw, L, N, tile)
-        U, Ut = _wino_filters(lib, ws, scales, Ci, dev, tile, T, any(ctx.needs_input_grad[5 + 2 * K:]))
-        V = _freq_buf(nf, Ci, T, dev)
+        need_dx = any(ctx.needs_input_grad[5 + 2 * K:])
+        h2 = _h2_ok(tile, Ci, Cos, T, dev)
         pre = hip.dense_f32(pre) if pre is not None else None
         affine = pre is not None and pre.dim() == 3   # (L*N, Ci, 2) scale / shift per (map, sample, channel): a folded GroupNorm + ReLU
         if affine and tuple(pre.shape) != (L * N, Ci, 2):
             raise hip.LgdHipError("affine pre-activation must be (L*N, C, 2) = (%d, %d, 2), got %s" % (L * N, Ci, tuple(pre.shape)))
         pre_bits = (torch.empty((Ci, T), dtype=mdt, device=dev)
-                    if pre is not None and any(ctx.needs_input_grad[5 + 2 * K:]) else None)
-        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), hw, L, N, Ci, tile, hip.ptr(V),
-                                  hip.ptr(pre) if pre is not None and not affine else None, hip.ptr(pre) if affine else None,
-                                  hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in")
+                    if pre is not None and need_dx else None)
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)  # bytes of one channel of the maps
         fb = 4 * nf * T                                        # bytes of one channel of a frequency buffer
-        _count_bytes("wino_in_kernel", (px + fb) * Ci)
-        M = _wino_gemm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
+        p_bias, p_aff = (hip.ptr(pre) if pre is not None and not affine else None), (hip.ptr(pre) if affine else None)
+        uinv = vinv = None
+        if h2:   # K10: V written as f16x2 split rows, the filter as an f16x2 image, the product on csrc/h2.hip
+            filt = _h2_filters(lib, ws, scales, Ci, dev, need_dx)
+            amax = _amax_bits(lib, xs, hw, pre, affine)
+            V, vinv, uinv = _h2_buf(Ci, T, dev), torch.empty(1, dtype=torch.float32, device=dev), filt.inv
+            hip.check(lib.lgd_wino_in_h2(hip.ptr_array(xs), hw, L, N, Ci, hip.ptr(V), p_bias, p_aff, hip.ptr(pre_bits) if pre_bits is not None else None,
+                                         hip.ptr(amax), hip.ptr(vinv), hip.stream_ptr()), "lgd_wino_in_h2")
+            _count_bytes("wino_in_kernel", (px + fb) * Ci)
+            M = _h2_product(lib, "fwd", filt.fwd, Ct, Ci, V, vinv, False, uinv, _freq_buf(nf, Ct, T, dev))
+            Ut = filt.bwd
+        else:
+            U, Ut = _wino_filters(lib, ws, scales, Ci, dev, tile, T, need_dx)
+            V = _freq_buf(nf, Ci, T, dev)
+            hip.check(lib.lgd_wino_in(hip.ptr_array(xs), hw, L, N, Ci, tile, hip.ptr(V), p_bias, p_aff,
+                                      hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in")
+            _count_bytes("wino_in_kernel", (px + fb) * Ci)
+            M = _wino_gemm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
         # ReLU mask for the backward: one bit per pixel, a table entry per tile, written by the output transform, so the backward
         # reads 1 bit instead of 4 bytes per pixel and the forward output is not kept alive
         bits = torch.empty((Ct, T), dtype=mdt, device=dev) if relu else None
@@ -1228,22 +1266,22 @@ class _Conv3x3K(torch.autograd.Function):
         for k in range(K):   # one output transform per filter: its channels are a contiguous slab of M ([C][nf][T])
             yk = [torch.empty((N, Cos[k]) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
             _count_bytes("wino_out_kernel", (px + fb + (mb * T if bits is not None else 0)) * Cos[k])
-            hip.check(lib.lgd_wino_out(hip.ptr(M[:, c0]), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Cos[k], tile, int(relu),
-                                       hip.ptr_array(yk), hip.ptr(bits[c0]) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
+            _wino_out(lib, M[:, c0], bs[k], hw, L, N, Cos[k], tile, relu, yk, bits[c0] if bits is not None else None)
             ys += yk
             c0 += Cos[k]
         need_w = any(ctx.needs_input_grad[5:5 + 2 * K:2])
-        ut_t, ctx.ut_shape = _pack_filter(Ut)
-        ctx.dev = dev
-        ctx.save_for_backward(ut_t, V if need_w else None, bits, pre_bits)   # the backward needs U^T (dV = U^T dM)
+        ut_t, ctx.ut_shape = (Ut, None) if h2 else _pack_filter(Ut)
+        ctx.dev, ctx.h2 = dev, h2
+        ctx.save_for_backward(ut_t, V if need_w else None, bits, pre_bits, uinv, vinv)   # the backward needs U^T (dV = U^T dM)
         ctx.scales = scales
         ctx.meta = (K, L, N, Ci, Cos, hw, T, [b is not None for b in bs], [tuple(x.shape[2:]) for x in xs], tile, px, fb)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
-        Ut, V, bits, pre_bits = ctx.saved_tensors
-        Ut = _unpack_filter(Ut, ctx.ut_shape)
+        Ut, V, bits, pre_bits, uinv, vinv = ctx.saved_tensors
+        if not ctx.h2:
+            Ut = _unpack_filter(Ut, ctx.ut_shape)
         K, L, N, Ci, Cos, hw, T, has_bias, shapes, tile, px, fb = ctx.meta
         Ct = sum(Cos)
         lib = hip.load()
@@ -1260,27 +1298,38 @@ class _Conv3x3K(torch.autograd.Function):
         dxs = [None] * L
         if not (need_x or need_w or any(need_bs)):
             return (None, None, None, None, None, *[None] * (2 * K), *dxs)
-        dM = _freq_buf(nf, Ct, T, dev)
+        if ctx.h2:
+            dM, dminv = _h2_buf(Ct, T, dev), torch.empty(64, dtype=torch.float32, device=dev)
+            amax = _amax_bits_groups(lib, [dys[k * L:(k + 1) * L] for k in range(K)], hw)   # ONE scale for the stacked gradients: K = C_out in dV = U^T dM
+        else:
+            dM = _freq_buf(nf, Ct, T, dev)
         c0 = 0
         for k in range(K):
             gk = dys[k * L:(k + 1) * L]
             _count_bytes("wino_out_t_kernel", (px + fb + (mb * T if bits is not None else 0)) * Cos[k])
-            hip.check(lib.lgd_wino_out_t(hip.ptr_array(gk), hip.ptr(bits[c0]) if bits is not None else None, hw, L, N, Cos[k], tile,
-                                         hip.ptr(dM[:, c0]), hip.stream_ptr()), "lgd_wino_out_t")
+            if ctx.h2:
+                hip.check(lib.lgd_wino_out_t_h2(hip.ptr_array(gk), hip.ptr(bits[c0]) if bits is not None else None, hw, L, N, Cos[k],
+                                                ctypes.c_void_p(dM.data_ptr() + 4 * c0 * nf * T), hip.ptr(amax), hip.ptr(dminv), hip.stream_ptr()),
+                          "lgd_wino_out_t_h2")
+            else:
+                hip.check(lib.lgd_wino_out_t(hip.ptr_array(gk), hip.ptr(bits[c0]) if bits is not None else None, hw, L, N, Cos[k], tile,
+                                             hip.ptr(dM[:, c0]), hip.stream_ptr()), "lgd_wino_out_t")
             c0 += Cos[k]
         if need_x:
             _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
-            dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
+            if ctx.h2:
+                dV = _h2_product(lib, "dx", Ut, Ci, Ct, dM, dminv, True, uinv, _freq_buf(nf, Ci, T, dev))
+            else:
+                dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
             dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-            hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs),
-                                        hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in_t")
+            _wino_in_t(lib, dV, hw, L, N, Ci, tile, dxs, pre_bits)
             del dV
         if need_w:
-            dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
+            dU = _h2_dw(lib, dM, dminv, V, vinv, Ct, Ci) if ctx.h2 else _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
             dws = _wino_filter_grads(lib, dU, ctx.scales, Cos, need_ws, Ci, tile)
         if any(need_bs):
             # A's row of the interpolation point 1 is all ones: that frequency of dM = A g A^T is the tile's gradient sum
-            db = dM[tile + 3].sum(1)
+            db = _h2_plane_sums(dM, tile + 3, dminv) if ctx.h2 else dM[tile + 3].sum(1)
             c0 = 0
             for k in range(K):
                 dbs[k] = db[c0:c0 + Cos[k]] if need_bs[k] else None
@@ -1449,25 +1498,38 @@ class _Conv3x3Chain(torch.autograd.Function):
         px = 4 * N * sum(h * w_ for h, w_ in shapes)   # bytes of one channel of the maps
         fb = 4 * nf * T                                # bytes of one channel of a frequency buffer
         need_ws = list(ctx.needs_input_grad[3:3 + 2 * K:2])
-        saved, cur, ut_shapes, dims = [], xs, [], []
+        saved, cur, ut_shapes, dims, h2s = [], xs, [], [], []
         for k in range(K):
             Co, Ci = ws[k].shape[0], ws[k].shape[1]
-            U, Ut = _wino_filters(lib, [ws[k]], [None], Ci, dev, tile, T, k > 0 or any(ctx.needs_input_grad[3 + 2 * K:]))
-            V = _freq_buf(nf, Ci, T, dev)
-            hip.check(lib.lgd_wino_in(hip.ptr_array(cur), hw, L, N, Ci, tile, hip.ptr(V), None, None, None, hip.stream_ptr()), "lgd_wino_in")
-            _count_bytes("wino_in_kernel", (px + fb) * Ci)
-            M = _wino_gemm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
+            need_dx = k > 0 or any(ctx.needs_input_grad[3 + 2 * K:])
+            h2 = _h2_ok(tile, Ci, [Co], T, dev)
+            uinv = vinv = None
+            if h2:
+                filt = _h2_filters(lib, [ws[k]], [None], Ci, dev, need_dx)
+                amax = _amax_bits(lib, cur, hw)   # (inside the chain: the tag the previous output transform left)
+                V, vinv, uinv = _h2_buf(Ci, T, dev), torch.empty(1, dtype=torch.float32, device=dev), filt.inv
+                hip.check(lib.lgd_wino_in_h2(hip.ptr_array(cur), hw, L, N, Ci, hip.ptr(V), None, None, None, hip.ptr(amax), hip.ptr(vinv),
+                                             hip.stream_ptr()), "lgd_wino_in_h2")
+                _count_bytes("wino_in_kernel", (px + fb) * Ci)
+                M = _h2_product(lib, "fwd", filt.fwd, Co, Ci, V, vinv, False, uinv, _freq_buf(nf, Co, T, dev))
+                ut_t, ut_shape = filt.bwd, None
+            else:
+                U, Ut = _wino_filters(lib, [ws[k]], [None], Ci, dev, tile, T, need_dx)
+                V = _freq_buf(nf, Ci, T, dev)
+                hip.check(lib.lgd_wino_in(hip.ptr_array(cur), hw, L, N, Ci, tile, hip.ptr(V), None, None, None, hip.stream_ptr()), "lgd_wino_in")
+                _count_bytes("wino_in_kernel", (px + fb) * Ci)
+                M = _wino_gemm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Co, T, dev))
+                ut_t, ut_shape = _pack_filter(Ut)
             bits = torch.empty((Co, T), dtype=mdt, device=dev) if relus[k] else None
             cur = [torch.empty((N, Co) + s, dtype=torch.float32, device=dev) for s in shapes]
             _count_bytes("wino_out_kernel", (px + fb + (mb * T if bits is not None else 0)) * Co)
-            hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Co, tile, int(relus[k]),
-                                       hip.ptr_array(cur), hip.ptr(bits) if bits is not None else None, hip.stream_ptr()), "lgd_wino_out")
+            _wino_out(lib, M, bs[k], hw, L, N, Co, tile, relus[k], cur, bits)
             del M
-            ut_t, ut_shape = _pack_filter(Ut)
             ut_shapes.append(ut_shape)
             dims.append((Ci, Co))
-            saved += [ut_t, V if need_ws[k] else None, bits]
-        ctx.ut_shapes, ctx.dims, ctx.dev = ut_shapes, dims, dev
+            h2s.append(h2)
+            saved += [ut_t, V if need_ws[k] else None, bits, uinv, vinv]
+        ctx.ut_shapes, ctx.dims, ctx.dev, ctx.h2s = ut_shapes, dims, dev, h2s
         ctx.save_for_backward(*saved)
         ctx.meta = (K, L, N, hw, T, shapes, [b is not None for b in bs], px, fb, tile)
         return tuple(cur)
@@ -1480,39 +1542,72 @@ class _Conv3x3Chain(torch.autograd.Function):
         nf = (tile + 2) ** 2
         mb = _WINO_MASK_DTYPE[tile].itemsize
         dev = ctx.dev
+        h2s = ctx.h2s
         need_ws = list(ctx.needs_input_grad[3:3 + 2 * K:2])
         need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[4:4 + 2 * K:2])]
         need_x = any(ctx.needs_input_grad[3 + 2 * K:])
         dws, dbs, dxs = [None] * K, [None] * K, [None] * L
         Co = ctx.dims[K - 1][1]
         dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Co) + shapes[i], dtype=torch.float32, device=dev) for i, g in enumerate(dys)]
-        bits = saved[3 * (K - 1) + 2]
-        dM = _freq_buf(nf, Co, T, dev)
-        _count_bytes("wino_out_t_kernel", (px + fb + (mb * T if bits is not None else 0)) * Co)
-        hip.check(lib.lgd_wino_out_t(hip.ptr_array(dys), hip.ptr(bits) if bits is not None else None, hw, L, N, Co, tile, hip.ptr(dM),
-                                     hip.stream_ptr()), "lgd_wino_out_t")
+
+        def out_t(maps, bits_k, C, h2):
+            """dM = A (g . mask) A^T of C channels, as split rows (h2) or fp32; returns (dM, per-frequency inverse scales or None)"""
+            _count_bytes("wino_out_t_kernel", (px + fb + (mb * T if bits_k is not None else 0)) * C)
+            if h2:
+                buf, inv = _h2_buf(C, T, dev), torch.empty(64, dtype=torch.float32, device=dev)
+                amax = _amax_bits(lib, maps, hw)
+                hip.check(lib.lgd_wino_out_t_h2(hip.ptr_array(maps), hip.ptr(bits_k) if bits_k is not None else None, hw, L, N, C, hip.ptr(buf),
+                                                hip.ptr(amax), hip.ptr(inv), hip.stream_ptr()), "lgd_wino_out_t_h2")
+                return buf, inv
+            buf = _freq_buf(nf, C, T, dev)
+            hip.check(lib.lgd_wino_out_t(hip.ptr_array(maps), hip.ptr(bits_k) if bits_k is not None else None, hw, L, N, C, tile, hip.ptr(buf),
+                                         hip.stream_ptr()), "lgd_wino_out_t")
+            return buf, None
+
+        dM, dminv = out_t(dys, saved[5 * (K - 1) + 2], Co, h2s[K - 1])
         for k in range(K - 1, -1, -1):
-            Ut, V = _unpack_filter(saved[3 * k], ctx.ut_shapes[k]), saved[3 * k + 1]
+            Ut, V, uinv, vinv = saved[5 * k], saved[5 * k + 1], saved[5 * k + 3], saved[5 * k + 4]
+            if not h2s[k]:
+                Ut = _unpack_filter(Ut, ctx.ut_shapes[k])
             Ci, Co = ctx.dims[k]
             if need_ws[k]:
-                dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
+                dU = _h2_dw(lib, dM, dminv, V, vinv, Co, Ci) if h2s[k] else _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
                 dws[k] = _wino_filter_grads(lib, dU, [None], [Co], [True], Ci, tile)[0]
-            if need_bs[k]:
-                dbs[k] = dM[tile + 3].sum(1)   # A's row of the interpolation point 1 is all ones: the tile's gradient sum
+            if need_bs[k]:   # A's row of the interpolation point 1 is all ones: the tile's gradient sum
+                dbs[k] = _h2_plane_sums(dM, tile + 3, dminv) if h2s[k] else dM[tile + 3].sum(1)
             if k == 0 and not need_x:
                 break
-            dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
+            fused_h2 = k > 0 and h2s[k] and h2s[k - 1]
+            if h2s[k]:
+                amax64 = torch.empty(64, dtype=torch.int32, device=dev) if fused_h2 else None   # max |dV[f]|: the bound of the link's dx
+                dV = _h2_product(lib, "dx", Ut, Ci, Co, dM, dminv, True, uinv, _freq_buf(nf, Ci, T, dev), amax64)
+            else:
+                dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
             del dM
             if k > 0:   # the link to conv k-1: dM_{k-1} = A (in_t(dV) . relu mask) A^T without the map in between
-                pb = saved[3 * (k - 1) + 2]
-                dM = _freq_buf(nf, Ci, T, dev)
-                _count_bytes("wino_in_t_out_t_kernel", (2 * fb + (mb * T if pb is not None else 0)) * Ci)
-                hip.check(lib.lgd_wino_in_t_out_t(hip.ptr(dV), hip.ptr(pb) if pb is not None else None, hw, L, N, Ci, tile, hip.ptr(dM),
-                                                  hip.stream_ptr()), "lgd_wino_in_t_out_t")
+                pb = saved[5 * (k - 1) + 2]
+                if fused_h2:
+                    bound = torch.empty(1, dtype=torch.int32, device=dev)
+                    hip.check(lib.lgd_h2_link_bound(hip.ptr(amax64), hip.ptr(bound), hip.stream_ptr()), "lgd_h2_link_bound")
+                    dM, dminv = _h2_buf(Ci, T, dev), torch.empty(64, dtype=torch.float32, device=dev)
+                    _count_bytes("wino_in_t_out_t_kernel", (2 * fb + (mb * T if pb is not None else 0)) * Ci)
+                    hip.check(lib.lgd_wino_in_t_out_t_h2(hip.ptr(dV), hip.ptr(pb) if pb is not None else None, hw, L, N, Ci, hip.ptr(dM), hip.ptr(bound),
+                                                         hip.ptr(dminv), hip.stream_ptr()), "lgd_wino_in_t_out_t_h2")
+                elif h2s[k - 1]:   # (conv k on the fp32 path: no per-frequency maxima of dV) through the gradient map
+                    mid = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
+                    _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
+                    _wino_in_t(lib, dV, hw, L, N, Ci, tile, mid, None)
+                    dM, dminv = out_t(mid, pb, Ci, True)
+                    del mid
+                else:
+                    dM, dminv = _freq_buf(nf, Ci, T, dev), None
+                    _count_bytes("wino_in_t_out_t_kernel", (2 * fb + (mb * T if pb is not None else 0)) * Ci)
+                    hip.check(lib.lgd_wino_in_t_out_t(hip.ptr(dV), hip.ptr(pb) if pb is not None else None, hw, L, N, Ci, tile, hip.ptr(dM),
+                                                      hip.stream_ptr()), "lgd_wino_in_t_out_t")
             else:
                 _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
                 dxs = [torch.empty((N, Ci) + s, dtype=torch.float32, device=dev) for s in shapes]
-                hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs), None, hip.stream_ptr()), "lgd_wino_in_t")
+                _wino_in_t(lib, dV, hw, L, N, Ci, tile, dxs, None)
             del dV
         return (None, None, None, *[g for pair in zip(dws, dbs) for g in pair], *dxs)
 
@@ -2347,6 +2442,156 @@ def _wino_gemm(name, a, b, out=None):
     if not _gemm3_ok(a, b, out):
         return _timed_bmm(name, a, b, out)
     return _timed_gemm3(name.replace("wino_gemm_", "wino_gemm3_"), a, b, out)
+
+
+# ---- K10: the Winograd channel products from f16x2 split operands (csrc/h2.hip): V / dM are WRITTEN split by the F(6x6) transforms, the
+# filter comes as an f16x2 image, forward / input-gradient / weight-gradient products run on v_mfma_f32_32x32x16_f16
+_H2_ON = os.environ.get("LGD_H2", "1") != "0"
+_H2_FORCE = False    # tests: take the h2 path wherever the kernels CAN run, whatever the speed policy says
+_H2_TAGS = os.environ.get("LGD_H2_TAGS", "1") != "0"   # 0: every bound by its own pass over the maps (A/B runs)
+
+
+def h2_backend(on=None, force=None):
+    """whether the F(6x6,3x3) convolutions run their channel products on csrc/h2.hip (default) or on csrc/gemm3.hip / the library (A/B runs,
+    tests); force: bypass the speed policy so that small test problems take the kernels too.  Returns the previous (on, force)."""
+    global _H2_ON, _H2_FORCE
+    prev = (_H2_ON, _H2_FORCE)
+    if on is not None:
+        _H2_ON = bool(on)
+    if force is not None:
+        _H2_FORCE = bool(force)
+    return prev
+
+
+def _h2_ok(tile, Ci, Cos, T, dev):
+    """the f16x2 pipeline takes a convolution when the kernels can run it (F(6x6); channel counts multiples of 16: the image kernel's
+    16 x 16 blocks and the products' 16-deep k-steps) and, unless forced, when the products fill the chip (the speed policy of gemm3)"""
+    if not (_H2_ON and tile == 6 and dev.type == "cuda" and Ci % 16 == 0 and all(c % 16 == 0 for c in Cos)):
+        return False
+    if _H2_FORCE:
+        return True
+    Ct = sum(Cos)
+    bm = 128 if ((Ct + 255) // 256 * 256 - Ct >= 64 and (Ct + 127) // 128 * 128 - Ct < 64) else 256
+    if Ci < 32 or T < 256 or Ct < 0.7 * bm * ((Ct + bm - 1) // bm):
+        return False
+    wgs = 64 * ((T + 127) // 128) * ((Ct + bm - 1) // bm)
+    return wgs >= _cu_count(dev)
+
+
+def _amax_tag(maps, amax):
+    """record, on tensors a kernel of this library has just written, the device word holding (the float bits of) a bound of their
+    magnitude: the next convolution derives its f16 scale from it instead of passing over the maps once more.  The tensor's version
+    is recorded with it: an in-place write invalidates the tag."""
+    if _H2_TAGS:
+        for m in maps:
+            m._lgd_amax = (amax, m._version)
+
+
+def _amax_bits(lib, xs, hw_levels, pre=None, affine=False):
+    """int32[1] device tensor: float bits of a bound of max |act(x)| over the maps xs (all (N, C, H_l, W_l); act = identity, relu(x + pre[c]) or the
+    (L*N, C, 2) scale / shift form).  Tags left by the producing kernels are used where every map has one; otherwise one pass over the maps."""
+    dev = xs[0].device
+    tags = [getattr(x, "_lgd_amax", None) for x in xs] if _H2_TAGS else [None]
+    if all(t is not None and t[1] == x._version for t, x in zip(tags, xs)):
+        uniq = []
+        for t in tags:
+            if not any(t[0] is u for u in uniq):
+                uniq.append(t[0])
+        a = uniq[0] if len(uniq) == 1 else torch.stack([u.view(()) for u in uniq]).max().view(1)   # non-negative floats order like their bits
+        if pre is None:
+            return a
+        af = a.view(torch.float32)
+        if affine:   # |relu(x s + b)| <= max(0, max|x| max|s| + max b)
+            b = (af * pre[..., 0].abs().max() + pre[..., 1].max()).clamp_min(0.0)
+        else:
+            b = (af + pre.max()).clamp_min(0.0)
+        return (b * 1.000001).view(torch.int32)   # (the roundings of the bound's own arithmetic)
+    out = torch.empty(1, dtype=torch.int32, device=dev)
+    L, N, C = len(xs), xs[0].shape[0], xs[0].shape[1]
+    hip.check(lib.lgd_h2_amax_maps(hip.ptr_array(xs), hw_levels, L, N, C, hip.ptr(pre) if pre is not None and not affine else None,
+                                   hip.ptr(pre) if pre is not None and affine else None, hip.ptr(out), 0, hip.stream_ptr()), "lgd_h2_amax_maps")
+    _count_bytes("h2_amax_maps_kernel", 4 * sum(x.numel() for x in xs))
+    return out
+
+
+def _amax_bits_groups(lib, groups, hw_levels):
+    """one bound over several groups of level maps with different channel counts (the K gradients of stacked filters)"""
+    if len(groups) == 1:
+        return _amax_bits(lib, groups[0], hw_levels)
+    parts = [_amax_bits(lib, g, hw_levels) for g in groups]
+    return torch.stack([p.view(()) for p in parts]).max().view(1)
+
+
+class _H2Filter:
+    """the filter operand of the f16x2 products: images of U (forward) and U^T (input gradient) and the 64 per-frequency inverse scales"""
+    __slots__ = ("fwd", "bwd", "inv", "Ct", "Ci")
+
+    def __init__(self, fwd, bwd, inv, Ct, Ci):
+        self.fwd, self.bwd, self.inv, self.Ct, self.Ci = fwd, bwd, inv, Ct, Ci
+
+
+def _h2_filters(lib, ws, scales, Ci, dev, need_dx):
+    """f16x2 images of the transformed filters of K convolutions stacked along C_out (lgd_wino_filter_images_h2): one scale per frequency for the
+    whole stack, from max |w * scale| over all K filters"""
+    Cos = [w.shape[0] for w in ws]
+    Ct = sum(Cos)
+    st = hip.stream_ptr()
+    amax = torch.empty(1, dtype=torch.int32, device=dev)
+    sc_arr = (ctypes.c_void_p * len(ws))(*[sc.data_ptr() if sc is not None else None for sc in scales])
+    hip.check(lib.lgd_h2_amax_filters(hip.ptr_array(ws), sc_arr, hip.int_array(Cos), len(ws), Ci * 9, hip.ptr(amax), st), "lgd_h2_amax_filters")
+    imf = torch.empty(lib.lgd_h2_image_bytes(64, Ct, Ci), dtype=torch.uint8, device=dev)
+    imb = torch.empty(lib.lgd_h2_image_bytes(64, Ci, Ct), dtype=torch.uint8, device=dev) if need_dx else None
+    inv = torch.empty(64, dtype=torch.float32, device=dev)
+    c0 = 0
+    for w, sc, Co in zip(ws, scales, Cos):
+        hip.check(lib.lgd_wino_filter_images_h2(hip.ptr(w), hip.ptr(sc) if sc is not None else None, Co, Ci, c0, Ct, hip.ptr(imf),
+                                                hip.ptr(imb) if imb is not None else None, hip.ptr(amax), hip.ptr(inv), st), "lgd_wino_filter_images_h2")
+        c0 += Co
+    return _H2Filter(imf, imb, inv, Ct, Ci)
+
+
+def _h2_buf(C, T, dev):
+    """a split frequency buffer [C][64][T], 4 bytes per element (int32 storage)"""
+    return torch.empty((C, 64, T), dtype=torch.int32, device=dev)
+
+
+def _h2_timed(name, flops, nbytes, fn):
+    if not _TIMER_ON:
+        return fn()
+    _count_bytes(name, nbytes)
+    _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + int(flops)
+    return fn()
+
+
+def _h2_product(lib, name, img, M, K, B, b_inv, b_inv_per_batch, a_inv, out, amax_out=None):
+    """out (64, M, T view of [M][64][T]) = image (64, M, K) . B ([K][64][T] split rows)"""
+    T = B.shape[2]
+    fn = lambda: hip.check(lib.lgd_h2_fwd(hip.ptr(img), hip.ptr(B), 4 * T, 4 * 64 * T, 4 * B.numel(), hip.ptr(out), out.stride(0), out.stride(1),   # noqa: E731
+                                          hip.ptr(a_inv), hip.ptr(b_inv), 1 if b_inv_per_batch else 0, hip.ptr(amax_out) if amax_out is not None else None,
+                                          64, M, T, K, hip.stream_ptr()), "lgd_h2_fwd")
+    _h2_timed("h2_fwd_kernel", 2.0 * 64 * M * K * T, 4.0 * 64 * T * (K + M) + 4.0 * 64 * M * K, fn)
+    return out
+
+
+def _h2_dw(lib, dM, dm_inv, V, v_inv, Ct, Ci):
+    """dU (64, Ct, Ci) = dM . V^T over the tiles, both split rows"""
+    T = V.shape[2]
+    dev = V.device
+    S = lib.lgd_h2_dw_splits(64, Ct, Ci, T)
+    out = torch.empty((64, Ct, Ci), dtype=torch.float32, device=dev)
+    part = torch.empty((S, 64, Ct, Ci), dtype=torch.float32, device=dev) if S > 1 else None
+    fn = lambda: hip.check(lib.lgd_h2_dw(hip.ptr(dM), 4 * 64 * T, 4 * T, 4 * dM.numel(), hip.ptr(dm_inv), 1, hip.ptr(V), 4 * 64 * T, 4 * T, 4 * V.numel(),   # noqa: E731
+                                         hip.ptr(v_inv), 0, hip.ptr(out), hip.ptr(part) if part is not None else None, S, 64, Ct, Ci, T, hip.stream_ptr()),
+                           "lgd_h2_dw")
+    _h2_timed("h2_dw_kernel", 2.0 * 64 * Ct * Ci * T, 4.0 * 64 * T * (Ct + Ci) + 4.0 * 64 * Ct * Ci * (2 * S if S > 1 else 1), fn)
+    return out
+
+
+def _h2_plane_sums(buf, f, inv):
+    """sum over the tiles of frequency plane f of a split buffer [C][64][T], per channel (the bias gradient: the frequency of the interpolation
+    point 1 of dM = A g A^T is the tile's gradient sum)"""
+    C, _, T = buf.shape
+    return buf[:, f].view(torch.float16).view(C, T // 32, 2, 32).float().sum((1, 2, 3)) * inv[f]
 
 
 def _timed_gemm(name, flops, fn, *args, **kw):

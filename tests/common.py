@@ -152,3 +152,49 @@ def fcos_head_inputs(B=2):
     probes = {kind: [synth.det_uniform((B, co[kind], h, w), 4200 + 10 * i + len(kind), -1.0, 1.0) for i, (h, w) in enumerate(FCOS_HEAD_LEVELS)]
               for kind in co}
     return feats, probes
+
+
+# ---- f16x2 split operands of csrc/h2.hip, built with torch ops (an independent statement of the two formats: include/lgd_hip.h, K10)
+def h2_pow2_scale(amax):
+    """per-batch power-of-two multipliers 2^e with amax * 2^e < 2^15 (amax > 0)"""
+    return torch.exp2(14 - torch.floor(torch.log2(amax)))
+
+
+def h2_split_rows(x, scale):
+    """x (rows, nb, T) fp32, scale (nb,) -> int32 (rows, nb, T) split rows: per row blocks of 32 tiles, 32 h values then 32 m values"""
+    rows, nb, T = x.shape
+    assert T % 32 == 0
+    t = x * scale.view(1, -1, 1)
+    h = t.half()
+    m = (t - h.float()).half()
+    pk = torch.stack([h.view(rows, nb, T // 32, 32), m.view(rows, nb, T // 32, 32)], dim=3).contiguous()
+    return pk.view(torch.int32).view(rows, nb, T)
+
+
+def h2_unsplit_rows(buf, inv):
+    """int32 (rows, nb, T) split rows -> fp32 (rows, nb, T) values (h + m) * inv[b] (inv: (nb,) or (1,))"""
+    rows, nb, T = buf.shape
+    pk = buf.contiguous().view(torch.float16).view(rows, nb, T // 32, 2, 32).float()
+    v = (pk[:, :, :, 0] + pk[:, :, :, 1]).reshape(rows, nb, T)
+    return v * (inv.view(1, -1, 1) if inv.numel() > 1 else inv)
+
+
+def h2_split_image(a, scale):
+    """a (nb, M, K) fp32, scale (nb,) -> uint8 image [nb][K/16][2 pieces][ceil(M/32)][lane = (k % 16 / 8) * 32 + m % 32][8 f16]"""
+    nb, M, K = a.shape
+    rbp, ktp = (M + 31) // 32, (K + 15) // 16
+    t = torch.zeros((nb, rbp * 32, ktp * 16), dtype=torch.float32, device=a.device)
+    t[:, :M, :K] = a * scale.view(-1, 1, 1)
+    h = t.half()
+    m = (t - h.float()).half()
+    frag = lambda p: p.view(nb, rbp, 32, ktp, 2, 8).permute(0, 3, 1, 4, 2, 5)   # noqa: E731   (nb, ktp, rbp, k-group, row, 8)
+    img = torch.stack([frag(h), frag(m)], dim=2).contiguous()                  # (nb, ktp, piece, rbp, k-group, row, 8)
+    return img.view(torch.uint8).view(-1)
+
+
+def h2_unsplit_image(img, nb, M, K, inv, padded=False):
+    """uint8 image -> fp32 (nb, M, K) values (h + m) * inv[b] (padded: the whole (nb, 32 ceil(M/32), 16 ceil(K/16)) array the image holds)"""
+    rbp, ktp = (M + 31) // 32, (K + 15) // 16
+    t = img.view(torch.float16).view(nb, ktp, 2, rbp, 2, 32, 8).float()
+    v = (t[:, :, 0] + t[:, :, 1]).permute(0, 2, 4, 1, 3, 5).reshape(nb, rbp * 32, ktp * 16)   # (nb, rbp, row, ktp, k-group, 8)
+    return (v if padded else v[:, :M, :K]) * inv.view(-1, 1, 1)

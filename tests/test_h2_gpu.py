@@ -1,0 +1,409 @@
+"""K10 (csrc/h2.hip): the Winograd channel products from f16x2 operands that are split in HBM, and the F(6x6,3x3) transforms that write
+them -- each held to fp64 / to the fp32 kernels it replaces, through the C-ABI.
+[ref: the arithmetic of nn.Conv2d(C, C', 3, padding=1): dynamic_teacher.py:57-73,145,280; sequential_convs.py:10-12; distillator.py:107-109]"""
+import ctypes
+
+import pytest
+import torch
+
+import common as cm
+from lgd_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _lib():
+    from lgd_amd import hip
+    return hip, hip.load()
+
+
+@pytest.mark.parametrize("nb,M,K,T", [(3, 256, 256, 1312),    # T not a multiple of the 128-column tile
+                                      (9, 720, 256, 384),     # cls_score: three row tiles, the last one 208 rows; nb not a multiple of 8 XCDs
+                                      (2, 256, 720, 544),     # its input gradient: 45 k-steps (odd)
+                                      (5, 208, 64, 256),      # a single partial row tile (128-row kernel), 4 k-steps
+                                      (64, 128, 16, 160),     # one k-step: the pipeline's prologue only
+                                      (16, 48, 32, 96)])      # rows far below a tile, T below one column tile
+def test_h2_fwd_fp32_class_product(nb, M, K, T):
+    """lgd_h2_fwd against an fp64 product of the SAME fp32 operands and against the library's fp32 GEMM: an fp32-class result (bar 2e-6 of
+    the output scale, and no worse than 3x the library's own error); per-batch magnitudes spread over 2^+-20, per-row over 2^+-3.  Scaling
+    the operands by powers of two (2^40, 2^-30: far outside the f16 range) scales the result EXACTLY: the scales are derived from the data."""
+    hip, lib = _lib()
+    g = torch.Generator(device=DEV).manual_seed(nb * 1000 + M)
+    fmag = torch.exp2(torch.linspace(-20, 20, nb, device=DEV))[torch.randperm(nb, device=DEV, generator=g)]
+    kmag = torch.exp2(torch.linspace(-3, 3, K, device=DEV))[torch.randperm(K, device=DEV, generator=g)]
+    a = torch.randn((nb, M, K), device=DEV, generator=g) * 0.05 * fmag.view(-1, 1, 1)
+    v = torch.randn((K, nb, T), device=DEV, generator=g) * kmag.view(-1, 1, 1) / fmag.view(1, -1, 1)
+
+    def product(a, v, amax=False):
+        sa, sv = cm.h2_pow2_scale(a.abs().amax((1, 2))), cm.h2_pow2_scale(v.abs().amax((0, 2)))
+        img, vs = cm.h2_split_image(a, sa), cm.h2_split_rows(v, sv)
+        assert img.numel() == lib.lgd_h2_image_bytes(nb, M, K)
+        out = torch.full((M, nb, T), float("nan"), device=DEV)
+        am = torch.full((nb,), -1, dtype=torch.int32, device=DEV) if amax else None
+        ia, iv = (1 / sa).contiguous(), (1 / sv).contiguous()   # (named: a temporary would be freed -- and its block reused -- before the launch)
+        hip.check(lib.lgd_h2_fwd(hip.ptr(img), hip.ptr(vs), 4 * T, 4 * nb * T, 4 * vs.numel(), hip.ptr(out), T, nb * T, hip.ptr(ia),
+                                 hip.ptr(iv), 1, hip.ptr(am) if amax else None, nb, M, T, K, hip.stream_ptr()), "lgd_h2_fwd")
+        return out.permute(1, 0, 2), am
+    c, am = product(a, v, amax=True)
+    vp = v.permute(1, 0, 2)
+    ref = torch.bmm(a.double(), vp.double())
+    scale = ref.abs().amax((1, 2))
+    e_new = float(((c.double() - ref).abs().amax((1, 2)) / scale).max())
+    e_lib = float(((torch.bmm(a, vp).double() - ref).abs().amax((1, 2)) / scale).max())
+    print("h2_fwd %dx[%dx%d].[%dx%d]: max error vs fp64 %.2e of the output scale (library fp32 GEMM: %.2e)" % (nb, M, K, K, T, e_new, e_lib))
+    assert e_new <= 2e-6 and e_new <= 3 * e_lib + 2e-7
+    assert torch.equal(am.view(torch.float32), c.abs().amax((1, 2)))          # the per-batch maxima of the epilogue are exact
+    c2, _ = product(a * 2.0 ** 40, v * 2.0 ** -30)
+    assert torch.equal(c2, c * 2.0 ** 10)
+    a0 = a.clone()
+    a0[:, 3, :] = 0.0
+    assert float(product(a0, v)[0][:, 3, :].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("nb,M,N,T,S", [(64, 256, 256, 1312, 0),   # the config-2 shape class: splits chosen by lgd_h2_dw_splits
+                                        (4, 720, 256, 544, 3),     # cls_score's weight gradient: three row tiles (the last 208 rows); 17 stages over 3 splits
+                                        (3, 48, 64, 96, 1),        # far below one tile, one split
+                                        (2, 256, 512, 64, 7),      # more splits than stages: empty splits write zeros
+                                        (8, 272, 48, 320, 2)])
+def test_h2_dw_fp32_class_product(nb, M, N, T, S):
+    """lgd_h2_dw (dU[b] = sum_t A[b][m][t] B[b][n][t], both operands split rows, split-K with a fixed-order reduction) against the fp64
+    product and the library's fp32 GEMM; bit-reproducible run to run."""
+    hip, lib = _lib()
+    g = torch.Generator(device=DEV).manual_seed(nb * 100 + M + N)
+    fmag = torch.exp2(torch.linspace(-15, 15, nb, device=DEV))[torch.randperm(nb, device=DEV, generator=g)]
+    a = torch.randn((M, nb, T), device=DEV, generator=g) * 1e-3 * fmag.view(1, -1, 1)
+    b = torch.randn((N, nb, T), device=DEV, generator=g) / fmag.view(1, -1, 1)
+    sa, sb = cm.h2_pow2_scale(a.abs().amax((0, 2))), cm.h2_pow2_scale(b.abs().amax((0, 2)))
+    As, Bs = cm.h2_split_rows(a, sa), cm.h2_split_rows(b, sb)
+    if S == 0:
+        S = lib.lgd_h2_dw_splits(nb, M, N, T)
+        assert S >= 1
+
+    ia, ib = (1 / sa).contiguous(), (1 / sb).contiguous()
+
+    def run():
+        out = torch.full((nb, M, N), float("nan"), device=DEV)
+        part = torch.full((S, nb, M, N), float("nan"), device=DEV) if S > 1 else None
+        hip.check(lib.lgd_h2_dw(hip.ptr(As), 4 * nb * T, 4 * T, 4 * As.numel(), hip.ptr(ia), 1, hip.ptr(Bs), 4 * nb * T, 4 * T,
+                                4 * Bs.numel(), hip.ptr(ib), 1, hip.ptr(out), hip.ptr(part) if part is not None else None, S, nb, M, N, T,
+                                hip.stream_ptr()), "lgd_h2_dw")
+        return out
+    c = run()
+    ap, bp = a.permute(1, 0, 2), b.permute(1, 2, 0)
+    ref = torch.bmm(ap.double(), bp.double())
+    scale = ref.abs().amax((1, 2))
+    e_new = float(((c.double() - ref).abs().amax((1, 2)) / scale).max())
+    e_lib = float(((torch.bmm(ap, bp).double() - ref).abs().amax((1, 2)) / scale).max())
+    print("h2_dw %dx[%dx%d].[%dx%d] S=%d: max error vs fp64 %.2e of the output scale (library fp32 GEMM: %.2e)" % (nb, M, T, T, N, S, e_new, e_lib))
+    assert e_new <= 2e-6 and e_new <= 3 * e_lib + 2e-7
+    assert torch.equal(run(), c)
+
+
+def _levels(N, C, hws, seed, lo=-2.0, hi=2.0):
+    return [torch.from_numpy(synth.det_uniform((N, C, h, w), seed + i, lo, hi)).to(DEV) for i, (h, w) in enumerate(hws)]
+
+
+@pytest.mark.parametrize("pre", [None, "bias", "affine"])
+@pytest.mark.parametrize("N,C,hws", [(2, 32, [(26, 36), (13, 18), (7, 9)]), (1, 16, [(67, 260)]), (3, 48, [(1, 1), (2, 3)])])
+def test_wino_in_h2_equals_fp32_transform(N, C, hws, pre):
+    """lgd_wino_in_h2 writes V * 2^e as (h, m) pairs: decoded, it equals the fp32 transform's V to the split's 2^-22 of each element plus
+    2^-40 of the bound; the scale comes from lgd_h2_amax_maps (exact max of the ACTIVATED input: identity / relu(x + bias) / relu(x s + b)),
+    nothing overflows (|h| < 2^15 < 65504), the activation bits are the fp32 transform's, pad tiles are zeros."""
+    hip, lib = _lib()
+    xs = _levels(N, C, hws, 5100)
+    xs = [x * (3.0 ** i) for i, x in enumerate(xs)]      # levels of different magnitude: the bound is the maximum over all of them
+    L = len(xs)
+    hw = hip.int_array([d for x in xs for d in x.shape[2:]])
+    T = lib.lgd_wino_tiles(hw, L, N, 6)
+    assert T % 32 == 0
+    bias = torch.from_numpy(synth.det_uniform((C,), 5200, -1.0, 1.0)).to(DEV) if pre == "bias" else None
+    aff = torch.from_numpy(synth.det_uniform((L * N, C, 2), 5300, -1.5, 1.5)).to(DEV) if pre == "affine" else None
+    p_b, p_a = (hip.ptr(bias) if bias is not None else None), (hip.ptr(aff) if aff is not None else None)
+    st = hip.stream_ptr()
+    V32, bits32 = torch.empty((C, 64, T), device=DEV), torch.zeros((C, T), dtype=torch.int64, device=DEV)
+    hip.check(lib.lgd_wino_in(hip.ptr_array(xs), hw, L, N, C, 6, hip.ptr(V32), p_b, p_a, hip.ptr(bits32) if pre else None, st), "lgd_wino_in")
+    amax = torch.empty(1, dtype=torch.int32, device=DEV)
+    hip.check(lib.lgd_h2_amax_maps(hip.ptr_array(xs), hw, L, N, C, p_b, p_a, hip.ptr(amax), 0, st), "lgd_h2_amax_maps")
+    act = lambda l, x: x if pre is None else (torch.relu(x + bias.view(1, -1, 1, 1)) if pre == "bias" else   # noqa: E731
+                                              torch.relu(x * aff[l * N:(l + 1) * N, :, 0, None, None] + aff[l * N:(l + 1) * N, :, 1, None, None]))
+    true_max = max(float(act(l, x).abs().max()) for l, x in enumerate(xs))
+    got_max = float(amax.view(torch.float32))
+    assert abs(got_max - true_max) <= 1e-6 * true_max
+    Vh = torch.full((C, 64, T), 0x7c007c00, dtype=torch.int32, device=DEV)   # (inf, inf) where nothing is written
+    inv, bits = torch.full((1,), float("nan"), device=DEV), torch.zeros((C, T), dtype=torch.int64, device=DEV)
+    hip.check(lib.lgd_wino_in_h2(hip.ptr_array(xs), hw, L, N, C, hip.ptr(Vh), p_b, p_a, hip.ptr(bits) if pre else None, hip.ptr(amax), hip.ptr(inv), st),
+              "lgd_wino_in_h2")
+    assert torch.equal(bits, bits32)
+    pieces = Vh.view(torch.float16).float().abs()
+    assert bool(torch.isfinite(pieces).all()) and float(pieces.max()) <= 2.0 ** 15
+    s = 1.0 / float(inv)
+    assert s == 2.0 ** round(torch.log2(torch.tensor(s)).item()) and got_max * 225.0 * s < 2.0 ** 15 <= got_max * 256.0 * s * 2.0
+    dec = cm.h2_unsplit_rows(Vh, inv)
+    err = (dec - V32).abs()
+    # the split's own error (2^-23 per piece) + the fp32 roundings of two compilations of the same transform (fma contraction differs; they act on
+    # intermediates of the size of the bound): losing the m piece would show as 2^-11 |V|
+    assert float((err - (2.0 ** -22 * V32.abs() + 2.0 ** -23 * 256.0 * got_max)).max()) <= 0.0
+    assert float(err.max()) <= 2.0 ** -20 * float(V32.abs().max())
+    assert float(dec[V32 == 0].abs().max() if bool((V32 == 0).any()) else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("N,C,hws", [(2, 32, [(26, 36), (13, 18), (7, 9)]), (1, 16, [(67, 260)])])
+def test_wino_out_t_h2_and_fused_link_equal_fp32_transforms(N, C, hws, masked):
+    """lgd_wino_out_t_h2 (dM = A (dy . mask) A^T as split rows, one scale per frequency) and lgd_wino_in_t_out_t_h2 (the fused backward
+    link, its bound from lgd_h2_link_bound) decoded against the fp32 kernels; the recorded inverse scales are the powers of two the bound
+    max|dy| x rowsum_i(A) x rowsum_j(A) prescribes."""
+    hip, lib = _lib()
+    gs = _levels(N, C, hws, 6100, -1.0, 1.0)
+    L = len(gs)
+    hw = hip.int_array([d for x in gs for d in x.shape[2:]])
+    T = lib.lgd_wino_tiles(hw, L, N, 6)
+    st = hip.stream_ptr()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    bits = (torch.randint(0, 2 ** 36, (C, T), dtype=torch.int64, device=DEV, generator=g) if masked else None)
+    pb = hip.ptr(bits) if masked else None
+    dM32 = torch.empty((C, 64, T), device=DEV)
+    hip.check(lib.lgd_wino_out_t(hip.ptr_array(gs), pb, hw, L, N, C, 6, hip.ptr(dM32), st), "lgd_wino_out_t")
+    amax = torch.empty(1, dtype=torch.int32, device=DEV)
+    hip.check(lib.lgd_h2_amax_maps(hip.ptr_array(gs), hw, L, N, C, None, None, hip.ptr(amax), 0, st), "lgd_h2_amax_maps")
+    gmax = float(amax.view(torch.float32))
+    dMh, inv = torch.full((C, 64, T), 0x7c007c00, dtype=torch.int32, device=DEV), torch.empty(64, device=DEV)
+    hip.check(lib.lgd_wino_out_t_h2(hip.ptr_array(gs), pb, hw, L, N, C, hip.ptr(dMh), hip.ptr(amax), hip.ptr(inv), st), "lgd_wino_out_t_h2")
+    rows = torch.tensor([1.0, 6.0, 6.0, 63.0, 63.0, 1.96875, 1.96875, 1.0], device=DEV)
+    bound = gmax * (rows.view(8, 1) * rows.view(1, 8)).reshape(64)
+    assert bool((bound / inv < 2.0 ** 15).all()) and bool((bound / inv * 4.2 >= 2.0 ** 14).all())   # never above the range, never far below it
+    pieces = dMh.view(torch.float16).float().abs()
+    assert bool(torch.isfinite(pieces).all()) and float(pieces.max()) <= 2.0 ** 15
+    dec = cm.h2_unsplit_rows(dMh, inv)
+    tol = 2.0 ** -22 * dM32.abs() + (2.0 ** -40 * inv * 2.0 ** 15).view(1, 64, 1)
+    assert float(((dec - dM32).abs() - tol).max()) <= 0.0
+    # the fused link: dV (any fp32 frequency buffer) -> in_t -> mask -> out_t
+    dV = torch.randn((C, 64, T), device=DEV, generator=g) * torch.exp2(torch.linspace(-6, 6, 64, device=DEV)).view(1, 64, 1)
+    link32 = torch.empty((C, 64, T), device=DEV)
+    hip.check(lib.lgd_wino_in_t_out_t(hip.ptr(dV), pb, hw, L, N, C, 6, hip.ptr(link32), st), "lgd_wino_in_t_out_t")
+    dx = [torch.empty_like(x) for x in gs]
+    hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, C, 6, hip.ptr_array(dx), None, st), "lgd_wino_in_t")
+    # per-frequency maxima over the REAL tiles (the pad tiles of dV are never produced by a product of zero operands; here they hold noise)
+    am64 = dV.abs().amax((0, 2)).contiguous().view(torch.int32)
+    bnd = torch.empty(1, dtype=torch.int32, device=DEV)
+    hip.check(lib.lgd_h2_link_bound(hip.ptr(am64), hip.ptr(bnd), st), "lgd_h2_link_bound")
+    dxmax = max(float(d.abs().max()) for d in dx)
+    b = float(bnd.view(torch.float32))
+    print("link bound %.3e for max |dx| %.3e (x%.1f)" % (b, dxmax, b / dxmax))
+    assert dxmax <= b
+    linkh, inv2 = torch.full((C, 64, T), 0x7c007c00, dtype=torch.int32, device=DEV), torch.empty(64, device=DEV)
+    hip.check(lib.lgd_wino_in_t_out_t_h2(hip.ptr(dV), pb, hw, L, N, C, hip.ptr(linkh), hip.ptr(bnd), hip.ptr(inv2), st), "lgd_wino_in_t_out_t_h2")
+    pieces = linkh.view(torch.float16).float().abs()
+    assert bool(torch.isfinite(pieces).all()) and float(pieces.max()) <= 2.0 ** 15
+    dec2 = cm.h2_unsplit_rows(linkh, inv2)
+    tol2 = 2.0 ** -22 * link32.abs() + (2.0 ** -40 * inv2 * 2.0 ** 15).view(1, 64, 1)
+    assert float(((dec2 - link32).abs() - tol2).max()) <= 0.0
+
+
+def test_wino_out_and_in_t_leave_their_maxima():
+    """lgd_wino_out_amax / lgd_wino_in_t_amax: the same maps as lgd_wino_out / lgd_wino_in_t, bit for bit, plus max |output| over the pixels
+    of the maps (overhanging tiles excluded)"""
+    hip, lib = _lib()
+    N, C, hws = 2, 16, [(26, 36), (13, 18), (7, 9)]
+    L = len(hws)
+    hw = hip.int_array([d for h in hws for d in h])
+    T = lib.lgd_wino_tiles(hw, L, N, 6)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    M = torch.randn((C, 64, T), device=DEV, generator=g)
+    bias = torch.randn(C, device=DEV, generator=g)
+    st = hip.stream_ptr()
+    for relu in (0, 1):
+        ya = [torch.empty((N, C, h, w), device=DEV) for h, w in hws]
+        yb = [torch.empty((N, C, h, w), device=DEV) for h, w in hws]
+        am = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+        hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(bias), hw, L, N, C, 6, relu, hip.ptr_array(ya), None, st), "lgd_wino_out")
+        hip.check(lib.lgd_wino_out_amax(hip.ptr(M), hip.ptr(bias), hw, L, N, C, relu, hip.ptr_array(yb), None, hip.ptr(am), st), "lgd_wino_out_amax")
+        assert all(torch.equal(a, b) for a, b in zip(ya, yb))
+        assert float(am.view(torch.float32)) == max(float(y.abs().max()) for y in ya)
+    da = [torch.empty((N, C, h, w), device=DEV) for h, w in hws]
+    db = [torch.empty((N, C, h, w), device=DEV) for h, w in hws]
+    am = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+    hip.check(lib.lgd_wino_in_t(hip.ptr(M), hw, L, N, C, 6, hip.ptr_array(da), None, st), "lgd_wino_in_t")
+    hip.check(lib.lgd_wino_in_t_amax(hip.ptr(M), hw, L, N, C, hip.ptr_array(db), None, hip.ptr(am), st), "lgd_wino_in_t_amax")
+    assert all(torch.equal(a, b) for a, b in zip(da, db))
+    assert float(am.view(torch.float32)) == max(float(d.abs().max()) for d in da)
+
+
+def test_filter_images_h2_equal_the_split_of_the_fp32_transform():
+    """lgd_wino_filter_images_h2 (stacked filters, FrozenBN scale folded) == the torch-built image of the fp32 transform U = G (s . g) G^T under the
+    scales it records; the scales follow from max |w s| (lgd_h2_amax_filters) and the row sums of G."""
+    hip, lib = _lib()
+    Ci, Cos = 48, (32, 16)
+    Ct = sum(Cos)
+    ws = [torch.from_numpy(synth.det_uniform((co, Ci, 3, 3), 7100 + k, -0.2, 0.2)).to(DEV) for k, co in enumerate(Cos)]
+    scs = [torch.from_numpy(synth.det_uniform((Cos[0],), 7200, 0.5, 3.0)).to(DEV), None]
+    st = hip.stream_ptr()
+    U = torch.empty((64, Ct, Ci), device=DEV)
+    c0 = 0
+    for w, sc, co in zip(ws, scs, Cos):
+        hip.check(lib.lgd_wino_filter_fwd(hip.ptr(w), hip.ptr(sc) if sc is not None else None, co, Ci, 6, ctypes.c_void_p(U.data_ptr() + 4 * c0 * Ci), Ct * Ci,
+                                          None, 0, 0, st), "lgd_wino_filter_fwd")
+        c0 += co
+    amax = torch.empty(1, dtype=torch.int32, device=DEV)
+    arr = (ctypes.c_void_p * 2)(scs[0].data_ptr(), None)
+    hip.check(lib.lgd_h2_amax_filters(hip.ptr_array(ws), arr, hip.int_array(Cos), 2, Ci * 9, hip.ptr(amax), st), "lgd_h2_amax_filters")
+    want = max(float((ws[0] * scs[0].view(-1, 1, 1, 1)).abs().max()), float(ws[1].abs().max()))
+    assert abs(float(amax.view(torch.float32)) - want) <= 1e-6 * want
+    imf = torch.zeros(lib.lgd_h2_image_bytes(64, Ct, Ci), dtype=torch.uint8, device=DEV)
+    imb = torch.zeros(lib.lgd_h2_image_bytes(64, Ci, Ct), dtype=torch.uint8, device=DEV)
+    inv = torch.empty(64, device=DEV)
+    c0 = 0
+    for w, sc, co in zip(ws, scs, Cos):
+        hip.check(lib.lgd_wino_filter_images_h2(hip.ptr(w), hip.ptr(sc) if sc is not None else None, co, Ci, c0, Ct, hip.ptr(imf), hip.ptr(imb), hip.ptr(amax),
+                                                hip.ptr(inv), st), "lgd_wino_filter_images_h2")
+        c0 += co
+    assert bool((U.abs().amax((1, 2)) / inv < 2.0 ** 15).all())
+    # (not bit-equal to the split of lgd_wino_filter_fwd's U: two compilations of the transform contract their fmas differently)
+    uf, ub = cm.h2_unsplit_image(imf, 64, Ct, Ci, inv), cm.h2_unsplit_image(imb, 64, Ci, Ct, inv)
+    tol = 2.0 ** -21 * U.abs() + (2.0 ** -24 * U.abs().amax((1, 2))).view(64, 1, 1)
+    assert float(((uf - U).abs() - tol).max()) <= 0.0
+    assert float(((ub - U.transpose(1, 2)).abs() - tol.transpose(1, 2)).max()) <= 0.0
+    # the images are whole: what lies beyond the 48 / 16 rows of the last 32-row blocks stays zero
+    assert float(cm.h2_unsplit_image(imf, 64, Ct, Ci, inv, padded=True)[:, Ct:].abs().max()) == 0.0
+    assert float(cm.h2_unsplit_image(imb, 64, Ci, Ct, inv, padded=True)[:, Ci:].abs().max()) == 0.0
+
+
+def _with_h2(fn):
+    from lgd_amd import ops
+    pw = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=6)
+    ph = ops.h2_backend(True, force=True)
+    seen = {"fwd": 0, "dw": 0}
+    rp, rd = ops._h2_product, ops._h2_dw
+    ops._h2_product = lambda *a, **k: (seen.__setitem__("fwd", seen["fwd"] + 1), rp(*a, **k))[1]
+    ops._h2_dw = lambda *a, **k: (seen.__setitem__("dw", seen["dw"] + 1), rd(*a, **k))[1]
+    try:
+        return fn(), seen
+    finally:
+        ops._h2_product, ops._h2_dw = rp, rd
+        ops.h2_backend(*ph)
+        ops.conv3x3_backend(*pw)
+
+
+@pytest.mark.parametrize("case", ["levels-scale-relu", "shared-input", "chain", "chain-mixed", "pre-bias", "pre-affine"])
+def test_conv3x3_nodes_on_h2_vs_fp64(case):
+    """the Winograd convolution nodes with every channel product -- forward, input gradient AND weight gradient -- forced onto csrc/h2.hip
+    against the fp64 direct convolution under the kernels' own ReLU masks: outputs and all gradients to the F(6x6) fp32 bar (1e-4 of scale);
+    chains incl. the fused backward link in the f16x2 format, and a chain whose last convolution (36 channels) stays on the fp32 products
+    [ref: dynamic_teacher.py:57-73, sequential_convs.py:10-12, retinanet head towers]."""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    hws = [(26, 36), (13, 18), (7, 9)]
+    N, Ci = 2, 64
+    xs0 = [torch.from_numpy(synth.det_uniform((N, Ci, h, w), 8201 + i, -2.0, 2.0)) for i, (h, w) in enumerate(hws)]
+    cos = (64, 48, 64, 36)
+    ws0 = [torch.from_numpy(synth.det_uniform((co, 64 if k != 3 else 48, 3, 3), 8210 + k, -0.1, 0.1)) for k, co in enumerate(cos)]
+    bs0 = [torch.from_numpy(synth.det_uniform((co,), 8220 + k, -0.5, 0.5)) for k, co in enumerate(cos)]
+    sc0 = torch.from_numpy(synth.det_uniform((64,), 8230, 0.5, 1.5))
+    pb0 = torch.from_numpy(synth.det_uniform((Ci,), 8240, -1.0, 1.0))
+    pa0 = torch.from_numpy(synth.det_uniform((len(hws) * N, Ci, 2), 8250, -1.5, 1.5))
+
+    def fns(dev, dt):
+        sc, pb, pa = sc0.to(dev, dt), pb0.to(dev, dt), pa0.to(dev, dt)
+        if dev == DEV:
+            return {"levels-scale-relu": lambda x, w, b: ops.conv3x3_levels(x, w[0], b[0], relu=True, scale=sc),
+                    "shared-input": lambda x, w, b: [y for ys in ops.conv3x3_shared_input(x, [(w[0], b[0]), (w[1], b[1])], relu=True) for y in ys],
+                    "chain": lambda x, w, b: ops.conv3x3_chain(x, [(w[0], b[0]), (w[2], b[2]), (w[1], b[1])], (True, True, False)),
+                    "chain-mixed": lambda x, w, b: ops.conv3x3_chain(x, [(w[0], b[0]), (w[1], b[1]), (w[3], b[3])], (True, True, False)),
+                    "pre-bias": lambda x, w, b: ops.conv3x3_levels(x, w[0], b[0], relu=False, pre=pb),
+                    "pre-affine": lambda x, w, b: ops.conv3x3_levels(x, w[0], b[0], relu=False, pre=pa)}[case]
+        conv = lambda x, w, b, relu=False, s=None: [(F.relu(y) if relu else y) for y in   # noqa: E731
+                                                    [F.conv2d(t, w if s is None else w * s.view(-1, 1, 1, 1), b, 1, 1) for t in x]]
+        seq = lambda x, layers: (x if not layers else seq(conv(x, layers[0][0], layers[0][1], layers[0][2]), layers[1:]))   # noqa: E731
+        return {"levels-scale-relu": lambda x, w, b: conv(x, w[0], b[0], True, sc),
+                "shared-input": lambda x, w, b: conv(x, w[0], b[0], True) + conv(x, w[1], b[1], True),
+                "chain": lambda x, w, b: seq(x, [(w[0], b[0], True), (w[2], b[2], True), (w[1], b[1], False)]),
+                "chain-mixed": lambda x, w, b: seq(x, [(w[0], b[0], True), (w[1], b[1], True), (w[3], b[3], False)]),
+                "pre-bias": lambda x, w, b: conv([F.relu(t + pb.view(1, -1, 1, 1)) for t in x], w[0], b[0]),
+                "pre-affine": lambda x, w, b: conv([F.relu(t * pa[l * N:(l + 1) * N, :, 0, None, None] + pa[l * N:(l + 1) * N, :, 1, None, None])
+                                                    for l, t in enumerate(x)], w[0], b[0])}[case]
+
+    def run(dev, dt):
+        x = [t.to(dev, dt).requires_grad_(True) for t in xs0]
+        w = [t.to(dev, dt).requires_grad_(True) for t in ws0]
+        b = [t.to(dev, dt).requires_grad_(True) for t in bs0]
+        ys = fns(dev, dt)(x, w, b)
+        gys = [torch.from_numpy(synth.det_uniform(tuple(y.shape), 8300 + i, -1.0, 1.0)).to(dev, dt) for i, y in enumerate(ys)]
+        torch.autograd.backward(ys, gys)
+        return [y.detach() for y in ys], [(t.grad if t.grad is not None else None) for t in x + w + b]
+    (ya, ga), seen = _with_h2(lambda: run(DEV, torch.float32))
+    assert seen["fwd"] >= 2 and seen["dw"] >= 1, seen
+    yb, gb = run("cpu", torch.float64)
+    if case == "pre-affine":   # the node hands back the gradient w.r.t. the activation's OUTPUT under its mask (group_norm_fold's backward does the rest)
+        for l in range(len(hws)):
+            s_ = pa0[l * N:(l + 1) * N, :, 0, None, None].double()
+            gb[l] = torch.where(s_ != 0, gb[l] / s_, torch.zeros_like(gb[l]))
+    tol = 1e-4 if "relu" not in case and "chain" not in case and case != "shared-input" else 3e-3   # ReLU flips of units within rounding of zero
+    for a, r in zip(ya, yb):
+        assert float((a.cpu().double() - r).abs().max()) <= 1e-4 * float(r.abs().max())
+    for a, r in zip(ga, gb):
+        assert (a is None) == (r is None)
+        if a is not None:
+            assert float((a.cpu().double() - r).abs().max()) <= tol * float(r.abs().max()), case
+
+
+def test_conv3x3_on_h2_equals_the_fp32_products_incl_masks():
+    """the same nodes on csrc/h2.hip and on the fp32-format pipeline (gemm3 / library products): without ReLU every output and gradient agrees to
+    2e-5 of its scale -- two fp32-class evaluations of the same graph"""
+    from lgd_amd import ops
+    hws = [(26, 36), (13, 18), (7, 9)]
+    N, Ci = 2, 64
+    xs = _levels(N, Ci, hws, 9201)
+    ws = [torch.from_numpy(synth.det_uniform((co, Ci, 3, 3), 9210 + k, -0.1, 0.1)).to(DEV) for k, co in enumerate((64, 48, 64))]
+    bs = [torch.from_numpy(synth.det_uniform((co,), 9220 + k, -0.5, 0.5)).to(DEV) for k, co in enumerate((64, 48, 64))]
+
+    def run():
+        x = [t.clone().requires_grad_(True) for t in xs]
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        ys = ops.conv3x3_chain(x, [(w[0], b[0]), (w[2], b[2]), (w[1], b[1])], (False, False, False))
+        ys = ys + [y for yk in ops.conv3x3_shared_input(x, [(w[0], b[0]), (w[1], b[1])], relu=False) for y in yk]
+        gys = [torch.from_numpy(synth.det_uniform(tuple(y.shape), 9250 + i, -1.0, 1.0)).to(DEV) for i, y in enumerate(ys)]
+        torch.autograd.backward(ys, gys)
+        return [y.detach() for y in ys] + [t.grad for t in x + w + b]
+    a, seen = _with_h2(run)
+    assert seen["fwd"] >= 8 and seen["dw"] >= 4, seen
+    pw = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=6)
+    ph = ops.h2_backend(False)
+    try:
+        b_ = run()
+    finally:
+        ops.h2_backend(*ph)
+        ops.conv3x3_backend(*pw)
+    for u, v in zip(a, b_):
+        assert float((u - v).abs().max()) <= 2e-5 * (float(v.abs().max()) + 1e-30)
+
+
+def test_amax_tags_travel_and_expire():
+    """the bound a producing kernel leaves on its output maps is found by the next convolution (no pass over the maps) and ignored once the
+    map has been written in place"""
+    from lgd_amd import ops
+    xs = _levels(2, 64, [(26, 36), (13, 18)], 9900)
+    w = torch.from_numpy(synth.det_uniform((64, 64, 3, 3), 9910, -0.1, 0.1)).to(DEV).requires_grad_(True)
+    calls = []
+    hip, lib = _lib()
+    real = ops._count_bytes
+
+    def run():
+        ys = ops.conv3x3_levels([x.clone().requires_grad_(True) for x in xs], w, None, relu=True)
+        assert all(getattr(y, "_lgd_amax", None) is not None for y in ys)
+        tag = ys[0]._lgd_amax[0]
+        assert float(tag.view(torch.float32)) == max(float(y.abs().max()) for y in ys)
+        n0 = len(calls)
+        zs = ops.conv3x3_levels(ys, w, None)
+        assert len(calls) == n0, "the tagged maps were passed over again"
+        with torch.no_grad():
+            ys[0].mul_(2.0)   # (in place: the version moves, the tag is stale)
+        ops.conv3x3_levels(ys, w, None)
+        assert len(calls) == n0 + 1, "a stale tag was trusted"
+        return zs
+    ops._count_bytes = lambda name, n: (calls.append(name) if name == "h2_amax_maps_kernel" else None, real(name, n))[1]
+    try:
+        _with_h2(run)
+    finally:
+        ops._count_bytes = real

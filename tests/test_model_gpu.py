@@ -42,7 +42,10 @@ def _teacher(name):
 
 # every golden case on the Winograd kernels (forced: the small cases have fewer tiles than the production threshold), the
 # small ones once more on the library convolutions (ops.conv3x3_backend(winograd=False))
-_RUNS = [(n, "winograd") for n in cm.CASES] + [(n, "library") for n in cm.SMALL_CASES]
+# round 5: every case once more with ALL channel products (forward, input and weight gradient) forced onto csrc/h2.hip (f16x2 split operands: the
+# shipped path at production sizes), and once with the f16x2 pipeline off and the products forced onto csrc/gemm3.hip
+_RUNS = ([(n, "winograd") for n in cm.CASES] + [(n, "winograd+h2") for n in cm.CASES] + [(n, "winograd+gemm3") for n in cm.CASES]
+         + [(n, "library") for n in cm.SMALL_CASES])
 
 
 @pytest.fixture(scope="module", params=_RUNS, ids=["%s-%s" % r for r in _RUNS])
@@ -50,7 +53,9 @@ def run(request):
     from lgd_amd import ops
     from lgd_amd.structures import ImageList
     name, backend = request.param
-    prev = ops.conv3x3_backend(winograd=(backend == "winograd"), min_tiles=0)
+    prev = ops.conv3x3_backend(winograd=backend.startswith("winograd"), min_tiles=0)
+    prev_h2 = ops.h2_backend(backend != "winograd+gemm3", force=(backend == "winograd+h2"))
+    prev_g3 = ops.gemm3_backend(True, force=(backend == "winograd+gemm3"))
     B, H, W, ctx, interact, fmt, coef, _ = cm.CASES[name]
     teacher = _teacher(name)
     feats = {k: v.to(DEV).requires_grad_(True) for k, v in cm.case_feats(name).items()}
@@ -69,6 +74,8 @@ def run(request):
         h.remove()
     yield dict(name=name, backend=backend, g=cm.golden(name), teacher=teacher, feats=feats, tea=tea, geom=geom, le=cap["le"],
                coef=coef, inst_labels=inst_labels, app=cap.get("app"), att=cap.get("att"), stride=cm.stride_of(name))
+    ops.gemm3_backend(*prev_g3)
+    ops.h2_backend(*prev_h2)
     ops.conv3x3_backend(*prev)
 
 
@@ -445,7 +452,9 @@ def test_single_head_pass_equals_two_passes(yaml_name, conv_backend):
     for got, want in ((pair[1], one_a[1:]), (pair[2], one_b[1:])):
         for go, wo in zip(got, want):
             for x, y in zip(getattr(go, "raw", go), getattr(wo, "raw", wo)):
-                assert cm.rel_err(x, y) < 1e-5
+                # (the pair's products may run on csrc/h2.hip -- twice the tiles pass its speed gate -- and the single passes on gemm3 / the library:
+                #  two fp32-class evaluations of five stacked convolutions)
+                assert cm.rel_err(x, y) < 3e-5
     data = synthetic_batch(2, 256, 320, 5, seed=5)
 
     def run(fused):
