@@ -373,8 +373,9 @@ int lgd_wino_in_t_out_t(const float* dV, const void* relu_bits, const int32_t* l
 size_t lgd_gemm3_image_bytes(int nb, int M, int K);
 int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_sk, int nb, int M, int K, void* image, void* stream);
 int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm,
-              const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits, int nb, int M, int N, int K,
-              void* stream);
+              const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits, uint32_t* amax_out, int nb, int M, int N,
+              int K, void* stream);
+/* (round 5) amax_out: optional word (zeroed by the caller) that receives max |C| as stored, as float bits: the magnitude bound of lgd_h2_*. */
 
 /* ---- K10: the Winograd channel products from f16x2 operands that are split in HBM (csrc/h2.hip; round 5).
  * Replaces, like lgd_gemm3, the arithmetic of every nn.Conv2d(C, C', 3, padding=1) of the path (dynamic_teacher.py:57,61,67-73,145,280;
@@ -386,13 +387,14 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
  *   image:      the filter operand, [batch][k-step of 16][2 pieces][32-row block][1 KB] (lgd_wino_filter_images_h2), lgd_h2_image_bytes bytes.
  * lgd_h2_fwd:   C[b] (M x N, fp32, C[b * c_sb + m * c_sm + n]) = image[b] (M x K) . B[b], B split rows with k-row stride b_sk and batch stride
  *               b_sb (bytes; extent b_bytes from B), rescaled by a_inv[b] * b_inv[b_inv_per_batch ? b : 0].  amax_out (optional, nb words):
- *               max |C[b]| as float bits (zeroed by the call).  K % 16 == 0.
+ *               max |C[b]| as float bits (words zeroed by the CALLER).  K % 16 == 0.
  * lgd_h2_dw:    out[b] (M x N, row-major fp32) = sum_t A[b][m][t] B[b][n][t], both split rows (row strides a_rs / b_rs, batch strides a_sb / b_sb,
  *               bytes), T % 32 == 0 (lgd_wino_tiles pads every level to 32); split-K over S workgroups per output tile (lgd_h2_dw_splits) through `partials` (S * nb * M * N floats,
- *               unused for S == 1), reduced in fixed order: bit-reproducible.
+ *               unused for S == 1), reduced in fixed order: bit-reproducible; out == NULL (S > 1)
+ *               leaves the partials for lgd_wino_filter_bwd_parts, which adds them while it reads.
  * lgd_h2_amax_maps / lgd_h2_amax_filters: max |act(x)| over the level maps (act = identity, relu(x + bias[c]) or relu(x * scale + shift) with
- *               the (L*N, C, 2) table of lgd_wino_in) / max |w * scale[co]| over K <= 8 filters, as float bits (zeroed by the call unless `accumulate`:
- *               the maximum over several calls): the bounds the transforms derive their scales from.  lgd_h2_link_bound: the bound of |dx| for the fused backward link from the 64
+ *               the (L*N, C, 2) table of lgd_wino_in) / max |w * scale[co]| over K <= 8 filters (word zeroed by the CALLER), as float bits (`accumulate` != 0: the word is NOT zeroed
+ *               first -- the maximum over several calls, or a word the caller zeroed): the bounds the transforms derive their scales from.  lgd_h2_link_bound: the bound of |dx| for the fused backward link from the 64
  *               per-frequency maxima of dV (lgd_h2_fwd's amax_out). */
 size_t lgd_h2_image_bytes(int nb, int M, int K);
 int lgd_h2_fwd(const void* image, const void* B, long long b_sb, long long b_sk, long long b_bytes, float* C, long long c_sb, long long c_sm,
@@ -409,7 +411,7 @@ int lgd_h2_link_bound(const uint32_t* amax64, uint32_t* out_bits, void* stream);
 /* The F(6x6,3x3) transforms around them.  *_h2: the frequency buffer WRITTEN is split rows scaled by a power of two derived from *amax_in (float
  * bits of an upper bound of the transform's input magnitude); inv_out receives the inverse scale(s): 1 float (lgd_wino_in_h2: one scale for all
  * frequencies) or 64 (per frequency).  lgd_wino_out_amax / lgd_wino_in_t_amax: lgd_wino_out / lgd_wino_in_t (tile 6) that also leave
- * max |output| in *amax_out (zeroed by the call).  lgd_wino_filter_images_h2: lgd_wino_filter_images writing the f16x2 images. */
+ * max |output| in *amax_out (a word zeroed by the CALLER: lgd_amd keeps a pool of zeroed words, one fill per 4096 bounds).  lgd_wino_filter_images_h2: lgd_wino_filter_images writing the f16x2 images. */
 int lgd_wino_in_h2(const float* const* x_host, const int32_t* level_hw_host, int L, int N, int C, void* V, const float* pre_bias,
                    const float* pre_affine, void* pre_bits, const uint32_t* amax_in, float* inv_out, void* stream);
 int lgd_wino_out_t_h2(const float* const* dy_host, const void* relu_bits, const int32_t* level_hw_host, int L, int N, int C, void* dM,
@@ -420,6 +422,8 @@ int lgd_wino_out_amax(const float* M, const float* bias, const int32_t* level_hw
                       void* relu_bits, uint32_t* amax_out, void* stream);
 int lgd_wino_in_t_amax(const float* dV, const int32_t* level_hw_host, int L, int N, int C, float* const* dx_host, const void* pre_bits,
                        uint32_t* amax_out, void* stream);
+int lgd_wino_filter_bwd_parts(const float* dU, long long du_plane, long long part_stride, int S, const float* scale, int Co, int Ci, float* dw,
+                              void* stream);   /* lgd_wino_filter_bwd (tile 6) over S split-K partials of dU (lgd_h2_dw with out == NULL), added in fixed order */
 int lgd_wino_filter_images_h2(const float* w, const float* scale, int Co, int Ci, int row0, int Ct, void* img_fwd, void* img_bwd,
                               const uint32_t* amax_in, float* inv_out64, void* stream);
 

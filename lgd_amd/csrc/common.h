@@ -68,6 +68,14 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void atomic_max_bits(unsigned* addr, unsigned v) {
     if (v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, v);
 }
+// the same from a 256-thread workgroup: `am` >= 0 is wave-uniform (a wave_max); `slots` = 4 floats of LDS nobody else touches until the next
+// barrier the caller executes.  ONE load (and rarely an atomic) per workgroup: even the loads serialise at ~1 per clock on their L2 line
+// (measured on the F(6x6) output transform: 45 K of them cost +19 us per launch).
+__device__ __forceinline__ void block_max_bits(unsigned* addr, float am, float* slots) {
+    if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_max_bits(addr, __builtin_bit_cast(unsigned, fmaxf(fmaxf(slots[0], slots[1]), fmaxf(slots[2], slots[3]))));
+}
 
 // ---- streaming (non-temporal) 16-byte load: data that is read exactly once should not displace L2 lines.
 // Measured on MI355X (tools/lab/bw_lab.hip): +11 % read bandwidth over plain loads for one-pass reductions.

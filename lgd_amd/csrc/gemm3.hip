@@ -66,6 +66,8 @@ struct Params {
     const float* shift;
     uint32_t* bits; int wpr;                     // ReLU mask: bit n % 32 of word (b * M + m) * wpr + n / 32 = (C(m, n) > 0)
     int relu;
+    unsigned* amax;                              // optional: atomic max of the float bits of |C| as stored (one word, zeroed by the caller): the bound
+                                                 // the NEXT convolution's f16x2 scale is derived from (csrc/h2.hip)
 };
 
 // EPI: 0 the plain product; otherwise the epilogue kernel with bit 0: R present, bit 1: shift present
@@ -339,6 +341,8 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
         const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(p.C + (long)b * p.c_sb + (long)wrow * ld + wcol, 0, 0xffffffffu, 0x00020000);
         const int c1 = ld * 4, c5 = ld * 20, mrem = p.M - mw;
         const bool colok[2] = {nw < p.N, nw + 32 < p.N};
+        const bool want_max = p.amax != nullptr;
+        uint32_t amax = 0u;
         auto epi = [&](auto HB, auto HF) {
             constexpr bool hb = decltype(HB)::value, hf = decltype(HF)::value;
             int cbase = (4 * g * ld + rr) * 4;
@@ -367,7 +371,10 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
 #if LGD_GEMM3_ABL == 4 || LGD_GEMM3_ABL == 5   // lab: no C stores (one conditional store keeps the accumulators alive)
                         if (v == 123456.f)
 #endif
-                        if (hf || (dm < mrem && colok[jn])) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
+                        if (hf || (dm < mrem && colok[jn])) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
+                            if (want_max) amax = max(amax, __builtin_bit_cast(uint32_t, v) & 0x7fffffffu);
+                        }
                         co += (e & 3) == 3 ? c5 : c1;
                         asm volatile("" : "+v"(co));
                     }
@@ -385,6 +392,11 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
             else { if (full) epi(NO(), Y()); else epi(NO(), NO()); }
         } else {
             if (full) epi(NO(), Y()); else epi(NO(), NO());
+        }
+        if (want_max) {   // (non-negative floats order like their bit patterns)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
+            if (lane == 0) atomic_max_bits(p.amax, amax);
         }
         if constexpr ((EPI & 2) != 0) __syncthreads();   // the next tile's prologue writes the LDS the shift values were read from
     }
@@ -429,8 +441,8 @@ int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_
 }
 
 int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm,
-              const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits, int nb, int M, int N, int K,
-              void* stream) {
+              const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits, uint32_t* amax_out, int nb, int M, int N,
+              int K, void* stream) {
     if (!image || !B || !C || nb <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 15) || ((uintptr_t)image & 15)) return LGD_EINVAL;
     // 256-row tiles unless that leaves more than a quarter of the rows of the last tile empty and 128-row tiles do not
     const bool epi = R || shift || relu || relu_bits;
@@ -441,12 +453,19 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
     p.Aimg = (const char*)image; p.a_sb = image_shared ? 0 : (long)p.ktp * 3 * p.rbp * 1024;
     p.B = B; p.b_sb = (long)b_sb; p.b_ld = (long)b_sk;
     p.C = C; p.c_sb = (long)c_sb; p.c_ld = (long)c_sm;
-    p.R = R; p.r_sb = (long)r_sb; p.r_ld = (long)r_sm; p.r_bytes = (((long)nb - 1) * r_sb + ((long)M - 1) * r_sm + N) * 4; p.shift = shift; p.bits = relu_bits; p.wpr = (N + 31) / 32; p.relu = relu ? 1 : 0;
+    p.R = R; p.r_sb = (long)r_sb; p.r_ld = (long)r_sm; p.r_bytes = (((long)nb - 1) * r_sb + ((long)M - 1) * r_sm + N) * 4; p.shift = shift; p.bits = relu_bits; p.amax = amax_out; p.wpr = (N + 31) / 32; p.relu = relu ? 1 : 0;
     p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + bm - 1) / bm; p.nt = (N + lgd::BN - 1) / lgd::BN;
     // 32-bit BYTE offsets from the descriptors' origins inside the kernel: one k-step of B rows, one tile of C / R rows
     if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 30) || 256L * c_sm >= (1L << 30) || c_sm < 0 || (R && (r_sb < 0 || r_sm < 0 || 256L * r_sm >= (1L << 30))))
         return LGD_EINVAL;
-    static bool attr = false;   // 72 KB of dynamic LDS: above the default 64 KB limit
+    // 72 KB of dynamic LDS: above the default 64 KB limit.  hipFuncAttributeMaxDynamicSharedMemorySize and the CU count are per DEVICE: cached per
+    // device index (a process that touched a second GPU launched without the attribute and with the first one's CU count)
+    static bool attr_dev[64] = {};
+    static int cus_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LGD_ELAUNCH;
+    bool& attr = attr_dev[dev];
+    int& cus = cus_dev[dev];
     if (!attr) {
         const void* big[5] = {(const void*)lgd::gemm3_kernel<256, 0>, (const void*)lgd::gemm3_kernel<256, 1>, (const void*)lgd::gemm3_kernel<256, 2>,
                               (const void*)lgd::gemm3_kernel<256, 3>, (const void*)lgd::gemm3_kernel<256, 4>};
@@ -458,11 +477,9 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
     // persistent launch: as many workgroups as are resident at once (2 per CU with the 256-row tile, 3 with the 128-row one); each walks
     // tiles id, id + grid, ...  Measured equal to one workgroup per tile on every shape of tools/gemm3_probe.py (dispatch is not what
     // the kernel waits for), so the default stays one workgroup per tile (the hardware balances edge tiles); LGD_GEMM3_PERSIST=1 selects it
-    static int cus = 0;
     if (!cus) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LGD_ELAUNCH;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LGD_ELAUNCH;
         cus = prop.multiProcessorCount;
     }
     const char* pe = getenv("LGD_GEMM3_PERSIST");

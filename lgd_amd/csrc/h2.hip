@@ -355,6 +355,7 @@ __global__ void h2_reduce_kernel(const float* __restrict__ P, float* __restrict_
 // ------------------------------------------------------------------------------------------------------------------ bounds of the operands
 // max |act(x)| over a list of NCHW maps (the pyramid levels), act = identity | relu(x + bias[c]) | relu(x * scale + shift) per (level, image,
 // channel): the bound the input transform's f16 scale is derived from.  Workgroup per 4096-element chunk of a plane.
+constexpr int kAmaxChunk = 16384;   // elements of a plane per workgroup
 struct AmaxArgs {
     const float* maps[LGD_MAX_LEVELS];
     unsigned blk_off[LGD_MAX_LEVELS + 1];
@@ -365,6 +366,7 @@ struct AmaxArgs {
 };
 
 __global__ __launch_bounds__(256) void h2_amax_maps_kernel(AmaxArgs a) {
+    __shared__ float slots[4];
     int l = 0;
 #pragma unroll
     for (int i = 1; i < LGD_MAX_LEVELS; ++i)
@@ -380,22 +382,28 @@ __global__ __launch_bounds__(256) void h2_amax_maps_kernel(AmaxArgs a) {
     if (a.affine) { const float2 v = reinterpret_cast<const float2*>(a.affine)[(size_t)l * a.N * a.C + plane]; s = v.x; sh = v.y; }
     else if (a.bias) sh = a.bias[plane % a.C];
     float am = 0.f;
-    const int e0 = ch * 4096, e1 = min(hw, e0 + 4096);
+    const int e0 = ch * kAmaxChunk, e1 = min(hw, e0 + kAmaxChunk);
     if ((hw & 3) == 0) {
+        for (int base = e0; base < e1; base += 4096) {   // four 16-byte loads per thread in flight
+            float4 v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = e0 + (k * 256 + threadIdx.x) * 4;
-            if (e < e1) {
-                const float4 v = ldg_stream4(x + e);
-                if (pre) am = fmaxf(am, fmaxf(fmaxf(fmaf(v.x, s, sh), fmaf(v.y, s, sh)), fmaxf(fmaf(v.z, s, sh), fmaf(v.w, s, sh))));
-                else am = fmaxf(am, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            for (int k = 0; k < 4; ++k) {
+                const int e = base + (k * 256 + threadIdx.x) * 4;
+                v[k] = e < e1 ? ldg_stream4(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = base + (k * 256 + threadIdx.x) * 4;
+                if (e >= e1) continue;
+                if (pre) am = fmaxf(am, fmaxf(fmaxf(fmaf(v[k].x, s, sh), fmaf(v[k].y, s, sh)), fmaxf(fmaf(v[k].z, s, sh), fmaf(v[k].w, s, sh))));
+                else am = fmaxf(am, fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w))));
             }
         }
     } else {
         for (int e = e0 + threadIdx.x; e < e1; e += 256) am = fmaxf(am, pre ? fmaf(x[e], s, sh) : fabsf(x[e]));
     }
     am = wave_max(am);   // (pre: relu(z) >= 0 and am starts at 0: max(relu(z)) = max(0, max z))
-    if ((threadIdx.x & 63) == 0) atomic_max_bits(a.out, __builtin_bit_cast(unsigned, am));
+    block_max_bits(a.out, am, slots);
 }
 
 // max |w[co][..] * scale[co]| over K filter tensors (rows = output channels of `row` elements each)
@@ -410,8 +418,9 @@ __global__ __launch_bounds__(256) void h2_amax_filter_kernel(AmaxFilterArgs a) {
     const float s = a.scale[k] ? fabsf(a.scale[k][co]) : 1.f;
     float am = 0.f;
     for (int e = threadIdx.x; e < a.row; e += 256) am = fmaxf(am, fabsf(w[e]));
+    __shared__ float slots[4];
     am = wave_max(am) * s;
-    if ((threadIdx.x & 63) == 0) atomic_max_bits(a.out, __builtin_bit_cast(unsigned, am));
+    block_max_bits(a.out, am, slots);
 }
 
 // bound of |dx| = |adjoint input transform of dV| from the per-frequency maxima of dV (the dx product's AMAX epilogue), for the fused backward
@@ -493,7 +502,6 @@ int lgd_h2_fwd(const void* image, const void* B, long long b_sb, long long b_sk,
     p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + bm - 1) / bm; p.nt = (N + 127) / 128;
     const unsigned total = (unsigned)(((nb + 7) / 8) * p.nt * p.mt * 8);
     hipStream_t st = (hipStream_t)stream;
-    if (amax_out && hipMemsetAsync(amax_out, 0, sizeof(uint32_t) * nb, st) != hipSuccess) return LGD_ELAUNCH;
     const dim3 grid(total), block(256);
     if (small) {
         if (amax_out) { LGD_LAUNCH("h2_fwd_kernel", (lgd::h2_fwd_kernel<128, true>), grid, block, lgd::kFwdLds128, st, p); }
@@ -522,7 +530,7 @@ int lgd_h2_dw_splits(int nb, int M, int N, int T) {
 int lgd_h2_dw(const void* A, long long a_rs, long long a_sb, long long a_bytes, const float* a_inv, int a_inv_per_batch, const void* B, long long b_rs,
               long long b_sb, long long b_bytes, const float* b_inv, int b_inv_per_batch, float* out, float* partials, int S, int nb, int M, int N, int T,
               void* stream) {
-    if (!A || !B || !out || !a_inv || !b_inv || nb <= 0 || M <= 0 || N <= 0 || T < 16 || (T & 31) || S < 1 || (S > 1 && !partials) ||
+    if (!A || !B || (!out && S == 1) || !a_inv || !b_inv || nb <= 0 || M <= 0 || N <= 0 || T < 16 || (T & 31) || S < 1 || (S > 1 && !partials) ||
         ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (a_rs & 15) || (b_rs & 15) || (a_sb & 15) || (b_sb & 15) || a_rs <= 0 || b_rs <= 0)
         return LGD_EINVAL;
     if (32 * a_rs >= (1LL << 31) || 32 * b_rs >= (1LL << 31)) return LGD_EINVAL;   // 32-bit byte offsets across a wave's 32 rows
@@ -535,7 +543,7 @@ int lgd_h2_dw(const void* A, long long a_rs, long long a_sb, long long a_bytes, 
     p.mt = (M + 255) / 256; p.nt = (N + 255) / 256;
     hipStream_t st = (hipStream_t)stream;
     LGD_LAUNCH("h2_dw_kernel", lgd::h2_dw_kernel, dim3((unsigned)(nb * S * p.mt * p.nt)), dim3(512), lgd::kDwLds, st, p);
-    if (S > 1) {
+    if (S > 1 && out) {   // (out == NULL: the partials are the result -- lgd_wino_filter_bwd_parts adds them while it reads)
         const long n = (long)nb * M * N;
         if (n & 3) return LGD_EINVAL;
         LGD_LAUNCH("h2_reduce_kernel", lgd::h2_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, partials, out, n / 4, S);
@@ -551,7 +559,7 @@ int lgd_h2_amax_maps(const float* const* x_host, const int32_t* level_hw_host, i
     for (int l = 0; l < L; ++l) {
         const long hw = (long)level_hw_host[2 * l] * level_hw_host[2 * l + 1];
         if (!x_host[l] || hw < 1 || hw >= (1L << 31)) return LGD_EINVAL;
-        a.maps[l] = x_host[l]; a.hw[l] = (int)hw; a.cpp[l] = (int)((hw + 4095) / 4096);
+        a.maps[l] = x_host[l]; a.hw[l] = (int)hw; a.cpp[l] = (int)((hw + lgd::kAmaxChunk - 1) / lgd::kAmaxChunk);
         a.blk_off[l] = blk;
         const long nblk = (long)N * C * a.cpp[l];
         if (blk + nblk >= (1L << 31)) return LGD_EINVAL;
@@ -577,7 +585,6 @@ int lgd_h2_amax_filters(const float* const* w_host, const float* const* scale_ho
     }
     a.row_off[K] = off; a.out = out_bits; a.K = K; a.row = row_elems;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out_bits, 0, sizeof(uint32_t), st) != hipSuccess) return LGD_ELAUNCH;
     LGD_LAUNCH("h2_amax_filter_kernel", lgd::h2_amax_filter_kernel, dim3(off), dim3(256), 0, st, a);
     return lgd::check_launch();
 }

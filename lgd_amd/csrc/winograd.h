@@ -148,6 +148,7 @@ struct FilterArgs {
     long long u_plane, ut_plane, ut_ld;
     int Co, Ci;
     char* img_fwd; char* img_bwd; int row0, Ct;   // wino6_filter_img_kernel: gemm3 operand images of the stacked filter (rows row0 .. row0 + Co of Ct)
+    int S; long long part_stride;                 // wino6_filter_bwd_kernel: dU as S split-K partials (0 / 1: plain)
     const unsigned* amax_in; float* inv_out;      // f16x2 images (csrc/h2.hip): bound of |w . scale| (float bits) in, the 64 inverse scales out
 };
 void wino6_launch_filter_fwd(const FilterArgs& a, hipStream_t st);

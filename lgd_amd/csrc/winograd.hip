@@ -781,6 +781,16 @@ int lgd_wino_filter_bwd(const float* dU, long long du_plane, const float* scale,
     return lgd::check_launch();
 }
 
+// lgd_wino_filter_bwd (tile 6) over S split-K partials of dU (partial s at dU + s * part_stride), added in fixed order while they are read
+int lgd_wino_filter_bwd_parts(const float* dU, long long du_plane, long long part_stride, int S, const float* scale, int Co, int Ci, float* dw,
+                              void* stream) {
+    if (!dU || !dw || Co < 1 || Ci < 1 || S < 1 || du_plane < (long long)Co * Ci) return LGD_EINVAL;
+    lgd::FilterArgs a{};
+    a.dU = dU; a.scale = scale; a.dw = dw; a.u_plane = du_plane; a.Co = Co; a.Ci = Ci; a.S = S; a.part_stride = part_stride;
+    lgd::wino6_launch_filter_bwd(a, (hipStream_t)stream);
+    return lgd::check_launch();
+}
+
 int lgd_wino_in_t_out_t(const float* dV, const void* relu_bits, const int32_t* level_hw_host, int L, int N, int C, int tile, float* dM,
                         void* stream) {
     lgd::WinoArgs a;
@@ -846,7 +856,6 @@ int lgd_wino_out_amax(const float* M, const float* bias, const int32_t* level_hw
         a.maps_out[l] = y_host[l];
     }
     a.buf_in = M; a.bias = bias; a.relu = relu ? 1 : 0; a.amax_out = amax_out;
-    if (hipMemsetAsync(amax_out, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return LGD_ELAUNCH;
     lgd::wino6_launch_out(a, blocks, (hipStream_t)stream);
     return lgd::check_launch();
 }
@@ -862,7 +871,6 @@ int lgd_wino_in_t_amax(const float* dV, const int32_t* level_hw_host, int L, int
         a.maps_out[l] = dx_host[l];
     }
     a.buf_in = dV; a.amax_out = amax_out;
-    if (hipMemsetAsync(amax_out, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return LGD_ELAUNCH;
     lgd::wino6_launch_in_t(a, blocks, false, (hipStream_t)stream);
     return lgd::check_launch();
 }

@@ -415,7 +415,8 @@ __device__ __forceinline__ void wino6_out_body(const WinoArgs& a, int l, float* 
     }
     if (a.amax_out) {
         am = wave_max(am);
-        if ((threadIdx.x & 63) == 0) atomic_max_bits(a.amax_out, __builtin_bit_cast(unsigned, am));
+        __syncthreads();   // (the last phase's LDS reads are done)
+        block_max_bits(a.amax_out, am, lds);
     }
 }
 
@@ -751,7 +752,8 @@ __device__ __forceinline__ void wino6_in_t_body(const WinoArgs& a, int l, float*
                 #pragma unroll
                 for (int j = 0; j < 6; ++j) am = fmaxf(am, (on && oy + r < H && ox + j < W) ? fabsf(z[r][j]) : 0.f);
             am = wave_max(am);
-            if ((threadIdx.x & 63) == 0) atomic_max_bits(a.amax_out, __builtin_bit_cast(unsigned, am));
+            __syncthreads();   // (the last gather phase's LDS reads are done)
+            block_max_bits(a.amax_out, am, lds);
         }
         if (!on) return;
         float* p = a.maps_out[l] + ((size_t)n * a.C + c) * H * W;
@@ -943,7 +945,12 @@ __global__ __launch_bounds__(256) void wino6_filter_bwd_kernel(FilterArgs a) {
     for (int b = 0; b < 8; ++b) {   // columns: G^T dU
         float col[8];
         #pragma unroll
-        for (int i = 0; i < 8; ++i) col[i] = a.dU[(size_t)(8 * i + b) * a.u_plane + idx];
+        for (int i = 0; i < 8; ++i) {
+            const float* q = a.dU + (size_t)(8 * i + b) * a.u_plane + idx;
+            float v = q[0];
+            for (int s = 1; s < a.S; ++s) v += q[(size_t)s * a.part_stride];   // split-K partials of csrc/h2.hip, fixed order
+            col[i] = v;
+        }
         float o[3];
         g8t(col, o);
         r[0][b] = o[0]; r[1][b] = o[1]; r[2][b] = o[2];

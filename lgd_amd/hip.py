@@ -77,11 +77,12 @@ SIGNATURES = {
     "lgd_wino_filter_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp]),
     "lgd_wino_filter_images": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_wino_filter_bwd": (c_i, [c_fp, ctypes.c_longlong, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "lgd_wino_filter_bwd_parts": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, c_i, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_wino_in_t_out_t": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_gemm3_image_bytes": (c_sz, [c_i, c_i, c_i]),
     "lgd_gemm3_split": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_gemm3": (c_i, [c_fp, c_i, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong,
-                        c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+                        c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "lgd_h2_image_bytes": (c_sz, [c_i, c_i, c_i]),
     "lgd_h2_fwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "lgd_h2_dw_splits": (c_i, [c_i, c_i, c_i, c_i]),

@@ -1155,12 +1155,18 @@ def _wino_filters(lib, ws, scales, Ci, dev, tile, T=None, need_dx=True):
 
 
 def _wino_filter_grads(lib, dU, scales, Cos, need, Ci, tile):
-    """dw_k = scale_k . G^T dU_k G for the filters that need it; dU (nf, sum Co, Ci) from the weight-gradient GEMM."""
+    """dw_k = scale_k . G^T dU_k G for the filters that need it; dU (nf, sum Co, Ci) from the weight-gradient GEMM, or (S, nf, sum Co, Ci): the
+    split-K partials of csrc/h2.hip, summed in fixed order by the transform while it reads them."""
     Ct = sum(Cos)
     out, c0 = [], 0
+    parts = dU.dim() == 4
     for sc, Co, nd in zip(scales, Cos, need):
         dw = None
-        if nd:
+        if nd and parts:
+            dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=dU.device)
+            hip.check(lib.lgd_wino_filter_bwd_parts(ctypes.c_void_p(dU.data_ptr() + 4 * c0 * Ci), Ct * Ci, dU.stride(0), dU.shape[0],
+                                                    hip.ptr(sc) if sc is not None else None, Co, Ci, hip.ptr(dw), hip.stream_ptr()), "lgd_wino_filter_bwd_parts")
+        elif nd:
             dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=dU.device)
             hip.check(lib.lgd_wino_filter_bwd(ctypes.c_void_p(dU.data_ptr() + 4 * c0 * Ci), Ct * Ci, hip.ptr(sc) if sc is not None else None,
                                               Co, Ci, tile, hip.ptr(dw), hip.stream_ptr()), "lgd_wino_filter_bwd")
@@ -1173,7 +1179,7 @@ def _wino_out(lib, Mk, bias, hw, L, N, Co, tile, relu, ys, bits):
     """output transform of Co channels of M (+ bias, ReLU, mask bits); with the f16x2 pipeline on (tile 6) it also leaves max |y| for the
     next convolution's scale and tags the maps with it"""
     if tile == 6 and _H2_ON and _H2_TAGS:
-        amax = torch.empty(1, dtype=torch.int32, device=ys[0].device)
+        amax = _zero_words(ys[0].device)
         hip.check(lib.lgd_wino_out_amax(hip.ptr(Mk), hip.ptr(bias) if bias is not None else None, hw, L, N, Co, int(relu), hip.ptr_array(ys),
                                         hip.ptr(bits) if bits is not None else None, hip.ptr(amax), hip.stream_ptr()), "lgd_wino_out_amax")
         _amax_tag(ys, amax)
@@ -1185,7 +1191,7 @@ def _wino_out(lib, Mk, bias, hw, L, N, Co, tile, relu, ys, bits):
 def _wino_in_t(lib, dV, hw, L, N, Ci, tile, dxs, pre_bits):
     """adjoint input transform (+ activation mask); tile 6 with the f16x2 pipeline on: also max |dx|, tagged on the gradient maps"""
     if tile == 6 and _H2_ON and _H2_TAGS:
-        amax = torch.empty(1, dtype=torch.int32, device=dxs[0].device)
+        amax = _zero_words(dxs[0].device)
         hip.check(lib.lgd_wino_in_t_amax(hip.ptr(dV), hw, L, N, Ci, hip.ptr_array(dxs), hip.ptr(pre_bits) if pre_bits is not None else None,
                                          hip.ptr(amax), hip.stream_ptr()), "lgd_wino_in_t_amax")
         _amax_tag(dxs, amax)
@@ -1221,7 +1227,7 @@ class _Conv3x3K(torch.autograd.Function):
         hip.require_gpu(*ws, *xs)
         lib = hip.load()
         ws = [hip.dense_f32(w) for w in ws]
-        xs = [hip.dense_f32(x) for x in xs]
+        xs = [_dense_tagged(x) for x in xs]
         bs = [hip.dense_f32(b) if b is not None else None for b in bs]
         L, N, Ci = len(xs), xs[0].shape[0], xs[0].shape[1]
         Cos = [w.shape[0] for w in ws]
@@ -1289,7 +1295,7 @@ class _Conv3x3K(torch.autograd.Function):
         nf = (tile + 2) ** 2
         mb = _WINO_MASK_DTYPE[tile].itemsize
         # an output nothing downstream used arrives as None
-        dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
+        dys = [_dense_tagged(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
                for i, g in enumerate(dys)]
         need_ws = list(ctx.needs_input_grad[5:5 + 2 * K:2])
         need_bs = [hb and nb for hb, nb in zip(has_bias, ctx.needs_input_grad[6:6 + 2 * K:2])]
@@ -1488,7 +1494,7 @@ class _Conv3x3Chain(torch.autograd.Function):
         nf = (tile + 2) ** 2
         mdt, mb = _WINO_MASK_DTYPE[tile], _WINO_MASK_DTYPE[tile].itemsize
         ws = [hip.dense_f32(w) for w in ws]
-        xs = [hip.dense_f32(x) for x in xs]
+        xs = [_dense_tagged(x) for x in xs]
         bs = [hip.dense_f32(b) if b is not None else None for b in bs]
         L, N = len(xs), xs[0].shape[0]
         dev = ws[0].device
@@ -1548,7 +1554,7 @@ class _Conv3x3Chain(torch.autograd.Function):
         need_x = any(ctx.needs_input_grad[3 + 2 * K:])
         dws, dbs, dxs = [None] * K, [None] * K, [None] * L
         Co = ctx.dims[K - 1][1]
-        dys = [hip.dense_f32(g) if g is not None else torch.zeros((N, Co) + shapes[i], dtype=torch.float32, device=dev) for i, g in enumerate(dys)]
+        dys = [_dense_tagged(g) if g is not None else torch.zeros((N, Co) + shapes[i], dtype=torch.float32, device=dev) for i, g in enumerate(dys)]
 
         def out_t(maps, bits_k, C, h2):
             """dM = A (g . mask) A^T of C channels, as split rows (h2) or fp32; returns (dM, per-frequency inverse scales or None)"""
@@ -1579,7 +1585,7 @@ class _Conv3x3Chain(torch.autograd.Function):
                 break
             fused_h2 = k > 0 and h2s[k] and h2s[k - 1]
             if h2s[k]:
-                amax64 = torch.empty(64, dtype=torch.int32, device=dev) if fused_h2 else None   # max |dV[f]|: the bound of the link's dx
+                amax64 = _zero_words(dev, 64) if fused_h2 else None   # max |dV[f]|: the bound of the link's dx
                 dV = _h2_product(lib, "dx", Ut, Ci, Co, dM, dminv, True, uinv, _freq_buf(nf, Ci, T, dev), amax64)
             else:
                 dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
@@ -1778,7 +1784,12 @@ def conv3x3_stride2(x, w, b=None):
     forward, input and weight gradient on the tuned channel GEMMs.  The library's strided implicit-GEMM kernels cost 2.1 ms/step at
     config 2 (forward, two split weight-gradient passes and NCHW <-> NHWC transposes of the 2048-channel map)."""
     if _wino_ok([x], w):
-        return conv3x3(x, w, b)[:, :, ::2, ::2]
+        y = conv3x3(x, w, b)
+        z = y[:, :, ::2, ::2]
+        tag = getattr(y, "_lgd_amax", None)
+        if tag is not None and tag[1] == y._version:   # (a subset of the pixels: the bound of the whole map holds)
+            _amax_tag([z], tag[0])
+        return z
     return F.conv2d(x, w, b, 2, 1)
 
 
@@ -2374,7 +2385,7 @@ def _gemm3_ok(a, b, out, accumulate=False):
     return out is None or (out.stride(2) == 1 and out.dtype == torch.float32 and 0 <= 256 * out.stride(1) < 1 << 30)
 
 
-def gemm3_bmm(a, b, out=None, accumulate=False, residual=None, shift=None, relu=False, relu_bits=None):
+def gemm3_bmm(a, b, out=None, accumulate=False, residual=None, shift=None, relu=False, relu_bits=None, amax_out=None):
     """out[i] = a[i] @ b[i] (accumulate: out[i] += ...) for fp32 (nb, M, K) x (nb, K, N): an fp32-class product (error vs fp64 as the
     library's fp32 GEMM) computed on v_mfma_f32_32x32x16_bf16 from three-way split operands.  a (the filter operand, any strides) is split
     ahead of the product into an MFMA-ordered image -- ONE image when a is the same matrix for every batch (stride 0: the student's 1x1
@@ -2403,7 +2414,8 @@ def gemm3_bmm(a, b, out=None, accumulate=False, residual=None, shift=None, relu=
     hip.check(lib.lgd_gemm3(hip.ptr(img), 1 if shared else 0, hip.ptr(b), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1),
                             hip.ptr(residual) if residual is not None else None, residual.stride(0) if residual is not None else 0,
                             residual.stride(1) if residual is not None else 0, hip.ptr(shift) if shift is not None else None, 1 if relu else 0,
-                            hip.ptr(relu_bits) if relu_bits is not None else None, nb, M, N, K, st), "lgd_gemm3")
+                            hip.ptr(relu_bits) if relu_bits is not None else None, hip.ptr(amax_out) if amax_out is not None else None, nb, M, N, K, st),
+              "lgd_gemm3")
     return out
 
 
@@ -2413,7 +2425,7 @@ def gemm3_image_bmm(img, b, out):
     if b.shape[0] != nb or b.shape[1] != K or out.shape[1] != M or b.stride(2) != 1 or out.stride(2) != 1:
         raise hip.LgdHipError("gemm3 image %s does not match B %s / C %s" % (img.shape, tuple(b.shape), tuple(out.shape)))
     hip.check(hip.load().lgd_gemm3(hip.ptr(img.t), 0, hip.ptr(b), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1),
-                                   None, 0, 0, None, 0, None, nb, M, b.shape[2], K, hip.stream_ptr()), "lgd_gemm3")
+                                   None, 0, 0, None, 0, None, None, nb, M, b.shape[2], K, hip.stream_ptr()), "lgd_gemm3")
     return out
 
 
@@ -2434,6 +2446,26 @@ def _timed_gemm3(name, a, b, out=None, accumulate=False, **epi):
     return r
 
 
+class _TaggedView:
+    """the (N, C, H, W) view of a product that carries the product's magnitude tag"""
+
+    def __init__(self, t, amax):
+        self.t, self.amax = t, amax
+
+    def view(self, *shape):
+        v = self.t.view(*shape)
+        if self.amax is not None:
+            _amax_tag([v], self.amax)
+        return v
+
+
+def _tagged_gemm3(name, a, b):
+    """_timed_gemm3 whose epilogue also leaves max |C| (the f16x2 scale of a 3x3 convolution that consumes the map: conv1 -> conv2 of a
+    bottleneck forward, conv3 -> conv2 backward)"""
+    amax = _zero_words(b.device) if (_H2_ON and _H2_TAGS) else None
+    return _TaggedView(_timed_gemm3(name, a, b, None, amax_out=amax), amax)
+
+
 def _wino_gemm(name, a, b, out=None):
     """one of the per-frequency channel products (forward M = U V, input gradient dV = U^T dM): csrc/gemm3.hip where its tile fits the
     shape, the library's fp32 GEMM otherwise.  Timed under `name` + '3' (its launches also appear as gemm3_kernel / gemm3_split_kernel)."""
@@ -2448,7 +2480,8 @@ def _wino_gemm(name, a, b, out=None):
 # filter comes as an f16x2 image, forward / input-gradient / weight-gradient products run on v_mfma_f32_32x32x16_f16
 _H2_ON = os.environ.get("LGD_H2", "1") != "0"
 _H2_FORCE = False    # tests: take the h2 path wherever the kernels CAN run, whatever the speed policy says
-_H2_TAGS = os.environ.get("LGD_H2_TAGS", "1") != "0"   # 0: every bound by its own pass over the maps (A/B runs)
+_H2_TAGS = os.environ.get("LGD_H2_TAGS", "1") != "0"
+_H2_DEBUG = os.environ.get("LGD_H2_DEBUG", "0") != "0"   # print every bound that takes its own pass over the maps, with the call site   # 0: every bound by its own pass over the maps (A/B runs)
 
 
 def h2_backend(on=None, force=None):
@@ -2478,6 +2511,22 @@ def _h2_ok(tile, Ci, Cos, T, dev):
     return wgs >= _cu_count(dev)
 
 
+_ZERO_POOL = {}
+
+
+def _zero_words(dev, n=1):
+    """n int32 words that are zero and that nobody has written: the running maxima of the bounds start from them.  Cut from a pool that is
+    filled once per 4096 words -- a fill launch per bound was 142 launches and 0.7 ms per step at BASELINE config 2"""
+    key = (dev.type, dev.index)
+    pool = _ZERO_POOL.get(key)
+    if pool is None or pool[1] + n > pool[0].numel():
+        pool = [torch.zeros(4096, dtype=torch.int32, device=dev), 0]
+        _ZERO_POOL[key] = pool
+    w = pool[0][pool[1]:pool[1] + n]
+    pool[1] += n
+    return w
+
+
 def _amax_tag(maps, amax):
     """record, on tensors a kernel of this library has just written, the device word holding (the float bits of) a bound of their
     magnitude: the next convolution derives its f16 scale from it instead of passing over the maps once more.  The tensor's version
@@ -2485,6 +2534,16 @@ def _amax_tag(maps, amax):
     if _H2_TAGS:
         for m in maps:
             m._lgd_amax = (amax, m._version)
+
+
+def _dense_tagged(t):
+    """hip.dense_f32 that carries a valid magnitude tag over to the copy it may have to make (a contiguous copy of a strided view)"""
+    d = hip.dense_f32(t)
+    if d is not t:
+        tag = getattr(t, "_lgd_amax", None)
+        if tag is not None and tag[1] == t._version:
+            _amax_tag([d], tag[0])
+    return d
 
 
 def _amax_bits(lib, xs, hw_levels, pre=None, affine=False):
@@ -2506,10 +2565,15 @@ def _amax_bits(lib, xs, hw_levels, pre=None, affine=False):
         else:
             b = (af + pre.max()).clamp_min(0.0)
         return (b * 1.000001).view(torch.int32)   # (the roundings of the bound's own arithmetic)
-    out = torch.empty(1, dtype=torch.int32, device=dev)
+    out = _zero_words(dev)
     L, N, C = len(xs), xs[0].shape[0], xs[0].shape[1]
+    if _H2_DEBUG:
+        import traceback
+        fr = [f for f in traceback.extract_stack()[:-1] if "ops.py" not in f.filename and "torch" not in f.filename][-2:]
+        print("[h2 amax pass] L=%d N=%d C=%d hw=%s pre=%s tags=%s  <- %s" % (L, N, C, [tuple(x.shape[2:]) for x in xs][:2], None if pre is None else ("affine" if affine else "bias"),
+                                                                    [t is not None for t in tags], " / ".join("%s:%d %s" % (f.filename.split("/")[-1], f.lineno, f.name) for f in fr)))
     hip.check(lib.lgd_h2_amax_maps(hip.ptr_array(xs), hw_levels, L, N, C, hip.ptr(pre) if pre is not None and not affine else None,
-                                   hip.ptr(pre) if pre is not None and affine else None, hip.ptr(out), 0, hip.stream_ptr()), "lgd_h2_amax_maps")
+                                   hip.ptr(pre) if pre is not None and affine else None, hip.ptr(out), 1, hip.stream_ptr()), "lgd_h2_amax_maps")
     _count_bytes("h2_amax_maps_kernel", 4 * sum(x.numel() for x in xs))
     return out
 
@@ -2536,7 +2600,7 @@ def _h2_filters(lib, ws, scales, Ci, dev, need_dx):
     Cos = [w.shape[0] for w in ws]
     Ct = sum(Cos)
     st = hip.stream_ptr()
-    amax = torch.empty(1, dtype=torch.int32, device=dev)
+    amax = _zero_words(dev)
     sc_arr = (ctypes.c_void_p * len(ws))(*[sc.data_ptr() if sc is not None else None for sc in scales])
     hip.check(lib.lgd_h2_amax_filters(hip.ptr_array(ws), sc_arr, hip.int_array(Cos), len(ws), Ci * 9, hip.ptr(amax), st), "lgd_h2_amax_filters")
     imf = torch.empty(lib.lgd_h2_image_bytes(64, Ct, Ci), dtype=torch.uint8, device=dev)
@@ -2578,12 +2642,11 @@ def _h2_dw(lib, dM, dm_inv, V, v_inv, Ct, Ci):
     T = V.shape[2]
     dev = V.device
     S = lib.lgd_h2_dw_splits(64, Ct, Ci, T)
-    out = torch.empty((64, Ct, Ci), dtype=torch.float32, device=dev)
-    part = torch.empty((S, 64, Ct, Ci), dtype=torch.float32, device=dev) if S > 1 else None
+    out = torch.empty((S, 64, Ct, Ci), dtype=torch.float32, device=dev)   # S > 1: split-K partials, added by the filter transform's adjoint while it reads
     fn = lambda: hip.check(lib.lgd_h2_dw(hip.ptr(dM), 4 * 64 * T, 4 * T, 4 * dM.numel(), hip.ptr(dm_inv), 1, hip.ptr(V), 4 * 64 * T, 4 * T, 4 * V.numel(),   # noqa: E731
-                                         hip.ptr(v_inv), 0, hip.ptr(out), hip.ptr(part) if part is not None else None, S, 64, Ct, Ci, T, hip.stream_ptr()),
-                           "lgd_h2_dw")
-    _h2_timed("h2_dw_kernel", 2.0 * 64 * Ct * Ci * T, 4.0 * 64 * T * (Ct + Ci) + 4.0 * 64 * Ct * Ci * (2 * S if S > 1 else 1), fn)
+                                         hip.ptr(v_inv), 0, hip.ptr(out) if S == 1 else None, hip.ptr(out) if S > 1 else None, S, 64, Ct, Ci, T,
+                                         hip.stream_ptr()), "lgd_h2_dw")
+    _h2_timed("h2_dw_kernel", 2.0 * 64 * Ct * Ci * T, 4.0 * 64 * T * (Ct + Ci) + 4.0 * 64 * Ct * Ci * S, fn)
     return out
 
 
@@ -2621,7 +2684,7 @@ def _conv1x1_fwd(x, wf):
     Co = wf.shape[0]
     a, b = wf.view(1, Co, Ci).expand(N, Co, Ci), x.view(N, Ci, H * W)
     if _gemm3_ok(a, b, None):   # csrc/gemm3.hip: one bf16x3 image of the filter for the whole batch
-        return _timed_gemm3("pw_gemm3_fwd", a, b).view(N, Co, H, W)
+        return _tagged_gemm3("pw_gemm3_fwd", a, b).view(N, Co, H, W)
     return _timed_gemm("pw_gemm_fwd", _pw_flops(x, Co), torch.bmm, a, b).view(N, Co, H, W)
 
 
@@ -2631,7 +2694,7 @@ def _conv1x1_dx(dz, x, wf):
     Co = wf.shape[0]
     a, b = wf.view(1, Co, Ci).transpose(1, 2).expand(N, Ci, Co), dz.view(N, Co, H * W)
     if _gemm3_ok(a, b, None):
-        return _timed_gemm3("pw_gemm3_dx", a, b).view(N, Ci, H, W)
+        return _tagged_gemm3("pw_gemm3_dx", a, b).view(N, Ci, H, W)
     return _timed_gemm("pw_gemm_dx", _pw_flops(x, Co), torch.bmm, a, b).view(N, Ci, H, W)
 
 

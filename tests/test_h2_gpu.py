@@ -40,7 +40,7 @@ def test_h2_fwd_fp32_class_product(nb, M, K, T):
         img, vs = cm.h2_split_image(a, sa), cm.h2_split_rows(v, sv)
         assert img.numel() == lib.lgd_h2_image_bytes(nb, M, K)
         out = torch.full((M, nb, T), float("nan"), device=DEV)
-        am = torch.full((nb,), -1, dtype=torch.int32, device=DEV) if amax else None
+        am = torch.zeros((nb,), dtype=torch.int32, device=DEV) if amax else None   # (running maxima: zeroed by the caller)
         ia, iv = (1 / sa).contiguous(), (1 / sv).contiguous()   # (named: a temporary would be freed -- and its block reused -- before the launch)
         hip.check(lib.lgd_h2_fwd(hip.ptr(img), hip.ptr(vs), 4 * T, 4 * nb * T, 4 * vs.numel(), hip.ptr(out), T, nb * T, hip.ptr(ia),
                                  hip.ptr(iv), 1, hip.ptr(am) if amax else None, nb, M, T, K, hip.stream_ptr()), "lgd_h2_fwd")
@@ -216,14 +216,14 @@ def test_wino_out_and_in_t_leave_their_maxima():
     for relu in (0, 1):
         ya = [torch.empty((N, C, h, w), device=DEV) for h, w in hws]
         yb = [torch.empty((N, C, h, w), device=DEV) for h, w in hws]
-        am = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+        am = torch.zeros((1,), dtype=torch.int32, device=DEV)
         hip.check(lib.lgd_wino_out(hip.ptr(M), hip.ptr(bias), hw, L, N, C, 6, relu, hip.ptr_array(ya), None, st), "lgd_wino_out")
         hip.check(lib.lgd_wino_out_amax(hip.ptr(M), hip.ptr(bias), hw, L, N, C, relu, hip.ptr_array(yb), None, hip.ptr(am), st), "lgd_wino_out_amax")
         assert all(torch.equal(a, b) for a, b in zip(ya, yb))
         assert float(am.view(torch.float32)) == max(float(y.abs().max()) for y in ya)
     da = [torch.empty((N, C, h, w), device=DEV) for h, w in hws]
     db = [torch.empty((N, C, h, w), device=DEV) for h, w in hws]
-    am = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+    am = torch.zeros((1,), dtype=torch.int32, device=DEV)
     hip.check(lib.lgd_wino_in_t(hip.ptr(M), hw, L, N, C, 6, hip.ptr_array(da), None, st), "lgd_wino_in_t")
     hip.check(lib.lgd_wino_in_t_amax(hip.ptr(M), hw, L, N, C, hip.ptr_array(db), None, hip.ptr(am), st), "lgd_wino_in_t_amax")
     assert all(torch.equal(a, b) for a, b in zip(da, db))
@@ -245,7 +245,7 @@ def test_filter_images_h2_equal_the_split_of_the_fp32_transform():
         hip.check(lib.lgd_wino_filter_fwd(hip.ptr(w), hip.ptr(sc) if sc is not None else None, co, Ci, 6, ctypes.c_void_p(U.data_ptr() + 4 * c0 * Ci), Ct * Ci,
                                           None, 0, 0, st), "lgd_wino_filter_fwd")
         c0 += co
-    amax = torch.empty(1, dtype=torch.int32, device=DEV)
+    amax = torch.zeros(1, dtype=torch.int32, device=DEV)
     arr = (ctypes.c_void_p * 2)(scs[0].data_ptr(), None)
     hip.check(lib.lgd_h2_amax_filters(hip.ptr_array(ws), arr, hip.int_array(Cos), 2, Ci * 9, hip.ptr(amax), st), "lgd_h2_amax_filters")
     want = max(float((ws[0] * scs[0].view(-1, 1, 1, 1)).abs().max()), float(ws[1].abs().max()))

@@ -32,6 +32,7 @@ def load():
     lib.h2_fwd.argtypes = [P, P, L, L, L, P, L, L, P, P, P, I, I, I, I, P]
     lib.h2_dw.argtypes = [P, L, L, L, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P]
     lib.h2_tr_probe.argtypes = [P, P]
+    lib.h2_fwd2.argtypes = [P, P, L, L, L, P, L, L, P, P, I, I, I, I, I, P]
     return lib
 
 
@@ -42,6 +43,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--what", default="probe,fwd,dw")
     ap.add_argument("--M", type=int, default=256)
+    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7")
     args = ap.parse_args()
     if args.build or not os.path.exists(LIB):
         build()
@@ -131,6 +133,19 @@ def main():
         flop = 2.0 * nf * M * C * T
         byt = 4.0 * nf * T * (C + M)
         print("   h2_fwd %.1f us (%.0f TFLOP/s fp32-eq, %.2f TB/s algorithmic)   library fp32 bmm %.1f us" % (t_h2, flop / t_h2 * 1e-6, byt / t_h2 * 1e-6, t_lib))
+        names = {0: "256x128 3 buffers (shipped)", 1: "256x256 8 waves 4 buffers", 2: "128x256 3 buffers", 3: "256x128 2 buffers", 4: "256x256 3 buffers",
+                 5: "256x256 5 buffers", 6: "128x256 4 buffers", 7: "128x128 2 waves 4 buffers"}
+        for variant in [int(v) for v in args.variants.split(",")]:
+            Cs[0].fill_(float("nan"))
+            rc = lib.h2_fwd2(img.data_ptr(), Vs.data_ptr(), T * 4, nf * T * 4, Vs.numel(), Cs[0].data_ptr(), T, nf * T, a_inv.data_ptr(), b_inv.data_ptr(),
+                             nf, M, T, C, variant, st())
+            torch.cuda.synchronize()
+            ref = torch.bmm(U.double(), V.permute(1, 0, 2).double())
+            e = err(Cs[0].permute(1, 0, 2), ref)
+            del ref
+            t_v = timeit(lambda i: lib.h2_fwd2(img.data_ptr(), Vss[i].data_ptr(), T * 4, nf * T * 4, Vs.numel(), Cs[i].data_ptr(), T, nf * T, a_inv.data_ptr(),
+                                               b_inv.data_ptr(), nf, M, T, C, variant, st()), sets, args.reps)
+            print("   variant %d %-28s rc %d error %.2e: %.1f us (%.2f TB/s algorithmic)" % (variant, names[variant], rc, e[0], t_v, byt / t_v * 1e-6))
         try:
             from lgd_amd import ops
             ops.gemm3_backend(True, force=True)

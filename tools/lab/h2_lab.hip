@@ -41,6 +41,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
 __device__ __forceinline__ void glds16(const __amdgpu_buffer_rsrc_t rs, uint32_t lds_addr, uint32_t voff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
 }
+constexpr int kBlk = 32;
+__host__ __device__ inline long piece_off(long t, int piece) { return (t / kBlk) * (4 * kBlk) + piece * (2 * kBlk) + (t % kBlk) * 2; }
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 
 // two elements -> packed h pair, packed m pair
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void h2_fwd_kernel(const FwdP p) {
     for (int jj = 0; jj < 2; ++jj) {
         const int jb = 2 * w + jj, pc = jb >> 2, rg = jb & 3, rl = lane >> 4, q = lane & 15;
         const int sc = (q - 4 * rl) & 15, rr = 4 * rg + rl;
-        boff[jj] = (uint32_t)(rr * (int)p.b_ld + ((n0 >> 4) + (sc >> 1)) * 64 + pc * 32 + (sc & 1) * 16);
+        boff[jj] = (uint32_t)(rr * (int)p.b_ld + piece_off(n0 + 8 * sc, pc));
     }
     const long bstep = 16 * p.b_ld;
     const long b_left0 = p.b_bytes - (long)b * p.b_sb;
@@ -251,13 +253,15 @@ __global__ __launch_bounds__(512) void h2_dw_kernel(const DwP p) {
     for (int jj = 0; jj < IPW; ++jj) {
         const int row = jj * RPI + rl;   // relative to the wave's first row (a multiple of 32: the swizzle sees the same bits)
         const int sw = KC == 4 ? (row >> 2) & 3 : (row >> 1) & 7;
-        offA[jj] = (uint32_t)((long)row * p.a_rs + (q ^ sw) * 16);
-        offB[jj] = (uint32_t)((long)row * p.b_rs + (q ^ sw) * 16);
+        const int sc_ = q ^ sw;
+        const int po = KC == 4 ? (sc_ >> 1) * (2 * kBlk) + (sc_ & 1) * 16 : (sc_ >> 2) * (2 * kBlk) + (sc_ & 3) * 16;   // KC 8: chunks [h0..h3 m0..m3] of one 32-tile block
+        offA[jj] = (uint32_t)((long)row * p.a_rs + po);
+        offB[jj] = (uint32_t)((long)row * p.b_rs + po);
     }
     const long a0 = (long)b * p.a_sb + (long)(m0 + w * IPW * RPI) * p.a_rs, b0 = (long)b * p.b_sb + (long)(n0 + w * IPW * RPI) * p.b_rs;
     auto dma = [&](int stg, int buf) {
         char* dst = lds + buf * BUF;
-        const long ko = (long)stg * ROWB;
+        const long ko = piece_off((long)stg * (KC * 4), 0);
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + a0 + ko, p.a_bytes - a0 - ko);
 #pragma unroll
         for (int jj = 0; jj < IPW; ++jj)
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(512) void h2_dw_kernel(const DwP p) {
 #pragma unroll
     for (int sb = 0; sb < SUB; ++sb)
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) xo[sb][pc] = ((sb * 4 + pc * 2 + g) ^ sw) * 16;
+        for (int pc = 0; pc < 2; ++pc) xo[sb][pc] = ((KC == 4 ? pc * 2 + g : pc * 4 + sb * 2 + g) ^ sw) * 16;
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i) dma(st0 + (i < nst ? i : nst - 1), i);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * DPW) : "memory");
@@ -365,9 +369,9 @@ __global__ void h2_split_rows_kernel(const float* __restrict__ X, const float* _
     uint32_t h[4], m[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) split2h(x[2 * e], x[2 * e + 1], s, h[e], m[e]);
-    char* d = out + pl * T * 4 + (o >> 1) * 64 + (o & 1) * 16;
-    *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
-    *reinterpret_cast<u32x4*>(d + 32) = (u32x4){m[0], m[1], m[2], m[3]};
+    char* d = out + pl * T * 4;
+    *reinterpret_cast<u32x4*>(d + piece_off(o * 8, 0)) = (u32x4){h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(d + piece_off(o * 8, 1)) = (u32x4){m[0], m[1], m[2], m[3]};
 }
 
 // A (nb, M, K) fp32 with strides -> image
@@ -476,6 +480,182 @@ int h2_dw(const void* A, long a_rs, long a_sb, long a_bytes, const void* B, long
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------ tile-shape variants of the forward product
+// BM x BN tile on (BM / 128) x (BN / 64) waves of 128 x 64, ST LDS buffers
+template <int BM, int BN, int ST>
+__global__ __launch_bounds__((BM / 128) * (BN / 64) * 64) void h2_fwd2_kernel(const FwdP p) {
+    constexpr int RB = BM / 32, MI = 4, WN = BN / 64, NW = (BM / 128) * WN;
+    constexpr int ROW = BN * 2;                                  // bytes of one k-row of one piece in LDS
+    constexpr int A_BYTES = 2 * RB * 1024, B_BYTES = 2 * 16 * ROW, BUF = A_BYTES + B_BYTES;
+    constexpr int ACH = 2 * RB / NW, BCH = (B_BYTES / 1024) / NW, DPW = ACH + BCH;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w / WN, wn = w % WN;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int per_b = p.nt * p.mt;
+    const int b = (j / per_b) * 8 + xcd;
+    const int r = j % per_b;
+    if (b >= p.nb) return;
+    const int tn = r / p.mt, sub = r % p.mt;
+    const int m0 = sub * BM, n0 = tn * BN, rb0 = sub * RB;
+    const int ksteps = p.K / 16;
+    const char* Ai = p.Aimg + (long)b * p.a_sb;
+    const char* Bb = p.B + (long)b * p.b_sb;
+    uint32_t aoff[ACH];
+#pragma unroll
+    for (int c = 0; c < ACH; ++c) {
+        const int ch = w * ACH + c, pc = ch / RB, rbl = ch % RB;
+        int rb = rb0 + rbl;
+        rb = rb < p.rbp ? rb : p.rbp - 1;
+        aoff[c] = (uint32_t)((pc * p.rbp + rb) * 1024 + lane * 16);
+    }
+    const long astep = (long)2 * p.rbp * 1024;
+    // B: instruction jb (1 KB = 1024 / ROW rows of one piece); lane -> (row, 256-byte half, chunk q): holds the half's chunk (q - 4 row) & 15
+    constexpr int RPI = 1024 / ROW, IPP = 16 / RPI;              // rows per instruction, instructions per piece
+    uint32_t boff[BCH];
+#pragma unroll
+    for (int jj = 0; jj < BCH; ++jj) {
+        const int jb = w * BCH + jj, pc = jb / IPP, rg = jb % IPP;
+        const int lr = (lane * 16) / ROW, lh = ((lane * 16) % ROW) / 256, q = lane & 15;
+        const int rr = rg * RPI + lr, sc = (q - 4 * rr) & 15;
+        boff[jj] = (uint32_t)(rr * (int)p.b_ld + piece_off(n0 + lh * 128 + 8 * sc, pc));
+    }
+    const long bstep = 16 * p.b_ld;
+    const long b_left0 = p.b_bytes - (long)b * p.b_sb;
+    auto dma = [&](int ks, int buf) {
+        char* dst = lds + buf * BUF;
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ai + ks * astep, 0x7fffffff);
+#pragma unroll
+        for (int c = 0; c < ACH; ++c) glds16(ra, lds_addr_of(dst + (w * ACH + c) * 1024), aoff[c]);
+        const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(Bb + ks * bstep, b_left0 - ks * bstep);
+#pragma unroll
+        for (int jj = 0; jj < BCH; ++jj) glds16(rb_, lds_addr_of(dst + A_BYTES + (w * BCH + jj) * 1024), boff[jj]);
+    };
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) asm volatile("" : "+a"(acc[i][jn]));
+    const int g = lane >> 5, cg = (lane >> 4) & 1, i16 = lane & 15;
+    int btr[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int col = wn * 64 + jn * 32 + cg * 16 + (i16 & 3) * 4;
+        btr[jn] = A_BYTES + (8 * g + (i16 >> 2)) * ROW + (col >> 7) * 256 + ((2 * (col & 127) + 64 * (i16 >> 2)) & 255);
+    }
+    const int slot = lane * 16;
+#pragma unroll
+    for (int i = 0; i < ST - 1; ++i) dma(i < ksteps ? i : ksteps - 1, i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * DPW) : "memory");
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const char* cur = lds + (ks % ST) * BUF;
+        f16x8 fa[2][MI], fb[2][2];
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(cur + btr[jn] + pc * (16 * ROW)));
+                const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(cur + btr[jn] + pc * (16 * ROW) + 4 * ROW));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                fb[pc][jn] = __builtin_bit_cast(f16x8, (u32x4){l2[0], l2[1], h2[0], h2[1]});
+            }
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[pc][i] = *reinterpret_cast<const f16x8*>(cur + pc * (RB * 1024) + (wm * MI + i) * 1024 + slot);
+        {
+            const int nx = ks + ST - 1 < ksteps ? ks + ST - 1 : ksteps - 1;
+            dma(nx, (ks + ST - 1) % ST);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][jn], acc[i][jn], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * DPW) : "memory");
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float inv = p.a_inv[b] * p.b_inv[b];
+    const int rr = lane & 31;
+    const int wrow = m0 + wm * 128, wcol = n0 + wn * 64;
+    const int mw = wrow + 4 * g, nw = wcol + rr;
+    const int ld = (int)p.c_ld;
+    const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
+    const __amdgpu_buffer_rsrc_t cs = make_rsrc(p.C + (long)b * p.c_sb + (long)wrow * ld + wcol, 0x7fffffff);
+    const int c1 = ld * 4, c5 = ld * 20, mrem = p.M - mw;
+    const bool colok[2] = {nw < p.N, nw + 32 < p.N};
+    auto epi = [&](auto HF) {
+        constexpr bool hf = decltype(HF)::value;
+        int cbase = (4 * g * ld + rr) * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                asm volatile("" : "+a"(acc[i][jn])::"memory");
+                int co = cbase;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
+                    const float v = acc[i][jn][e] * inv;
+                    if (hf || (dm < mrem && colok[jn])) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
+                    co += (e & 3) == 3 ? c5 : c1;
+                    asm volatile("" : "+v"(co));
+                }
+                if (jn == 1) cbase = co;
+            }
+        }
+    };
+    if (full) epi(std::true_type()); else epi(std::false_type());
+}
+
+template <int BM, int BN, int ST>
+static int launch_fwd2(FwdP p, int nb, int M, int N, hipStream_t st) {
+    constexpr int L = ST * (2 * (BM / 32) * 1024 + 2 * 16 * BN * 2);
+    p.mt = (M + BM - 1) / BM; p.nt = (N + BN - 1) / BN;
+    p.total = ((nb + 7) / 8) * p.nt * p.mt * 8;
+    (void)hipFuncSetAttribute((const void*)h2_fwd2_kernel<BM, BN, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, L);
+    hipLaunchKernelGGL((h2_fwd2_kernel<BM, BN, ST>), dim3(p.total), dim3((BM / 128) * (BN / 64) * 64), L, st, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int h2_fwd2(const void* img, const void* B, long b_sb, long b_ld, long b_bytes, float* C, long c_sb, long c_ld, const float* a_inv, const float* b_inv,
+                       int nb, int M, int N, int K, int variant, void* stream) {
+    if (K & 15) return -1;
+    FwdP p;
+    p.rbp = (M + 31) / 32;
+    p.Aimg = (const char*)img; p.a_sb = (long)(K / 16) * 2 * p.rbp * 1024;
+    p.B = (const char*)B; p.b_sb = b_sb; p.b_ld = b_ld; p.b_bytes = b_bytes;
+    p.C = C; p.c_sb = c_sb; p.c_ld = c_ld; p.a_inv = a_inv; p.b_inv = b_inv; p.amax_out = nullptr;
+    p.nb = nb; p.M = M; p.N = N; p.K = K;
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+        case 0: return launch_fwd2<256, 128, 3>(p, nb, M, N, st);
+        case 1: return launch_fwd2<256, 256, 4>(p, nb, M, N, st);
+        case 2: return launch_fwd2<128, 256, 3>(p, nb, M, N, st);
+        case 3: return launch_fwd2<256, 128, 2>(p, nb, M, N, st);
+        case 4: return launch_fwd2<256, 256, 3>(p, nb, M, N, st);
+        case 5: return launch_fwd2<256, 256, 5>(p, nb, M, N, st);
+        case 6: return launch_fwd2<128, 256, 4>(p, nb, M, N, st);
+        case 7: return launch_fwd2<128, 128, 4>(p, nb, M, N, st);
+    }
+    return -2;
+}
 
 // probe of ds_read_b64_tr_b16: LDS holds the f16 values 0, 1, 2, ...; lane l reads at byte address 8 l (+ base); out[l][0..3]
 __global__ void h2_tr_probe_kernel(float* out) {
