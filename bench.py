@@ -283,6 +283,17 @@ def main():
             trainer.step(data_sets[it[0] % nb], it[0])
             it[0] += 1
 
+    def prefetched(n, host_sets):
+        """n steps over HOST batches through lgd_amd.data.DevicePrefetcher (the copy of batch k + 1 on a side stream under step k); the
+        loader is created -- and its first copy issued -- by the caller, ahead of the timed region, like a loader that runs ahead"""
+        from lgd_amd.data import DevicePrefetcher
+        return DevicePrefetcher((host_sets[(it[0] + i) % nb] for i in range(n)), dev)
+
+    def run_prefetched(pf):
+        for b in pf:
+            trainer.step(b, it[0])
+            it[0] += 1
+
     run_steps(max(args.warmup, nb if args.multiscale else 0), batches)   # multi-scale: every batch shape once (library kernel selection)
     trainer.fetch_metrics()
     sync()
@@ -296,14 +307,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     # the same steps with the batches handed over as pinned host tensors (N = 1 only; never `value` unless --host-batch)
-    dt_host = None
+    dt_host = dt_host_inline = None
     if host_batches is not None and not args.host_batch and world == 1 and not args.no_host_pass:
-        run_steps(min(2, args.steps), host_batches)
+        run_prefetched(prefetched(min(2, args.steps), host_batches))
+        pf = prefetched(args.steps, host_batches)
+        sync()
+        t0 = time.perf_counter()
+        run_prefetched(pf)
+        sync()
+        dt_host = time.perf_counter() - t0
+        trainer.fetch_metrics()
+        # (and the reference's literal form: the copies inside the step, on the step's stream)
         sync()
         t0 = time.perf_counter()
         run_steps(args.steps, host_batches)
         sync()
-        dt_host = time.perf_counter() - t0
+        dt_host_inline = time.perf_counter() - t0
         trainer.fetch_metrics()
     # second pass, instrumented: an event pair around every launch of the library and around the Winograd GEMMs
     ktimes, kbytes, kflops, dt_instr = {}, {}, {}, None
@@ -349,21 +368,36 @@ def main():
                 kernels[name]["TFLOPs"] = kflops[name] / (1e-3 * ms) / 1e12
         is_cfg1 = (os.path.abspath(args.config) == os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml") and Bg == 8
                    and (args.height, args.width) == (800, 1333))
-        hbm_bound = [k for k in kernels if k in alg and not k.startswith("focal") and k != "gemm3_kernel"]  # focal is exp/log bound, gemm3 MFMA bound
+        hbm_bound = [k for k in kernels if k in alg and not k.startswith("focal") and k != "gemm3_kernel" and "amax" not in k]  # focal is exp/log bound, gemm3 MFMA bound
         dom = max(hbm_bound, key=lambda k: kernels[k]["total_ms"], default=None)
         roofline = roofline_mfma = None
+        PMC = "r05_pmc_traffic.json"
+
+        def pmc_traffic(name):
+            """HBM bytes per launch of `name` from the tracked counter summary (tools/pmc_bench.sh collects the CSV and this JSON in ONE command)
+            -- refused when its launches per step are not this run's: a stale file must not price another launch mix"""
+            tf = os.path.join(ROOT, "profiles", PMC)
+            if not (os.path.exists(tf) and is_cfg1 and name in kernels):   # the counters were collected on configs[1]
+                return None, None
+            e = json.load(open(tf)).get(name)
+            if not e or not e.get("steps_profiled"):
+                return None, None
+            mine, theirs = kernels[name]["launches"] / args.steps, e["launches"] / e["steps_profiled"]
+            if abs(mine - theirs) > 0.01:
+                return None, "profiles/%s REFUSED: %.2f launches of %s per step there, %.2f in this run -- re-run tools/pmc_bench.sh" % (PMC, theirs, name, mine)
+            return e["hbm_bytes_per_launch"], ("static profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE passes over this command, "
+                                               "%.0f launches per step as in this run; not re-measured in this run)" % (PMC, theirs))
         if dom:
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-            if os.path.exists(tf) and is_cfg1:  # the counters were collected on configs[1]
-                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+            traffic, tsrc = pmc_traffic(dom)
             k = kernels[dom]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
-                        "traffic_source": "static profile: profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                          "over this command, not re-measured in this run)" if traffic is not None else None,
+                        "traffic_source": tsrc,
                         "alg_bytes_per_launch": alg[dom], "avg_launch_us": k["avg_us"], "min_launch_us": k["min_us"],
-                        "max_launch_us": k["max_us"],
+                        "max_launch_us": k["max_us"], "ms_per_step": k["total_ms"] / args.steps,
+                        # (the f16x2 products: MFMA work issued = 3 f16 MFMA flops per fp32 flop, against the 2.5 PFLOP/s dense f16 peak -- they are HBM-bound)
+                        "mfma_frac_of_f16_peak": (3.0 * kflops[dom] / (1e-3 * k["total_ms"]) / 1e12 / MFMA_BF16_PEAK_TFLOPS) if dom in kflops else None,
+                        "fp32_equivalent_TFLOPs": (kflops[dom] / (1e-3 * k["total_ms"]) / 1e12) if dom in kflops else None,
                         "all_hip_kernels": {n: {"avg_us": round(v["avg_us"], 2), "min_us": round(v["min_us"], 2),
                                                 "max_us": round(v["max_us"], 2), "GBps": round(v.get("GBps", 0.0), 1),
                                                 "launches_per_step": v["launches"] / args.steps}
@@ -375,14 +409,10 @@ def main():
         if "gemm3_kernel" in kernels and g3_fl and (dom is None or kernels["gemm3_kernel"]["total_ms"] > kernels[dom]["total_ms"]):
             k = kernels["gemm3_kernel"]
             ach = 6.0 * g3_fl / (1e-3 * k["total_ms"]) / 1e12
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-            if os.path.exists(tf) and is_cfg1:
-                traffic = json.load(open(tf)).get("gemm3_kernel", {}).get("hbm_bytes_per_launch")
+            traffic, tsrc = pmc_traffic("gemm3_kernel")
             roofline = {"bound": "mfma", "kernel": "gemm3_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                        "traffic_source": "static profile: profiles/r04_pmc_traffic.json (HBM bytes per launch, separate FETCH_SIZE x 2 / WRITE_SIZE "
-                                          "passes over this command)" if traffic is not None else None,
+                        "traffic_source": tsrc,
                         "flop_per_launch": 6.0 * g3_fl / k["launches"], "fp32_equivalent_TFLOPs": g3_fl / (1e-3 * k["total_ms"]) / 1e12,
                         "alg_bytes_per_launch": kbytes.get("gemm3_kernel", 0) / max(k["launches"], 1) or None,
                         "avg_launch_us": k["avg_us"], "min_launch_us": k["min_us"], "max_launch_us": k["max_us"],
@@ -438,6 +468,18 @@ def main():
                                             MFMA_F32_PEAK_TFLOPS, 1.0)
             if not g3:
                 roofline_mfma, roofline_mfma_lib = roofline_mfma_lib, None
+        def h2_object(name, what):
+            if name not in kernels or name not in alg:
+                return None
+            k = kernels[name]
+            traffic, tsrc = pmc_traffic(name)
+            return {"bound": "hbm", "kernel": name, "what": what, "achieved": k["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBPS,
+                    "traffic": traffic, "traffic_source": tsrc, "alg_bytes_per_launch": alg[name], "avg_launch_us": k["avg_us"], "min_launch_us": k["min_us"],
+                    "max_launch_us": k["max_us"], "launches_per_step": k["launches"] / args.steps, "ms_per_step": k["total_ms"] / args.steps,
+                    "fp32_equivalent_TFLOPs": kflops[name] / (1e-3 * k["total_ms"]) / 1e12,
+                    "mfma_frac_of_f16_peak": 3.0 * kflops[name] / (1e-3 * k["total_ms"]) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        roofline_h2 = {"forward_and_input_gradient": h2_object("h2_fwd_kernel", "M = U V and dV = U^T dM of the F(6x6,3x3) convolutions: filter image x f16x2 split rows"),
+                       "weight_gradient": h2_object("h2_dw_kernel", "dU = dM V^T: split rows x split rows, split-K (partials added by the filter transform's adjoint)")}
         arch = cfg.MODEL.META_ARCHITECTURE.replace("Distillator", "")
         default_cfg = os.path.abspath(args.config) == os.path.join(ROOT, "configs", "lgd_retinanet_r50.yaml")
         out = {
@@ -451,14 +493,19 @@ def main():
             "host_threads_pinned": None if pinned_cpus is None else "%d CPUs per rank (rank 0: %d-%d)" % (len(pinned_cpus), pinned_cpus[0], pinned_cpus[-1]),
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (bf16x3 split products, fp32 accumulate)" if ops._GEMM3_ON else "f32",
+            "dtype": ("f32 (3x3 convolutions: f16x2 split products, 1x1: bf16x3 split products; fp32 accumulate)" if (ops._H2_ON and ops._GEMM3_ON) else
+                      "f32 (bf16x3 split products, fp32 accumulate)" if ops._GEMM3_ON else "f32"),
+            "winograd_products": "csrc/h2.hip (f16x2 operands split in HBM by the transforms: forward, input and weight gradient)" if ops._H2_ON else
+                                 ("csrc/gemm3.hip (forward, input gradient) + library (weight gradient)" if ops._GEMM3_ON else "library"),
             "filter_images_from_transform": bool(ops._GEMM3_ON and ops._FILTER_IMAGES),
             "data": ("synthetic (%d distinct batches rotated; %s)" % (nb, "pinned HOST batches copied inside every step" if args.host_batch
                                                                       else "device-resident when the timed region starts, no H2D copy inside it")),
             "host_batch": None if dt_host is None else {
                 "value": Bg * args.steps / dt_host, "unit": "images/sec", "ms_per_step": 1e3 * dt_host / args.steps,
-                "note": "the same %d steps with the batches as pinned host tensors copied inside every step (non-blocking, on the step's "
-                        "stream): what the reference's step contains (retinanet.py:48)" % args.steps},
+                "copies_inside_the_step": {"value": Bg * args.steps / dt_host_inline, "ms_per_step": 1e3 * dt_host_inline / args.steps},
+                "note": "the same %d steps with the batches handed over as pinned HOST tensors: the reference's step contains the copy "
+                        "(retinanet.py:48); here lgd_amd.data.DevicePrefetcher issues the copy of batch k + 1 on a side stream under step k "
+                        "(`value`), next to the literal form with the copies inside the step on its own stream (`copies_inside_the_step`)" % args.steps},
             "config": {"workload": "%s%s R-%d FPN + LGD, %d img/GPU, %dx%d (padded %dx%d), "
                                    "%d GT boxes/img, ctx box %s, phase=%s (fwd+bwd+clip+2xSGD)%s"
                                    % ("BASELINE configs[1]: " if default_cfg and Bg == 8 and not args.multiscale else "", arch,
@@ -477,7 +524,7 @@ def main():
             "fused_clip_sgd": trainer._fused_sgd is not None,
             "head_pass": "single (student + teacher pyramids in one pass)" if getattr(model, "fused_head_pass", False) else "two passes",
             "roofline": roofline, "roofline_hbm": roofline_hbm if roofline_hbm is not roofline else None, "roofline_mfma": roofline_mfma, "roofline_mfma_library": roofline_mfma_lib, "roofline_mfma_pointwise": roofline_pw,
-            "roofline_lgd_forward": lgd_fwd,
+            "roofline_lgd_forward": lgd_fwd, "roofline_h2_products": roofline_h2 if any(roofline_h2.values()) else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.boxes, ctx)

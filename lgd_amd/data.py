@@ -47,3 +47,60 @@ def synthetic_batch(B, h=800, w=1333, n_boxes=10, seed=0, table=False, device="c
         out.append({"image": img.to(device), "height": hb, "width": wb,
                     "instances": Instances((hb, wb), gt_boxes=Boxes(boxes.to(device)), gt_classes=cls.to(device))})
     return out
+
+
+class DevicePrefetcher:
+    """Hands the step DEVICE batches while the loader produces HOST batches: the host -> device copy of batch k + 1 is issued on a side
+    stream while step k runs (pinned tensors, non-blocking copies; the step's stream waits for the copy's event, and the tensors are
+    recorded on it so that the caching allocator does not recycle them under the step).  The reference copies inside the step
+    (models/customized_detectors/retinanet.py:48, `x["image"].to(self.device)` in preprocess_image); here the same bytes move per step,
+    off the step's critical path (bench.py `host_batch`: the rate with the batches handed over as host tensors)."""
+
+    def __init__(self, batches, device):
+        self.it = iter(batches)
+        self.dev = torch.device(device)
+        self.stream = torch.cuda.Stream(self.dev)
+        self._next = self._ev = None
+        self._preload()
+
+    def _move(self, batch):
+        out = []
+        for x in batch:
+            y = dict(x)
+            y["image"] = x["image"].to(self.dev, non_blocking=True)
+            if "instances" in x:
+                y["instances"] = x["instances"].to(self.dev)
+            out.append(y)
+        return out
+
+    def _preload(self):
+        try:
+            b = next(self.it)
+        except StopIteration:
+            self._next = None
+            return
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))   # (never ahead of the step that may still read the buffers being recycled)
+        with torch.cuda.stream(self.stream):
+            self._next = self._move(b)
+            self._ev = torch.cuda.Event()
+            self._ev.record(self.stream)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            raise StopIteration
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self._ev)
+        b = self._next
+        for x in b:
+            x["image"].record_stream(cur)
+            inst = x.get("instances")
+            if inst is not None:
+                for v in getattr(inst, "_fields", {}).values():
+                    t = getattr(v, "tensor", v)
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)
+        self._preload()
+        return b

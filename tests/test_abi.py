@@ -67,3 +67,101 @@ def test_product_path_fails_loudly_without_gpu(lib):
         ops.BoxGeometry(torch.zeros(1, 4), [1], (64, 64), [(8, 8)])
     with pytest.raises(hip.LgdHipError):
         ops.distill_in_mse([torch.zeros(1, 4, 8, 8)], [torch.zeros(1, 4, 8, 8)], 1.0)
+
+
+# ---- the counted waits of the LDS-DMA pipelines ("nothing enforces this at build time")
+def _asm_of(src):
+    """hipcc -S of one csrc file with the library's flags (cached under build/asm while the source is older)"""
+    import subprocess
+    import __graft_entry__ as g
+    out_dir = os.path.join(ROOT, "build", "asm")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(ROOT, "lgd_amd", "csrc", src)
+    out = os.path.join(out_dir, src.replace(".hip", ".s"))
+    deps = [path, os.path.join(ROOT, "lgd_amd", "csrc", "common.h"), os.path.join(ROOT, "lgd_amd", "csrc", "winograd.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        flags = [f for f in g.FLAGS if f not in ("-shared", "-fPIC")]
+        subprocess.check_call([g.HIPCC] + flags + ["-S", "--cuda-device-only", path, "-o", out])
+    return open(out).read()
+
+
+def _kernels(asm, pattern):
+    """{mangled name: (instruction lines, ScratchSize)} of the kernels whose name matches"""
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:(.*?)^; ScratchSize: (\d+)", asm, flags=re.S | re.M):
+        if re.search(pattern, m.group(1)):
+            lines = [l.strip() for l in m.group(2).splitlines() if l.strip() and not l.strip().startswith(";")]
+            out[m.group(1)] = (lines, int(m.group(4)))
+    return out
+
+
+def _mfma_loops(lines):
+    """bodies (lists of lines) of the loops that contain MFMAs: a conditional branch back to a label seen earlier"""
+    pos = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    loops = []
+    for i, l in enumerate(lines):
+        m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        if m and m.group(1) in pos and pos[m.group(1)] < i:
+            body = lines[pos[m.group(1)]:i]
+            if any("v_mfma" in b for b in body):
+                loops.append(body)
+    return loops
+
+
+_VMEM = re.compile(r"^(buffer_|global_|flat_|scratch_)(load|store|atomic)")
+
+
+def test_h2_kloop_has_only_counted_waits():
+    """csrc/h2.hip issues its LDS-DMA from inline asm and counts its own waits: inside each k-loop there must be exactly DPW LDS-DMA
+    instructions per wave, NO other vector-memory instruction, exactly one vmcnt wait -- for DPW (forward: the youngest group may still be in
+    flight) / 2 DPW (weight gradient, four buffers) -- no scratch, and the transposing LDS reads must have survived."""
+    asm = _asm_of("h2.hip")
+    want = {"h2_fwd_kernelILi256ELb0": (6, 6), "h2_fwd_kernelILi256ELb1": (6, 6), "h2_fwd_kernelILi128ELb0": (4, 4), "h2_fwd_kernelILi128ELb1": (4, 4),
+            "h2_dw_kernel": (4, 8)}
+    ks = _kernels(asm, r"h2_fwd_kernel|h2_dw_kernel")
+    assert len(ks) == 5, sorted(ks)
+    for name, (lines, scratch) in ks.items():
+        key = next(k for k in want if k in name)
+        dpw, wait = want[key]
+        assert scratch == 0, (name, scratch)
+        loops = _mfma_loops(lines)
+        assert len(loops) == 1, (name, len(loops))
+        body = loops[0]
+        dma = [l for l in body if re.match(r"buffer_load_dwordx4 .* lds$", l)]
+        vmem = [l for l in body if _VMEM.match(l)]
+        waits = [int(m.group(1)) for l in body for m in [re.search(r"vmcnt\((\d+)\)", l)] if m and l.startswith("s_waitcnt")]
+        assert len(dma) == dpw and len(vmem) == dpw, (name, len(dma), len(vmem))
+        assert waits == [wait], (name, waits)
+        assert sum("v_mfma_f32_32x32x16_f16" in l for l in body) == (12 if "ILi128E" in name else 24), name
+        if "fwd" in name:
+            assert sum("ds_read_b64_tr_b16" in l for l in body) == 8, name
+
+
+def test_gemm3_kernels_keep_their_counted_waits_and_no_scratch():
+    """csrc/gemm3.hip: the k-loop waits `vmcnt(8)` for the image DMA of the next k-step, relying on exactly 8 B loads having been issued behind
+    it.  Build-time guard on every instance: no scratch (a spill would put extra loads into the counted window), the counted
+    wait still stands directly in front of the k-loop's barriers, the LDS-DMA and the 8-load groups are there in the expected numbers.  (The
+    run-time side -- products under memory pressure from a second stream, bit-equal to the quiet run -- is tests/test_kernels_gpu.py::
+    test_gemm3_and_h2_products_under_load.)"""
+    asm = _asm_of("gemm3.hip")
+    ks = _kernels(asm, r"gemm3_kernel")
+    assert len(ks) == 10, sorted(ks)
+    for name, (lines, scratch) in ks.items():
+        assert scratch == 0, (name, scratch)
+        ch = 6 if "ILi256E" in name else 3          # LDS-DMA instructions per wave and k-step (3 pieces x BM / 32 row blocks / 4 waves)
+        dma = [i for i, l in enumerate(lines) if re.match(r"buffer_load_dwordx4 .* lds$", l)]
+        assert dma and len(dma) % ch == 0, (name, len(dma))
+        counted = [i for i, l in enumerate(lines) if l.startswith("s_waitcnt vmcnt(8)") and any(x.startswith("s_barrier") for x in lines[i + 1:i + 4])]
+        assert len(counted) >= 2, (name, len(counted))   # prologue + k-loop
+        # every DMA group is followed by exactly 8 dword loads of B before anything else enters the memory pipe or a wait is taken
+        groups = [dma[j] for j in range(ch - 1, len(dma), ch)]
+        ok = 0
+        for g in groups:
+            n = 0
+            for l in lines[g + 1:g + 200]:
+                if re.match(r"buffer_load_dword v", l):
+                    n += 1
+                elif _VMEM.match(l) or l.startswith("s_waitcnt vmcnt") or l.startswith("s_barrier"):
+                    break
+            ok += n == 8
+        assert ok >= 1, (name, ok, len(groups))

@@ -407,3 +407,47 @@ def test_amax_tags_travel_and_expire():
         _with_h2(run)
     finally:
         ops._count_bytes = real
+
+
+def test_gemm3_and_h2_products_under_load():
+    """the counted-wait pipelines (csrc/gemm3.hip: vmcnt(8) behind the image DMA; csrc/h2.hip: vmcnt(DPW)) assume the memory pipe returns loads in
+    order and that nothing else enters it inside the window -- true by construction, held here at run time: the products run while a second
+    stream saturates HBM with copies (different latencies, different arrival patterns) and must equal the quiet run bit for bit, ten times
+    over ('an earlier counted variant produced wrong tiles under load')."""
+    from lgd_amd import ops
+    hip, lib = _lib()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    nb, M, K, T = 64, 256, 256, 1312
+    a = torch.randn((nb, M, K), device=DEV, generator=g) * 0.05
+    v = torch.randn((K, nb, T), device=DEV, generator=g)
+    sa, sv = cm.h2_pow2_scale(a.abs().amax((1, 2))), cm.h2_pow2_scale(v.abs().amax((0, 2)))
+    img, vs = cm.h2_split_image(a, sa), cm.h2_split_rows(v, sv)
+    ia, iv = (1 / sa).contiguous(), (1 / sv).contiguous()
+    dm = torch.randn((M, nb, T), device=DEV, generator=g)
+    sd = cm.h2_pow2_scale(dm.abs().amax((0, 2)))
+    ds, idm = cm.h2_split_rows(dm, sd), (1 / sd).contiguous()
+    S = lib.lgd_h2_dw_splits(nb, M, K, T)
+    part = torch.empty((max(S, 1), nb, M, K), device=DEV)
+
+    def run():
+        out = torch.empty((M, nb, T), device=DEV)
+        hip.check(lib.lgd_h2_fwd(hip.ptr(img), hip.ptr(vs), 4 * T, 4 * nb * T, 4 * vs.numel(), hip.ptr(out), T, nb * T, hip.ptr(ia), hip.ptr(iv), 1, None,
+                                 nb, M, T, K, hip.stream_ptr()), "lgd_h2_fwd")
+        du = torch.empty((nb, M, K), device=DEV)
+        hip.check(lib.lgd_h2_dw(hip.ptr(ds), 4 * nb * T, 4 * T, 4 * ds.numel(), hip.ptr(idm), 1, hip.ptr(vs), 4 * nb * T, 4 * T, 4 * vs.numel(), hip.ptr(iv), 1,
+                                hip.ptr(du), hip.ptr(part), S, nb, M, K, T, hip.stream_ptr()), "lgd_h2_dw")
+        c3 = ops.gemm3_bmm(a, v.permute(1, 0, 2))
+        return out, du, c3
+    quiet = run()
+    torch.cuda.synchronize()
+    hog_src = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+    for _ in range(10):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                hog_dst.copy_(hog_src)
+        loud = run()
+        torch.cuda.synchronize()
+        for q, l in zip(quiet, loud):
+            assert torch.equal(q, l)

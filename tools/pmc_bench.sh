@@ -1,5 +1,7 @@
 #!/bin/bash
-# two counter passes over the bench's own launch mix (run on the GPU box): FETCH_SIZE and WRITE_SIZE separately
+# two counter passes over the bench's own launch mix; ONE command writes the per-kernel CSV and the JSON bench.py reads (steps 2 + warmup 2 = 4 steps
+# profiled: the JSON records it so that bench.py can check launches per step against its own run)
+# (run on the GPU box): FETCH_SIZE and WRITE_SIZE separately
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -11,5 +13,5 @@ done
 F=$(ls /tmp/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1)
 W=$(ls /tmp/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
 mkdir -p $R/gpurun_out
-python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r04_bench_pmc_fetch_write.csv $R/gpurun_out/r04_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing --no-host-pass (BASELINE configs[1], B=8 800x1333; round 4 launch mix: F(6x6,3x3), channel products on gemm3.hip)"
-cat $R/gpurun_out/r04_bench_pmc_fetch_write.csv
+STEPS_PROFILED=4 python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r05_bench_pmc_fetch_write.csv $R/gpurun_out/r05_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing --no-host-pass (BASELINE configs[1], B=8 800x1333; round 5 launch mix: F(6x6,3x3), 3x3 channel products on h2.hip, 1x1 on gemm3.hip)"
+cat $R/gpurun_out/r05_bench_pmc_fetch_write.csv

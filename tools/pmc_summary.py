@@ -57,9 +57,11 @@ def short(name):
     m = re.match(r"box_pool_kernel<([01]),", n)                                       # <GN, CH>
     if m:
         return ["gn_pool_kernel" if m.group(1) == "1" else "box_sum_kernel"]
-    if re.match(r"wino[46]_in_kernel<(true|false)>$", n):                            # <PRE>
+    if re.match(r"wino[46]_in_kernel<", n):                                           # <PRE[, H2]>
         return ["wino_in_kernel"]
-    m = re.match(r"wino[46]_in_t_kernel<(true|false)>$", n)                         # <FUSE>
+    if re.match(r"wino6_out_t_kernel<", n):                                           # <H2>
+        return ["wino_out_t_kernel"]
+    m = re.match(r"wino[46]_in_t_kernel<(true|false)", n)                           # <FUSE[, H2]>
     if m:
         return ["wino_in_t_out_t_kernel" if m.group(1) == "true" else "wino_in_t_kernel"]
     base = re.sub(r"<.*$", "", n)
@@ -78,7 +80,9 @@ def traffic_json(summary_csv, out_json, note):
         for t in short(k):
             acc[t][0] += n
             acc[t][1] += n * (rd + wr) * 1e6
-    js = {t: {"hbm_bytes_per_launch": int(b / n), "launches": n,
+    import os
+    steps = int(os.environ.get("STEPS_PROFILED", "0")) or None
+    js = {t: {"hbm_bytes_per_launch": int(b / n), "launches": n, "steps_profiled": steps,
               "source": "%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; mean over the launches of: %s)"
                         % (summary_csv.split("/")[-1], note)} for t, (n, b) in sorted(acc.items())}
     json.dump(js, open(out_json, "w"), indent=1)
