@@ -408,6 +408,11 @@ int lgd_h2_amax_maps(const float* const* x_host, const int32_t* level_hw_host, i
 int lgd_h2_amax_filters(const float* const* w_host, const float* const* scale_host, const int32_t* rows_host, int K, int row_elems, uint32_t* out_bits,
                         void* stream);
 int lgd_h2_link_bound(const uint32_t* amax64, uint32_t* out_bits, void* stream);
+/* bound of the GroupNorm-backward gradient lgd_wino_out_t_gn(_h2) forms on the fly, from the coefficient table (n_entries x 4 floats) and the maxima of
+ * the gradient maps / the convolution's own outputs; accumulates into *out_bits (a word zeroed by the caller: one bound for stacked filters) */
+int lgd_h2_gn_bound(const float* coef, long long n_entries, const uint32_t* amax_g, const uint32_t* amax_y, uint32_t* out_bits, void* stream);
+int lgd_wino_out_t_gn_h2(const float* const* g_host, const float* const* y_host, const float* coef, const int32_t* level_hw_host, int L, int N, int C,
+                         void* dM, const uint32_t* amax_in, float* inv_out64, void* stream);
 /* The F(6x6,3x3) transforms around them.  *_h2: the frequency buffer WRITTEN is split rows scaled by a power of two derived from *amax_in (float
  * bits of an upper bound of the transform's input magnitude); inv_out receives the inverse scale(s): 1 float (lgd_wino_in_h2: one scale for all
  * frequencies) or 64 (per frequency).  lgd_wino_out_amax / lgd_wino_in_t_amax: lgd_wino_out / lgd_wino_in_t (tile 6) that also leave

@@ -834,6 +834,24 @@ int lgd_wino_out_t_h2(const float* const* dy_host, const void* relu_bits, const 
     return lgd::check_launch();
 }
 
+// lgd_wino_out_t_gn writing dM as split rows; *amax_in bounds |ca g - cm - (y - mean) cb| (lgd_h2_gn_bound)
+int lgd_wino_out_t_gn_h2(const float* const* g_host, const float* const* y_host, const float* coef, const int32_t* level_hw_host, int L, int N, int C,
+                         void* dM, const uint32_t* amax_in, float* inv_out64, void* stream) {
+    lgd::WinoArgs a;
+    unsigned blocks;
+    if (!g_host || !y_host || !coef || !dM || !amax_in || !inv_out64 || ((uintptr_t)dM & 15) || lgd::wino_fill(a, level_hw_host, L, N, C, 6, &blocks) != LGD_OK)
+        return LGD_EINVAL;
+    for (int l = 0; l < L; ++l) {
+        if (!g_host[l] || !y_host[l]) return LGD_EINVAL;
+        a.maps_in[l] = g_host[l];
+        a.maps_in2[l] = y_host[l];
+    }
+    a.gn_coef = coef;
+    a.buf_out = (float*)dM; a.h2 = 1; a.amax_in = amax_in; a.scale_out = inv_out64;
+    lgd::wino6_launch_out_t(a, blocks, (hipStream_t)stream);
+    return lgd::check_launch();
+}
+
 int lgd_wino_in_t_out_t_h2(const float* dV, const void* relu_bits, const int32_t* level_hw_host, int L, int N, int C, void* dM,
                            const uint32_t* bound_in, float* inv_out64, void* stream) {
     lgd::WinoArgs a;

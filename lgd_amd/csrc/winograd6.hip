@@ -570,11 +570,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_OUTT
 }
 
 // the same with the backward apply of a GroupNorm that follows the convolution folded into the load (WinoArgs::gn_coef)
+template <bool H2>
 __global__ __launch_bounds__(256) void wino6_out_t_gn_kernel(WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
     const int l = wino_level(a);
-    if (a.pair[l]) wino6_out_t_body<true, true, false>(a, l, lds);
-    else wino6_out_t_body<false, true, false>(a, l, lds);
+    if (a.pair[l]) wino6_out_t_body<true, true, H2>(a, l, lds);
+    else wino6_out_t_body<false, true, H2>(a, l, lds);
 }
 
 // dx = adjoint of wino6_in: the 8x8 windows Z_t = B G_t B^T (G = dV) of neighbouring tiles overlap by two pixels and are summed
@@ -977,7 +978,8 @@ void wino6_launch_out(const WinoArgs& a, unsigned blocks, hipStream_t st) {
     LGD_LAUNCH("wino_out_kernel", wino6_out_kernel, dim3(blocks, a.C), dim3(256), 0, st, a);
 }
 void wino6_launch_out_t(const WinoArgs& a, unsigned blocks, hipStream_t st) {
-    if (a.gn_coef) { LGD_LAUNCH("wino_out_t_gn_kernel", wino6_out_t_gn_kernel, dim3(blocks, a.C), dim3(256), 0, st, a); }
+    if (a.gn_coef && a.h2) { LGD_LAUNCH("wino_out_t_gn_kernel", wino6_out_t_gn_kernel<true>, dim3(blocks, a.C), dim3(256), 0, st, a); }
+    else if (a.gn_coef) { LGD_LAUNCH("wino_out_t_gn_kernel", wino6_out_t_gn_kernel<false>, dim3(blocks, a.C), dim3(256), 0, st, a); }
     else if (a.h2) { LGD_LAUNCH("wino_out_t_kernel", wino6_out_t_kernel<true>, dim3(blocks, a.C), dim3(256), 0, st, a); }
     else { LGD_LAUNCH("wino_out_t_kernel", wino6_out_t_kernel<false>, dim3(blocks, a.C), dim3(256), 0, st, a); }
 }

@@ -90,6 +90,8 @@ SIGNATURES = {
     "lgd_h2_amax_maps": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp]),
     "lgd_h2_amax_filters": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_h2_link_bound": (c_i, [c_fp, c_fp, c_fp]),
+    "lgd_h2_gn_bound": (c_i, [c_fp, ctypes.c_longlong, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_wino_out_t_gn_h2": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_in_h2": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_out_t_h2": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_in_t_out_t_h2": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),

@@ -1178,7 +1178,7 @@ def _wino_filter_grads(lib, dU, scales, Cos, need, Ci, tile):
 def _wino_out(lib, Mk, bias, hw, L, N, Co, tile, relu, ys, bits):
     """output transform of Co channels of M (+ bias, ReLU, mask bits); with the f16x2 pipeline on (tile 6) it also leaves max |y| for the
     next convolution's scale and tags the maps with it"""
-    if tile == 6 and _H2_ON and _H2_TAGS:
+    if tile == 6 and _tags_wanted(sum(N * ((y.shape[2] + 5) // 6) * ((y.shape[3] + 5) // 6) for y in ys)):
         amax = _zero_words(ys[0].device)
         hip.check(lib.lgd_wino_out_amax(hip.ptr(Mk), hip.ptr(bias) if bias is not None else None, hw, L, N, Co, int(relu), hip.ptr_array(ys),
                                         hip.ptr(bits) if bits is not None else None, hip.ptr(amax), hip.stream_ptr()), "lgd_wino_out_amax")
@@ -1190,7 +1190,7 @@ def _wino_out(lib, Mk, bias, hw, L, N, Co, tile, relu, ys, bits):
 
 def _wino_in_t(lib, dV, hw, L, N, Ci, tile, dxs, pre_bits):
     """adjoint input transform (+ activation mask); tile 6 with the f16x2 pipeline on: also max |dx|, tagged on the gradient maps"""
-    if tile == 6 and _H2_ON and _H2_TAGS:
+    if tile == 6 and _tags_wanted(sum(N * ((d.shape[2] + 5) // 6) * ((d.shape[3] + 5) // 6) for d in dxs)):
         amax = _zero_words(dxs[0].device)
         hip.check(lib.lgd_wino_in_t_amax(hip.ptr(dV), hw, L, N, Ci, hip.ptr_array(dxs), hip.ptr(pre_bits) if pre_bits is not None else None,
                                          hip.ptr(amax), hip.stream_ptr()), "lgd_wino_in_t_amax")
@@ -1363,7 +1363,7 @@ class _Conv3x3GN(torch.autograd.Function):
         hip.require_gpu(*ws, *xs)
         lib = hip.load()
         ws = [hip.dense_f32(w) for w in ws]
-        xs = [hip.dense_f32(x) for x in xs]
+        xs = [_dense_tagged(x) for x in xs]
         bs = [hip.dense_f32(b) if b is not None else None for b in bs]
         gammas = [hip.dense_f32(g) if g is not None else None for g in gammas]
         betas = [hip.dense_f32(b) if b is not None else None for b in betas]
@@ -1375,26 +1375,40 @@ class _Conv3x3GN(torch.autograd.Function):
         mdt = _WINO_MASK_DTYPE[tile]
         hw = hip.int_array([d for x in xs for d in x.shape[2:]])
         T = lib.lgd_wino_tiles(hw, L, N, tile)
-        U, Ut = _wino_filters(lib, ws, [None] * K, Ci, dev, tile, T, any(ctx.needs_input_grad[4 + 4 * K:]))
-        V = _freq_buf(nf, Ci, T, dev)
+        need_dx = any(ctx.needs_input_grad[4 + 4 * K:])
+        h2 = _h2_ok(tile, Ci, Cos, T, dev)
         pre = hip.dense_f32(pre) if pre is not None else None
         affine_in = pre is not None and pre.dim() == 3
         if affine_in and tuple(pre.shape) != (L * N, Ci, 2):
             raise hip.LgdHipError("affine pre-activation must be (L*N, C, 2) = (%d, %d, 2), got %s" % (L * N, Ci, tuple(pre.shape)))
-        pre_bits = (torch.empty((Ci, T), dtype=mdt, device=dev) if pre is not None and any(ctx.needs_input_grad[4 + 4 * K:]) else None)
-        hip.check(lib.lgd_wino_in(hip.ptr_array(xs), hw, L, N, Ci, tile, hip.ptr(V),
-                                  hip.ptr(pre) if pre is not None and not affine_in else None, hip.ptr(pre) if affine_in else None,
-                                  hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in")
+        pre_bits = (torch.empty((Ci, T), dtype=mdt, device=dev) if pre is not None and need_dx else None)
         px = 4 * N * sum(x.shape[2] * x.shape[3] for x in xs)
         fb = 4 * nf * T
-        _count_bytes("wino_in_kernel", (px + fb) * Ci)
-        M = _wino_gemm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
-        ys, affs, stats, c0 = [], [], [], 0
+        p_bias, p_aff = (hip.ptr(pre) if pre is not None and not affine_in else None), (hip.ptr(pre) if affine_in else None)
+        uinv = vinv = None
+        if h2:   # K10: as _Conv3x3K
+            filt = _h2_filters(lib, ws, [None] * K, Ci, dev, need_dx)
+            amax = _amax_bits(lib, xs, hw, pre, affine_in)
+            V, vinv, uinv = _h2_buf(Ci, T, dev), torch.empty(1, dtype=torch.float32, device=dev), filt.inv
+            hip.check(lib.lgd_wino_in_h2(hip.ptr_array(xs), hw, L, N, Ci, hip.ptr(V), p_bias, p_aff, hip.ptr(pre_bits) if pre_bits is not None else None,
+                                         hip.ptr(amax), hip.ptr(vinv), hip.stream_ptr()), "lgd_wino_in_h2")
+            _count_bytes("wino_in_kernel", (px + fb) * Ci)
+            M = _h2_product(lib, "fwd", filt.fwd, Ct, Ci, V, vinv, False, uinv, _freq_buf(nf, Ct, T, dev))
+            Ut = filt.bwd
+        else:
+            U, Ut = _wino_filters(lib, ws, [None] * K, Ci, dev, tile, T, need_dx)
+            V = _freq_buf(nf, Ci, T, dev)
+            hip.check(lib.lgd_wino_in(hip.ptr_array(xs), hw, L, N, Ci, tile, hip.ptr(V), p_bias, p_aff,
+                                      hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in")
+            _count_bytes("wino_in_kernel", (px + fb) * Ci)
+            M = _wino_gemm("wino_gemm_fwd", U, V, out=_freq_buf(nf, Ct, T, dev))
+        ys, affs, stats, yamax, c0 = [], [], [], [], 0
         for k in range(K):
             yk = [torch.empty((N, Cos[k]) + tuple(x.shape[2:]), dtype=torch.float32, device=dev) for x in xs]
             _count_bytes("wino_out_kernel", (px + fb) * Cos[k])
-            hip.check(lib.lgd_wino_out(hip.ptr(M[:, c0]), hip.ptr(bs[k]) if bs[k] is not None else None, hw, L, N, Cos[k], tile, 0,
-                                       hip.ptr_array(yk), None, hip.stream_ptr()), "lgd_wino_out")
+            _wino_out(lib, M[:, c0], bs[k], hw, L, N, Cos[k], tile, False, yk, None)
+            tag = getattr(yk[0], "_lgd_amax", None)
+            yamax.append(tag[0] if tag is not None else None)   # max |y|: the backward's bound of the GroupNorm gradient needs it
             # (the statistics in the output transform's epilogue -- per-plane fp64 sums by atomics -- were measured: the transform slows down by
             #  what the pass costs)
             gws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, N, Cos[k]), dtype=torch.float64, device=dev)
@@ -1410,9 +1424,9 @@ class _Conv3x3GN(torch.autograd.Function):
             stats.append(st)
             c0 += Cos[k]
         need_w = any(ctx.needs_input_grad[4:4 + 4 * K:4])
-        ut_t, ctx.ut_shape = _pack_filter(Ut)
-        ctx.dev = dev
-        ctx.save_for_backward(ut_t, V if need_w else None, pre_bits, *stats, *gammas, *ys)
+        ut_t, ctx.ut_shape = (Ut, None) if h2 else _pack_filter(Ut)
+        ctx.dev, ctx.h2, ctx.yamax = dev, h2, yamax
+        ctx.save_for_backward(ut_t, V if need_w else None, pre_bits, uinv, vinv, *stats, *gammas, *ys)
         ctx.meta = (K, L, N, Ci, Cos, hw, T, [b is not None for b in bs], [b is not None for b in betas],
                     [tuple(x.shape[2:]) for x in xs], tile, groups, px, fb)
         ctx.mark_non_differentiable(*affs)
@@ -1421,17 +1435,18 @@ class _Conv3x3GN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         K, L, N, Ci, Cos, hw, T, has_bias, has_beta, shapes, tile, groups, px, fb = ctx.meta
-        Ut, V, pre_bits = ctx.saved_tensors[:3]
-        Ut = _unpack_filter(Ut, ctx.ut_shape)
-        stats = ctx.saved_tensors[3:3 + K]
-        gammas = ctx.saved_tensors[3 + K:3 + 2 * K]
-        ys = ctx.saved_tensors[3 + 2 * K:]
+        Ut, V, pre_bits, uinv, vinv = ctx.saved_tensors[:5]
+        if not ctx.h2:
+            Ut = _unpack_filter(Ut, ctx.ut_shape)
+        stats = ctx.saved_tensors[5:5 + K]
+        gammas = ctx.saved_tensors[5 + K:5 + 2 * K]
+        ys = ctx.saved_tensors[5 + 2 * K:]
         gs = grads[K:]
         Ct = sum(Cos)
         lib = hip.load()
         dev = ctx.dev
         nf = (tile + 2) ** 2
-        gs = [hip.dense_f32(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
+        gs = [_dense_tagged(g) if g is not None else torch.zeros((N, Cos[i // L]) + shapes[i % L], dtype=torch.float32, device=dev)
               for i, g in enumerate(gs)]
         nig = ctx.needs_input_grad
         need_ws = list(nig[4:4 + 4 * K:4])
@@ -1439,8 +1454,12 @@ class _Conv3x3GN(torch.autograd.Function):
         need_w, need_x = any(need_ws), any(nig[4 + 4 * K:])
         dws, dbs, dgs, dbes = [None] * K, [None] * K, [None] * K, [None] * K
         dxs = [None] * L
-        dM = _freq_buf(nf, Ct, T, dev)
-        c0 = 0
+        h2 = ctx.h2
+        if h2:
+            dM, dminv, bound = _h2_buf(Ct, T, dev), torch.empty(64, dtype=torch.float32, device=dev), _zero_words(dev)
+        else:
+            dM = _freq_buf(nf, Ct, T, dev)
+        coefs, c0 = [], 0
         for k in range(K):
             gk, yk = gs[k * L:(k + 1) * L], list(ys[k * L:(k + 1) * L])
             gws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, N, Cos[k]), dtype=torch.float64, device=dev)
@@ -1452,25 +1471,41 @@ class _Conv3x3GN(torch.autograd.Function):
                                                 hip.ptr(gammas[k]) if gammas[k] is not None else None, hip.ptr(stats[k]), hip.ptr(gws),
                                                 hip.ptr(bst), hip.ptr(psums), hip.ptr(coef), hip.stream_ptr()), "lgd_gn_group_bwd_coef")
             _count_bytes("wino_out_t_gn_kernel", (2 * px + fb) * Cos[k])
-            hip.check(lib.lgd_wino_out_t_gn(hip.ptr_array(gk), hip.ptr_array(yk), hip.ptr(coef), hw, L, N, Cos[k], tile, hip.ptr(dM[:, c0]),
-                                            hip.stream_ptr()), "lgd_wino_out_t_gn")
+            if h2:   # ONE scale for the stacked gradients: the bound accumulates over the K filters, the transforms run behind the loop
+                ag = _amax_bits(lib, gk, hw)
+                ay = ctx.yamax[k] if ctx.yamax[k] is not None else _amax_bits(lib, yk, hw)
+                hip.check(lib.lgd_h2_gn_bound(hip.ptr(coef), L * N * Cos[k], hip.ptr(ag), hip.ptr(ay), hip.ptr(bound), hip.stream_ptr()), "lgd_h2_gn_bound")
+                coefs.append(coef)
+            else:
+                hip.check(lib.lgd_wino_out_t_gn(hip.ptr_array(gk), hip.ptr_array(yk), hip.ptr(coef), hw, L, N, Cos[k], tile, hip.ptr(dM[:, c0]),
+                                                hip.stream_ptr()), "lgd_wino_out_t_gn")
             if (gammas[k] is not None and nig[6 + 4 * k]) or (has_beta[k] and nig[7 + 4 * k]):
                 s = psums.sum(0)
                 dgs[k] = s[:, 1].contiguous() if gammas[k] is not None and nig[6 + 4 * k] else None
                 dbes[k] = s[:, 0].contiguous() if has_beta[k] and nig[7 + 4 * k] else None
             c0 += Cos[k]
+        if h2:
+            c0 = 0
+            for k in range(K):
+                gk, yk = gs[k * L:(k + 1) * L], list(ys[k * L:(k + 1) * L])
+                hip.check(lib.lgd_wino_out_t_gn_h2(hip.ptr_array(gk), hip.ptr_array(yk), hip.ptr(coefs[k]), hw, L, N, Cos[k],
+                                                   ctypes.c_void_p(dM.data_ptr() + 4 * c0 * nf * T), hip.ptr(bound), hip.ptr(dminv), hip.stream_ptr()),
+                          "lgd_wino_out_t_gn_h2")
+                c0 += Cos[k]
         if need_x:
             _count_bytes("wino_in_t_kernel", (px + fb) * Ci)
-            dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
+            if h2:
+                dV = _h2_product(lib, "dx", Ut, Ci, Ct, dM, dminv, True, uinv, _freq_buf(nf, Ci, T, dev))
+            else:
+                dV = _wino_gemm("wino_gemm_dx", Ut, dM, out=_freq_buf(nf, Ci, T, dev))
             dxs = [torch.empty((N, Ci) + sh, dtype=torch.float32, device=dev) for sh in shapes]
-            hip.check(lib.lgd_wino_in_t(hip.ptr(dV), hw, L, N, Ci, tile, hip.ptr_array(dxs),
-                                        hip.ptr(pre_bits) if pre_bits is not None else None, hip.stream_ptr()), "lgd_wino_in_t")
+            _wino_in_t(lib, dV, hw, L, N, Ci, tile, dxs, pre_bits)
             del dV
         if need_w:
-            dU = _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
+            dU = _h2_dw(lib, dM, dminv, V, vinv, Ct, Ci) if h2 else _timed_bmm("wino_gemm_dw", dM, V.transpose(1, 2))
             dws = _wino_filter_grads(lib, dU, [None] * K, Cos, need_ws, Ci, tile)
         if any(need_bs):
-            db = dM[tile + 3].sum(1)   # the frequency of the interpolation point 1: the tile's gradient sum
+            db = _h2_plane_sums(dM, tile + 3, dminv) if h2 else dM[tile + 3].sum(1)   # the frequency of the interpolation point 1: the tile's gradient sum
             c0 = 0
             for k in range(K):
                 dbs[k] = db[c0:c0 + Cos[k]] if need_bs[k] else None
@@ -2462,7 +2497,7 @@ class _TaggedView:
 def _tagged_gemm3(name, a, b):
     """_timed_gemm3 whose epilogue also leaves max |C| (the f16x2 scale of a 3x3 convolution that consumes the map: conv1 -> conv2 of a
     bottleneck forward, conv3 -> conv2 backward)"""
-    amax = _zero_words(b.device) if (_H2_ON and _H2_TAGS) else None
+    amax = _zero_words(b.device) if _tags_wanted(b.shape[0] * b.shape[2] // 36) else None
     return _TaggedView(_timed_gemm3(name, a, b, None, amax_out=amax), amax)
 
 
@@ -2481,6 +2516,10 @@ def _wino_gemm(name, a, b, out=None):
 _H2_ON = os.environ.get("LGD_H2", "1") != "0"
 _H2_FORCE = False    # tests: take the h2 path wherever the kernels CAN run, whatever the speed policy says
 _H2_TAGS = os.environ.get("LGD_H2_TAGS", "1") != "0"
+# fewest tiles (all levels, padded) of a convolution that takes the f16x2 pipeline: at 2 images per GPU (BASELINE configs 4 / 5) one pyramid is 1376
+# tiles and its products are ~40 us launches -- the bound's bookkeeping costs what the faster products gain (config 4, same call, 30 steps: every
+# convolution on h2 30.1 ms, from 1500 tiles 29.1, none 29.6 with the producers still leaving their maxima / 29.0 without)
+_H2_MIN_T = int(os.environ.get("LGD_H2_MIN_T", "1500"))
 _H2_DEBUG = os.environ.get("LGD_H2_DEBUG", "0") != "0"   # print every bound that takes its own pass over the maps, with the call site   # 0: every bound by its own pass over the maps (A/B runs)
 
 
@@ -2505,7 +2544,7 @@ def _h2_ok(tile, Ci, Cos, T, dev):
         return True
     Ct = sum(Cos)
     bm = 128 if ((Ct + 255) // 256 * 256 - Ct >= 64 and (Ct + 127) // 128 * 128 - Ct < 64) else 256
-    if Ci < 32 or T < 256 or Ct < 0.7 * bm * ((Ct + bm - 1) // bm):
+    if Ci < 32 or T < _H2_MIN_T or Ct < 0.7 * bm * ((Ct + bm - 1) // bm):
         return False
     wgs = 64 * ((T + 127) // 128) * ((Ct + bm - 1) // bm)
     return wgs >= _cu_count(dev)
@@ -2525,6 +2564,12 @@ def _zero_words(dev, n=1):
     w = pool[0][pool[1]:pool[1] + n]
     pool[1] += n
     return w
+
+
+def _tags_wanted(n_tiles):
+    """whether a kernel that writes maps of n_tiles 6x6 tiles should leave their maximum: only where a consumer could take the f16x2 pipeline (the
+    one-pass head runs over two pyramids: twice the tiles of the maps it reads)"""
+    return _H2_ON and _H2_TAGS and (_H2_FORCE or 2 * n_tiles >= _H2_MIN_T)
 
 
 def _amax_tag(maps, amax):

@@ -1436,9 +1436,10 @@ def test_group_norm_folded_into_conv3x3(tile, B, C, Co, G, level_hw):
         assert cm.rel_err(t.grad, r.grad) < 2 * tol
 
 
+@pytest.mark.parametrize("products", ["policy", "h2"])   # h2: every channel product of the towers forced onto csrc/h2.hip (the GroupNorm gradient's bound: lgd_h2_gn_bound)
 @pytest.mark.parametrize("mode", ["one_node", "two_nodes"])
 @pytest.mark.parametrize("B,C,G,level_hw", [(2, 64, 8, [(20, 28), (13, 21), (7, 11)]), (3, 256, 32, [(12, 16), (6, 7), (2, 3)])])
-def test_conv3x3_group_norm_tower_backward_folded(mode, B, C, G, level_hw):
+def test_conv3x3_group_norm_tower_backward_folded(mode, B, C, G, level_hw, products):
     """two tower layers conv3x3 -> GroupNorm(G) -> ReLU and a final conv3x3, the first layer with two filters on the same maps (the FCOS
     towers, thirdparty_heads/fcos.py:455-470) through ops.conv3x3_gn: one autograd node per convolution + GroupNorm whose backward
     applies the GroupNorm gradient inside the adjoint output transform (lgd_gn_group_bwd_coef + lgd_wino_out_t_gn: aligned and unaligned
@@ -1458,6 +1459,7 @@ def test_conv3x3_group_norm_tower_backward_folded(mode, B, C, G, level_hw):
     gys = {n: [torch.from_numpy(synth.det_uniform((B, 24, h, w), seed + i, -1.0, 1.0)).to(DEV) for i, (h, w) in enumerate(level_hw)]
            for n, seed in (("a", 1770), ("b", 1780))}
     prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=6)
+    prev_h2 = ops.h2_backend(True, force=(products == "h2"))
     was = ops._GN_FUSED_BWD
     ops._GN_FUSED_BWD = mode == "one_node"
     try:
@@ -1468,6 +1470,7 @@ def test_conv3x3_group_norm_tower_backward_folded(mode, B, C, G, level_hw):
         yb = ops.conv3x3_levels(mb, *fin["b"], pre=pb)
         torch.autograd.backward(list(ya) + list(yb), gys["a"] + gys["b"])
     finally:
+        ops.h2_backend(*prev_h2)
         ops._GN_FUSED_BWD = was
         ops.conv3x3_backend(*prev)
 
@@ -1488,7 +1491,11 @@ def test_conv3x3_group_norm_tower_backward_folded(mode, B, C, G, level_hw):
     for y, r in zip(list(ya) + list(yb), ra + rb):
         assert cm.rel_err(y, r) < tol
     for x, xr in zip(xs, x64):
-        ok, msg = cm.kink_robust_close(x.grad, xr.grad, tol=2 * tol, max_outlier_frac=2e-3, max_rel=1e-2)
+        # (which units sit within rounding of a ReLU kink depends on the product kernel; on the 2x3 / 6x7 maps of the second case ONE flipped unit of a
+        #  tower reaches every input pixel of its level: with the products on h2.hip 0.8 % of the elements move by more than 4e-4 -- at 2e-4 of the
+        #  tensor in L2 -- where the gemm3 / library products happen to flip fewer.  A single convolution on these maps is held to fp64 at 1.2e-5
+        #  (y), 9.5e-6 (dx), 5e-6 (dw) on h2.hip against 1.7e-5 / 1.25e-5 / 4.9e-6 on the fp32-format path: tools/h2_num_probe.py)
+        ok, msg = cm.kink_robust_close(x.grad, xr.grad, tol=2 * tol, max_outlier_frac=1e-2 if products == "h2" else 2e-3, max_rel=1e-2)
         assert ok, msg
     for n in lay:
         for t, r, what in zip(lay[n], l64[n], ("w", "b", "gamma", "beta")):
