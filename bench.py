@@ -405,23 +405,27 @@ def main():
         # the dominant hand-written kernel of the step overall: since round 4 that is gemm3_kernel (MFMA bound), not a transform.  `roofline`
         # names whichever has more in-step time; the dominant HBM-bound kernel stays on the line as `roofline_hbm`
         roofline_hbm = roofline
-        g3_fl = sum(v for n, v in kflops.items() if "_gemm3_" in n)
-        if "gemm3_kernel" in kernels and g3_fl and (dom is None or kernels["gemm3_kernel"]["total_ms"] > kernels[dom]["total_ms"]):
-            k = kernels["gemm3_kernel"]
-            ach = 6.0 * g3_fl / (1e-3 * k["total_ms"]) / 1e12
-            traffic, tsrc = pmc_traffic("gemm3_kernel")
-            roofline = {"bound": "mfma", "kernel": "gemm3_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                        "traffic_source": tsrc,
-                        "flop_per_launch": 6.0 * g3_fl / k["launches"], "fp32_equivalent_TFLOPs": g3_fl / (1e-3 * k["total_ms"]) / 1e12,
-                        "alg_bytes_per_launch": kbytes.get("gemm3_kernel", 0) / max(k["launches"], 1) or None,
-                        "avg_launch_us": k["avg_us"], "min_launch_us": k["min_us"], "max_launch_us": k["max_us"],
-                        "ms_per_step": k["total_ms"] / args.steps,
-                        "note": "bf16 MFMA flops issued = 6 per fp32 multiply-add pair (three-way split operands, 6 of 9 cross products); the kernel's "
-                                "launches alone (HIP events inside the library), filter-image launches not included",
-                        "all_hip_kernels": (roofline_hbm or {}).get("all_hip_kernels")}
-            if roofline_hbm:
-                roofline_hbm = {k_: v for k_, v in roofline_hbm.items() if k_ != "all_hip_kernels"}
+        # the dominant hand-written kernel of the step overall may be an MFMA-bound product kernel (csrc/gemm3.hip: bf16x3, 6 MFMA flops per fp32 flop;
+        # its f16x2 form lgd_gemm2h: 3) instead of an HBM-bound one: `roofline` names whichever has most in-step time; the dominant HBM-bound
+        # kernel stays on the line as `roofline_hbm`
+        for kname, tag, mult, what in (("gemm3_kernel", "_gemm3_", 6.0, "bf16 MFMA flops issued = 6 per fp32 multiply-add pair (three-way split operands, 6 of 9 cross products)"),
+                                       ("gemm2h_kernel", "_gemm2h_", 3.0, "f16 MFMA flops issued = 3 per fp32 multiply-add pair (two-piece split operands, 3 of 4 cross products)")):
+            fl = sum(v for n, v in kflops.items() if tag in n)
+            best = kernels[roofline["kernel"]]["total_ms"] if roofline else 0.0
+            if kname in kernels and fl and kernels[kname]["total_ms"] > best:
+                k = kernels[kname]
+                ach = mult * fl / (1e-3 * k["total_ms"]) / 1e12
+                traffic, tsrc = pmc_traffic(kname)
+                roofline = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                            "flop_per_launch": mult * fl / k["launches"], "fp32_equivalent_TFLOPs": fl / (1e-3 * k["total_ms"]) / 1e12,
+                            "alg_bytes_per_launch": kbytes.get(kname, 0) / max(k["launches"], 1) or None,
+                            "avg_launch_us": k["avg_us"], "min_launch_us": k["min_us"], "max_launch_us": k["max_us"],
+                            "ms_per_step": k["total_ms"] / args.steps,
+                            "note": what + "; the kernel's launches alone (HIP events inside the library), filter-image launches not included",
+                            "all_hip_kernels": (roofline_hbm or {}).get("all_hip_kernels")}
+        if roofline is not roofline_hbm and roofline_hbm:
+            roofline_hbm = {k_: v for k_, v in roofline_hbm.items() if k_ != "all_hip_kernels"}
         # the north star's aggregate: the LGD distill forward = mask pooling (fused with GN + ReLU) + rendering paint + distill moments,
         # one launch each per step, 4 P of algorithmic bytes together
         lgd_fwd = None
@@ -458,6 +462,10 @@ def main():
         # timed together) and the library's fp32 GEMMs (weight gradient; shapes outside gemm3's tile)
         g3 = {n: v for n, v in kernels.items() if n.startswith("wino_gemm3_") or n.startswith("pw_gemm3_")}
         gl = {n: v for n, v in kernels.items() if n.startswith("wino_gemm_")}
+        g2 = {n: v for n, v in kernels.items() if n.startswith("pw_gemm2h_")}
+        roofline_mfma_1x1 = (mfma_object(g2, "lgd_gemm2h (csrc/gemm3.hip, f16x2 form): the student's 1x1 convolutions, forward + input gradient (filter as a two-piece f16 image, "
+                                         "activations split in registers, 3 of 4 cross products on v_mfma_f32_32x32x16_f16, fp32 accumulate; image launch included)",
+                                         MFMA_BF16_PEAK_TFLOPS, 3.0) if g2 else None)
         roofline_mfma_lib = None
         if g3:
             roofline_mfma = mfma_object(g3, "csrc/gemm3.hip: Winograd channel products and the student's 1x1 convolutions, forward + input gradient (fp32 operands "
@@ -493,7 +501,8 @@ def main():
             "host_threads_pinned": None if pinned_cpus is None else "%d CPUs per rank (rank 0: %d-%d)" % (len(pinned_cpus), pinned_cpus[0], pinned_cpus[-1]),
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (3x3 convolutions: f16x2 split products, 1x1: bf16x3 split products; fp32 accumulate)" if (ops._H2_ON and ops._GEMM3_ON) else
+            "dtype": ("f32 (f16x2 split products, fp32 accumulate)" if (ops._H2_ON and ops._GEMM3_ON and ops._GEMM2H_ON) else
+                      "f32 (3x3 convolutions: f16x2 split products, 1x1: bf16x3 split products; fp32 accumulate)" if (ops._H2_ON and ops._GEMM3_ON) else
                       "f32 (bf16x3 split products, fp32 accumulate)" if ops._GEMM3_ON else "f32"),
             "winograd_products": "csrc/h2.hip (f16x2 operands split in HBM by the transforms: forward, input and weight gradient)" if ops._H2_ON else
                                  ("csrc/gemm3.hip (forward, input gradient) + library (weight gradient)" if ops._GEMM3_ON else "library"),
@@ -523,7 +532,7 @@ def main():
             "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,
             "fused_clip_sgd": trainer._fused_sgd is not None,
             "head_pass": "single (student + teacher pyramids in one pass)" if getattr(model, "fused_head_pass", False) else "two passes",
-            "roofline": roofline, "roofline_hbm": roofline_hbm if roofline_hbm is not roofline else None, "roofline_mfma": roofline_mfma, "roofline_mfma_library": roofline_mfma_lib, "roofline_mfma_pointwise": roofline_pw,
+            "roofline": roofline, "roofline_hbm": roofline_hbm if roofline_hbm is not roofline else None, "roofline_mfma": roofline_mfma, "roofline_mfma_library": roofline_mfma_lib, "roofline_mfma_pointwise": roofline_pw, "roofline_mfma_1x1_f16x2": roofline_mfma_1x1,
             "roofline_lgd_forward": lgd_fwd, "roofline_h2_products": roofline_h2 if any(roofline_h2.values()) else None,
         }
         if world == 1 and not args.no_cpu_baseline:

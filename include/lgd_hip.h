@@ -177,7 +177,9 @@ int lgd_gn_group_bwd(const float* const* x_host, const float* const* dy_host, co
  * (thirdparty_heads/fcos.py:455-470) never runs and dx is never written or re-read. */
 int lgd_gn_group_bwd_coef(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L, int B, int C,
                           int G, const float* gamma, const float* stats, double* ws, float* bstats, float* plane_sums, float* coef,
-                          void* stream);
+                          float* wmax, uint32_t* bound_out, void* stream);
+/* (round 5) wmax (as many floats as lgd_gn_group_ws_doubles counts doubles) + bound_out (a word zeroed by the caller), both optional: max |dx| of
+ * the gradient lgd_wino_out_t_gn(_h2) will form, bounded PER PLANE from the chunk maxima of |g| and |xhat| -- the f16x2 scale of that transform. */
 
 /* ------------------------------------------------------------------ K3b: ReLU(x + ctx[b,c]) epilogue of the rendering
  * [ref: dynamic_teacher.py:151  F.relu(inst_featmap + ctx_feature[:, :, None, None])]
@@ -376,6 +378,16 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
               const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits, uint32_t* amax_out, int nb, int M, int N,
               int K, void* stream);
 /* (round 5) amax_out: optional word (zeroed by the caller) that receives max |C| as stored, as float bits: the magnitude bound of lgd_h2_*. */
+/* lgd_gemm2h: the same product, tiles and epilogues in the f16x2 form of K10 -- the student's 1x1 convolutions (an fp32-class product: error against fp64 as
+ * lgd_gemm3's): the filter as ONE two-piece f16 image for all batches (lgd_gemm2h_split: A 2^ea, ea from the bound *a_amax of |A|, 2^-ea recorded in
+ * a_inv[0]), the activation operand scaled by the power of two its bound *b_amax (max |B|, float bits: the tag the producing kernel left, or
+ * lgd_h2_amax_maps) prescribes and split in registers: three MFMAs per k-step instead of six, half the split arithmetic, two thirds of the LDS traffic. */
+size_t lgd_gemm2h_image_bytes(int nb, int M, int K);
+int lgd_gemm2h_split(const float* A, long long a_sb, long long a_sm, long long a_sk, int nb, int M, int K, const uint32_t* a_amax, void* image, float* a_inv,
+                     void* stream);
+int lgd_gemm2h(const void* image, int image_shared, const float* a_inv, const float* B, const uint32_t* b_amax, long long b_sb, long long b_sk, float* C,
+               long long c_sb, long long c_sm, const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits,
+               uint32_t* amax_out, int nb, int M, int N, int K, void* stream);
 
 /* ---- K10: the Winograd channel products from f16x2 operands that are split in HBM (csrc/h2.hip; round 5).
  * Replaces, like lgd_gemm3, the arithmetic of every nn.Conv2d(C, C', 3, padding=1) of the path (dynamic_teacher.py:57,61,67-73,145,280;
@@ -408,9 +420,7 @@ int lgd_h2_amax_maps(const float* const* x_host, const int32_t* level_hw_host, i
 int lgd_h2_amax_filters(const float* const* w_host, const float* const* scale_host, const int32_t* rows_host, int K, int row_elems, uint32_t* out_bits,
                         void* stream);
 int lgd_h2_link_bound(const uint32_t* amax64, uint32_t* out_bits, void* stream);
-/* bound of the GroupNorm-backward gradient lgd_wino_out_t_gn(_h2) forms on the fly, from the coefficient table (n_entries x 4 floats) and the maxima of
- * the gradient maps / the convolution's own outputs; accumulates into *out_bits (a word zeroed by the caller: one bound for stacked filters) */
-int lgd_h2_gn_bound(const float* coef, long long n_entries, const uint32_t* amax_g, const uint32_t* amax_y, uint32_t* out_bits, void* stream);
+/* lgd_wino_out_t_gn writing dM as split rows; *amax_in: the bound lgd_gn_group_bwd_coef(bound_out) leaves */
 int lgd_wino_out_t_gn_h2(const float* const* g_host, const float* const* y_host, const float* coef, const int32_t* level_hw_host, int L, int N, int C,
                          void* dM, const uint32_t* amax_in, float* inv_out64, void* stream);
 /* The F(6x6,3x3) transforms around them.  *_h2: the frequency buffer WRITTEN is split rows scaled by a power of two derived from *amax_in (float

@@ -27,12 +27,13 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "winograd.h"   // h2_exponent / h2_pow2: the power-of-two scales of the f16x2 form
 
 namespace lgd {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef lgd_u32x4 u32x4;
 
@@ -46,14 +47,27 @@ constexpr int BN = 128, BK = 16, NT = 256;
 
 // tile rows BM = 256 (4 x 2 MFMA blocks per wave, 2 workgroups per CU) or 128 (2 x 2 blocks, 64 accumulator registers, 3 workgroups per
 // CU: C' = 128 layers, whose 256-row tile would idle half of every MFMA)
-template <int BM> struct Tile {
+// PCS: pieces per operand -- 3: bf16 (x = h + m + l, six of nine cross products); 2: f16 (x 2^e = h + m, three of four: the f16x2 form of
+// csrc/h2.hip with the activation operand split in registers -- the student's 1x1 convolutions, whose maps arrive as fp32; round 5)
+template <int BM, int PCS = 3> struct Tile {
     static constexpr int RB = BM / 32, MI = BM / 64;                      // 32-row blocks per tile / per wave
-    static constexpr int A_BYTES = 3 * RB * 1024, B_BYTES = 3 * 4 * 1024, BUF = A_BYTES + B_BYTES, LDS_BYTES = 2 * BUF;   // 72 / 48 KB
-    static constexpr int CHUNKS = 3 * RB / 4;                             // 1 KB LDS-DMA pieces per wave and k-step
+    static constexpr int A_BYTES = PCS * RB * 1024, B_BYTES = PCS * 4 * 1024, BUF = A_BYTES + B_BYTES, LDS_BYTES = 2 * BUF;   // 72 / 48 KB (48 / 32)
+    static constexpr int CHUNKS = PCS * RB / 4;                           // 1 KB LDS-DMA pieces per wave and k-step
 };
 
 #define LGD_GLDS16(src, dst) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(const f16x8& a, const f16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// two (already scaled) elements -> packed h pair, packed m pair of the f16x2 form (csrc/h2.hip)
+__device__ __forceinline__ void split2_f16(float t0, float t1, uint32_t& h, uint32_t& m) {
+    typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
+    const hx2 hh = __builtin_convertvector((lgd_f32x2){t0, t1}, hx2);
+    const hx2 mm = __builtin_convertvector((lgd_f32x2){t0 - (float)hh[0], t1 - (float)hh[1]}, hx2);
+    h = __builtin_bit_cast(uint32_t, hh);
+    m = __builtin_bit_cast(uint32_t, mm);
+}
 
 struct Params {
     const char* Aimg; long a_sb; int rbp, ktp;   // image [nb][ktp][3][rbp][1024 B]; a_sb in bytes
@@ -66,14 +80,16 @@ struct Params {
     const float* shift;
     uint32_t* bits; int wpr;                     // ReLU mask: bit n % 32 of word (b * M + m) * wpr + n / 32 = (C(m, n) > 0)
     int relu;
+    const float* a_inv; const unsigned* b_amax;  // PCS == 2: inverse scale of the image (one per image), bound of |B| (float bits): B is scaled by 2^eb in the kernel
     unsigned* amax;                              // optional: atomic max of the float bits of |C| as stored (one word, zeroed by the caller): the bound
                                                  // the NEXT convolution's f16x2 scale is derived from (csrc/h2.hip)
 };
 
 // EPI: 0 the plain product; otherwise the epilogue kernel with bit 0: R present, bit 1: shift present
-template <int BM, int EPI>
+template <int BM, int EPI, int PCS>
 __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
-    typedef Tile<BM> TL;
+    typedef Tile<BM, PCS> TL;
+    typedef typename std::conditional<PCS == 3, bf16x8, f16x8>::type frag_t;
     constexpr int A_BYTES = TL::A_BYTES, BUF = TL::BUF, MI = TL::MI, RB = TL::RB, CH = TL::CHUNKS;
     extern __shared__ __attribute__((aligned(1024))) char lds[];   // ONE LDS object (a second one makes hipcc drain vmcnt(0) before every ds_read)
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 1, wn = w & 1;
@@ -115,6 +131,18 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     for (int e = 0; e < 8; ++e) boff[e] = (uint32_t)((kg * 8 + e) * (int)p.b_ld + ncol) * 4u;   // bytes
     const long bstep = (long)BK * p.b_ld;
     const int bslot = A_BYTES + (nl >> 5) * 1024 + kg * 512 + (nl & 31) * 16;   // 8 consecutive lanes -> 128 contiguous bytes: no conflicts
+    // PCS == 2: power-of-two scale of B from its bound; the total exponent stays <= 100 so that an accumulator started from R 2^(ea + eb) cannot
+    // overflow when the filter is (nearly) zero: a zero-initialised layer has ea = 126
+    float bscale = 1.f, inv_tot = 1.f, sc_tot = 1.f;
+    if constexpr (PCS == 2) {
+        const float ainv = p.a_inv[p.a_sb != 0 ? b : 0];
+        const int ea = 127 - (int)((__builtin_bit_cast(unsigned, ainv) >> 23) & 0xffu);
+        int eb = h2_exponent(*p.b_amax, 0);
+        eb = eb > 100 - ea ? 100 - ea : eb;
+        bscale = h2_pow2(eb);
+        sc_tot = h2_pow2(ea + eb);
+        inv_tot = h2_pow2(-(ea + eb));
+    }
     float bv[8];
     // buffer loads: the k-step's origin in the descriptor (scalar), the eight per-thread offsets as they are -- no 64-bit address per load
     auto load_b = [&](int ks) {
@@ -130,6 +158,14 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
         return;
 #endif
         uint32_t h[4], m[4], l[4];
+        char* d = buf + bslot;
+        if constexpr (PCS == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2_f16(bv[2 * e] * bscale, bv[2 * e + 1] * bscale, h[e], m[e]);
+            *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4*>(d + 4096) = (u32x4){m[0], m[1], m[2], m[3]};
+            return;
+        }
 #if LGD_GEMM3_ABL == 1   // lab: the LDS store without the split's arithmetic
 #pragma unroll
         for (int e = 0; e < 4; ++e) h[e] = m[e] = l[e] = __builtin_bit_cast(uint32_t, bv[2 * e]) ^ __builtin_bit_cast(uint32_t, bv[2 * e + 1]);
@@ -137,7 +173,6 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) split2(bv[2 * e], bv[2 * e + 1], h[e], m[e], l[e]);
 #endif
-        char* d = buf + bslot;
         *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
         *reinterpret_cast<u32x4*>(d + 4096) = (u32x4){m[0], m[1], m[2], m[3]};
         *reinterpret_cast<u32x4*>(d + 8192) = (u32x4){l[0], l[1], l[2], l[3]};
@@ -152,7 +187,7 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
         rb = rb < p.rbp ? rb : p.rbp - 1;
         aoff[c] = (uint32_t)((pc * p.rbp + rb) * 1024 + lane * 16);
     }
-    const long astep = (long)3 * p.rbp * 1024;
+    const long astep = (long)PCS * p.rbp * 1024;
     auto dma_a = [&](int ks, char* buf) {
 #if LGD_GEMM3_ABL == 3 || LGD_GEMM3_ABL == 5
         return;
@@ -193,6 +228,7 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
                 if constexpr ((EPI & 1) != 0) {
                     acc[i][0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_src, ro, 0, 0));
                     acc[i][1][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_src, ro + 128, 0, 0));
+                    if constexpr (PCS == 2) { acc[i][0][e] *= sc_tot; acc[i][1][e] *= sc_tot; }   // (the product on top of it is scaled by 2^(ea + eb))
                     ro += (e & 3) == 3 ? r5 : r1;
                     asm volatile("" : "+v"(ro));
                 } else {
@@ -236,28 +272,28 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
     __syncthreads();
     for (int ks = 0; ks < ksteps; ++ks) {
         char* cur = lds + (ks & 1) * BUF;
-        bf16x8 fb[3][2], fa[MI];
+        frag_t fb[PCS][2], fa[MI];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = 0; pc < PCS; ++pc)
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn)
-                fb[pc][jn] = *reinterpret_cast<const bf16x8*>(cur + A_BYTES + pc * 4096 + (wn * 2 + jn) * 1024 + slot);
+                fb[pc][jn] = *reinterpret_cast<const frag_t*>(cur + A_BYTES + pc * 4096 + (wn * 2 + jn) * 1024 + slot);
 #pragma unroll
-        for (int pa = 2; pa >= 1; --pa) {            // smallest pieces first
+        for (int pa = PCS - 1; pa >= 1; --pa) {      // smallest pieces first
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(cur + pa * (RB * 1024) + (wm * MI + i) * 1024 + slot);
+                fa[i] = *reinterpret_cast<const frag_t*>(cur + pa * (RB * 1024) + (wm * MI + i) * 1024 + slot);
 #pragma unroll
-            for (int pb = 2 - pa; pb >= 0; --pb)     // pa + pb <= 2: the six kept products
+            for (int pb = PCS - 1 - pa; pb >= 0; --pb)   // pa + pb <= PCS - 1: the six (three) kept products
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[pb][jn], acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = mfma16(fa[i], fb[pb][jn], acc[i][jn]);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-            fa[i] = *reinterpret_cast<const bf16x8*>(cur + (wm * MI + i) * 1024 + slot);
+            fa[i] = *reinterpret_cast<const frag_t*>(cur + (wm * MI + i) * 1024 + slot);
         // the image DMA of k-step ks + 1 (issued behind the previous barrier) must have LANDED before anybody passes this one; hipcc's own
         // wait insertion loses an LDS-DMA across the loop's back-edge (it emitted no vmcnt wait here at all), and vmcnt(0) would also
         // drain the 8 B loads issued behind that DMA, which nobody needs before store_b.  The memory pipe returns in order: vmcnt(8).
@@ -269,15 +305,16 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
         }
         if (ks + 1 < ksteps) load_b(ks + 3 < ksteps ? ks + 3 : ksteps - 1);   // (the last ones re-read a valid k-step: the count stays 8)
 #pragma unroll
-        for (int pb = 2; pb >= 0; --pb)
+        for (int pb = PCS - 1; pb >= 0; --pb)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[pb][jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = mfma16(fa[i], fb[pb][jn], acc[i][jn]);
     }
     __syncthreads();       // (the epilogue and the next tile's prologue reuse the buffers)
 #else
+    static_assert(PCS == 3, "the lab form of the k-loop exists for bf16x3 only");
     // prologue: k-step 0 into buffer 0, B of k-step 1 into registers
     dma_a(0, lds);
     load_b(0);
@@ -352,10 +389,12 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
                 for (int jn = 0; jn < 2; ++jn) {
                     asm volatile("" : "+a"(acc[i][jn]) :: "memory");   // one block out of the accumulator file at a time (all at once: 64+ VGPRs)
                     int words = 0, co = cbase;
+                    uint32_t bm = 0u;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
                         float v = acc[i][jn][e];
+                        if constexpr (PCS == 2) v *= inv_tot;
                         if constexpr ((EPI & 2) != 0) v += lsh[dm];
                         if constexpr (EPI != 0) {
                             const bool pos = v > 0.f;
@@ -371,16 +410,17 @@ __global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
 #if LGD_GEMM3_ABL == 4 || LGD_GEMM3_ABL == 5   // lab: no C stores (one conditional store keeps the accumulators alive)
                         if (v == 123456.f)
 #endif
-                        if (hf || (dm < mrem && colok[jn])) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
-                            if (want_max) amax = max(amax, __builtin_bit_cast(uint32_t, v) & 0x7fffffffu);
-                        }
+                        const bool ok = hf || (dm < mrem && colok[jn]);
+                        if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
+                        bm = max(bm, ok ? __builtin_bit_cast(uint32_t, v) & 0x7fffffffu : 0u);   // (always: a branch per element costs registers, not time)
                         co += (e & 3) == 3 ? c5 : c1;
                         asm volatile("" : "+v"(co));
                     }
                     if constexpr (hb) {
                         if (lane < 32 && wrow + i * 32 + brow < p.M && wcol + jn * 32 < p.N) bwl[(long)(i * 32) * p.wpr + jn] = (uint32_t)words;
                     }
+                    amax = max(amax, bm);
+                    asm volatile("" : "+v"(amax));
                     if (jn == 1) cbase = co;
                 }
             }
@@ -421,6 +461,34 @@ __global__ void split_a_kernel(const float* __restrict__ A, long a_sb, long sm, 
     store_split8(x, img + gemm3_image_off(b, ktp, rbp, m, k0), rbp);
 }
 
+// the same for the f16x2 form: [batch][k-step][2 pieces][rbp][1 KB] of A 2^e, e from the bound *amax of |A| (one scale for all batches); thread 0
+// records the inverse scale
+__global__ void split_a_h2_kernel(const float* __restrict__ A, long a_sb, long sm, long sk, int nb, int M, int K, int rbp, int ktp, const unsigned* __restrict__ amax,
+                                  char* __restrict__ img, float* __restrict__ inv_out) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = h2_exponent(*amax, 0);
+    if (q == 0) inv_out[0] = h2_pow2(-e);
+    const long total = (long)nb * ktp * rbp * 64;
+    if (q >= total) return;
+    const float s = h2_pow2(e);
+    const int lane = (int)(q & 63);
+    long r = q >> 6;
+    const int rb = (int)(r % rbp); r /= rbp;
+    const int kt = (int)(r % ktp);
+    const int b = (int)(r / ktp);
+    const int m = rb * 32 + (lane & 31), k0 = kt * 16 + (lane >> 5) * 8;
+    uint32_t h[4], mm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = (m < M && k0 + 2 * i < K) ? A[(long)b * a_sb + (long)m * sm + (long)(k0 + 2 * i) * sk] : 0.f;
+        const float x1 = (m < M && k0 + 2 * i + 1 < K) ? A[(long)b * a_sb + (long)m * sm + (long)(k0 + 2 * i + 1) * sk] : 0.f;
+        split2_f16(x0 * s, x1 * s, h[i], mm[i]);
+    }
+    char* d = img + ((((long)b * ktp + kt) * 2) * rbp + rb) * 1024 + lane * 16;
+    *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(d + (long)rbp * 1024) = (u32x4){mm[0], mm[1], mm[2], mm[3]};
+}
+
 }  // namespace
 }  // namespace lgd
 
@@ -440,9 +508,12 @@ int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_
     return lgd::check_launch();
 }
 
-int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm,
-              const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits, uint32_t* amax_out, int nb, int M, int N,
-              int K, void* stream) {
+}  // extern "C"
+
+template <int PCS>
+static int gemm3_launch(const void* image, int image_shared, const float* a_inv, const float* B, const uint32_t* b_amax, long long b_sb, long long b_sk,
+                        float* C, long long c_sb, long long c_sm, const float* R, long long r_sb, long long r_sm, const float* shift, int relu,
+                        uint32_t* relu_bits, uint32_t* amax_out, int nb, int M, int N, int K, void* stream) {
     if (!image || !B || !C || nb <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 15) || ((uintptr_t)image & 15)) return LGD_EINVAL;
     // 256-row tiles unless that leaves more than a quarter of the rows of the last tile empty and 128-row tiles do not
     const bool epi = R || shift || relu || relu_bits;
@@ -450,7 +521,8 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
     const int bm = small ? 128 : 256;
     lgd::Params p;
     p.rbp = (M + 31) / 32; p.ktp = K / 16;
-    p.Aimg = (const char*)image; p.a_sb = image_shared ? 0 : (long)p.ktp * 3 * p.rbp * 1024;
+    p.Aimg = (const char*)image; p.a_sb = image_shared ? 0 : (long)p.ktp * PCS * p.rbp * 1024;
+    p.a_inv = a_inv; p.b_amax = b_amax;
     p.B = B; p.b_sb = (long)b_sb; p.b_ld = (long)b_sk;
     p.C = C; p.c_sb = (long)c_sb; p.c_ld = (long)c_sm;
     p.R = R; p.r_sb = (long)r_sb; p.r_ld = (long)r_sm; p.r_bytes = (((long)nb - 1) * r_sb + ((long)M - 1) * r_sm + N) * 4; p.shift = shift; p.bits = relu_bits; p.amax = amax_out; p.wpr = (N + 31) / 32; p.relu = relu ? 1 : 0;
@@ -460,17 +532,17 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
         return LGD_EINVAL;
     // 72 KB of dynamic LDS: above the default 64 KB limit.  hipFuncAttributeMaxDynamicSharedMemorySize and the CU count are per DEVICE: cached per
     // device index (a process that touched a second GPU launched without the attribute and with the first one's CU count)
-    static bool attr_dev[64] = {};
+    static bool attr_dev[64] = {};   // (one pair of caches per instantiation: PCS 3 / 2)
     static int cus_dev[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LGD_ELAUNCH;
     bool& attr = attr_dev[dev];
     int& cus = cus_dev[dev];
     if (!attr) {
-        const void* big[5] = {(const void*)lgd::gemm3_kernel<256, 0>, (const void*)lgd::gemm3_kernel<256, 1>, (const void*)lgd::gemm3_kernel<256, 2>,
-                              (const void*)lgd::gemm3_kernel<256, 3>, (const void*)lgd::gemm3_kernel<256, 4>};
+        const void* big[5] = {(const void*)lgd::gemm3_kernel<256, 0, PCS>, (const void*)lgd::gemm3_kernel<256, 1, PCS>, (const void*)lgd::gemm3_kernel<256, 2, PCS>,
+                              (const void*)lgd::gemm3_kernel<256, 3, PCS>, (const void*)lgd::gemm3_kernel<256, 4, PCS>};
         for (const void* f : big)
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lgd::Tile<256>::LDS_BYTES) != hipSuccess) return LGD_ELAUNCH;
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lgd::Tile<256, PCS>::LDS_BYTES) != hipSuccess) return LGD_ELAUNCH;
         attr = true;
     }
     p.total = (int)((image_shared ? ((long)nb * p.nt + 7) / 8 : (long)((nb + 7) / 8) * p.nt) * p.mt * 8);
@@ -489,7 +561,7 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
     hipStream_t st = (hipStream_t)stream;
     const int kind = !epi ? 0 : (R ? 1 : 0) | (shift ? 2 : 0) ? (R ? 1 : 0) | (shift ? 2 : 0) : 4;
 #define LGD_GEMM3_CASE(BM_, E_) \
-    case E_: LGD_LAUNCH("gemm3_kernel", (lgd::gemm3_kernel<BM_, E_>), grid, block, lgd::Tile<BM_>::LDS_BYTES, st, p); break;
+    case E_: LGD_LAUNCH(PCS == 3 ? "gemm3_kernel" : "gemm2h_kernel", (lgd::gemm3_kernel<BM_, E_, PCS>), grid, block, (lgd::Tile<BM_, PCS>::LDS_BYTES), st, p); break;
     if (small) {
         switch (kind) { LGD_GEMM3_CASE(128, 0) LGD_GEMM3_CASE(128, 1) LGD_GEMM3_CASE(128, 2) LGD_GEMM3_CASE(128, 3) LGD_GEMM3_CASE(128, 4) }
     } else {
@@ -497,6 +569,41 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
     }
 #undef LGD_GEMM3_CASE
     return lgd::check_launch();
+}
+
+extern "C" {
+
+int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm,
+              const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits, uint32_t* amax_out, int nb, int M, int N,
+              int K, void* stream) {
+    return gemm3_launch<3>(image, image_shared, nullptr, B, nullptr, b_sb, b_sk, C, c_sb, c_sm, R, r_sb, r_sm, shift, relu, relu_bits, amax_out, nb, M, N, K,
+                           stream);
+}
+
+// ---- the f16x2 form of the same product (round 5): A as a two-piece f16 image scaled by a power of two (lgd_gemm2h_split: scale from the bound
+// *a_amax of |A|, inverse recorded in a_inv), B split in registers after scaling by the power of two its bound *b_amax prescribes: three MFMAs per
+// k-step instead of six and half the split arithmetic.  Same tiles, epilogues and arguments as lgd_gemm3.
+size_t lgd_gemm2h_image_bytes(int nb, int M, int K) {
+    if (nb <= 0 || M <= 0 || K <= 0) return 0;
+    return (size_t)nb * ((K + 15) / 16) * 2 * ((M + 31) / 32) * 1024;
+}
+
+int lgd_gemm2h_split(const float* A, long long a_sb, long long a_sm, long long a_sk, int nb, int M, int K, const uint32_t* a_amax, void* image, float* a_inv,
+                     void* stream) {
+    if (!A || !image || !a_amax || !a_inv || nb <= 0 || M <= 0 || K <= 0 || ((uintptr_t)image & 15)) return LGD_EINVAL;
+    const int rbp = (M + 31) / 32, ktp = (K + 15) / 16;
+    const long total = (long)nb * ktp * rbp * 64;
+    LGD_LAUNCH("gemm2h_split_kernel", lgd::split_a_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, (long)a_sb,
+               (long)a_sm, (long)a_sk, nb, M, K, rbp, ktp, a_amax, (char*)image, a_inv);
+    return lgd::check_launch();
+}
+
+int lgd_gemm2h(const void* image, int image_shared, const float* a_inv, const float* B, const uint32_t* b_amax, long long b_sb, long long b_sk, float* C,
+               long long c_sb, long long c_sm, const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits,
+               uint32_t* amax_out, int nb, int M, int N, int K, void* stream) {
+    if (!a_inv || !b_amax || !image_shared) return LGD_EINVAL;   // (one image and one scale for all batches: the student's 1x1 convolutions)
+    return gemm3_launch<2>(image, image_shared, a_inv, B, b_amax, b_sb, b_sk, C, c_sb, c_sm, R, r_sb, r_sm, shift, relu, relu_bits, amax_out, nb, M, N, K,
+                           stream);
 }
 
 }  // extern "C"

@@ -34,6 +34,8 @@ struct GgArgs {
     float* bstats;                  // [L*B*G][2] m1, m2 (backward)
     float* plane_sums;              // [L*B*C][2] sum g, sum g*xhat (backward)
     float* affine;                  // optional (forward finalize): [L*B][C][2] rstd*gamma, beta - mean*rstd*gamma
+    float* wmax;                    // optional (backward, with coef): [nwaves][2] max |g|, max |xhat| of every chunk -- the finalize turns them into
+    unsigned* bound_out;            //   max |dx| over everything (float bits, atomic max into a word the caller zeroed): the f16x2 scale of lgd_wino_out_t_gn_h2
     float* coef;                    // optional (backward finalize): [L*B][C][4] ca = rstd*gamma, cm = rstd*m1, mean, cb = rstd^2*m2 --
                                     //   dx = ca*g - cm - (x - mean)*cb, applied by the producing convolution's lgd_wino_out_t_gn
 };
@@ -72,12 +74,14 @@ __global__ __launch_bounds__(256) void gg_stats_kernel(GgArgs a) {
     }
     const int e0 = q.chunk * a.chunk[q.l], e1 = min(HW, e0 + a.chunk[q.l]);
     double s0 = 0, s1 = 0;
+    float mg = 0.f, mx = 0.f;
     auto acc = [&](float x, float d) {
         if (MODE == 0) { const double xd = x; s0 += xd; s1 = fma(xd, xd, s1); }
         else {
             const float xh = gg_hat(x, mu, r);
             const float g = (a.relu && !(gg_affine(xh, ga, be) > 0.f)) ? 0.f : d;
             s0 += (double)g; s1 = fma((double)g, (double)xh, s1);
+            mg = fmaxf(mg, fabsf(g)); mx = fmaxf(mx, fabsf(xh));
         }
     };
     if ((HW & 3) == 0) {
@@ -100,6 +104,10 @@ __global__ __launch_bounds__(256) void gg_stats_kernel(GgArgs a) {
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1);
     if (lane == 0) { a.ws[2 * (size_t)w] = s0; a.ws[2 * (size_t)w + 1] = s1; }
+    if (MODE == 1 && a.wmax) {
+        mg = wave_max(mg); mx = wave_max(mx);
+        if (lane == 0) { a.wmax[2 * (size_t)w] = mg; a.wmax[2 * (size_t)w + 1] = mx; }
+    }
 }
 
 // one workgroup per (level, sample, group): its C/G planes x cpp chunks are contiguous in ws.  A THREAD owns a channel plane (its cpp
@@ -163,6 +171,21 @@ __global__ __launch_bounds__(256) void gg_finalize_kernel(GgArgs a) {
             float* k = a.coef + 4 * ((size_t)lb * a.C + c);
             k[0] = r * (a.gamma ? a.gamma[c] : 1.f); k[1] = r * m1; k[2] = mu; k[3] = r * r * m2;
         }
+        if (a.wmax && a.bound_out) {
+            // |dx| = |ca g - cm - (x - mean) cb| <= |ca| max|g| + |cm| + |r m2| max|xhat| PER PLANE (x - mean = xhat / r): the maxima of one plane
+            // against the coefficients of the same plane -- a global max|g| max|ca| multiplies maxima of different channels (a channel group
+            // with a tiny variance has a huge rstd and tiny gradients) and wastes the f16 pair's precision window
+            float bnd = 0.f;
+            for (int j = t; j < cg; j += 256) {
+                const int c = g * cg + j, plane = b * a.C + c;
+                const float* pm = a.wmax + 2 * ((size_t)a.wave0[l] + (size_t)plane * cpp);
+                float pg = 0.f, px = 0.f;
+                for (int k = 0; k < cpp; ++k) { pg = fmaxf(pg, pm[2 * k]); px = fmaxf(px, pm[2 * k + 1]); }
+                bnd = fmaxf(bnd, fabsf(r * (a.gamma ? a.gamma[c] : 1.f)) * pg + fabsf(r * m1) + fabsf(r * m2) * px);
+            }
+            bnd = wave_max(bnd) * 1.00001f;
+            if (lane == 0) atomic_max_bits(a.bound_out, __builtin_bit_cast(unsigned, bnd));
+        }
     }
 }
 
@@ -216,6 +239,7 @@ __global__ __launch_bounds__(256) void gg_apply_kernel(GgArgs a) {
 static int gg_fill(GgArgs& a, const float* const* x_host, const int32_t* level_hw_host, int L, int B, int C, int G, int relu) {
     if (!x_host || !level_hw_host || L < 1 || L > LGD_MAX_LEVELS || B < 1 || C < 1 || G < 1 || C % G) return LGD_EINVAL;
     a.L = L; a.B = B; a.C = C; a.G = G; a.relu = relu ? 1 : 0;
+    a.wmax = nullptr; a.bound_out = nullptr;
     long long w = 0;
     for (int l = 0; l < LGD_MAX_LEVELS; ++l) {
         a.x[l] = nullptr; a.dy[l] = nullptr; a.out[l] = nullptr;
@@ -296,7 +320,7 @@ int lgd_gn_group_bwd(const float* const* x_host, const float* const* dy_host, co
 
 int lgd_gn_group_bwd_coef(const float* const* x_host, const float* const* dy_host, const int32_t* level_hw_host, int L, int B, int C,
                           int G, const float* gamma, const float* stats, double* ws, float* bstats, float* plane_sums, float* coef,
-                          void* stream) {
+                          float* wmax, uint32_t* bound_out, void* stream) {
     lgd::GgArgs a;
     if (lgd::gg_fill(a, x_host, level_hw_host, L, B, C, G, 0) != LGD_OK || !dy_host || !stats || !ws || !bstats || !plane_sums || !coef)
         return LGD_EINVAL;
@@ -305,6 +329,7 @@ int lgd_gn_group_bwd_coef(const float* const* x_host, const float* const* dy_hos
         a.dy[l] = dy_host[l];
     }
     a.gamma = gamma; a.ws = ws; a.stats = const_cast<float*>(stats); a.bstats = bstats; a.plane_sums = plane_sums; a.coef = coef;
+    a.wmax = wmax; a.bound_out = (wmax && bound_out) ? bound_out : nullptr;
     hipStream_t s = (hipStream_t)stream;
     LGD_LAUNCH("gn_group_bwd_stats_kernel", lgd::gg_stats_kernel<1>, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
     LGD_LAUNCH("gn_group_bwd_finalize_kernel", lgd::gg_finalize_kernel<1>, dim3(L * B * G), dim3(256), 0, s, a);

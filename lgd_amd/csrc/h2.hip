@@ -455,21 +455,6 @@ __global__ __launch_bounds__(64) void h2_link_bound_kernel(const unsigned* __res
     if (t == 0) out[0] = __builtin_bit_cast(unsigned, tot);
 }
 
-// bound of the GroupNorm-backward gradient the adjoint output transform forms on the fly (wino6_out_t_body<.., GN>): dy = ca g - cm - (y - mu) cb
-// per (level, image, channel), from max |g| and max |y| of the maps: max over the table of |ca| Ag + |cm| + |cb| (Ay + |mu|)
-__global__ __launch_bounds__(256) void h2_gn_bound_kernel(const float* __restrict__ coef, long n, const unsigned* __restrict__ ag, const unsigned* __restrict__ ay,
-                                                          unsigned* __restrict__ out) {
-    __shared__ float slots[4];
-    const float Ag = __builtin_bit_cast(float, *ag), Ay = __builtin_bit_cast(float, *ay);
-    float am = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const float4 k = reinterpret_cast<const float4*>(coef)[i];
-        am = fmaxf(am, fmaf(fabsf(k.x), Ag, fabsf(k.y)) + fabsf(k.w) * (Ay + fabsf(k.z)));
-    }
-    am = wave_max(am) * 1.00001f;
-    block_max_bits(out, am, slots);
-}
-
 constexpr int kFwdLds256 = 3 * (2 * 8 * 1024 + 8192), kFwdLds128 = 3 * (2 * 4 * 1024 + 8192), kDwLds = 4 * 2 * 256 * 64;
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, device)
@@ -601,13 +586,6 @@ int lgd_h2_amax_filters(const float* const* w_host, const float* const* scale_ho
     a.row_off[K] = off; a.out = out_bits; a.K = K; a.row = row_elems;
     hipStream_t st = (hipStream_t)stream;
     LGD_LAUNCH("h2_amax_filter_kernel", lgd::h2_amax_filter_kernel, dim3(off), dim3(256), 0, st, a);
-    return lgd::check_launch();
-}
-
-int lgd_h2_gn_bound(const float* coef, long long n_entries, const uint32_t* amax_g, const uint32_t* amax_y, uint32_t* out_bits, void* stream) {
-    if (!coef || !amax_g || !amax_y || !out_bits || n_entries < 1) return LGD_EINVAL;
-    const unsigned grid = (unsigned)((n_entries + 255) / 256 > 256 ? 256 : (n_entries + 255) / 256);
-    LGD_LAUNCH("h2_gn_bound_kernel", lgd::h2_gn_bound_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, coef, (long)n_entries, amax_g, amax_y, out_bits);
     return lgd::check_launch();
 }
 

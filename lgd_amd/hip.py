@@ -46,7 +46,7 @@ SIGNATURES = {
     "lgd_gn_group_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn_group_stats_affine": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gn_group_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
-    "lgd_gn_group_bwd_coef": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gn_group_bwd_coef": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_fcos_targets": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_ctx_relu_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_ctx_relu_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
@@ -90,7 +90,6 @@ SIGNATURES = {
     "lgd_h2_amax_maps": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp]),
     "lgd_h2_amax_filters": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_h2_link_bound": (c_i, [c_fp, c_fp, c_fp]),
-    "lgd_h2_gn_bound": (c_i, [c_fp, ctypes.c_longlong, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_out_t_gn_h2": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_in_h2": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_out_t_h2": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
@@ -98,6 +97,9 @@ SIGNATURES = {
     "lgd_wino_out_amax": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_in_t_amax": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_filter_images_h2": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gemm2h_image_bytes": (c_sz, [c_i, c_i, c_i]),
+    "lgd_gemm2h_split": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_gemm2h": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "lgd_relu_rowbits_words": (c_sz, [ctypes.c_longlong, c_i]),
     "lgd_relu_rowbits_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_i, c_fp, c_fp]),
     "lgd_relu_bits_words": (c_sz, [ctypes.c_longlong]),

@@ -1467,14 +1467,13 @@ class _Conv3x3GN(torch.autograd.Function):
             psums = torch.empty((L * N, Cos[k], 2), dtype=torch.float32, device=dev)
             coef = torch.empty((L * N, Cos[k], 4), dtype=torch.float32, device=dev)
             _count_bytes("gn_group_bwd_stats_kernel", 2 * px * Cos[k])
+            wmax = torch.empty(gws.numel(), dtype=torch.float32, device=dev) if h2 else None   # chunk maxima of |g| and |xhat|: the gradient's bound per plane
             hip.check(lib.lgd_gn_group_bwd_coef(hip.ptr_array(yk), hip.ptr_array(gk), hw, L, N, Cos[k], groups,
                                                 hip.ptr(gammas[k]) if gammas[k] is not None else None, hip.ptr(stats[k]), hip.ptr(gws),
-                                                hip.ptr(bst), hip.ptr(psums), hip.ptr(coef), hip.stream_ptr()), "lgd_gn_group_bwd_coef")
+                                                hip.ptr(bst), hip.ptr(psums), hip.ptr(coef), hip.ptr(wmax) if h2 else None, hip.ptr(bound) if h2 else None,
+                                                hip.stream_ptr()), "lgd_gn_group_bwd_coef")
             _count_bytes("wino_out_t_gn_kernel", (2 * px + fb) * Cos[k])
-            if h2:   # ONE scale for the stacked gradients: the bound accumulates over the K filters, the transforms run behind the loop
-                ag = _amax_bits(lib, gk, hw)
-                ay = ctx.yamax[k] if ctx.yamax[k] is not None else _amax_bits(lib, yk, hw)
-                hip.check(lib.lgd_h2_gn_bound(hip.ptr(coef), L * N * Cos[k], hip.ptr(ag), hip.ptr(ay), hip.ptr(bound), hip.stream_ptr()), "lgd_h2_gn_bound")
+            if h2:   # ONE scale for the stacked gradients: the bound (lgd_gn_group_bwd_coef) accumulates over the K filters, the transforms run behind the loop
                 coefs.append(coef)
             else:
                 hip.check(lib.lgd_wino_out_t_gn(hip.ptr_array(gk), hip.ptr_array(yk), hip.ptr(coef), hw, L, N, Cos[k], tile, hip.ptr(dM[:, c0]),
@@ -2073,8 +2072,13 @@ class _Subsample2(torch.autograd.Function):
 def subsample2(x):
     """every other pixel of every other row of an NCHW map [d2-memory: the stride of a 1x1 / stride 2 convolution, applied ahead of it]"""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and os.environ.get("LGD_SUBSAMPLE2", "1") != "0":
-        return _Subsample2.apply(x)
-    return x[:, :, ::2, ::2].contiguous()
+        y = _Subsample2.apply(x)
+    else:
+        y = x[:, :, ::2, ::2].contiguous()
+    tag = getattr(x, "_lgd_amax", None)
+    if tag is not None and tag[1] == x._version:   # (a subset of the pixels: the bound of the whole map holds)
+        _amax_tag([y], tag[0])
+    return y
 
 
 def stem_bias_relu_maxpool(y, bias):
@@ -2157,8 +2161,9 @@ def _conv1x1_epilogue(ctx, x, wf, scale, shift, residual, relu):
     bits = None
     if relu and any(ctx.needs_input_grad):
         bits = torch.empty(int(lib.lgd_relu_rowbits_words(N * Co, H * W)), dtype=torch.int32, device=x.device)
-    out = _timed_gemm3("pw_gemm3_fwd", a, b, None, residual=residual.view(N, Co, H * W) if residual is not None else None,
-                       shift=hip.dense_f32(shift) if shift is not None else None, relu=bool(relu), relu_bits=bits).view(N, Co, H, W)
+    r, amax = _pw_product("pw_gemm3_fwd", a, b, x, None, residual=residual.view(N, Co, H * W) if residual is not None else None,
+                          shift=hip.dense_f32(shift) if shift is not None else None, relu=bool(relu), relu_bits=bits)
+    out = _TaggedView(r, amax).view(N, Co, H, W)
     ctx.relu = bool(relu)
     ctx.rowbits = True
     ctx.save_for_backward(x, wf, scale, bits)
@@ -2173,6 +2178,9 @@ def _relu_bits_bwd(ctx, bits, dy):
                                                   hip.stream_ptr()), "lgd_relu_rowbits_bwd")
     else:
         hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()), "lgd_relu_bits_bwd")
+    tag = getattr(dy, "_lgd_amax", None)
+    if tag is not None and tag[1] == dy._version:   # (a mask only removes elements: the bound of dy holds for dz)
+        _amax_tag([dz], tag[0])
     return dz
 
 
@@ -2233,7 +2241,8 @@ class _PointwiseConvBNSkip(torch.autograd.Function):
                 a3 = acc.view(N, Ci, -1)
                 wt, dz3 = wf.view(Co, Ci).t().unsqueeze(0).expand(N, Ci, Co), dz.view(N, Co, -1)
                 if own and _gemm3_ok(wt, dz3, a3, accumulate=True):   # csrc/gemm3.hip with its accumulators initialised from the gradient
-                    dx = _timed_gemm3("pw_gemm3_dx", wt, dz3, a3, accumulate=True).view_as(x)
+                    r, amax = _pw_product("pw_gemm3_dx", wt, dz3, dz, a3, accumulate=True)
+                    dx = _TaggedView(r, amax).view(*x.shape)
                 else:
                     dx = _timed_gemm("pw_gemm_dx", _pw_flops(x, Co), torch.baddbmm, a3, wt, dz3, **({"out": a3} if own else {})).view_as(x)
         if ctx.needs_input_grad[1] and dz is not None:
@@ -2454,6 +2463,53 @@ def gemm3_bmm(a, b, out=None, accumulate=False, residual=None, shift=None, relu=
     return out
 
 
+_GEMM2H_ON = os.environ.get("LGD_GEMM2H", "1") != "0"   # 0: the student's 1x1 convolutions on the bf16x3 form of csrc/gemm3.hip (A/B runs)
+
+
+def gemm2h_bmm(a, b, b_amax, out=None, accumulate=False, residual=None, shift=None, relu=False, relu_bits=None, amax_out=None):
+    """gemm3_bmm in the f16x2 form (lgd_gemm2h: three MFMAs per k-step instead of six): a must be ONE matrix for the whole batch (stride 0: the
+    student's 1x1 convolutions); b_amax: int32[1], float bits of a bound of max |b| (the tag its producer left, or _amax_bits)."""
+    lib = hip.load()
+    nb, M, K = a.shape
+    N = b.shape[2]
+    if out is None:
+        if accumulate:
+            raise hip.LgdHipError("accumulate needs the tensor to accumulate onto")
+        out = torch.empty((nb, M, N), dtype=torch.float32, device=a.device)
+    if accumulate:
+        if residual is not None:
+            raise hip.LgdHipError("accumulate and residual are the same slot of the epilogue")
+        residual = out
+    if residual is not None and (tuple(residual.shape) != (nb, M, N) or residual.stride(2) != 1 or residual.dtype != torch.float32):
+        raise hip.LgdHipError("residual must be an fp32 (nb, M, N) map with its last axis contiguous")
+    if shift is not None and (shift.numel() != M or not shift.is_contiguous() or shift.dtype != torch.float32):
+        raise hip.LgdHipError("shift must be M contiguous fp32 values")
+    if not (a.stride(0) == 0 or nb == 1):
+        raise hip.LgdHipError("lgd_gemm2h takes one filter matrix for the whole batch")
+    a0 = a[0]
+    # max |w|: one small launch per filter and step -- W and its transposed view (forward and input gradient) are views of ONE tensor object, which
+    # carries the word with the version it was taken at (keyed by the object, never by its address: the allocator hands the same address to next
+    # step's filter)
+    root = a0._base if a0._base is not None else a0
+    cached = getattr(root, "_lgd_w_amax", None)
+    if cached is not None and cached[1] == root._version and cached[2] == root.numel() and a0.numel() == root.numel():
+        a_amax = cached[0]
+    else:
+        a_amax = torch.linalg.vector_norm(a0, float("inf")).reshape(1).view(torch.int32)
+        if a0.numel() == root.numel():
+            root._lgd_w_amax = (a_amax, root._version, root.numel())
+    img = torch.empty(lib.lgd_gemm2h_image_bytes(1, M, K), dtype=torch.uint8, device=a.device)
+    a_inv = torch.empty(1, dtype=torch.float32, device=a.device)
+    st = hip.stream_ptr()
+    hip.check(lib.lgd_gemm2h_split(hip.ptr(a0), 0, a0.stride(0), a0.stride(1), 1, M, K, hip.ptr(a_amax), hip.ptr(img), hip.ptr(a_inv), st), "lgd_gemm2h_split")
+    hip.check(lib.lgd_gemm2h(hip.ptr(img), 1, hip.ptr(a_inv), hip.ptr(b), hip.ptr(b_amax), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1),
+                             hip.ptr(residual) if residual is not None else None, residual.stride(0) if residual is not None else 0,
+                             residual.stride(1) if residual is not None else 0, hip.ptr(shift) if shift is not None else None, 1 if relu else 0,
+                             hip.ptr(relu_bits) if relu_bits is not None else None, hip.ptr(amax_out) if amax_out is not None else None, nb, M, N, K, st),
+              "lgd_gemm2h")
+    return out
+
+
 def gemm3_image_bmm(img, b, out):
     """out[i] = A[i] @ b[i] with A given as its gemm3 image (_FilterImage of an (nb, M, K) operand)"""
     nb, M, K = img.shape
@@ -2494,11 +2550,39 @@ class _TaggedView:
         return v
 
 
-def _tagged_gemm3(name, a, b):
-    """_timed_gemm3 whose epilogue also leaves max |C| (the f16x2 scale of a 3x3 convolution that consumes the map: conv1 -> conv2 of a
-    bottleneck forward, conv3 -> conv2 backward)"""
-    amax = _zero_words(b.device) if _tags_wanted(b.shape[0] * b.shape[2] // 36) else None
-    return _TaggedView(_timed_gemm3(name, a, b, None, amax_out=amax), amax)
+def _pw_product(name, a, b, bmap, out=None, accumulate=False, **epi):
+    """a product of a 1x1 convolution on csrc/gemm3.hip -- a (nb, M, K) the filter as a stride-0 batch, b (nb, K, HW) the view of the NCHW map
+    `bmap` (its magnitude tag is looked up on it) -- in the f16x2 form (lgd_gemm2h) unless switched off, with the epilogue's max |C| recorded
+    for the consumer.  Returns (out, amax word or None)."""
+    amax = _zero_words(b.device) if (_tags_wanted(b.shape[0] * b.shape[2] // 36) or _GEMM2H_ON) else None
+    tag = getattr(bmap, "_lgd_amax", None) if (_GEMM2H_ON and _H2_TAGS) else None
+    if tag is not None and tag[1] == bmap._version and (a.stride(0) == 0 or a.shape[0] == 1):
+        # the f16x2 form needs B's bound: taken where the producing kernel left it (every product and output transform of this library does); a map
+        # without one (a sum autograd built, the stem's output) runs the bf16x3 form, which needs none -- never a pass over the map for a 1x1 product
+        b_amax = tag[0]
+        fn = lambda: gemm2h_bmm(a, b, b_amax, out, accumulate, amax_out=amax, **epi)   # noqa: E731
+        name = name.replace("_gemm3_", "_gemm2h_")
+    else:
+        fn = lambda: gemm3_bmm(a, b, out, accumulate, amax_out=amax, **epi)   # noqa: E731
+    if not _TIMER_ON:
+        return fn(), amax
+    nb_, M_, K_ = a.shape
+    reads_c = accumulate or epi.get("residual") is not None
+    _count_bytes("gemm2h_kernel" if "_gemm2h_" in name else "gemm3_kernel", 4 * nb_ * b.shape[2] * (K_ + M_ * (2 if reads_c else 1)) + 4 * M_ * K_)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    _GEMM_EVENTS.append((name, e0, e1))
+    _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + 2 * nb_ * M_ * K_ * b.shape[2]
+    return r, amax
+
+
+def _tagged_gemm3(name, a, b, bmap):
+    """_pw_product as a view factory: the (N, C, H, W) view of the result carries the epilogue's max |C| (the f16x2 scale of the convolution that
+    consumes the map: conv1 -> conv2 of a bottleneck forward, conv3 -> conv2 backward)"""
+    r, amax = _pw_product(name, a, b, bmap)
+    return _TaggedView(r, amax)
 
 
 def _wino_gemm(name, a, b, out=None):
@@ -2595,7 +2679,9 @@ def _amax_bits(lib, xs, hw_levels, pre=None, affine=False):
     """int32[1] device tensor: float bits of a bound of max |act(x)| over the maps xs (all (N, C, H_l, W_l); act = identity, relu(x + pre[c]) or the
     (L*N, C, 2) scale / shift form).  Tags left by the producing kernels are used where every map has one; otherwise one pass over the maps."""
     dev = xs[0].device
-    tags = [getattr(x, "_lgd_amax", None) for x in xs] if _H2_TAGS else [None]
+    # (an affine pre-activation takes its own pass: max|x| max|scale| + max shift multiplies maxima of DIFFERENT channels -- a GroupNorm channel with a
+    #  tiny variance has a huge scale and small values -- and a bound 2^10 too loose spends the f16 pair's precision window on nothing)
+    tags = [getattr(x, "_lgd_amax", None) for x in xs] if (_H2_TAGS and not affine) else [None]
     if all(t is not None and t[1] == x._version for t, x in zip(tags, xs)):
         uniq = []
         for t in tags:
@@ -2605,10 +2691,7 @@ def _amax_bits(lib, xs, hw_levels, pre=None, affine=False):
         if pre is None:
             return a
         af = a.view(torch.float32)
-        if affine:   # |relu(x s + b)| <= max(0, max|x| max|s| + max b)
-            b = (af * pre[..., 0].abs().max() + pre[..., 1].max()).clamp_min(0.0)
-        else:
-            b = (af + pre.max()).clamp_min(0.0)
+        b = (af + pre.max()).clamp_min(0.0)   # |relu(x + b[c])| <= max(0, max|x| + max b)
         return (b * 1.000001).view(torch.int32)   # (the roundings of the bound's own arithmetic)
     out = _zero_words(dev)
     L, N, C = len(xs), xs[0].shape[0], xs[0].shape[1]
@@ -2729,7 +2812,7 @@ def _conv1x1_fwd(x, wf):
     Co = wf.shape[0]
     a, b = wf.view(1, Co, Ci).expand(N, Co, Ci), x.view(N, Ci, H * W)
     if _gemm3_ok(a, b, None):   # csrc/gemm3.hip: one bf16x3 image of the filter for the whole batch
-        return _tagged_gemm3("pw_gemm3_fwd", a, b).view(N, Co, H, W)
+        return _tagged_gemm3("pw_gemm3_fwd", a, b, x).view(N, Co, H, W)
     return _timed_gemm("pw_gemm_fwd", _pw_flops(x, Co), torch.bmm, a, b).view(N, Co, H, W)
 
 
@@ -2739,7 +2822,7 @@ def _conv1x1_dx(dz, x, wf):
     Co = wf.shape[0]
     a, b = wf.view(1, Co, Ci).transpose(1, 2).expand(N, Ci, Co), dz.view(N, Co, H * W)
     if _gemm3_ok(a, b, None):
-        return _tagged_gemm3("pw_gemm3_dx", a, b).view(N, Ci, H, W)
+        return _tagged_gemm3("pw_gemm3_dx", a, b, dz).view(N, Ci, H, W)
     return _timed_gemm("pw_gemm_dx", _pw_flops(x, Co), torch.bmm, a, b).view(N, Ci, H, W)
 
 
