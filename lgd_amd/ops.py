@@ -2770,11 +2770,14 @@ def _h2_dw(lib, dM, dm_inv, V, v_inv, Ct, Ci):
     T = V.shape[2]
     dev = V.device
     S = lib.lgd_h2_dw_splits(64, Ct, Ci, T)
-    out = torch.empty((S, 64, Ct, Ci), dtype=torch.float32, device=dev)   # S > 1: split-K partials, added by the filter transform's adjoint while it reads
+    out = torch.empty((64, Ct, Ci), dtype=torch.float32, device=dev)
+    # (the split-K partials are added by lgd_h2_dw's own 12 us reduce launch: reading them inside the filter transform's adjoint instead
+    #  -- lgd_wino_filter_bwd_parts, one launch less -- measured 37 us against 10 + 12: its 256 workgroups walk S x 64 strided planes each)
+    part = torch.empty((S, 64, Ct, Ci), dtype=torch.float32, device=dev) if S > 1 else None
     fn = lambda: hip.check(lib.lgd_h2_dw(hip.ptr(dM), 4 * 64 * T, 4 * T, 4 * dM.numel(), hip.ptr(dm_inv), 1, hip.ptr(V), 4 * 64 * T, 4 * T, 4 * V.numel(),   # noqa: E731
-                                         hip.ptr(v_inv), 0, hip.ptr(out) if S == 1 else None, hip.ptr(out) if S > 1 else None, S, 64, Ct, Ci, T,
-                                         hip.stream_ptr()), "lgd_h2_dw")
-    _h2_timed("h2_dw_kernel", 2.0 * 64 * Ct * Ci * T, 4.0 * 64 * T * (Ct + Ci) + 4.0 * 64 * Ct * Ci * S, fn)
+                                         hip.ptr(v_inv), 0, hip.ptr(out), hip.ptr(part) if part is not None else None, S, 64, Ct, Ci, T, hip.stream_ptr()),
+                           "lgd_h2_dw")
+    _h2_timed("h2_dw_kernel", 2.0 * 64 * Ct * Ci * T, 4.0 * 64 * T * (Ct + Ci) + 4.0 * 64 * Ct * Ci * (2 * S if S > 1 else 1), fn)
     return out
 
 
