@@ -464,7 +464,8 @@ def main():
         gl = {n: v for n, v in kernels.items() if n.startswith("wino_gemm_")}
         g2 = {n: v for n, v in kernels.items() if n.startswith("pw_gemm2h_")}
         roofline_mfma_1x1 = (mfma_object(g2, "lgd_gemm2h (csrc/gemm3.hip, f16x2 form): the student's 1x1 convolutions, forward + input gradient (filter as a two-piece f16 image, "
-                                         "activations split in registers, 3 of 4 cross products on v_mfma_f32_32x32x16_f16, fp32 accumulate; image launch included)",
+                                         "activations split in registers) and weight gradient (lgd_h2_pwdw: both operands split in registers); 3 of 4 cross products on "
+                                         "v_mfma_f32_32x32x16_f16, fp32 accumulate; image launch included",
                                          MFMA_BF16_PEAK_TFLOPS, 3.0) if g2 else None)
         roofline_mfma_lib = None
         if g3:

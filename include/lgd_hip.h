@@ -415,6 +415,13 @@ int lgd_h2_dw_splits(int nb, int M, int N, int T);
 int lgd_h2_dw(const void* A, long long a_rs, long long a_sb, long long a_bytes, const float* a_inv, int a_inv_per_batch, const void* B, long long b_rs,
               long long b_sb, long long b_bytes, const float* b_inv, int b_inv_per_batch, float* out, float* partials, int S, int nb, int M, int N, int T,
               void* stream);
+/* lgd_h2_pwdw: the weight gradient of a 1x1 convolution, partials[s] (M x N) = sum over split s of the (image, pixel) range of dz[n][m][px] x[n][k][px]
+ * (dz (nimg, M, HW), x (nimg, N, HW) fp32 NCHW maps, HW % 4 == 0), both operands scaled by the powers of two their bounds *a_amax / *b_amax prescribe and
+ * split into f16 pairs in registers; S = lgd_h2_pwdw_splits(...) partials, added (with the frozen per-row scale) by lgd_sum_batch_scale(partials, scale,
+ * S, M, N, dw). */
+int lgd_h2_pwdw_splits(int nimg, int M, int N, int HW);
+int lgd_h2_pwdw(const float* dz, const float* x, const uint32_t* a_amax, const uint32_t* b_amax, float* partials, int S, int nimg, int M, int N, int HW,
+                void* stream);
 int lgd_h2_amax_maps(const float* const* x_host, const int32_t* level_hw_host, int L, int N, int C, const float* pre_bias, const float* pre_affine,
                      uint32_t* out_bits, int accumulate, void* stream);
 int lgd_h2_amax_filters(const float* const* w_host, const float* const* scale_host, const int32_t* rows_host, int K, int row_elems, uint32_t* out_bits,

@@ -352,6 +352,143 @@ __global__ void h2_reduce_kernel(const float* __restrict__ P, float* __restrict_
     reinterpret_cast<float4*>(out)[i] = a;
 }
 
+// ------------------------------------------------------------------------------------------------------------------ 1x1 weight gradient
+// P[s] (M x N) = sum over the (image, pixel) range of split s of A[n][m][px] B[n][k][px]:  dW of a pointwise convolution, A = dz (N, M, HW),
+// B = x (N, Nn, HW) fp32 NCHW maps.  Both operands are activations that exist only as fp32: they are scaled (2^ea, 2^eb from their bounds) and
+// split into f16 pairs in REGISTERS -- 3 VALU per element, against 24 MFMAs per 16 pixels of a 256 x 256 tile: a quarter of the MFMA time, where
+// the bf16x3 form of both operands (11 per pair, 48 MFMAs) was issue-bound at the library's speed.  256 x 256 x 32 tile,
+// 8 waves (128 x 64 each), register double buffering (the loads of stage s + 1 fly under the MFMAs of stage s), two 64 KB LDS buffers, rows of
+// 128 B = 8 chunks [sub-step][piece][k-group] swizzled by (row >> 1) & 7 like the DMA-fed form; split-K over the flat (image, 32-pixel stage) index,
+// partials summed (and scaled by a frozen per-row factor) by lgd_sum_batch_scale.  HW % 4 == 0.
+struct PwDwP {
+    const float* A; const float* B;      // (n, M, HW), (n, N, HW) contiguous
+    float* P;                            // partials [S][M][N]
+    const unsigned* a_amax; const unsigned* b_amax;
+    int nimg, M, N, HW, spi, nstage, S, per, mt, nt;   // spi: 32-pixel stages per image
+};
+
+__global__ __launch_bounds__(512) void h2_pwdw_kernel(const PwDwP p) {
+    constexpr int ROWB = 128, OPB = 256 * ROWB, BUF = 2 * OPB;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wm = w >> 2, wn = w & 3;
+    int id = blockIdx.x;
+    const int tn = id % p.nt; id /= p.nt;
+    const int tm = id % p.mt; id /= p.mt;
+    const int s = id;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int st0 = s * p.per, st1 = min(st0 + p.per, p.nstage), nst = st1 - st0;
+    const int ea = h2_exponent(*p.a_amax, 0), eb = h2_exponent(*p.b_amax, 0);
+    const float sa = h2_pow2(ea), sb = h2_pow2(eb);
+    // loads: thread -> (row = t >> 3 (+ 64 i), 16-byte chunk q = t & 7 of the row's 32 pixels); a row's 128 bytes = 8 consecutive lanes
+    const int q = t & 7, r0 = t >> 3;
+    const float* pa[4]; const float* pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = min(m0 + r0 + 64 * i, p.M - 1), rb = min(n0 + r0 + 64 * i, p.N - 1);   // rows past the operand repeat its last one: never stored
+        pa[i] = p.A + (size_t)ra * p.HW + 4 * q;
+        pb[i] = p.B + (size_t)rb * p.HW + 4 * q;
+    }
+    const size_t a_img = (size_t)p.M * p.HW, b_img = (size_t)p.N * p.HW;
+    float4 va[4], vb[4];
+    auto load = [&](int stg) {
+        const int n = stg / p.spi, ps = stg - n * p.spi;
+        const int px = 32 * ps + 4 * q;
+        const bool ok = px < p.HW;       // (HW % 4 == 0: a chunk lies inside the plane or beyond it)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            va[i] = ok ? ldg_stream4(pa[i] + n * a_img + 32 * ps) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[i] = ok ? ldg_stream4(pb[i] + n * b_img + 32 * ps) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // LDS: chunk c = sub * 4 + piece * 2 + g holds 8 consecutive pixels (16 * sub + 8 * g ..) of one piece; this thread's 4 pixels are half q & 1 of
+    // chunk (sub = q >> 2, g = (q >> 1) & 1)
+    const int csub = q >> 2, cg = (q >> 1) & 1, half = q & 1;
+    auto store = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 64 * i, sw = (row >> 1) & 7;
+            uint32_t h0, m0_, h1, m1_;
+            {
+                typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
+                typedef float fx2 __attribute__((ext_vector_type(2)));
+                auto sp = [](float t0, float t1, uint32_t& h, uint32_t& m) {
+                    const hx2 hh = __builtin_convertvector((fx2){t0, t1}, hx2);
+                    const hx2 mm = __builtin_convertvector((fx2){t0 - (float)hh[0], t1 - (float)hh[1]}, hx2);
+                    h = __builtin_bit_cast(uint32_t, hh); m = __builtin_bit_cast(uint32_t, mm);
+                };
+                sp(va[i].x * sa, va[i].y * sa, h0, m0_); sp(va[i].z * sa, va[i].w * sa, h1, m1_);
+                char* d = buf + row * ROWB + half * 8;
+                *reinterpret_cast<u32x2*>(d + (((csub * 4 + cg) ^ sw) << 4)) = (u32x2){h0, h1};
+                *reinterpret_cast<u32x2*>(d + (((csub * 4 + 2 + cg) ^ sw) << 4)) = (u32x2){m0_, m1_};
+                sp(vb[i].x * sb, vb[i].y * sb, h0, m0_); sp(vb[i].z * sb, vb[i].w * sb, h1, m1_);
+                d += OPB;
+                *reinterpret_cast<u32x2*>(d + (((csub * 4 + cg) ^ sw) << 4)) = (u32x2){h0, h1};
+                *reinterpret_cast<u32x2*>(d + (((csub * 4 + 2 + cg) ^ sw) << 4)) = (u32x2){m0_, m1_};
+            }
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+    const int rib = lane & 31, g = lane >> 5;
+    // a wave whose 128 rows (64 columns) lie beyond M (N) multiplies nothing: the other wave of its SIMD gets the pipe (C' = 128 layers)
+    const bool live = m0 + wm * 128 < p.M && n0 + wn * 64 < p.N;
+    if (nst > 0) {
+        const int sw = (rib >> 1) & 7;
+        const int abase = (wm * 128 + rib) * ROWB, bbase = OPB + (wn * 64 + rib) * ROWB;
+        load(st0);
+        store(lds);
+        __syncthreads();
+        for (int it = 0; it < nst; ++it) {
+            const char* cur = lds + (it & 1) * BUF;
+            if (it + 1 < nst) load(st0 + it + 1);
+            if (live) {
+#pragma unroll
+                for (int sb_ = 0; sb_ < 2; ++sb_) {
+                    f16x8 fa[2][4], fb[2][2];
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int xo = ((sb_ * 4 + pc * 2 + g) ^ sw) << 4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fa[pc][i] = *reinterpret_cast<const f16x8*>(cur + abase + i * 32 * ROWB + xo);
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn) fb[pc][jn] = *reinterpret_cast<const f16x8*>(cur + bbase + jn * 32 * ROWB + xo);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][jn], acc[i][jn], 0, 0, 0);
+                }
+            }
+            if (it + 1 < nst) store(lds + ((it + 1) & 1) * BUF);   // (the other buffer: everybody left it before the previous barrier)
+            __syncthreads();
+        }
+    }
+    const float inv = h2_pow2(-(ea + eb));
+    float* P = p.P + (size_t)s * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * g, n = n0 + wn * 64 + jn * 32 + rib;
+                if (m < p.M && n < p.N) P[(size_t)m * p.N + n] = acc[i][jn][e] * inv;
+            }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ bounds of the operands
 // max |act(x)| over a list of NCHW maps (the pyramid levels), act = identity | relu(x + bias[c]) | relu(x * scale + shift) per (level, image,
 // channel): the bound the input transform's f16 scale is derived from.  Workgroup per 4096-element chunk of a plane.
@@ -455,7 +592,7 @@ __global__ __launch_bounds__(64) void h2_link_bound_kernel(const unsigned* __res
     if (t == 0) out[0] = __builtin_bit_cast(unsigned, tot);
 }
 
-constexpr int kFwdLds256 = 3 * (2 * 8 * 1024 + 8192), kFwdLds128 = 3 * (2 * 4 * 1024 + 8192), kDwLds = 4 * 2 * 256 * 64;
+constexpr int kFwdLds256 = 3 * (2 * 8 * 1024 + 8192), kFwdLds128 = 3 * (2 * 4 * 1024 + 8192), kDwLds = 4 * 2 * 256 * 64, kPwDwLds = 2 * 2 * 256 * 128;
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, device)
 int ensure_attrs() {
@@ -470,6 +607,7 @@ int ensure_attrs() {
     for (const void* f : f128)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds128) != hipSuccess) return LGD_ELAUNCH;
     if (hipFuncSetAttribute((const void*)h2_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLds) != hipSuccess) return LGD_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)h2_pwdw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPwDwLds) != hipSuccess) return LGD_ELAUNCH;
     done[dev] = true;
     return LGD_OK;
 }
@@ -548,6 +686,32 @@ int lgd_h2_dw(const void* A, long long a_rs, long long a_sb, long long a_bytes, 
         if (n & 3) return LGD_EINVAL;
         LGD_LAUNCH("h2_reduce_kernel", lgd::h2_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, partials, out, n / 4, S);
     }
+    return lgd::check_launch();
+}
+
+int lgd_h2_pwdw_splits(int nimg, int M, int N, int HW) {
+    if (nimg <= 0 || M <= 0 || N <= 0 || HW <= 0) return 1;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256), nstage = (long)nimg * ((HW + 31) / 32);
+    long S = (cus + tiles - 1) / tiles;           // one workgroup per CU
+    while (S > 1 && nstage / S < 8) --S;
+    return (int)(S < 1 ? 1 : S);
+}
+
+// partials[s] (M x N, row-major) = sum over split s of the (image, pixel) range of dz[n][m][px] x[n][k][px]; the caller adds the S partials
+// (lgd_sum_batch_scale: fixed order, with the frozen per-row scale).  a_amax / b_amax: bounds of |dz| / |x| (float bits).
+int lgd_h2_pwdw(const float* dz, const float* x, const uint32_t* a_amax, const uint32_t* b_amax, float* partials, int S, int nimg, int M, int N, int HW,
+                void* stream) {
+    if (!dz || !x || !a_amax || !b_amax || !partials || S < 1 || nimg < 1 || M < 1 || N < 1 || HW < 4 || (HW & 3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15))
+        return LGD_EINVAL;
+    if (lgd::ensure_attrs() != LGD_OK) return LGD_ELAUNCH;
+    lgd::PwDwP p;
+    p.A = dz; p.B = x; p.P = partials; p.a_amax = a_amax; p.b_amax = b_amax;
+    p.nimg = nimg; p.M = M; p.N = N; p.HW = HW; p.spi = (HW + 31) / 32; p.nstage = nimg * p.spi; p.S = S; p.per = (p.nstage + S - 1) / S;
+    p.mt = (M + 255) / 256; p.nt = (N + 255) / 256;
+    LGD_LAUNCH("h2_pwdw_kernel", lgd::h2_pwdw_kernel, dim3((unsigned)(S * p.mt * p.nt)), dim3(512), lgd::kPwDwLds, (hipStream_t)stream, p);
     return lgd::check_launch();
 }
 

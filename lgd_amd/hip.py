@@ -87,6 +87,8 @@ SIGNATURES = {
     "lgd_h2_fwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "lgd_h2_dw_splits": (c_i, [c_i, c_i, c_i, c_i]),
     "lgd_h2_dw": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "lgd_h2_pwdw_splits": (c_i, [c_i, c_i, c_i, c_i]),
+    "lgd_h2_pwdw": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "lgd_h2_amax_maps": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp]),
     "lgd_h2_amax_filters": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_h2_link_bound": (c_i, [c_fp, c_fp, c_fp]),

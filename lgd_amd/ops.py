@@ -2035,14 +2035,39 @@ def bias_act(x, bias=None, residual=None, relu=True):
     return _BiasAct.apply(x, bias, residual, bool(relu))
 
 
+def _valid_tag(t):
+    tag = getattr(t, "_lgd_amax", None) if _H2_TAGS else None
+    return tag[0] if tag is not None and tag[1] == t._version else None
+
+
 def _pointwise_dw(dz, x, scale=None):
-    """dW (Co, Ci, 1, 1) = scale[o] * sum_n dz[n] (Co x HW) @ x[n]^T (HW x Ci): per-image NT GEMMs on the NCHW maps (one batched
-    launch), then batch sum + frozen scale in one small kernel."""
+    """dW (Co, Ci, 1, 1) = scale[o] * sum_n dz[n] (Co x HW) @ x[n]^T (HW x Ci).  Where both maps carry their producers' maxima: lgd_h2_pwdw (both
+    operands split into f16 pairs in registers, split-K over (image, pixel) ranges) -- otherwise per-image NT GEMMs of the library on the NCHW maps
+    (one batched launch); the partials are added, with the frozen per-row scale, by one small kernel either way."""
     N, Co, Ci = dz.shape[0], dz.shape[1], x.shape[1]
-    part = _timed_gemm("pw_gemm_dw", _pw_flops(x, Co), torch.bmm, dz.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2))
+    HW = dz.shape[2] * dz.shape[3]
+    lib = hip.load()
+    ta, tb = (_valid_tag(dz), _valid_tag(x)) if (_GEMM2H_ON and _H2_ON) else (None, None)
+    if ta is not None and tb is not None and HW % 4 == 0 and Co >= 64 and Ci >= 64 and dz.is_contiguous() and x.is_contiguous():
+        S = lib.lgd_h2_pwdw_splits(N, Co, Ci, HW)
+        part = torch.empty((S, Co, Ci), dtype=torch.float32, device=dz.device)
+        fn = lambda: hip.check(lib.lgd_h2_pwdw(hip.ptr(dz), hip.ptr(x), hip.ptr(ta), hip.ptr(tb), hip.ptr(part), S, N, Co, Ci, HW, hip.stream_ptr()), "lgd_h2_pwdw")   # noqa: E731
+        if _TIMER_ON:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            _GEMM_EVENTS.append(("pw_gemm2h_dw", e0, e1))
+            _GEMM_FLOPS["pw_gemm2h_dw"] = _GEMM_FLOPS.get("pw_gemm2h_dw", 0) + _pw_flops(x, Co)
+        else:
+            fn()
+        nparts = S
+    else:
+        part = _timed_gemm("pw_gemm_dw", _pw_flops(x, Co), torch.bmm, dz.view(N, Co, -1), x.view(N, Ci, -1).transpose(1, 2))
+        nparts = N
     dw = torch.empty((Co, Ci, 1, 1), dtype=torch.float32, device=dz.device)
-    hip.check(hip.load().lgd_sum_batch_scale(hip.ptr(part), hip.ptr(scale) if scale is not None else None, N, Co, Ci, hip.ptr(dw),
-                                             hip.stream_ptr()), "lgd_sum_batch_scale")
+    hip.check(lib.lgd_sum_batch_scale(hip.ptr(part), hip.ptr(scale) if scale is not None else None, nparts, Co, Ci, hip.ptr(dw),
+                                      hip.stream_ptr()), "lgd_sum_batch_scale")
     return dw
 
 

@@ -451,3 +451,52 @@ def test_gemm3_and_h2_products_under_load():
         torch.cuda.synchronize()
         for q, l in zip(quiet, loud):
             assert torch.equal(q, l)
+
+
+@pytest.mark.parametrize("N,Co,Ci,H,W", [(3, 256, 128, 20, 28),     # one tile, 128 of its 256 columns used
+                                         (2, 512, 256, 13, 20),     # two row tiles; HW = 260: the last 32-pixel stage of an image is ragged
+                                         (4, 128, 512, 7, 12),      # C' = 128: half the waves idle; two column tiles
+                                         (1, 64, 2048, 5, 8),       # narrow map (one stage per image and a bit), 8 column tiles
+                                         (8, 1024, 256, 25, 44)])   # res4-sized: four row tiles, many stages per split
+def test_pointwise_weight_gradient_h2(N, Co, Ci, H, W):
+    """lgd_h2_pwdw (dW of a 1x1 convolution: both operands scaled and split into f16 pairs in registers, split-K over (image, pixel) ranges) +
+    lgd_sum_batch_scale against the fp64 sum over images and pixels and against the library's per-image NT GEMMs; bit-reproducible; operand
+    magnitudes 2^12 apart [d2-memory: BottleneckBlock 1x1 convolutions with FrozenBN; SURVEY.md appendix A]."""
+    hip, lib = _lib()
+    g = torch.Generator(device=DEV).manual_seed(N * 100 + Co)
+    dz = torch.randn((N, Co, H, W), device=DEV, generator=g) * 2.0 ** -9
+    x = torch.randn((N, Ci, H, W), device=DEV, generator=g) * 8.0
+    scale = torch.rand(Co, device=DEV, generator=g) + 0.5
+    ta = dz.abs().max().reshape(1).view(torch.int32)
+    tb = x.abs().max().reshape(1).view(torch.int32)
+    HW = H * W
+    S = lib.lgd_h2_pwdw_splits(N, Co, Ci, HW)
+
+    def run():
+        part = torch.full((S, Co, Ci), float("nan"), device=DEV)
+        hip.check(lib.lgd_h2_pwdw(hip.ptr(dz), hip.ptr(x), hip.ptr(ta), hip.ptr(tb), hip.ptr(part), S, N, Co, Ci, HW, hip.stream_ptr()), "lgd_h2_pwdw")
+        dw = torch.empty((Co, Ci), device=DEV)
+        hip.check(lib.lgd_sum_batch_scale(hip.ptr(part), hip.ptr(scale), S, Co, Ci, hip.ptr(dw), hip.stream_ptr()), "lgd_sum_batch_scale")
+        return dw
+    dw = run()
+    ref = torch.einsum("nop,ncp->oc", dz.double().view(N, Co, HW), x.double().view(N, Ci, HW)) * scale.double().view(-1, 1)
+    lib32 = torch.bmm(dz.view(N, Co, HW), x.view(N, Ci, HW).transpose(1, 2)).sum(0) * scale.view(-1, 1)
+    e, e_lib = float((dw.double() - ref).abs().max() / ref.abs().max()), float((lib32.double() - ref).abs().max() / ref.abs().max())
+    print("pwdw %dx%d over %d x %d px, S=%d: error vs fp64 %.2e (library per-image GEMMs + sum %.2e)" % (Co, Ci, N, HW, S, e, e_lib))
+    assert e <= 2e-6 and e <= 3 * e_lib + 2e-7
+    assert torch.equal(run(), dw)
+
+
+def test_filter_bwd_over_split_k_partials():
+    """lgd_wino_filter_bwd_parts (the filter transform's adjoint reading S split-K partials of dU, fixed order) == lgd_wino_filter_bwd of their sum"""
+    hip, lib = _lib()
+    Co, Ci, S = 48, 32, 3
+    g = torch.Generator(device=DEV).manual_seed(4)
+    parts = torch.randn((S, 64, Co, Ci), device=DEV, generator=g)
+    sc = torch.rand(Co, device=DEV, generator=g) + 0.5
+    a, b = torch.empty((Co, Ci, 3, 3), device=DEV), torch.empty((Co, Ci, 3, 3), device=DEV)
+    tot = (parts[0] + parts[1]) + parts[2]
+    st = hip.stream_ptr()
+    hip.check(lib.lgd_wino_filter_bwd(hip.ptr(tot), Co * Ci, hip.ptr(sc), Co, Ci, 6, hip.ptr(a), st), "lgd_wino_filter_bwd")
+    hip.check(lib.lgd_wino_filter_bwd_parts(hip.ptr(parts), Co * Ci, parts.stride(0), S, hip.ptr(sc), Co, Ci, hip.ptr(b), st), "lgd_wino_filter_bwd_parts")
+    assert torch.equal(a, b)
