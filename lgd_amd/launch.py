@@ -95,6 +95,17 @@ def pin_host_threads(local_rank, local_world, pci_bus_ids=None, max_threads=8):
     cpus = plan_affinity(local_rank, local_world, allowed, node_of_rank, cpus_of_node)
     if not cpus:
         return None
+    # every thread of the process, not only the calling one: the HIP runtime's worker / signal threads exist as soon as the device has been
+    # touched and keep their old mask otherwise; threads created later inherit the caller's
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except OSError:
+            pass   # (a thread that exited in between)
     os.sched_setaffinity(0, cpus)
     n = max(1, min(len(cpus), max_threads))
     os.environ["OMP_NUM_THREADS"] = str(n)

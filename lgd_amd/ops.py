@@ -479,8 +479,10 @@ class _CtxShiftFold(torch.autograd.Function):
             return (None, *dxs)
         # d ctx[l, b, c] = the plane sum of the gradient: per-plane means in ONE pass over all levels (the GroupNorm statistics kernel with one
         # group per channel, fp64 partials) times the plane sizes
-        lib = hip.load()
         L, B, C, hw = ctx.meta
+        if not dxs[0].is_cuda:   # (the forward is pure torch and runs anywhere; so does this form of its adjoint)
+            return (torch.stack([d.sum((2, 3)) for d in dxs]), *dxs)
+        lib = hip.load()
         gs = [hip.dense_f32(d) for d in dxs]
         dev = gs[0].device
         ws = torch.empty(lib.lgd_gn_group_ws_doubles(hw, L, B, C), dtype=torch.float64, device=dev)

@@ -306,7 +306,6 @@ class StepFolds:
         # the views were rewritten behind autograd's back (a raw kernel on their storage): bump their version counters, so that a graph that
         # saved LAST step's folds (gradient accumulation, an evaluation forward between step and backward) raises instead of running its
         # backward with this step's filters
-        for v in self.views:
-            torch.autograd.graph.increment_version(v)
+        torch.autograd.graph.increment_version(self.flat)   # (one bump: the views share their base's version counter -- ADVICE r4)
         for m, v, sc in zip(self.mods, self.views, self.scales):
             m._step_fold = ((m.weight._version, id(sc)), v)
