@@ -496,7 +496,7 @@ constexpr int kAmaxChunk = 16384;   // elements of a plane per workgroup
 struct AmaxArgs {
     const float* maps[LGD_MAX_LEVELS];
     unsigned blk_off[LGD_MAX_LEVELS + 1];
-    int hw[LGD_MAX_LEVELS], cpp[LGD_MAX_LEVELS];   // plane size, chunks per plane
+    int hw[LGD_MAX_LEVELS], cpp[LGD_MAX_LEVELS], chunk[LGD_MAX_LEVELS];   // plane size, chunks per plane, elements per chunk (balanced, a multiple of 4)
     const float* bias; const float* affine;
     unsigned* out;
     int L, N, C;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void h2_amax_maps_kernel(AmaxArgs a) {
     if (a.affine) { const float2 v = reinterpret_cast<const float2*>(a.affine)[(size_t)l * a.N * a.C + plane]; s = v.x; sh = v.y; }
     else if (a.bias) sh = a.bias[plane % a.C];
     float am = 0.f;
-    const int e0 = ch * kAmaxChunk, e1 = min(hw, e0 + kAmaxChunk);
+    const int e0 = ch * a.chunk[l], e1 = min(hw, e0 + a.chunk[l]);   // (balanced: a 16,800-pixel p3 plane is two chunks of 8,400, not 16,384 + 416)
     if ((hw & 3) == 0) {
         for (int base = e0; base < e1; base += 4096) {   // four 16-byte loads per thread in flight
             float4 v[4];
@@ -724,6 +724,7 @@ int lgd_h2_amax_maps(const float* const* x_host, const int32_t* level_hw_host, i
         const long hw = (long)level_hw_host[2 * l] * level_hw_host[2 * l + 1];
         if (!x_host[l] || hw < 1 || hw >= (1L << 31)) return LGD_EINVAL;
         a.maps[l] = x_host[l]; a.hw[l] = (int)hw; a.cpp[l] = (int)((hw + lgd::kAmaxChunk - 1) / lgd::kAmaxChunk);
+        a.chunk[l] = (int)(((hw + a.cpp[l] - 1) / a.cpp[l] + 3) & ~3L);
         a.blk_off[l] = blk;
         const long nblk = (long)N * C * a.cpp[l];
         if (blk + nblk >= (1L << 31)) return LGD_EINVAL;

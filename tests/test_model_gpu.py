@@ -1236,3 +1236,26 @@ def test_full_size_multiscale_dcn_step():
         for k in la[i]:
             assert np.isfinite(la[i][k]) and abs(la[i][k] - lb[i][k]) <= 2e-4 * abs(lb[i][k]) + 1e-6, (i, k, la[i][k], lb[i][k])
     print("config 5, multi-scale %s: step-2 losses F(6x6) %s / F(4x4) %s" % (sizes, la[1], lb[1]))
+
+
+@pytest.mark.gpu
+def test_device_prefetcher_hands_over_the_loaders_batches():
+    """lgd_amd.data.DevicePrefetcher (the host -> device copy of batch k + 1 on a side stream under step k): the batches arrive on the device in
+    order, equal to the host tensors, while the step's stream is kept busy; exhausted after the last one [ref: retinanet.py:48 copies inside the step]."""
+    from lgd_amd.data import DevicePrefetcher, synthetic_batch
+    host = [synthetic_batch(2, 64, 96, 3, seed=100 + i, pin=True) for i in range(4)]
+    busy = torch.empty(1 << 24, device=DEV)
+    pf = DevicePrefetcher(iter(host), DEV)
+    n = 0
+    for b, h in zip(pf, host):
+        busy.mul_(1.0001)   # (work on the step's stream between hand-overs)
+        assert len(b) == len(h)
+        for x, y in zip(b, h):
+            assert x["image"].is_cuda and torch.equal(x["image"].cpu(), y["image"])
+            assert torch.equal(x["instances"].gt_boxes.tensor.cpu(), y["instances"].gt_boxes.tensor)
+            assert torch.equal(x["instances"].gt_classes.cpu(), y["instances"].gt_classes)
+            assert (x["height"], x["width"]) == (y["height"], y["width"])
+        n += 1
+    assert n == 4
+    with pytest.raises(StopIteration):
+        next(pf)
