@@ -2692,47 +2692,6 @@ def _amax_tag(maps, amax):
             m._lgd_amax = (amax, m._version)
 
 
-_FANOUT = os.environ.get("LGD_FANOUT", "1") != "0"   # 0: autograd sums the gradients of multiply-read maps itself (A/B runs)
-
-
-class _FanOut(torch.autograd.Function):
-    """k aliases of one map for k consumers (a stage output that feeds the next stage and an FPN lateral; an FPN inner map that feeds its output
-    convolution and the next level's up-sampling).  Forward: views, the magnitude tag copied.  Backward: the sum autograd would have formed --
-    but formed HERE, so that it can carry a bound: |g1 + ... + gk| <= max|g1| + ... + max|gk| where every incoming gradient has a valid tag (two
-    scalar launches), which lets the 1x1 products of the consumer's backward take the f16x2 form and a 3x3 backward skip its pass over the map."""
-
-    @staticmethod
-    def forward(ctx, k, x):
-        outs = tuple(x.view_as(x) for _ in range(k))
-        tag = getattr(x, "_lgd_amax", None)
-        if tag is not None and tag[1] == x._version:
-            _amax_tag(outs, tag[0])
-        return outs
-
-    @staticmethod
-    def backward(ctx, *gs):
-        live = [g for g in gs if g is not None]
-        if not live:
-            return None, None
-        if len(live) == 1:
-            return None, live[0]
-        tags = [_valid_tag(g) for g in live]
-        tot = live[0] + live[1]
-        for g in live[2:]:
-            tot = tot.add_(g)
-        if all(t is not None for t in tags):
-            bound = torch.stack([t.view(torch.float32).view(()) for t in tags]).sum().mul_(1.000001).reshape(1).view(torch.int32)
-            _amax_tag([tot], bound)
-        return None, tot
-
-
-def fan_out(x, k=2):
-    """k aliases of x whose gradients are summed by this library (with a magnitude bound) instead of by autograd; plain aliases off the GPU"""
-    if k < 2 or not (_FANOUT and x.is_cuda and x.requires_grad and _H2_ON and _H2_TAGS and torch.is_grad_enabled()):
-        return (x,) * k
-    return _FanOut.apply(k, x)
-
-
 def _dense_tagged(t):
     """hip.dense_f32 that carries a valid magnitude tag over to the copy it may have to make (a contiguous copy of a strided view)"""
     d = hip.dense_f32(t)

@@ -63,9 +63,7 @@ class FPN(nn.Module):
                 if up is not None:
                     lat = lat + up
             prev = lat
-            if idx != self.stages[0] and lat.is_cuda:   # (read by the output convolution and by the next level's up-sampling)
-                prev, lat = ops.fan_out(lat, 2)
-            results.insert(0, getattr(self, "fpn_output%d" % idx)(lat))
+            results.insert(0, getattr(self, "fpn_output%d" % idx)(prev))
         if self.top_block is not None:
             results.extend(self.top_block(feats[self.top_block.in_feature]))
         return dict(zip(self.out_features, results))

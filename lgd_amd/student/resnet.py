@@ -246,10 +246,7 @@ class ResNet(nn.Module):
             else:
                 x = getattr(self, name)(x)
             if name in self.out_features:
-                if idx < 1 + len(self.stage_names):   # (also read by the next stage: ops.fan_out sums the two gradients and keeps their bound)
-                    x, outs[name] = ops.fan_out(x, 2)
-                else:
-                    outs[name] = x
+                outs[name] = x
         return outs
 
 
