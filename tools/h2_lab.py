@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--what", default="probe,fwd,dw")
     ap.add_argument("--M", type=int, default=256)
-    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--variants", default="0,8,9")
     args = ap.parse_args()
     if args.build or not os.path.exists(LIB):
         build()
@@ -134,7 +134,7 @@ def main():
         byt = 4.0 * nf * T * (C + M)
         print("   h2_fwd %.1f us (%.0f TFLOP/s fp32-eq, %.2f TB/s algorithmic)   library fp32 bmm %.1f us" % (t_h2, flop / t_h2 * 1e-6, byt / t_h2 * 1e-6, t_lib))
         names = {0: "256x128 3 buffers (shipped)", 1: "256x256 8 waves 4 buffers", 2: "128x256 3 buffers", 3: "256x128 2 buffers", 4: "256x256 3 buffers",
-                 5: "256x256 5 buffers", 6: "128x256 4 buffers", 7: "128x128 2 waves 4 buffers"}
+                 5: "256x256 5 buffers", 6: "128x256 4 buffers", 7: "128x128 2 waves 4 buffers", 8: "256x128x3 + nt stores of C", 9: "256x128x3 + nt stores + nt DMA of B"}
         for variant in [int(v) for v in args.variants.split(",")]:
             Cs[0].fill_(float("nan"))
             rc = lib.h2_fwd2(img.data_ptr(), Vs.data_ptr(), T * 4, nf * T * 4, Vs.numel(), Cs[0].data_ptr(), T, nf * T, a_inv.data_ptr(), b_inv.data_ptr(),
@@ -146,6 +146,20 @@ def main():
             t_v = timeit(lambda i: lib.h2_fwd2(img.data_ptr(), Vss[i].data_ptr(), T * 4, nf * T * 4, Vs.numel(), Cs[i].data_ptr(), T, nf * T, a_inv.data_ptr(),
                                                b_inv.data_ptr(), nf, M, T, C, variant, st()), sets, args.reps)
             print("   variant %d %-28s rc %d error %.2e: %.1f us (%.2f TB/s algorithmic)" % (variant, names[variant], rc, e[0], t_v, byt / t_v * 1e-6))
+        # layout experiment (timing only: one filter image for every batch): the same bytes with every tile's B operand CONTIGUOUS -- [tile block][f][C][128 tiles]
+        # emulated as 64 x 41 "batches" of one 128-column tile each, k-row stride 512 B, batch stride 128 KB; C likewise [batch][M][128]
+        nbx = nf * (T // 128)
+        Vx = torch.empty(nbx * C * 128, dtype=torch.int32, device=dev).random_(0, 2 ** 14)
+        Vxs = [Vx] + [Vx.clone() for _ in range(sets - 1)]
+        Cx = [torch.empty(nbx * M * 128, device=dev) for _ in range(sets)]
+        ainv = torch.ones(nbx, device=dev)
+        for variant in (0, 100):
+            if variant == 0:
+                fnx = lambda i: lib.h2_fwd2(img.data_ptr(), Vss[i].data_ptr(), T * 4, nf * T * 4, Vs.numel(), Cs[i].data_ptr(), T, nf * T, a_inv.data_ptr(), b_inv.data_ptr(), nf, M, T, C, 0, st())  # noqa: E731
+            else:
+                fnx = lambda i: lib.h2_fwd2(img.data_ptr(), Vxs[i].data_ptr(), C * 512, 512, Vx.numel() * 4, Cx[i].data_ptr(), M * 128, 128, ainv.data_ptr(), ainv.data_ptr(), nbx, M, 128, C, 100, st())  # noqa: E731
+            print("   layout experiment %s: %.1f us" % ("strided rows [C][f][T] (shipped)" if variant == 0 else "contiguous tiles [T/128][f][C][128]", timeit(fnx, sets, args.reps)))
+        del Vxs, Cx
         try:
             from lgd_amd import ops
             ops.gemm3_backend(True, force=True)

@@ -483,8 +483,12 @@ int h2_dw(const void* A, long a_rs, long a_sb, long a_bytes, const void* B, long
 
 // ------------------------------------------------------------------------------------------------------------------ tile-shape variants of the forward product
 // BM x BN tile on (BM / 128) x (BN / 64) waves of 128 x 64, ST LDS buffers
-template <int BM, int BN, int ST>
+__device__ __forceinline__ void glds16_nt(const __amdgpu_buffer_rsrc_t rs, uint32_t lds_addr, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+template <int BM, int BN, int STX>
 __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64) void h2_fwd2_kernel(const FwdP p) {
+    constexpr int ST = STX % 10, NTS = (STX / 10) >= 1 ? 2 : 0; constexpr bool NTL = (STX / 10) >= 2;
     constexpr int RB = BM / 32, MI = 4, WN = BN / 64, NW = (BM / 128) * WN;
     constexpr int ROW = BN * 2;                                  // bytes of one k-row of one piece in LDS
     constexpr int A_BYTES = 2 * RB * 1024, B_BYTES = 2 * 16 * ROW, BUF = A_BYTES + B_BYTES;
@@ -530,7 +534,7 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64) void h2_fwd2_kernel(co
         for (int c = 0; c < ACH; ++c) glds16(ra, lds_addr_of(dst + (w * ACH + c) * 1024), aoff[c]);
         const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(Bb + ks * bstep, b_left0 - ks * bstep);
 #pragma unroll
-        for (int jj = 0; jj < BCH; ++jj) glds16(rb_, lds_addr_of(dst + A_BYTES + (w * BCH + jj) * 1024), boff[jj]);
+        for (int jj = 0; jj < BCH; ++jj) { if constexpr (NTL) glds16_nt(rb_, lds_addr_of(dst + A_BYTES + (w * BCH + jj) * 1024), boff[jj]); else glds16(rb_, lds_addr_of(dst + A_BYTES + (w * BCH + jj) * 1024), boff[jj]); }
     };
     f32x16 acc[MI][2];
 #pragma unroll
@@ -613,7 +617,7 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64) void h2_fwd2_kernel(co
                 for (int e = 0; e < 16; ++e) {
                     const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
                     const float v = acc[i][jn][e] * inv;
-                    if (hf || (dm < mrem && colok[jn])) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
+                    if (hf || (dm < mrem && colok[jn])) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, NTS);
                     co += (e & 3) == 3 ? c5 : c1;
                     asm volatile("" : "+v"(co));
                 }
@@ -624,13 +628,14 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64) void h2_fwd2_kernel(co
     if (full) epi(std::true_type()); else epi(std::false_type());
 }
 
-template <int BM, int BN, int ST>
+template <int BM, int BN, int STX>
 static int launch_fwd2(FwdP p, int nb, int M, int N, hipStream_t st) {
+    constexpr int ST = STX % 10;
     constexpr int L = ST * (2 * (BM / 32) * 1024 + 2 * 16 * BN * 2);
     p.mt = (M + BM - 1) / BM; p.nt = (N + BN - 1) / BN;
     p.total = ((nb + 7) / 8) * p.nt * p.mt * 8;
-    (void)hipFuncSetAttribute((const void*)h2_fwd2_kernel<BM, BN, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, L);
-    hipLaunchKernelGGL((h2_fwd2_kernel<BM, BN, ST>), dim3(p.total), dim3((BM / 128) * (BN / 64) * 64), L, st, p);
+    (void)hipFuncSetAttribute((const void*)h2_fwd2_kernel<BM, BN, STX>, hipFuncAttributeMaxDynamicSharedMemorySize, L);
+    hipLaunchKernelGGL((h2_fwd2_kernel<BM, BN, STX>), dim3(p.total), dim3((BM / 128) * (BN / 64) * 64), L, st, p);
     return (int)hipGetLastError();
 }
 
@@ -643,6 +648,7 @@ extern "C" int h2_fwd2(const void* img, const void* B, long b_sb, long b_ld, lon
     p.B = (const char*)B; p.b_sb = b_sb; p.b_ld = b_ld; p.b_bytes = b_bytes;
     p.C = C; p.c_sb = c_sb; p.c_ld = c_ld; p.a_inv = a_inv; p.b_inv = b_inv; p.amax_out = nullptr;
     p.nb = nb; p.M = M; p.N = N; p.K = K;
+    if (variant >= 100) { p.a_sb = 0; variant -= 100; }   // timing experiments: one image for every batch
     hipStream_t st = (hipStream_t)stream;
     switch (variant) {
         case 0: return launch_fwd2<256, 128, 3>(p, nb, M, N, st);
@@ -653,6 +659,8 @@ extern "C" int h2_fwd2(const void* img, const void* B, long b_sb, long b_ld, lon
         case 5: return launch_fwd2<256, 256, 5>(p, nb, M, N, st);
         case 6: return launch_fwd2<128, 256, 4>(p, nb, M, N, st);
         case 7: return launch_fwd2<128, 128, 4>(p, nb, M, N, st);
+        case 8: return launch_fwd2<256, 128, 13>(p, nb, M, N, st);   // nt stores of C
+        case 9: return launch_fwd2<256, 128, 23>(p, nb, M, N, st);   // nt stores of C + nt DMA of B
     }
     return -2;
 }
