@@ -2439,7 +2439,7 @@ def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False):
     # k-loop without a co-resident partner and the filter split are the whole launch and the library's smaller tiles win
     # (tools/gemm3_probe.py, profiles/r04_gemm3_probe.log: res5's 288 tiles x0.61, the 2048 -> 256 lateral x0.55; from one round up x1.05-1.6)
     wgs, cus = nb * ((N + 127) // 128) * ((M + bm - 1) // bm), _cu_count(device)
-    if wgs >= cus * (3 if small else 2):
+    if wgs >= cus * (3 if small else 2) * _PW_MIN_FILL:
         return True
     # one round of 256-row tiles is enough when the k-loop is long (64+ steps amortise a tile's prologue and epilogue): the 1024 -> 256
     # convolutions of res4 and the 1024-channel lateral at 8 images, x1.05-1.10 (profiles/r04_gemm3_probe_buffer_addressing.log)
@@ -2490,7 +2490,9 @@ def gemm3_bmm(a, b, out=None, accumulate=False, residual=None, shift=None, relu=
     return out
 
 
-_GEMM2H_ON = os.environ.get("LGD_GEMM2H", "1") != "0"   # 0: the student's 1x1 convolutions on the bf16x3 form of csrc/gemm3.hip (A/B runs)
+_GEMM2H_ON = os.environ.get("LGD_GEMM2H", "1") != "0"
+_PW_MIN_FILL = float(os.environ.get("LGD_PW_MIN_FILL", "1.0"))   # fraction of "two rounds of workgroups" a product must fill to leave the library (experiments)
+_PW_TAGS_ALWAYS = os.environ.get("LGD_PW_TAGS_ALWAYS", "0") != "0"   # 1: every output transform leaves its maximum, whatever the map's size (experiments)
 
 
 def gemm2h_bmm(a, b, b_amax, out=None, accumulate=False, residual=None, shift=None, relu=False, relu_bits=None, amax_out=None):
@@ -2581,7 +2583,7 @@ def _pw_product(name, a, b, bmap, out=None, accumulate=False, **epi):
     """a product of a 1x1 convolution on csrc/gemm3.hip -- a (nb, M, K) the filter as a stride-0 batch, b (nb, K, HW) the view of the NCHW map
     `bmap` (its magnitude tag is looked up on it) -- in the f16x2 form (lgd_gemm2h) unless switched off, with the epilogue's max |C| recorded
     for the consumer.  Returns (out, amax word or None)."""
-    amax = _zero_words(b.device) if (_tags_wanted(b.shape[0] * b.shape[2] // 36) or _GEMM2H_ON) else None
+    amax = _zero_words(b.device) if (_tags_wanted(b.shape[0] * b.shape[2] // 36) or _GEMM2H_ON) else None   # (the next 1x1 product's f16x2 form needs it whatever the map's size)
     tag = getattr(bmap, "_lgd_amax", None) if (_GEMM2H_ON and _H2_TAGS) else None
     if tag is not None and tag[1] == bmap._version and (a.stride(0) == 0 or a.shape[0] == 1):
         # the f16x2 form needs B's bound: taken where the producing kernel left it (every product and output transform of this library does); a map
@@ -2680,7 +2682,7 @@ def _zero_words(dev, n=1):
 def _tags_wanted(n_tiles):
     """whether a kernel that writes maps of n_tiles 6x6 tiles should leave their maximum: only where a consumer could take the f16x2 pipeline (the
     one-pass head runs over two pyramids: twice the tiles of the maps it reads)"""
-    return _H2_ON and _H2_TAGS and (_H2_FORCE or 2 * n_tiles >= _H2_MIN_T)
+    return _H2_ON and _H2_TAGS and (_H2_FORCE or _PW_TAGS_ALWAYS or 2 * n_tiles >= _H2_MIN_T)
 
 
 def _amax_tag(maps, amax):
