@@ -427,6 +427,10 @@ int lgd_h2_amax_maps(const float* const* x_host, const int32_t* level_hw_host, i
 int lgd_h2_amax_filters(const float* const* w_host, const float* const* scale_host, const int32_t* rows_host, int K, int row_elems, uint32_t* out_bits,
                         void* stream);
 int lgd_h2_link_bound(const uint32_t* amax64, uint32_t* out_bits, void* stream);
+/* out[c] = inv[0] * sum over the T tiles of one frequency plane of a split buffer: buf = the plane's row of channel 0, ch_bytes = distance between
+ * channels (64 * 4 * T for [C][64][T]), T % 32 == 0.  The bias gradient of a 3x3 convolution on the f16x2 path: plane tile + 3 of dM
+ * [ref: the bias of every nn.Conv2d(., ., 3, padding=1) of the path, dynamic_teacher.py:57-73, sequential_convs.py:10-12]. */
+int lgd_h2_plane_sums(const void* buf, long long ch_bytes, int C, int T, const float* inv, float* out, void* stream);
 /* lgd_wino_out_t_gn writing dM as split rows; *amax_in: the bound lgd_gn_group_bwd_coef(bound_out) leaves */
 int lgd_wino_out_t_gn_h2(const float* const* g_host, const float* const* y_host, const float* coef, const int32_t* level_hw_host, int L, int N, int C,
                          void* dM, const uint32_t* amax_in, float* inv_out64, void* stream);
@@ -490,9 +494,10 @@ int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, i
 int lgd_sum_batch_scale(const float* part, const float* scale, int N, int Co, int Ci, float* out, void* stream);
 /* out_t[r][c] = w_t[r][c] * scale_t[r] for a table of n tensors in one launch (the w * scale filter folds of every trainable 1x1
  * convolution in front of a FrozenBN, once per step): tasks_dev = n lgd_rows_task records in device memory, blk0_dev[t] = first
- * workgroup of task t (a workgroup covers 1024 elements), nblocks = their total. */
+ * workgroup of task t (a workgroup covers 1024 elements), nblocks = their total.  amax_out: NULL, or n words the caller zeroed: the float bits
+ * of max |out_t| per task (the f16x2 scale of the filter's image, lgd_gemm2h_split). */
 typedef struct lgd_rows_task { unsigned long long w, scale, out; int rows, cols; } lgd_rows_task;
-int lgd_scale_rows_multi(const void* tasks_dev, const int32_t* blk0_dev, int n, int nblocks, void* stream);
+int lgd_scale_rows_multi(const void* tasks_dev, const int32_t* blk0_dev, int n, int nblocks, uint32_t* amax_out, void* stream);
 int lgd_relu_bits_bwd(const uint32_t* relu_bits, const float* dy, long long total, float* dx, void* stream);
 int lgd_relu_mask_bwd(const float* y, const float* dy, long long total, float* dx, void* stream);
 /* y = x[..., ::2, ::2] of `planes` (image, channel) planes of H x W (the input of a 1x1 / stride 2 convolution: detectron2 BottleneckBlock with

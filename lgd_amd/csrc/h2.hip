@@ -592,6 +592,26 @@ __global__ __launch_bounds__(64) void h2_link_bound_kernel(const unsigned* __res
     if (t == 0) out[0] = __builtin_bit_cast(unsigned, tot);
 }
 
+// per-channel sum over the tiles of ONE frequency plane of a split buffer [C][64][T] (rows of T / 32 blocks: 32 f16 h, 32 f16 m), times the plane's
+// inverse scale: the bias gradient of a convolution is the sum of dM at the frequency of the interpolation point 1 (a tile's gradient sum) --
+// one launch instead of the convert / reduce / scale passes of the tensor library
+__global__ __launch_bounds__(256) void h2_plane_sums_kernel(const char* __restrict__ buf, long long ch_bytes, int T, const float* __restrict__ inv,
+                                                            float* __restrict__ out) {
+    __shared__ float slots[4];
+    typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
+    const char* row = buf + (long long)blockIdx.x * ch_bytes;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < T / 4; i += 256) {   // 16 bytes = 8 halves (h or m alike: both are summed)
+        const hx8 v = *reinterpret_cast<const hx8*>(row + (size_t)i * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)v[e];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ((slots[0] + slots[1]) + (slots[2] + slots[3])) * inv[0];
+}
+
 constexpr int kFwdLds256 = 3 * (2 * 8 * 1024 + 8192), kFwdLds128 = 3 * (2 * 4 * 1024 + 8192), kDwLds = 4 * 2 * 256 * 64, kPwDwLds = 2 * 2 * 256 * 128;
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, device)
@@ -757,6 +777,12 @@ int lgd_h2_amax_filters(const float* const* w_host, const float* const* scale_ho
 int lgd_h2_link_bound(const uint32_t* amax64, uint32_t* out_bits, void* stream) {
     if (!amax64 || !out_bits) return LGD_EINVAL;
     LGD_LAUNCH("h2_link_bound_kernel", lgd::h2_link_bound_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, amax64, out_bits);
+    return lgd::check_launch();
+}
+
+int lgd_h2_plane_sums(const void* buf, long long ch_bytes, int C, int T, const float* inv, float* out, void* stream) {
+    if (!buf || !inv || !out || C < 1 || T < 32 || T % 32 || ch_bytes < 4LL * T) return LGD_EINVAL;
+    LGD_LAUNCH("h2_plane_sums_kernel", lgd::h2_plane_sums_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const char*)buf, ch_bytes, T, inv, out);
     return lgd::check_launch();
 }
 

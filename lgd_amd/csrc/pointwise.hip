@@ -311,7 +311,8 @@ namespace lgd {
 // out_t[i] = w_t[i] * scale_t[i / cols_t] for a table of tensors in ONE launch: the filter folds w * scale of every trainable 1x1
 // convolution that is followed by a FrozenBN (62 of them in R-101), which each cost a 5 us launch per step
 // [d2-memory: conv -> FrozenBN of the bottleneck blocks; SURVEY.md appendix A].  Block -> tensor by binary search in the block prefix.
-__global__ __launch_bounds__(256) void scale_rows_multi_kernel(const lgd_rows_task* tasks, const int* blk0, int n) {
+__global__ __launch_bounds__(256) void scale_rows_multi_kernel(const lgd_rows_task* tasks, const int* blk0, int n, unsigned* amax) {
+    __shared__ float slots[4];
     int lo = 0, hi = n - 1;
     while (lo < hi) {   // last task whose first block is <= blockIdx.x
         const int mid = (lo + hi + 1) >> 1;
@@ -320,24 +321,34 @@ __global__ __launch_bounds__(256) void scale_rows_multi_kernel(const lgd_rows_ta
     const lgd_rows_task t = tasks[lo];
     const long long total = (long long)t.rows * t.cols;
     const long long i = ((long long)(blockIdx.x - blk0[lo]) * 256 + threadIdx.x) * 4;
-    if (i >= total) return;
-    const float* w = reinterpret_cast<const float*>(t.w);
-    const float* sc = reinterpret_cast<const float*>(t.scale);
-    float* o = reinterpret_cast<float*>(t.out);
-    if ((t.cols & 3) == 0 && ((t.w | t.out) & 15) == 0) {   // a vector lies inside one row
-        const float4 v = *reinterpret_cast<const float4*>(w + i);
-        const float f = sc[i / t.cols];
-        *reinterpret_cast<float4*>(o + i) = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
-    } else {
-        for (long long e = i; e < i + 4 && e < total; ++e) o[e] = w[e] * sc[e / t.cols];
+    float am = 0.f;
+    if (i < total) {
+        const float* w = reinterpret_cast<const float*>(t.w);
+        const float* sc = reinterpret_cast<const float*>(t.scale);
+        float* o = reinterpret_cast<float*>(t.out);
+        if ((t.cols & 3) == 0 && ((t.w | t.out) & 15) == 0) {   // a vector lies inside one row
+            const float4 v = *reinterpret_cast<const float4*>(w + i);
+            const float f = sc[i / t.cols];
+            const float4 r = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+            *reinterpret_cast<float4*>(o + i) = r;
+            am = fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w)));
+        } else {
+            for (long long e = i; e < i + 4 && e < total; ++e) {
+                const float r = w[e] * sc[e / t.cols];
+                o[e] = r;
+                am = fmaxf(am, fabsf(r));
+            }
+        }
     }
+    // max |w * scale| of the task: the f16x2 scale of the filter image (lgd_gemm2h_split) without a pass of its own per filter and step
+    if (amax) block_max_bits(amax + lo, wave_max(am), slots);
 }
 
 }  // namespace lgd
 
-extern "C" int lgd_scale_rows_multi(const void* tasks_dev, const int32_t* blk0_dev, int n, int nblocks, void* stream) {
+extern "C" int lgd_scale_rows_multi(const void* tasks_dev, const int32_t* blk0_dev, int n, int nblocks, uint32_t* amax_out, void* stream) {
     if (!tasks_dev || !blk0_dev || n < 1 || nblocks < 1) return LGD_EINVAL;
     LGD_LAUNCH("scale_rows_multi_kernel", lgd::scale_rows_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream,
-               reinterpret_cast<const lgd_rows_task*>(tasks_dev), reinterpret_cast<const int*>(blk0_dev), n);
+               reinterpret_cast<const lgd_rows_task*>(tasks_dev), reinterpret_cast<const int*>(blk0_dev), n, amax_out);
     return lgd::check_launch();
 }

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.environ.get("LGD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")   # LGD_HIP_LIB: a lab build
 _lib = None
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -92,6 +92,7 @@ SIGNATURES = {
     "lgd_h2_amax_maps": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp]),
     "lgd_h2_amax_filters": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_h2_link_bound": (c_i, [c_fp, c_fp, c_fp]),
+    "lgd_h2_plane_sums": (c_i, [c_fp, ctypes.c_longlong, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_wino_out_t_gn_h2": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_in_h2": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_out_t_h2": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
@@ -108,7 +109,7 @@ SIGNATURES = {
     "lgd_bias_act_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_stem_bias_relu_maxpool": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "lgd_sum_batch_scale": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
-    "lgd_scale_rows_multi": (c_i, [c_fp, c_fp, c_i, c_i, c_fp]),
+    "lgd_scale_rows_multi": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_relu_bits_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_relu_mask_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "lgd_subsample2_fwd": (c_i, [c_fp, ctypes.c_longlong, c_i, c_i, c_fp, c_fp]),

@@ -287,6 +287,10 @@ class StepFolds:
         self.blk0 = torch.from_numpy(blk0).to(dev)
         self.nblk = blk
         self.mods = mods
+        # max |w * scale| per fold, left by the same launch (the f16x2 scale of the filter images: ops.gemm2h_bmm looks a filter up by its offset
+        # in `flat`)
+        self.amax = torch.zeros(len(mods), dtype=torch.int32, device=dev)
+        self._amax_of = {v.storage_offset(): (self.amax[i:i + 1], v.numel()) for i, v in enumerate(self.views)}
 
     @torch.no_grad()
     def prepare(self):
@@ -301,11 +305,13 @@ class StepFolds:
             self._build(mods)
             self._key = key
         lib = hip.load()
-        hip.check(lib.lgd_scale_rows_multi(hip.ptr(self.tab), hip.ptr(self.blk0), len(self.mods), self.nblk, hip.stream_ptr()),
+        self.amax.zero_()
+        hip.check(lib.lgd_scale_rows_multi(hip.ptr(self.tab), hip.ptr(self.blk0), len(self.mods), self.nblk, hip.ptr(self.amax), hip.stream_ptr()),
                   "lgd_scale_rows_multi")
         # the views were rewritten behind autograd's back (a raw kernel on their storage): bump their version counters, so that a graph that
         # saved LAST step's folds (gradient accumulation, an evaluation forward between step and backward) raises instead of running its
         # backward with this step's filters
         torch.autograd.graph.increment_version(self.flat)   # (one bump: the views share their base's version counter -- ADVICE r4)
+        self.flat._lgd_w_amax_table = (self._amax_of, self.flat._version)
         for m, v, sc in zip(self.mods, self.views, self.scales):
             m._step_fold = ((m.weight._version, id(sc)), v)

@@ -500,3 +500,51 @@ def test_filter_bwd_over_split_k_partials():
     hip.check(lib.lgd_wino_filter_bwd(hip.ptr(tot), Co * Ci, hip.ptr(sc), Co, Ci, 6, hip.ptr(a), st), "lgd_wino_filter_bwd")
     hip.check(lib.lgd_wino_filter_bwd_parts(hip.ptr(parts), Co * Ci, parts.stride(0), S, hip.ptr(sc), Co, Ci, hip.ptr(b), st), "lgd_wino_filter_bwd_parts")
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C,T,f", [(256, 5248, 9), (48, 32, 0), (20, 1376, 63)])
+def test_plane_sums_of_a_split_buffer(C, T, f):
+    """lgd_h2_plane_sums (the bias gradient of a 3x3 convolution on the f16x2 path: per-channel sum of one frequency plane of dM) against the fp64
+    sum of the pieces, which are exact f16 values"""
+    hip, lib = _lib()
+    g = torch.Generator(device=DEV).manual_seed(C + f)
+    buf = torch.empty((C, 64, T), dtype=torch.int32, device=DEV)
+    buf.view(torch.float16).copy_(torch.randn(buf.view(torch.float16).shape, device=DEV, generator=g))
+    inv = torch.rand(64, device=DEV, generator=g) + 0.5
+    out = torch.full((C,), float("nan"), device=DEV)
+    hip.check(lib.lgd_h2_plane_sums(ctypes.c_void_p(buf.data_ptr() + 4 * T * f), 4 * 64 * T, C, T, ctypes.c_void_p(inv.data_ptr() + 4 * f), hip.ptr(out),
+                                    hip.stream_ptr()), "lgd_h2_plane_sums")
+    halves = buf[:, f].contiguous().view(torch.float16).double()
+    ref = halves.sum(1) * inv[f].double()
+    scale = halves.abs().sum(1).max() * inv[f].double()
+    assert ((out.double() - ref).abs().max() / scale).item() < 1e-6
+    assert lib.lgd_h2_plane_sums(None, 4 * 64 * T, C, T, hip.ptr(inv), hip.ptr(out), hip.stream_ptr()) != 0
+    assert lib.lgd_h2_plane_sums(hip.ptr(buf), 4 * 64 * T, C, T + 1, hip.ptr(inv), hip.ptr(out), hip.stream_ptr()) != 0
+
+
+def test_gemm2h_takes_the_fold_launch_maximum(monkeypatch):
+    """ops.gemm2h_bmm finds max |W| of a filter that is a view of StepFolds' flat buffer in the table the fold launch left (no reduction pass of its
+    own, forward and transposed view alike); a stale table (the buffer written since) is not used"""
+    from lgd_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    flat = torch.randn(4096 + 128 * 64, device=DEV, generator=g) * 0.1
+    w = flat[4096:].view(128, 64)
+    words = w.abs().max().reshape(1).view(torch.int32)
+    flat._lgd_w_amax_table = ({w.storage_offset(): (words, w.numel())}, flat._version)
+    x = torch.randn(2, 64, 1000, device=DEV, generator=g)
+    xa = x.abs().max().reshape(1).view(torch.int32)
+    calls = []
+    real = torch.linalg.vector_norm
+    monkeypatch.setattr(torch.linalg, "vector_norm", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    y = ops.gemm2h_bmm(w.view(1, 128, 64).expand(2, 128, 64), x, xa)
+    dz = torch.randn(2, 128, 1000, device=DEV, generator=g)
+    dx = ops.gemm2h_bmm(w.t().unsqueeze(0).expand(2, 64, 128), dz, dz.abs().max().reshape(1).view(torch.int32))
+    assert not calls
+    ref = torch.matmul(w.double(), x.double())
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    refx = torch.matmul(w.t().double(), dz.double())
+    assert ((dx.double() - refx).abs().max() / refx.abs().max()).item() < 2e-6
+    flat.mul_(2.0)                                   # written behind the table's back: the version moved, the table is stale
+    y2 = ops.gemm2h_bmm(w.view(1, 128, 64).expand(2, 128, 64), x, xa)
+    assert calls
+    assert ((y2.double() - 2 * ref).abs().max() / ref.abs().max()).item() < 4e-6

@@ -821,6 +821,12 @@ def test_step_folds_equal_per_op_folds():
     for m in mods:
         scale = m.norm.scale_shift()[0]
         assert torch.equal(m._cached_fold(scale), m.weight.detach() * scale.view(-1, 1, 1, 1))
+    # the same launch leaves max |w * scale| of every fold (the f16x2 scale of the filter's image: ops.gemm2h_bmm finds it by the fold's offset)
+    table, version = sf.flat._lgd_w_amax_table
+    assert version == sf.flat._version and len(table) == len(mods)
+    for v in sf.views:
+        word, numel = table[v.storage_offset()]
+        assert numel == v.numel() and word.view(torch.float32).item() == v.abs().max().item()
     with torch.no_grad():
         mods[0].weight.mul_(1.5)                      # written after prepare(): the cached fold is stale and must not be used
     assert mods[0]._cached_fold(mods[0].norm.scale_shift()[0]) is None

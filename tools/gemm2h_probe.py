@@ -1,0 +1,50 @@
+"""The student's 1x1 products on lgd_gemm2h in isolation (config 2: 8 images of 800x1344): us and ALGORITHMIC TB/s per shape and epilogue form --
+B read once, C written once, the residual read once; these products are HBM bound (K = 64 .. 1024: 8 .. 130 flop per byte at fp32).
+   python tools/gemm2h_probe.py [n_images]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lgd_amd import ops, hip
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+SH = [("res2 conv1 256->64", 256, 64, 200, 336, 0), ("res2 conv3 64->256 +R", 64, 256, 200, 336, 1),
+      ("res3 conv1 512->128", 512, 128, 100, 168, 0), ("res3 conv3 128->512 +R", 128, 512, 100, 168, 1), ("res3 dx 512->128 (K=512)", 512, 128, 100, 168, 0),
+      ("res3 dx conv3 (K=512->128)", 512, 128, 100, 168, 0), ("res3 dx conv1 128->512 +acc", 128, 512, 100, 168, 1),
+      ("res4 conv1 1024->256", 1024, 256, 50, 84, 0), ("res4 conv3 256->1024 +R", 256, 1024, 50, 84, 1),
+      ("fpn lateral 512->256", 512, 256, 100, 168, 0), ("fpn lateral 1024->256", 1024, 256, 50, 84, 0)]
+NSET = 3
+
+
+def run(fn, reps=12):
+    for i in range(3):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+for name, K, M, H, W, res in SH:
+    HW = H * W
+    xs = [torch.randn(N, K, HW, device="cuda") for _ in range(NSET)]
+    rs = [torch.randn(N, M, HW, device="cuda") for _ in range(NSET)] if res else None
+    outs = [torch.empty(N, M, HW, device="cuda") for _ in range(NSET)]
+    w = torch.randn(M, K, device="cuda") * 0.05
+    shift = torch.randn(M, device="cuda")
+    am = xs[0].abs().max().reshape(1).view(torch.int32) + 0
+    a = w.view(1, M, K).expand(N, M, K)
+    bits = torch.empty(int(hip.load().lgd_relu_rowbits_words(N * M, HW)), dtype=torch.int32, device="cuda")
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nbytes = 4.0 * N * HW * (K + M * (2 if res else 1))
+    t_plain = run(lambda i: ops.gemm2h_bmm(a, xs[i % NSET], am, out=outs[i % NSET]))
+    t_epi = run(lambda i: ops.gemm2h_bmm(a, xs[i % NSET], am, out=outs[i % NSET], residual=rs[i % NSET] if res else None, shift=shift, relu=True, relu_bits=bits,
+                                        amax_out=word))
+    t3 = run(lambda i: ops.gemm3_bmm(a, xs[i % NSET], out=outs[i % NSET]))
+    t_lib = run(lambda i: torch.matmul(w, xs[i % NSET], out=outs[i % NSET]))
+    pb = 4.0 * N * HW * (K + M)
+    print("%-30s plain %6.1f us %5.2f TB/s | epilogue %6.1f us %5.2f TB/s | bf16x3 plain %6.1f us | library %6.1f us %5.2f TB/s  (%.0f flop/B)" % (
+        name, t_plain, pb / t_plain / 1e6, t_epi, nbytes / t_epi / 1e6, t3, t_lib, pb / t_lib / 1e6, 2.0 * K * M / (4 * (K + M))), flush=True)
