@@ -86,8 +86,12 @@ struct Params {
 };
 
 // EPI: 0 the plain product; otherwise the epilogue kernel with bit 0: R present, bit 1: shift present
+// waves per SIMD the register allocator is held to: three workgroups per CU for the 128-row tile (left alone the epilogue forms take 172-180
+// registers -- two workgroups; tools/gemm2h_probe.py: res3's 512 -> 128 convolution with its epilogue 124 -> 101 us).  One instance
+// (bf16x3, shift only) would spill at 168.
+template <int BM, int EPI, int PCS> constexpr int gemm3_waves() { return BM == 128 && !(PCS == 3 && EPI == 2) ? 3 : 2; }
 template <int BM, int EPI, int PCS>
-__global__ __launch_bounds__(NT) void gemm3_kernel(const Params p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm3_waves<BM, EPI, PCS>()))) void gemm3_kernel(const Params p) {
     typedef Tile<BM, PCS> TL;
     typedef typename std::conditional<PCS == 3, bf16x8, f16x8>::type frag_t;
     constexpr int A_BYTES = TL::A_BYTES, BUF = TL::BUF, MI = TL::MI, RB = TL::RB, CH = TL::CHUNKS;
@@ -517,7 +521,12 @@ static int gemm3_launch(const void* image, int image_shared, const float* a_inv,
     if (!image || !B || !C || nb <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 15) || ((uintptr_t)image & 15)) return LGD_EINVAL;
     // 256-row tiles unless that leaves more than a quarter of the rows of the last tile empty and 128-row tiles do not
     const bool epi = R || shift || relu || relu_bits;
-    const bool small = ((M + 255) / 256 * 256 - M >= 64 && (M + 127) / 128 * 128 - M < 64);
+    // The f16x2 form (the student's 1x1 convolutions: HBM bound, 8 .. 130 flop per byte) always takes 128-row tiles: three workgroups per CU keep
+    // more loads in flight than two, and a grid of twice as many tiles fills the chip where the 256-row one leaves CUs with one workgroup or none
+    // (tools/gemm2h_probe.py, 8 images: res3 128 -> 512 + shortcut 188 -> 171 us, res4 256 -> 1024 + shortcut 144 -> 130, 1024 -> 256 97 -> 90;
+    // B tiles are re-read by the neighbouring m-tiles from the same L2).  bf16x3 (the Winograd products: MFMA bound, B split once per 256 rows)
+    // keeps the row-count rule.
+    const bool small = PCS == 2 || ((M + 255) / 256 * 256 - M >= 64 && (M + 127) / 128 * 128 - M < 64);
     const int bm = small ? 128 : 256;
     lgd::Params p;
     p.rbp = (M + 31) / 32; p.ktp = K / 16;

@@ -2423,15 +2423,16 @@ def _cu_count(device):
     return _CU_COUNT[i]
 
 
-def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False):
-    """the speed policy of csrc/gemm3.hip on plain sizes (tile choice as in lgd_gemm3)"""
+def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False, shared=False):
+    """the speed policy of csrc/gemm3.hip on plain sizes (tile choice as in lgd_gemm3 / lgd_gemm2h); shared: one filter for the whole batch (the
+    student's 1x1 convolutions, which take the f16x2 form and its 128-row tiles)"""
     if not _GEMM3_ON:
         return False
     if _GEMM3_FORCE:
         return K % 16 == 0
     # the kernel's tile spans 256 (or 128) rows of A: shapes that would leave more than ~30 % of the MFMA rows empty (C' = 36, 64, 320 ...) and
     # tiny problems stay on the library; K % 16: the k-step
-    small = (M + 255) // 256 * 256 - M >= 64 and (M + 127) // 128 * 128 - M < 64
+    small = (shared and _GEMM2H_ON) or ((M + 255) // 256 * 256 - M >= 64 and (M + 127) // 128 * 128 - M < 64)
     bm = 128 if small else 256
     if K % 16 or K < 32 or N < 256 or M < 0.7 * bm * ((M + bm - 1) // bm):
         return False
@@ -2441,15 +2442,15 @@ def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False):
     wgs, cus = nb * ((N + 127) // 128) * ((M + bm - 1) // bm), _cu_count(device)
     if wgs >= cus * (3 if small else 2) * _PW_MIN_FILL:
         return True
-    # one round of 256-row tiles is enough when the k-loop is long (64+ steps amortise a tile's prologue and epilogue): the 1024 -> 256
+    # one workgroup per CU is enough when the k-loop is long (64+ steps amortise a tile's prologue and epilogue): the 1024 -> 256
     # convolutions of res4 and the 1024-channel lateral at 8 images, x1.05-1.10 (profiles/r04_gemm3_probe_buffer_addressing.log)
-    return _GEMM3_ONE_ROUND and (not small) and wgs >= cus and K >= 1024
+    return _GEMM3_ONE_ROUND and wgs >= cus * _PW_ONE_ROUND_FILL and K >= 1024
 
 
 def _gemm3_ok(a, b, out, accumulate=False):
     if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 3 and b.dim() == 3):
         return False
-    if not _gemm3_shape_ok(a.shape[0], a.shape[1], a.shape[2], b.shape[2], a.device, accumulate):
+    if not _gemm3_shape_ok(a.shape[0], a.shape[1], a.shape[2], b.shape[2], a.device, accumulate, shared=a.stride(0) == 0):
         return False
     if b.stride(2) != 1 or 17 * b.stride(1) + b.shape[2] >= 1 << 30:   # the kernel's 32-bit byte offsets (lgd_gemm3 returns LGD_EINVAL beyond)
         return False
@@ -2492,6 +2493,7 @@ def gemm3_bmm(a, b, out=None, accumulate=False, residual=None, shift=None, relu=
 
 _GEMM2H_ON = os.environ.get("LGD_GEMM2H", "1") != "0"
 _PW_MIN_FILL = float(os.environ.get("LGD_PW_MIN_FILL", "1.0"))   # fraction of "two rounds of workgroups" a product must fill to leave the library (experiments)
+_PW_ONE_ROUND_FILL = float(os.environ.get("LGD_PW_ONE_ROUND_FILL", "1.0"))   # workgroups per CU a long-K product must reach (experiments)
 _PW_TAGS_ALWAYS = os.environ.get("LGD_PW_TAGS_ALWAYS", "0") != "0"   # 1: every output transform leaves its maximum, whatever the map's size (experiments)
 
 
