@@ -255,6 +255,9 @@ int lgd_segmax_bwd(const float* dout, const int32_t* off, const int32_t* arg, in
  * logits -- for a loss that is divided by a normaliser known when it is evaluated (detectron2's EMA of the positive count,
  * FCOS's foreground count) and whose upstream gradient in the step is 1; its backward is lgd_scale_unless_one(grads, upstream):
  * x_l *= g[0] for the L tensors unless g[0] == 1 (then every workgroup leaves after one load).
+ * bound_out (may be NULL): receives the float bits of |grad_scale| max(alpha, 1 - alpha) (1 + gamma / e) >= max |gradient| -- the magnitude tag the
+ * class convolution's backward derives its f16x2 scale from (csrc/h2.hip) without a pass over the gradient maps; lgd_scale_unless_one multiplies
+ * *bound_inout (may be NULL) by |g[0]| along with the maps.
  */
 size_t lgd_focal_ws_doubles(const int32_t* level_hw_host, int L, int N, int A, int K);
 int lgd_focal_loss_fwd(const float* const* logits_host, const int32_t* const* labels_host,
@@ -262,8 +265,8 @@ int lgd_focal_loss_fwd(const float* const* logits_host, const int32_t* const* la
                        double* ws, float* loss, void* stream);
 int lgd_focal_loss_fwd_grad(const float* const* logits_host, const int32_t* const* labels_host,
                             const int32_t* level_hw_host, int L, int N, int A, int K, float alpha, float gamma,
-                            const float* grad_scale, double* ws, float* loss, float* const* grad_logits_host, void* stream);
-int lgd_scale_unless_one(float* const* x_host, const long long* n_host, int L, const float* g, void* stream);
+                            const float* grad_scale, double* ws, float* loss, float* const* grad_logits_host, uint32_t* bound_out, void* stream);
+int lgd_scale_unless_one(float* const* x_host, const long long* n_host, int L, const float* g, uint32_t* bound_inout, void* stream);
 int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* labels_host,
                        const int32_t* level_hw_host, int L, int N, int A, int K, float alpha, float gamma,
                        const float* grad_loss, float* const* grad_logits_host, void* stream);
@@ -385,6 +388,12 @@ int lgd_gemm3(const void* image, int image_shared, const float* B, long long b_s
 size_t lgd_gemm2h_image_bytes(int nb, int M, int K);
 int lgd_gemm2h_split(const float* A, long long a_sb, long long a_sm, long long a_sk, int nb, int M, int K, const uint32_t* a_amax, void* image, float* a_inv,
                      void* stream);
+/* lgd_gemm2h_split for a table of n filters in ONE launch (the images W and W^T of every trainable 1x1 convolution, once per step): tasks_dev = n
+ * lgd_split_task records in device memory -- a: the matrix (element (m, k) at a[m * sm + k * sk], floats), img: its image (lgd_gemm2h_image_bytes(1, M, K),
+ * 16-byte aligned), amax: the word holding the float bits of a bound of max |a|, inv: the float that receives the image's inverse scale -- blk0_dev[t] =
+ * first workgroup of task t (a workgroup covers 256 of the task's ceil(K/16) * ceil(M/32) * 64 fragment slots), nblocks = their total. */
+typedef struct lgd_split_task { unsigned long long a, img, amax, inv; int M, K, sm, sk; } lgd_split_task;
+int lgd_gemm2h_split_multi(const void* tasks_dev, const int32_t* blk0_dev, int n, int nblocks, void* stream);
 int lgd_gemm2h(const void* image, int image_shared, const float* a_inv, const float* B, const uint32_t* b_amax, long long b_sb, long long b_sk, float* C,
                long long c_sb, long long c_sm, const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits,
                uint32_t* amax_out, int nb, int M, int N, int K, void* stream);
@@ -427,6 +436,9 @@ int lgd_h2_amax_maps(const float* const* x_host, const int32_t* level_hw_host, i
 int lgd_h2_amax_filters(const float* const* w_host, const float* const* scale_host, const int32_t* rows_host, int K, int row_elems, uint32_t* out_bits,
                         void* stream);
 int lgd_h2_link_bound(const uint32_t* amax64, uint32_t* out_bits, void* stream);
+/* *out = max(*out, *words[0], ..., *words[n-1]) on float bits of non-negative floats (n <= 16 device words, host array of pointers): the bounds of
+ * several producers' maps combined for one convolution that reads them all (one 64-thread launch) */
+int lgd_h2_words_max(const uint32_t* const* words_host, int n, uint32_t* out, void* stream);
 /* out[c] = inv[0] * sum over the T tiles of one frequency plane of a split buffer: buf = the plane's row of channel 0, ch_bytes = distance between
  * channels (64 * 4 * T for [C][64][T]), T % 32 == 0.  The bias gradient of a 3x3 convolution on the f16x2 path: plane tile + 3 of dM
  * [ref: the bias of every nn.Conv2d(., ., 3, padding=1) of the path, dynamic_teacher.py:57-73, sequential_convs.py:10-12]. */

@@ -28,6 +28,7 @@ struct FocalArgs {
     double* ws;        // [nwaves] partial sums | [nfin] block sums
     float* loss;
     const float* gscale;
+    unsigned* bound;   // MODE 2, optional: receives the float bits of a bound of |grad| (below)
 };
 
 // One exp, one log and one reciprocal per element: e = exp(-|x|), p = sigmoid(x), softplus(+-x) share log1p(e).
@@ -82,6 +83,15 @@ __device__ __forceinline__ void focal_both(float x, bool t, float alpha, float g
 template <int MODE>  // 0 forward, 1 backward, 2 forward + gradient (pre-scaled by gscale[0])
 __global__ __launch_bounds__(256) void focal_kernel(FocalArgs a) {
     const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (MODE == 2 && a.bound && blockIdx.x == 0 && threadIdx.x == 0) {
+        // |d focal / dx| <= max(alpha, 1 - alpha) (1 + gamma / e):  t = 1: alpha (1-p)^g |g p log p - (1-p)|,  t = 0: (1-alpha) p^g |p - g (1-p) log(1-p)|,
+        // and u |log u| <= 1 / e on (0, 1).  The magnitude tag of the gradient maps (the f16x2 scale of the class convolution's backward,
+        // csrc/h2.hip) without a pass over them: within ~2^2 of the true maximum while positives exist, and exact bookkeeping is not needed --
+        // the scale only has to keep the pair's 2^-22 window around the large elements.
+        const float at = a.alpha >= 0.f ? fmaxf(a.alpha, 1.f - a.alpha) : 1.f;
+        const float gsb = a.gscale ? fabsf(a.gscale[0]) : 1.f;
+        *a.bound = __builtin_bit_cast(unsigned, at * (1.f + a.gamma * 0.36787945f) * gsb * 1.0001f);
+    }
     if (w >= a.nwaves) return;
     const int lane = threadIdx.x & 63;
     int l = 0;
@@ -160,9 +170,11 @@ __global__ __launch_bounds__(256) void focal_kernel(FocalArgs a) {
 
 // x *= g[0] unless g[0] == 1 (the usual case in a training step: every block leaves after one scalar load)
 struct ScaleArgs { float* x[LGD_MAX_LEVELS]; long long n[LGD_MAX_LEVELS]; int L; };
-__global__ __launch_bounds__(256) void scale_unless_one_kernel(ScaleArgs a, const float* g) {
+__global__ __launch_bounds__(256) void scale_unless_one_kernel(ScaleArgs a, const float* g, unsigned* bound) {
     const float s = g[0];
     if (s == 1.f) return;
+    if (bound && blockIdx.x == 0 && threadIdx.x == 0)   // the maps' magnitude bound moves with them
+        *bound = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, *bound) * fabsf(s) * 1.0001f);
     for (int l = 0; l < a.L; ++l) {
         float* x = a.x[l];
         const long long n = a.n[l], n4 = (reinterpret_cast<size_t>(x) & 15) == 0 ? n >> 2 : 0;
@@ -237,7 +249,7 @@ int lgd_focal_loss_fwd(const float* const* logits_host, const int32_t* const* la
     lgd::FocalArgs a;
     if (lgd::focal_fill(a, logits_host, labels_host, level_hw_host, L, N, A, K, alpha, gamma) != LGD_OK || !ws || !loss)
         return LGD_EINVAL;
-    a.ws = ws; a.loss = loss; a.gscale = nullptr;
+    a.ws = ws; a.loss = loss; a.gscale = nullptr; a.bound = nullptr;
     hipStream_t s = (hipStream_t)stream;
     LGD_LAUNCH("focal_fwd_kernel", lgd::focal_kernel<0>, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
     LGD_LAUNCH("focal_reduce_kernel", lgd::focal_reduce_kernel, dim3(a.nfin), dim3(256), 0, s, a, 0);
@@ -247,12 +259,12 @@ int lgd_focal_loss_fwd(const float* const* logits_host, const int32_t* const* la
 
 int lgd_focal_loss_fwd_grad(const float* const* logits_host, const int32_t* const* labels_host, const int32_t* level_hw_host, int L,
                             int N, int A, int K, float alpha, float gamma, const float* grad_scale, double* ws, float* loss,
-                            float* const* grad_logits_host, void* stream) {
+                            float* const* grad_logits_host, uint32_t* bound_out, void* stream) {
     lgd::FocalArgs a;
     if (lgd::focal_fill(a, logits_host, labels_host, level_hw_host, L, N, A, K, alpha, gamma) != LGD_OK || !ws || !loss || !grad_logits_host)
         return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!grad_logits_host[l]) return LGD_EINVAL; a.gx[l] = grad_logits_host[l]; }
-    a.ws = ws; a.loss = loss; a.gscale = grad_scale;
+    a.ws = ws; a.loss = loss; a.gscale = grad_scale; a.bound = bound_out;
     hipStream_t s = (hipStream_t)stream;
     LGD_LAUNCH("focal_fwd_grad_kernel", lgd::focal_kernel<2>, dim3((a.nwaves + 3) / 4), dim3(256), 0, s, a);
     LGD_LAUNCH("focal_reduce_kernel", lgd::focal_reduce_kernel, dim3(a.nfin), dim3(256), 0, s, a, 0);
@@ -260,13 +272,13 @@ int lgd_focal_loss_fwd_grad(const float* const* logits_host, const int32_t* cons
     return lgd::check_launch();
 }
 
-int lgd_scale_unless_one(float* const* x_host, const long long* n_host, int L, const float* g, void* stream) {
+int lgd_scale_unless_one(float* const* x_host, const long long* n_host, int L, const float* g, uint32_t* bound_inout, void* stream) {
     if (!x_host || !n_host || !g || L < 1 || L > LGD_MAX_LEVELS) return LGD_EINVAL;
     lgd::ScaleArgs a;
     for (int l = 0; l < LGD_MAX_LEVELS; ++l) { a.x[l] = nullptr; a.n[l] = 0; }
     for (int l = 0; l < L; ++l) { if (!x_host[l] || n_host[l] < 0) return LGD_EINVAL; a.x[l] = x_host[l]; a.n[l] = n_host[l]; }
     a.L = L;
-    LGD_LAUNCH("scale_unless_one_kernel", lgd::scale_unless_one_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, a, g);
+    LGD_LAUNCH("scale_unless_one_kernel", lgd::scale_unless_one_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, a, g, bound_inout);
     return lgd::check_launch();
 }
 
@@ -278,7 +290,7 @@ int lgd_focal_loss_bwd(const float* const* logits_host, const int32_t* const* la
         !grad_logits_host)
         return LGD_EINVAL;
     for (int l = 0; l < L; ++l) { if (!grad_logits_host[l]) return LGD_EINVAL; a.gx[l] = grad_logits_host[l]; }
-    a.ws = nullptr; a.loss = nullptr; a.gscale = grad_loss;
+    a.ws = nullptr; a.loss = nullptr; a.gscale = grad_loss; a.bound = nullptr;
     LGD_LAUNCH("focal_bwd_kernel", lgd::focal_kernel<1>, dim3((a.nwaves + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }

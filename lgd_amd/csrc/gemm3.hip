@@ -493,10 +493,49 @@ __global__ void split_a_h2_kernel(const float* __restrict__ A, long a_sb, long s
     *reinterpret_cast<u32x4*>(d + (long)rbp * 1024) = (u32x4){mm[0], mm[1], mm[2], mm[3]};
 }
 
+// split_a_h2_kernel for a TABLE of filters in one launch (block -> task by binary search in the block prefix, as lgd_scale_rows_multi): the images
+// of every trainable 1x1 convolution, W and W^T, once per step instead of a ~5 us launch in front of every product
+__global__ __launch_bounds__(256) void split_a_h2_multi_kernel(const lgd_split_task* __restrict__ tasks, const int* __restrict__ blk0, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const lgd_split_task t = tasks[lo];
+    const long q = (long)(blockIdx.x - blk0[lo]) * 256 + threadIdx.x;
+    const int e = h2_exponent(*reinterpret_cast<const unsigned*>(t.amax), 0);
+    if (q == 0) *reinterpret_cast<float*>(t.inv) = h2_pow2(-e);
+    const int rbp = (t.M + 31) / 32, ktp = (t.K + 15) / 16;
+    if (q >= (long)ktp * rbp * 64) return;
+    const float s = h2_pow2(e);
+    const float* A = reinterpret_cast<const float*>(t.a);
+    const int lane = (int)(q & 63);
+    const long r = q >> 6;
+    const int rb = (int)(r % rbp), kt = (int)(r / rbp);
+    const int m = rb * 32 + (lane & 31), k0 = kt * 16 + (lane >> 5) * 8;
+    uint32_t h[4], mm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = (m < t.M && k0 + 2 * i < t.K) ? A[(long)m * t.sm + (long)(k0 + 2 * i) * t.sk] : 0.f;
+        const float x1 = (m < t.M && k0 + 2 * i + 1 < t.K) ? A[(long)m * t.sm + (long)(k0 + 2 * i + 1) * t.sk] : 0.f;
+        split2_f16(x0 * s, x1 * s, h[i], mm[i]);
+    }
+    char* d = reinterpret_cast<char*>(t.img) + (((long)kt * 2) * rbp + rb) * 1024 + lane * 16;
+    *reinterpret_cast<u32x4*>(d) = (u32x4){h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(d + (long)rbp * 1024) = (u32x4){mm[0], mm[1], mm[2], mm[3]};
+}
+
 }  // namespace
 }  // namespace lgd
 
 extern "C" {
+
+int lgd_gemm2h_split_multi(const void* tasks_dev, const int32_t* blk0_dev, int n, int nblocks, void* stream) {
+    if (!tasks_dev || !blk0_dev || n < 1 || nblocks < 1) return LGD_EINVAL;
+    LGD_LAUNCH("gemm2h_split_multi_kernel", lgd::split_a_h2_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+               reinterpret_cast<const lgd_split_task*>(tasks_dev), reinterpret_cast<const int*>(blk0_dev), n);
+    return lgd::check_launch();
+}
 
 size_t lgd_gemm3_image_bytes(int nb, int M, int K) {
     if (nb <= 0 || M <= 0 || K <= 0) return 0;

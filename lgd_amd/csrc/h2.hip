@@ -612,6 +612,14 @@ __global__ __launch_bounds__(256) void h2_plane_sums_kernel(const char* __restri
     if (threadIdx.x == 0) out[blockIdx.x] = ((slots[0] + slots[1]) + (slots[2] + slots[3])) * inv[0];
 }
 
+struct WordsArgs { const unsigned* w[16]; int n; unsigned* out; };
+__global__ __launch_bounds__(64) void h2_words_max_kernel(WordsArgs a) {
+    unsigned v = threadIdx.x < (unsigned)a.n ? *a.w[threadIdx.x] : 0u;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    if (threadIdx.x == 0) *a.out = max(*a.out, v);
+}
+
 constexpr int kFwdLds256 = 3 * (2 * 8 * 1024 + 8192), kFwdLds128 = 3 * (2 * 4 * 1024 + 8192), kDwLds = 4 * 2 * 256 * 64, kPwDwLds = 2 * 2 * 256 * 128;
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, device)
@@ -771,6 +779,15 @@ int lgd_h2_amax_filters(const float* const* w_host, const float* const* scale_ho
     a.row_off[K] = off; a.out = out_bits; a.K = K; a.row = row_elems;
     hipStream_t st = (hipStream_t)stream;
     LGD_LAUNCH("h2_amax_filter_kernel", lgd::h2_amax_filter_kernel, dim3(off), dim3(256), 0, st, a);
+    return lgd::check_launch();
+}
+
+int lgd_h2_words_max(const uint32_t* const* words_host, int n, uint32_t* out, void* stream) {
+    if (!words_host || !out || n < 1 || n > 16) return LGD_EINVAL;
+    lgd::WordsArgs a{};
+    for (int i = 0; i < n; ++i) { if (!words_host[i]) return LGD_EINVAL; a.w[i] = words_host[i]; }
+    a.n = n; a.out = out;
+    LGD_LAUNCH("h2_words_max_kernel", lgd::h2_words_max_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     return lgd::check_launch();
 }
 

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.environ.get("LGD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")   # LGD_HIP_LIB: a lab build
 _lib = None
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -62,8 +62,8 @@ SIGNATURES = {
     "lgd_segmax_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_focal_ws_doubles": (c_sz, [c_fp, c_i, c_i, c_i, c_i]),
     "lgd_focal_loss_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
-    "lgd_focal_loss_fwd_grad": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp, c_fp, c_fp]),
-    "lgd_scale_unless_one": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp]),
+    "lgd_focal_loss_fwd_grad": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "lgd_scale_unless_one": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp, c_fp]),
     "lgd_fcos_loss_ws_doubles": (c_sz, [c_fp, c_i, c_i]),
     "lgd_fcos_loss_fwd_grad": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_focal_loss_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_fp]),
@@ -92,6 +92,7 @@ SIGNATURES = {
     "lgd_h2_amax_maps": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp]),
     "lgd_h2_amax_filters": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "lgd_h2_link_bound": (c_i, [c_fp, c_fp, c_fp]),
+    "lgd_h2_words_max": (c_i, [c_fp, c_i, c_fp, c_fp]),
     "lgd_h2_plane_sums": (c_i, [c_fp, ctypes.c_longlong, c_i, c_i, c_fp, c_fp, c_fp]),
     "lgd_wino_out_t_gn_h2": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_in_h2": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     "lgd_wino_in_t_amax": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_wino_filter_images_h2": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gemm2h_image_bytes": (c_sz, [c_i, c_i, c_i]),
+    "lgd_gemm2h_split_multi": (c_i, [c_fp, c_fp, c_i, c_i, c_fp]),
     "lgd_gemm2h_split": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "lgd_gemm2h": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "lgd_relu_rowbits_words": (c_sz, [ctypes.c_longlong, c_i]),

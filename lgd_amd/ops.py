@@ -915,10 +915,11 @@ class _FocalSumNorm(torch.autograd.Function):
         ws = torch.empty(lib.lgd_focal_ws_doubles(hw, n_levels, N, A, K), dtype=torch.float64, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         grads = [torch.empty_like(x) for x in logits]
+        bound = torch.empty(1, dtype=torch.int32, device=dev)   # bound of |gradient| (the class convolution's f16x2 backward takes its scale from it)
         hip.check(lib.lgd_focal_loss_fwd_grad(hip.ptr_array(logits), hip.ptr_array(labels), hw, n_levels, N, A, K, float(alpha),
-                                              float(gamma), hip.ptr(inv), hip.ptr(ws), hip.ptr(loss), hip.ptr_array(grads),
+                                              float(gamma), hip.ptr(inv), hip.ptr(ws), hip.ptr(loss), hip.ptr_array(grads), hip.ptr(bound),
                                               hip.stream_ptr()), "lgd_focal_loss_fwd_grad")
-        ctx.save_for_backward(*grads)
+        ctx.save_for_backward(*grads, bound)
         ctx.sizes = (ctypes.c_longlong * n_levels)(*[g.numel() for g in grads])
         return loss * inv
 
@@ -927,9 +928,10 @@ class _FocalSumNorm(torch.autograd.Function):
     def backward(ctx, g):
         lib = hip.load()
         _consume_once(ctx, "focal_loss_sum")
-        grads = list(ctx.saved_tensors)
+        *grads, bound = ctx.saved_tensors
         g = g.contiguous().to(torch.float32)
-        hip.check(lib.lgd_scale_unless_one(hip.ptr_array(grads), ctx.sizes, len(grads), hip.ptr(g), hip.stream_ptr()), "lgd_scale_unless_one")
+        hip.check(lib.lgd_scale_unless_one(hip.ptr_array(grads), ctx.sizes, len(grads), hip.ptr(g), hip.ptr(bound), hip.stream_ptr()), "lgd_scale_unless_one")
+        _amax_tag(grads, bound)
         return (None, None, None, None, None, None, *grads, *([None] * len(grads)))
 
 
@@ -1007,8 +1009,8 @@ class _FcosRegCtrLoss(torch.autograd.Function):
         g_reg, g_ctr = list(g[:L]), list(g[L:])
         g_box = (g_box if g_box is not None else torch.zeros((), device=out.device)).contiguous().to(torch.float32)
         g_c = (g_c if g_c is not None else torch.zeros((), device=out.device)).contiguous().to(torch.float32)
-        hip.check(lib.lgd_scale_unless_one(hip.ptr_array(g_reg), ctx.sizes[0], L, hip.ptr(g_box), hip.stream_ptr()), "lgd_scale_unless_one")
-        hip.check(lib.lgd_scale_unless_one(hip.ptr_array(g_ctr), ctx.sizes[1], L, hip.ptr(g_c), hip.stream_ptr()), "lgd_scale_unless_one")
+        hip.check(lib.lgd_scale_unless_one(hip.ptr_array(g_reg), ctx.sizes[0], L, hip.ptr(g_box), None, hip.stream_ptr()), "lgd_scale_unless_one")
+        hip.check(lib.lgd_scale_unless_one(hip.ptr_array(g_ctr), ctx.sizes[1], L, hip.ptr(g_c), None, hip.stream_ptr()), "lgd_scale_unless_one")
         d_scales = out[2:] * g_box if ctx.needs_input_grad[3] else None
         return (None, None, None, d_scales, None, None, None, None, *g_reg, *g_ctr)
 
@@ -2497,6 +2499,9 @@ _PW_ONE_ROUND_FILL = float(os.environ.get("LGD_PW_ONE_ROUND_FILL", "1.0"))   # w
 _PW_TAGS_ALWAYS = os.environ.get("LGD_PW_TAGS_ALWAYS", "0") != "0"   # 1: every output transform leaves its maximum, whatever the map's size (experiments)
 
 
+_SPLIT_CALLS = [0]   # filter images made in front of a product (tests)
+
+
 def gemm2h_bmm(a, b, b_amax, out=None, accumulate=False, residual=None, shift=None, relu=False, relu_bits=None, amax_out=None):
     """gemm3_bmm in the f16x2 form (lgd_gemm2h: three MFMAs per k-step instead of six): a must be ONE matrix for the whole batch (stride 0: the
     student's 1x1 convolutions); b_amax: int32[1], float bits of a bound of max |b| (the tag its producer left, or _amax_bits)."""
@@ -2533,10 +2538,26 @@ def gemm2h_bmm(a, b, b_amax, out=None, accumulate=False, residual=None, shift=No
         a_amax = torch.linalg.vector_norm(a0, float("inf")).reshape(1).view(torch.int32)
         if a0.numel() == root.numel():
             root._lgd_w_amax = (a_amax, root._version, root.numel())
-    img = torch.empty(lib.lgd_gemm2h_image_bytes(1, M, K), dtype=torch.uint8, device=a.device)
-    a_inv = torch.empty(1, dtype=torch.float32, device=a.device)
     st = hip.stream_ptr()
-    hip.check(lib.lgd_gemm2h_split(hip.ptr(a0), 0, a0.stride(0), a0.stride(1), 1, M, K, hip.ptr(a_amax), hip.ptr(img), hip.ptr(a_inv), st), "lgd_gemm2h_split")
+    # the filter's image: this step's, where student.resnet.StepFolds split all of them in one launch; a frozen filter's from its first product;
+    # otherwise made here
+    images = getattr(root, "_lgd_w_img_table", None)
+    key = (a0.storage_offset(), a0.stride(0) == 1 and M > 1)
+    hit = images[0].get(key) if images is not None and images[1] == root._version else None
+    kept = getattr(root, "_lgd_w_img", None) if hit is None else None
+    if hit is not None and hit[2] == a0.numel() and a0.is_contiguous() != key[1]:
+        img, a_inv = hit[0], hit[1]
+    elif kept is not None and key in kept and kept[key][2] == root._version and kept[key][3] == tuple(a0.shape) + tuple(a0.stride()):
+        img, a_inv = kept[key][0], kept[key][1]
+    else:
+        img = torch.empty(lib.lgd_gemm2h_image_bytes(1, M, K), dtype=torch.uint8, device=a.device)
+        a_inv = torch.empty(1, dtype=torch.float32, device=a.device)
+        hip.check(lib.lgd_gemm2h_split(hip.ptr(a0), 0, a0.stride(0), a0.stride(1), 1, M, K, hip.ptr(a_amax), hip.ptr(img), hip.ptr(a_inv), st), "lgd_gemm2h_split")
+        _SPLIT_CALLS[0] += 1
+        if not root.requires_grad and a0.numel() == root.numel():   # a frozen filter (res2, a frozen backbone): split once, until somebody writes it
+            if kept is None:
+                kept = root._lgd_w_img = {}
+            kept[key] = (img, a_inv, root._version, tuple(a0.shape) + tuple(a0.stride()))
     hip.check(lib.lgd_gemm2h(hip.ptr(img), 1, hip.ptr(a_inv), hip.ptr(b), hip.ptr(b_amax), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1),
                              hip.ptr(residual) if residual is not None else None, residual.stride(0) if residual is not None else 0,
                              residual.stride(1) if residual is not None else 0, hip.ptr(shift) if shift is not None else None, 1 if relu else 0,
@@ -2716,28 +2737,40 @@ def _amax_bits(lib, xs, hw_levels, pre=None, affine=False):
     dev = xs[0].device
     # (an affine pre-activation takes its own pass: max|x| max|scale| + max shift multiplies maxima of DIFFERENT channels -- a GroupNorm channel with a
     #  tiny variance has a huge scale and small values -- and a bound 2^10 too loose spends the f16 pair's precision window on nothing)
-    tags = [getattr(x, "_lgd_amax", None) for x in xs] if (_H2_TAGS and not affine) else [None]
-    if all(t is not None and t[1] == x._version for t, x in zip(tags, xs)):
-        uniq = []
-        for t in tags:
-            if not any(t[0] is u for u in uniq):
-                uniq.append(t[0])
-        a = uniq[0] if len(uniq) == 1 else torch.stack([u.view(()) for u in uniq]).max().view(1)   # non-negative floats order like their bits
-        if pre is None:
-            return a
-        af = a.view(torch.float32)
-        b = (af + pre.max()).clamp_min(0.0)   # |relu(x + b[c])| <= max(0, max|x| + max b)
-        return (b * 1.000001).view(torch.int32)   # (the roundings of the bound's own arithmetic)
+    tags = [getattr(x, "_lgd_amax", None) for x in xs] if (_H2_TAGS and not affine) else [None] * len(xs)
+    tags = [t if t is not None and t[1] == x._version else None for t, x in zip(tags, xs)]
+    uniq = []
+    for t in tags:
+        if t is not None and not any(t[0] is u for u in uniq):
+            uniq.append(t[0])
+    rest = [i for i, t in enumerate(tags) if t is None]
+    if not rest and len(uniq) == 1 and pre is None:
+        return uniq[0]
     out = _zero_words(dev)
-    L, N, C = len(xs), xs[0].shape[0], xs[0].shape[1]
+    if uniq and len(uniq) <= 16:   # the tagged maps' bounds, folded into one word by one small launch (non-negative floats order like their bits)
+        hip.check(lib.lgd_h2_words_max(hip.ptr_array(uniq), len(uniq), hip.ptr(out), hip.stream_ptr()), "lgd_h2_words_max")
+    elif uniq:
+        rest = list(range(len(xs)))
+    if not rest:
+        if pre is None:
+            return out
+        b = (out.view(torch.float32) + pre.max()).clamp_min(0.0)   # |relu(x + b[c])| <= max(0, max|x| + max b)
+        return (b * 1.000001).view(torch.int32)   # (the roundings of the bound's own arithmetic)
+    if pre is not None and len(rest) < len(xs):   # (a pre-activation's bound is taken over all maps or from tags alone)
+        rest = list(range(len(xs)))
+        out = _zero_words(dev)
+    # the maps without a (valid) tag -- the small levels the library's convolutions produced, sums autograd built -- take one pass, added onto the
+    # tagged ones' bound
+    L, N, C = len(rest), xs[0].shape[0], xs[0].shape[1]
     if _H2_DEBUG:
         import traceback
         fr = [f for f in traceback.extract_stack()[:-1] if "ops.py" not in f.filename and "torch" not in f.filename][-2:]
-        print("[h2 amax pass] L=%d N=%d C=%d hw=%s pre=%s tags=%s  <- %s" % (L, N, C, [tuple(x.shape[2:]) for x in xs][:2], None if pre is None else ("affine" if affine else "bias"),
-                                                                    [t is not None for t in tags], " / ".join("%s:%d %s" % (f.filename.split("/")[-1], f.lineno, f.name) for f in fr)))
-    hip.check(lib.lgd_h2_amax_maps(hip.ptr_array(xs), hw_levels, L, N, C, hip.ptr(pre) if pre is not None and not affine else None,
+        print("[h2 amax pass] L=%d of %d N=%d C=%d hw=%s pre=%s <- %s" % (L, len(xs), N, C, [tuple(xs[i].shape[2:]) for i in rest][:2], None if pre is None else ("affine" if affine else "bias"),
+                                                                         " / ".join("%s:%d %s" % (f.filename.split("/")[-1], f.lineno, f.name) for f in fr)))
+    hw_rest = hw_levels if len(rest) == len(xs) else hip.int_array([v for i in rest for v in xs[i].shape[-2:]])
+    hip.check(lib.lgd_h2_amax_maps(hip.ptr_array([xs[i] for i in rest]), hw_rest, L, N, C, hip.ptr(pre) if pre is not None and not affine else None,
                                    hip.ptr(pre) if pre is not None and affine else None, hip.ptr(out), 1, hip.stream_ptr()), "lgd_h2_amax_maps")
-    _count_bytes("h2_amax_maps_kernel", 4 * sum(x.numel() for x in xs))
+    _count_bytes("h2_amax_maps_kernel", 4 * sum(xs[i].numel() for i in rest))
     return out
 
 
@@ -2746,7 +2779,9 @@ def _amax_bits_groups(lib, groups, hw_levels):
     if len(groups) == 1:
         return _amax_bits(lib, groups[0], hw_levels)
     parts = [_amax_bits(lib, g, hw_levels) for g in groups]
-    return torch.stack([p.view(()) for p in parts]).max().view(1)
+    out = _zero_words(parts[0].device)
+    hip.check(lib.lgd_h2_words_max(hip.ptr_array(parts), len(parts), hip.ptr(out), hip.stream_ptr()), "lgd_h2_words_max")
+    return out
 
 
 class _H2Filter:

@@ -1,6 +1,8 @@
 """ResNet-50/101 bottom-up backbone with FrozenBN, detectron2 parameter names
 (`stem.conv1.weight`, `res3.0.conv2.norm.running_var`, `res4.5.shortcut.weight`, ...)
 [d2-memory: detectron2/modeling/backbone/resnet.py @ v0.3; SURVEY.md appendix A]."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -250,6 +252,9 @@ class ResNet(nn.Module):
         return outs
 
 
+_STEP_IMAGES = os.environ.get("LGD_STEP_IMAGES", "1") != "0"   # 0: every 1x1 product splits its filter in front of itself (A/B runs)
+
+
 class StepFolds:
     """w * scale of EVERY trainable pointwise ConvBN of a model in one launch per step (lgd_scale_rows_multi) instead of one 5 us launch
     per convolution inside its op (62 per step for R-101): at 2 images per GPU the step is bound by the device's ~1,100 short launches.
@@ -291,6 +296,32 @@ class StepFolds:
         # in `flat`)
         self.amax = torch.zeros(len(mods), dtype=torch.int32, device=dev)
         self._amax_of = {v.storage_offset(): (self.amax[i:i + 1], v.numel()) for i, v in enumerate(self.views)}
+        # ... and ONE more launch splits every fold into the f16x2 images of its two products (W: forward, W^T: input gradient) instead of a ~5 us
+        # launch in front of each of them (lgd_gemm2h_split_multi; ops.gemm2h_bmm finds an image by the fold's offset and orientation)
+        from .. import hip
+        lib = hip.load()
+        st = np.dtype([("a", "<u8"), ("img", "<u8"), ("amax", "<u8"), ("inv", "<u8"), ("M", "<i4"), ("K", "<i4"), ("sm", "<i4"), ("sk", "<i4")])
+        shapes = []
+        for v in self.views:
+            co, ci = v.shape[0], v.numel() // v.shape[0]
+            shapes += [(co, ci, ci, 1), (ci, co, 1, ci)]     # (M, K, stride of m, stride of k)
+        sizes = [int(lib.lgd_gemm2h_image_bytes(1, m_, k_)) for m_, k_, _, _ in shapes]
+        self.images = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+        self.img_inv = torch.empty(len(shapes), dtype=torch.float32, device=dev)
+        stab = np.zeros(len(shapes), dtype=st)
+        sblk0 = np.zeros(len(shapes), dtype=np.int32)
+        self._image_of = {}
+        ioff = blk = 0
+        for j, (m_, k_, sm_, sk_) in enumerate(shapes):
+            v = self.views[j // 2]
+            stab[j] = (v.data_ptr(), self.images.data_ptr() + ioff, self.amax.data_ptr() + 4 * (j // 2), self.img_inv.data_ptr() + 4 * j, m_, k_, sm_, sk_)
+            sblk0[j] = blk
+            blk += ((k_ + 15) // 16 * ((m_ + 31) // 32) * 64 + 255) // 256
+            self._image_of[(v.storage_offset(), sm_ == 1)] = (self.images[ioff:ioff + sizes[j]], self.img_inv[j:j + 1], v.numel())
+            ioff += sizes[j]
+        self.stab = torch.from_numpy(stab.view(np.uint8).copy()).to(dev)
+        self.sblk0 = torch.from_numpy(sblk0).to(dev)
+        self.snblk = blk
 
     @torch.no_grad()
     def prepare(self):
@@ -313,5 +344,9 @@ class StepFolds:
         # backward with this step's filters
         torch.autograd.graph.increment_version(self.flat)   # (one bump: the views share their base's version counter -- ADVICE r4)
         self.flat._lgd_w_amax_table = (self._amax_of, self.flat._version)
+        if _STEP_IMAGES:
+            hip.check(lib.lgd_gemm2h_split_multi(hip.ptr(self.stab), hip.ptr(self.sblk0), len(self._image_of), self.snblk, hip.stream_ptr()),
+                      "lgd_gemm2h_split_multi")
+            self.flat._lgd_w_img_table = (self._image_of, self.flat._version)
         for m, v, sc in zip(self.mods, self.views, self.scales):
             m._step_fold = ((m.weight._version, id(sc)), v)

@@ -544,7 +544,77 @@ def test_gemm2h_takes_the_fold_launch_maximum(monkeypatch):
     assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
     refx = torch.matmul(w.t().double(), dz.double())
     assert ((dx.double() - refx).abs().max() / refx.abs().max()).item() < 2e-6
+    # a table of images (StepFolds' second launch) is taken the same way, by offset and orientation; a frozen filter keeps its image
+    from lgd_amd import hip
+    lib = hip.load()
+    real_split = lib.lgd_gemm2h_split
+    imgs = {}
+    for a0, tr in ((w, False), (w.t(), True)):
+        img = torch.empty(lib.lgd_gemm2h_image_bytes(1, a0.shape[0], a0.shape[1]), dtype=torch.uint8, device=DEV)
+        inv = torch.empty(1, device=DEV)
+        hip.check(real_split(hip.ptr(a0), 0, a0.stride(0), a0.stride(1), 1, a0.shape[0], a0.shape[1], hip.ptr(words), hip.ptr(img), hip.ptr(inv), hip.stream_ptr()), "split")
+        imgs[(w.storage_offset(), tr)] = (img, inv, w.numel())
+    flat._lgd_w_img_table = (imgs, flat._version)
+    n0 = ops._SPLIT_CALLS[0]
+    y1 = ops.gemm2h_bmm(w.view(1, 128, 64).expand(2, 128, 64), x, xa)
+    dx1 = ops.gemm2h_bmm(w.t().unsqueeze(0).expand(2, 64, 128), dz, dz.abs().max().reshape(1).view(torch.int32))
+    assert ops._SPLIT_CALLS[0] == n0 and torch.equal(y1, y) and torch.equal(dx1, dx)
+    frozen = (torch.randn(128, 64, device=DEV, generator=g) * 0.1)
+    y3 = ops.gemm2h_bmm(frozen.view(1, 128, 64).expand(2, 128, 64), x, xa)
+    n1 = ops._SPLIT_CALLS[0]
+    y4 = ops.gemm2h_bmm(frozen.view(1, 128, 64).expand(2, 128, 64), x, xa)
+    assert ops._SPLIT_CALLS[0] == n1 and torch.equal(y3, y4)
+    frozen.mul_(0.5)
+    y5 = ops.gemm2h_bmm(frozen.view(1, 128, 64).expand(2, 128, 64), x, xa)
+    assert ops._SPLIT_CALLS[0] == n1 + 1 and ((y5.double() * 2 - y3.double()).abs().max() / y3.abs().max()).item() < 2e-6
     flat.mul_(2.0)                                   # written behind the table's back: the version moved, the table is stale
     y2 = ops.gemm2h_bmm(w.view(1, 128, 64).expand(2, 128, 64), x, xa)
     assert calls
     assert ((y2.double() - 2 * ref).abs().max() / ref.abs().max()).item() < 4e-6
+
+
+def test_bounds_of_partly_tagged_maps():
+    """ops._amax_bits over maps of which only some carry a producer's tag: the tagged ones' words are folded by lgd_h2_words_max and ONE pass runs over
+    the others only -- the result is the maximum over all of them, as a pass over all maps gives"""
+    from lgd_amd import ops, hip
+    lib = hip.load()
+    g = torch.Generator(device=DEV).manual_seed(21)
+    xs = [torch.randn(2, 32, h, w, device=DEV, generator=g) * s for (h, w), s in zip([(24, 36), (12, 18), (6, 9), (3, 5)], (1.0, 3.0, 0.5, 2.0))]
+    hw = hip.int_array([v for x in xs for v in x.shape[-2:]])
+    full = ops._amax_bits(lib, xs, hw)
+    assert float(full.view(torch.float32)) == max(float(x.abs().max()) for x in xs)
+    passes = []
+    real = ops._count_bytes
+    ops._count_bytes = lambda name, n: (passes.append(n) if name == "h2_amax_maps_kernel" else None, real(name, n))[1]
+    try:
+        for tagged in ([0, 1], [1], [0, 1, 2, 3], [2, 3]):
+            ys = [x.clone() for x in xs]
+            for i in tagged:   # (a bound, not necessarily the maximum: a producer may leave a larger word)
+                ops._amax_tag([ys[i]], (ys[i].abs().max() * (1.5 if i == 1 else 1.0)).reshape(1).view(torch.int32))
+            del passes[:]
+            got = ops._amax_bits(lib, ys, hw)
+            want = max(float(x.abs().max()) * (1.5 if (i == 1 and i in tagged) else 1.0) for i, x in enumerate(xs))
+            assert float(got.view(torch.float32)) == want, (tagged, float(got.view(torch.float32)), want)
+            rest = [i for i in range(4) if i not in tagged]
+            assert passes == ([4 * sum(xs[i].numel() for i in rest)] if rest else []), (tagged, passes)
+        # a bias + ReLU in front: bound from the tags alone when every map has one, one pass over ALL maps otherwise
+        pre = torch.randn(32, device=DEV, generator=g)
+        ys = [x.clone() for x in xs]
+        for i in (0, 1):
+            ops._amax_tag([ys[i]], ys[i].abs().max().reshape(1).view(torch.int32))
+        got = float(ops._amax_bits(lib, ys, hw, pre=pre).view(torch.float32))
+        assert got == max(float(torch.relu(x + pre.view(1, -1, 1, 1)).max()) for x in xs)
+    finally:
+        ops._count_bytes = real
+
+
+def test_words_max():
+    hip, lib = _lib()
+    vals = torch.tensor([0.5, 3.25, 0.0, 7.5, 1e-30], device=DEV)
+    words = [vals[i:i + 1].view(torch.int32) for i in range(5)]
+    out = torch.tensor([2.0], device=DEV).view(torch.int32)
+    hip.check(lib.lgd_h2_words_max(hip.ptr_array(words[:3]), 3, hip.ptr(out), hip.stream_ptr()), "lgd_h2_words_max")
+    assert float(out.view(torch.float32)) == 3.25
+    hip.check(lib.lgd_h2_words_max(hip.ptr_array(words), 5, hip.ptr(out), hip.stream_ptr()), "lgd_h2_words_max")
+    assert float(out.view(torch.float32)) == 7.5
+    assert lib.lgd_h2_words_max(hip.ptr_array(words), 17, hip.ptr(out), hip.stream_ptr()) != 0

@@ -422,10 +422,19 @@ def test_focal_loss_normalised_one_pass(N, A, K, level_hw, gamma, upstream):
     rc = [x.clone().requires_grad_(True) for x in raw]
     ref = SO.sigmoid_focal_sum(torch.cat([SO.flatten_head_output(x, K) for x in rc], 1), labels, K, 0.25, gamma) / norm
     assert abs(loss.item() - ref.item()) / ref.item() < 1e-5
+    seen = []
+    for x in rg:
+        x.register_hook(lambda g_: seen.append((g_, getattr(g_, "_lgd_amax", None))))
     (loss * upstream).backward()
     (ref * upstream).backward()
     for a, b in zip(rg, rc):
         assert cm.rel_err(a.grad, b.grad) < FTOL
+    # the gradient maps carry a magnitude bound (the f16x2 scale of the class convolution's backward, no pass over them): above the true maximum,
+    # within 2^3 of it, and rescaled with the maps when the upstream gradient is not 1
+    assert len(seen) == len(rg) and all(t is not None and t[1] == g_._version for g_, t in seen)
+    bound = float(seen[0][1][0].view(torch.float32))
+    true = max(float(g_.abs().max()) for g_, _ in seen)
+    assert true <= bound <= 8 * true, (true, bound)
     r2 = [x.to(DEV).requires_grad_(True) for x in raw]
     two = ops.focal_loss_sum(r2, planes, A, K, 0.25, gamma) / norm.to(DEV)
     (two * upstream).backward()

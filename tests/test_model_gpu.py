@@ -827,6 +827,21 @@ def test_step_folds_equal_per_op_folds():
     for v in sf.views:
         word, numel = table[v.storage_offset()]
         assert numel == v.numel() and word.view(torch.float32).item() == v.abs().max().item()
+    # ... and one more launch the f16x2 images of both products of every fold (W, W^T): byte for byte what lgd_gemm2h_split makes of each
+    from lgd_amd import hip
+    lib = hip.load()
+    images, version = sf.flat._lgd_w_img_table
+    assert version == sf.flat._version and len(images) == 2 * len(mods)
+    for v in sf.views[:3] + sf.views[-3:]:
+        w2 = v.view(v.shape[0], -1)
+        for a0, tr in ((w2, False), (w2.t(), True)):
+            img, inv, numel = images[(v.storage_offset(), tr)]
+            M, K = a0.shape
+            ref = torch.empty(lib.lgd_gemm2h_image_bytes(1, M, K), dtype=torch.uint8, device=DEV)
+            rinv = torch.empty(1, device=DEV)
+            hip.check(lib.lgd_gemm2h_split(hip.ptr(a0), 0, a0.stride(0), a0.stride(1), 1, M, K, hip.ptr(table[v.storage_offset()][0]), hip.ptr(ref), hip.ptr(rinv),
+                                           hip.stream_ptr()), "lgd_gemm2h_split")
+            assert numel == v.numel() and torch.equal(img, ref) and torch.equal(inv, rinv), (tuple(v.shape), tr)
     with torch.no_grad():
         mods[0].weight.mul_(1.5)                      # written after prepare(): the cached fold is stale and must not be used
     assert mods[0]._cached_fold(mods[0].norm.scale_shift()[0]) is None
