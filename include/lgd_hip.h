@@ -499,6 +499,17 @@ size_t lgd_relu_bits_words(long long total);
 /* frozen stem epilogue [d2-memory: BasicStem -- conv1 -> FrozenBN -> relu -> max_pool2d(3, stride 2, padding 1)]:
  * out (N, C, (H-1)/2+1, (W-1)/2+1) = max_pool2d(relu(y + bias[c]), 3, 2, 1) of the conv output y (N, C, H, W) in one pass. Forward only. */
 int lgd_stem_bias_relu_maxpool(const float* y, const float* bias, int N, int C, int H, int W, float* out, void* stream);
+/* K11 (csrc/stem.hip): the frozen ResNet stem in ONE kernel -- out (N, 64, Hp, Wp) = max_pool2d(relu(conv2d(x, w, stride 2, padding 3) + shift[c]), 3, 2, 1)
+ * for x (N, 3, H, W) fp32 and w (64, 3, 7, 7) fp32 (the FrozenBN scale folded in), forward only [d2-memory: detectron2 BasicStem, frozen by
+ * MODEL.BACKBONE.FREEZE_AT = 2 in every config of the reference; the student of distillator.py:100-112].  The convolution is an implicit GEMM on
+ * v_mfma_f32_32x32x16_f16 from two-piece f16 operands (fp32-class: error vs fp64 ~5e-7 of the output scale); the conv output never reaches memory.
+ * lgd_stem7_image: the filter as MFMA fragments (lgd_stem7_image_bytes() bytes, 16-byte aligned) scaled by the power of two that the bound *w_amax
+ * (float bits of max |w|) prescribes, inverse scale in *w_inv -- once per (frozen) filter.  lgd_stem7_conv_pool: *x_amax = float bits of a bound of
+ * max |x| (lgd_h2_amax_maps); Ho = (H - 1) / 2 + 1, Hp = (Ho - 1) / 2 + 1 (W alike). */
+size_t lgd_stem7_image_bytes(void);
+int lgd_stem7_image(const float* w, const uint32_t* w_amax, void* image, float* w_inv, void* stream);
+int lgd_stem7_conv_pool(const float* x, const void* image, const float* w_inv, const uint32_t* x_amax, const float* shift, int N, int H, int W, float* out,
+                        void* stream);
 int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, int N, int C, int HW, int relu, float* out,
                      uint32_t* relu_bits, void* stream);
 /* weight gradient of a pointwise convolution from per-image partial products: out[o][i] = scale[o] * sum_n part[n][o][i]

@@ -2121,6 +2121,44 @@ def stem_bias_relu_maxpool(y, bias):
     return out
 
 
+_STEM7_ON = os.environ.get("LGD_STEM7", "1") != "0"   # 0: the library's convolution + the pooling pass (A/B runs)
+
+
+def stem_conv_pool_ok(x, wf):
+    """whether csrc/stem.hip takes the stem: the frozen 7x7 / stride 2 / padding 3 convolution of 3 -> 64 channels on an fp32 CUDA batch"""
+    return (_STEM7_ON and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and tuple(wf.shape) == (64, 3, 7, 7)
+            and wf.dtype == torch.float32 and x.shape[2] * x.shape[3] <= 1 << 27)
+
+
+def stem_conv_pool(x, wf, shift):
+    """max_pool2d(relu(conv2d(x, wf, stride 2, padding 3) + shift[c]), 3, 2, 1) in one kernel (lgd_stem7_conv_pool; no autograd: the stem is frozen).
+    The filter's f16x2 image is made once per filter tensor and version."""
+    hip.require_gpu(x, wf, shift)
+    lib = hip.load()
+    x, shift = hip.dense_f32(x.detach()), hip.dense_f32(shift.detach())
+    st = hip.stream_ptr()
+    kept = getattr(wf, "_lgd_stem7", None)
+    if kept is None or kept[2] != wf._version:
+        wc = hip.dense_f32(wf.detach())
+        wa = torch.linalg.vector_norm(wc, float("inf")).reshape(1).view(torch.int32)
+        img = torch.empty(lib.lgd_stem7_image_bytes(), dtype=torch.uint8, device=x.device)
+        winv = torch.empty(1, dtype=torch.float32, device=x.device)
+        hip.check(lib.lgd_stem7_image(hip.ptr(wc), hip.ptr(wa), hip.ptr(img), hip.ptr(winv), st), "lgd_stem7_image")
+        kept = (img, winv, wf._version)
+        try:
+            wf._lgd_stem7 = kept
+        except AttributeError:
+            pass
+    N, _, H, W = x.shape
+    xa = _zero_words(x.device)
+    hip.check(lib.lgd_h2_amax_maps(hip.ptr_array([x]), hip.int_array([H, W]), 1, N, 3, None, None, hip.ptr(xa), 1, st), "lgd_h2_amax_maps")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, 64, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    hip.check(lib.lgd_stem7_conv_pool(hip.ptr(x), hip.ptr(kept[0]), hip.ptr(kept[1]), hip.ptr(xa), hip.ptr(shift), N, H, W, hip.ptr(out), st),
+              "lgd_stem7_conv_pool")
+    return out
+
+
 class _PointwiseConvBN(torch.autograd.Function):
     """1x1 / stride 1 convolution with a folded frozen per-channel affine, as ONE autograd node:
         out = relu?( conv(x, w * scale[:, None, None, None]) + shift[c] (+ residual) )

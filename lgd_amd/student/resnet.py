@@ -192,7 +192,10 @@ class Stem(nn.Module):
             # in ONE pass over the 550 MB conv output (ops.stem_bias_relu_maxpool) instead of an epilogue pass and a pooling pass
             scale, shift = c.norm.scale_shift()
             with torch.no_grad():
-                return ops.stem_bias_relu_maxpool(F.conv2d(x, c._frozen_fold(scale), None, c.stride, c.padding), shift)
+                wf = c._frozen_fold(scale)
+                if ops.stem_conv_pool_ok(x, wf) and c.stride == (2, 2) and c.padding == (3, 3):
+                    return ops.stem_conv_pool(x, wf, shift)   # csrc/stem.hip: convolution, shift, ReLU and the pool in one kernel
+                return ops.stem_bias_relu_maxpool(F.conv2d(x, wf, None, c.stride, c.padding), shift)
         return F.max_pool2d(self.conv1(x, relu=True), 3, 2, 1)
 
 

@@ -2198,3 +2198,36 @@ def test_deform_conv3x3_packed_offsets_and_mask_logits(N, C, O, H, W, stride, ga
     y2 = ops.deform_conv3x3(x2, torch.cat((p1, p2), 1), pm.sigmoid(), w2, None, stride, 1, 1)
     y2.backward(gy)
     assert cm.rel_err(y, y2) < 1e-6 and cm.rel_err(om.grad, om2.grad) < 1e-5 and cm.rel_err(x.grad, x2.grad) < 1e-5
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 50, 70), (1, 37, 41), (3, 33, 130), (1, 128, 1344 // 4)])
+def test_stem_conv_pool_vs_fp64(N, H, W):
+    """csrc/stem.hip (the frozen stem as one kernel: 7x7 / 2 convolution on f16x2 MFMA operands, shift, ReLU and the 3x3 / 2 max-pool on the
+    accumulators) against the fp64 composition of the three operators [d2-memory: BasicStem; forward only, FREEZE_AT = 2]: fp32-class, odd sizes
+    (partial tiles, pooling windows over the conv output's edge), image values as large as un-normalised pixels"""
+    import torch.nn.functional as F
+    from lgd_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    x = (torch.rand((N, 3, H, W), generator=g) * 255.0 - 120.0)
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.05
+    shift = torch.randn(64, generator=g) * 2.0
+    ref = F.max_pool2d(torch.relu(F.conv2d(x.double(), w.double(), None, 2, 3) + shift.double().view(1, -1, 1, 1)), 3, 2, 1)
+    pre = F.conv2d(x.double(), w.double(), None, 2, 3)
+    assert ops.stem_conv_pool_ok(x.to(DEV), w.to(DEV))
+    wd = w.to(DEV)
+    out = ops.stem_conv_pool(x.to(DEV), wd, shift.to(DEV))
+    assert tuple(out.shape) == tuple(ref.shape)
+    err = (out.double().cpu() - ref).abs().max().item() / pre.abs().max().item()
+    assert err < 2e-6, err
+    # the library convolution + the pooling pass it replaces: the same to fp32 rounding
+    lib = ops.stem_bias_relu_maxpool(F.conv2d(x.to(DEV), wd, None, 2, 3), shift.to(DEV))
+    assert ((out - lib).abs().max() / pre.abs().max()).item() < 1e-5
+    # the filter's image is made once per filter version
+    made = wd._lgd_stem7
+    ops.stem_conv_pool(x.to(DEV), wd, shift.to(DEV))
+    assert wd._lgd_stem7 is made
+    wd.mul_(0.5)
+    out2 = ops.stem_conv_pool(x.to(DEV), wd, shift.to(DEV))
+    assert wd._lgd_stem7 is not made
+    ref2 = F.max_pool2d(torch.relu(pre * 0.5 + shift.double().view(1, -1, 1, 1)), 3, 2, 1)
+    assert (out2.double().cpu() - ref2).abs().max().item() / pre.abs().max().item() < 2e-6
