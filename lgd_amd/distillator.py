@@ -22,7 +22,8 @@ class _Distillator(BaseDistillator):
     def forward(self, batched_inputs, **kwargs):
         if self.training and self.fused_head_pass:
             s = self.student
-            r_features, features, images, gt_instances = s.backbone_features(batched_inputs)
+            r_features, features, images, gt_instances = s.backbone_features(
+                batched_inputs, after_preprocess=lambda images: self.teacher.encode_ahead(batched_inputs, images))
             features_tea, inst_labels, geom = self.teacher((batched_inputs, images, r_features, features))
             losses, losses_tea = self._pair_losses([features[f] for f in s.head_in_features],
                                                    [features_tea[f] for f in s.head_in_features], gt_instances)

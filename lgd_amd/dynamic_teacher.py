@@ -13,6 +13,8 @@ so released checkpoints load and the meta-arch above it is unchanged.  What diff
 The third value returned by forward() is the BoxGeometry (the reference returns the dense
 masks there; nothing downstream reads them -- base_distillator.py:34-64 ignores the argument).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -132,7 +134,7 @@ class LabelEncoder(nn.Module):
 
     def forward(self, x0):
         batched_inputs, images, _, fpn = x0
-        device = fpn["p3"].device if isinstance(fpn, dict) else fpn[0].device
+        device = fpn if isinstance(fpn, torch.device) else (fpn["p3"].device if isinstance(fpn, dict) else fpn[0].device)
         _, _, h, w = images.tensor.shape
         targets = [x["instances"] for x in batched_inputs]
         x, boxes, counts, img_off, inst_labels = self.encode_descriptors(targets, h, w, device)
@@ -216,12 +218,36 @@ class DynamicTeacher(nn.Module):
             xs = ops.gn1(m[idx].levels(xs, pre=pre if idx == 0 else None), relu=relu)
         return xs
 
-    def interactive_remapping(self, label_embed, boxes, counts, feats, img_size_dict):
+    # The label encoder (PointNet over the box descriptors: two spatial transformers, ~30 small GEMM / LayerNorm launches of a handful of
+    # workgroups each, a serial chain that leaves the chip idle for ~0.5 ms forward and ~0.7 ms backward) depends on the annotations only, not
+    # on the student's features: encode_ahead() issues it on a SIDE stream before the backbone, where it runs under the backbone's kernels;
+    # autograd runs its backward on the same stream, under the backbone's backward.  LGD_TEACHER_STREAM=0: in line, on the caller's stream.
+    side_stream = os.environ.get("LGD_TEACHER_STREAM", "1") != "0"
+
+    def encode_ahead(self, batched_inputs, images):
+        """label encoder + canonical projection of this mini-batch on the side stream (a no-op off the GPU or when switched off); forward()
+        picks the result up.  Called by the distillator between the student's preprocessing and its backbone."""
+        self._ahead = None
+        dev = images.tensor.device
+        if not (self.side_stream and dev.type == "cuda"):
+            return
+        main = torch.cuda.current_stream(dev)
+        side = getattr(self, "_side", None)
+        if side is None or side.device != dev:
+            side = self._side = torch.cuda.Stream(dev)
+        side.wait_stream(main)   # the weights last step's optimizer wrote, the annotations the loader copied
+        with torch.cuda.stream(side):
+            enc = self.label_encoder_((batched_inputs, images, None, dev))
+            canoni = _lin_ln_relu(self.canoni_proj_1D[0][0], enc[0])
+        self._ahead = (id(batched_inputs), enc, canoni, side)
+
+    def interactive_remapping(self, label_embed, boxes, counts, feats, img_size_dict, canoni=None):
         """[ref: dynamic_teacher.py:209-283]"""
         if self.detach_appearance_embed:
             feats = {k: v.detach() for k, v in feats.items()}
         keys = list(feats.keys())
-        canoni = _lin_ln_relu(self.canoni_proj_1D[0][0], label_embed)
+        if canoni is None:
+            canoni = _lin_ln_relu(self.canoni_proj_1D[0][0], label_embed)
         sp = self.student_proj_2D[0][0]
         geom = ops.BoxGeometry(boxes, counts, (img_size_dict["h"], img_size_dict["w"]),
                                [tuple(feats[k].shape[-2:]) for k in keys])
@@ -243,8 +269,18 @@ class DynamicTeacher(nn.Module):
         return tea, geom
 
     def forward(self, info_list):
-        x, _, _, boxes, img_size_dict, inst_labels, counts = self.label_encoder_(info_list)
-        tea, geom = self.interactive_remapping(x, boxes, counts, info_list[-1], img_size_dict)
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        canoni = None
+        if ahead is not None and ahead[0] == id(info_list[0]):
+            _, enc, canoni, side = ahead
+            main = torch.cuda.current_stream(canoni.device)
+            main.wait_stream(side)
+            for t in (canoni, enc[0], enc[3]):   # made on the side stream, read on this one: keep their memory until this stream is done with it
+                t.record_stream(main)
+        else:
+            enc = self.label_encoder_(info_list)
+        x, _, _, boxes, img_size_dict, inst_labels, counts = enc
+        tea, geom = self.interactive_remapping(x, boxes, counts, info_list[-1], img_size_dict, canoni=canoni)
         return tea, inst_labels, geom
 
 

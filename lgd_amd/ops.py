@@ -2734,7 +2734,8 @@ _ZERO_POOL = {}
 def _zero_words(dev, n=1):
     """n int32 words that are zero and that nobody has written: the running maxima of the bounds start from them.  Cut from a pool that is
     filled once per 4096 words -- a fill launch per bound was 142 launches and 0.7 ms per step at BASELINE config 2"""
-    key = (dev.type, dev.index)
+    # (a pool per stream: the fill and the kernels that start from the words are ordered by the stream they were issued on)
+    key = (dev.type, dev.index, torch._C._cuda_getCurrentRawStream(dev.index) if dev.type == "cuda" and dev.index is not None else 0)
     pool = _ZERO_POOL.get(key)
     if pool is None or pool[1] + n > pool[0].numel():
         pool = [torch.zeros(4096, dtype=torch.int32, device=dev), 0]

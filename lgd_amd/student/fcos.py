@@ -245,9 +245,11 @@ class FCOSCT(nn.Module):
         loss_ctr = torch.where(fg, bce, torch.zeros_like(bce)).sum() / num_fg
         return {"loss_cls": loss_cls, "loss_box_reg": loss_box, "loss_centerness": loss_ctr}
 
-    def backbone_features(self, batched_inputs):
+    def backbone_features(self, batched_inputs, after_preprocess=None):
         """bottom-up + FPN only (see RetinaNetCT.backbone_features)."""
         images = self.preprocess_image(batched_inputs)
+        if after_preprocess is not None:   # (the distillator starts the teacher's label encoder here, on its side stream, ahead of the backbone)
+            after_preprocess(images)
         raw_features = self.raw_backbone(images.tensor)
         features = self.fpn(raw_features)
         features = {f: features[f] for f in self.in_features}

@@ -271,11 +271,13 @@ class RetinaNetCT(nn.Module):
                                         self.smooth_l1_beta, self.bbox_reg_weights)
         return {"loss_cls": loss_cls, "loss_box_reg": loss_box / self.loss_normalizer}
 
-    def backbone_features(self, batched_inputs):
+    def backbone_features(self, batched_inputs, after_preprocess=None):
         """bottom-up + FPN only (no head pass): (raw_features, features dict, images, gt_instances | None).  The
         distillator defers the student's head pass until the teacher features exist and runs the head ONCE over both
         (ref: distillator.py:107-112 re-runs student.predict on the teacher features)."""
         images = self.preprocess_image(batched_inputs)
+        if after_preprocess is not None:   # (the distillator starts the teacher's label encoder here, on its side stream, ahead of the backbone)
+            after_preprocess(images)
         raw_features = self.raw_backbone(images.tensor)
         features = self.fpn(raw_features)
         features = {f: features[f] for f in self.head_in_features}

@@ -798,6 +798,39 @@ def test_trainer_fused_sgd_equals_torch_optimizers():
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), n
 
 
+def test_label_encoder_on_the_side_stream_equals_in_line():
+    """DynamicTeacher.encode_ahead: the label encoder (annotations only) issued on a side stream ahead of the backbone, its backward on that stream
+    under the backbone's -- against the in-line order (side_stream = False) from the same weights: losses and parameters after three trainer steps
+    across the phase switches equal to the run-to-run noise of the step (fp32 atomics in the pooling reductions), and the side stream is really used."""
+    import copy
+    from lgd_amd import config
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    base = build_model(cfg)
+    twin = copy.deepcopy(base)
+    assert base.teacher.side_stream
+    twin.teacher.side_stream = False
+    data = synthetic_batch(2, 256, 320, 5, seed=6)
+    a = Trainer(cfg, base, distributed=False)
+    b = Trainer(cfg, twin, distributed=False)
+    seen = []
+    enc = base.teacher.label_encoder_.forward
+    base.teacher.label_encoder_.forward = lambda x0: (seen.append(torch.cuda.current_stream() != torch.cuda.default_stream()), enc(x0))[1]
+    for it in (0, 25000, 40000):
+        la, lb = a.step(data, it), b.step(data, it)
+        for k in la:
+            va, vb = float(la[k].detach()), float(lb[k].detach())
+            assert abs(va - vb) <= 1e-5 * max(1.0, abs(vb)), (it, k, va, vb)
+    assert seen == [True, True, True]
+    assert getattr(twin.teacher, "_side", None) is None
+    for (n, p), (_, q) in zip(base.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), (n, float((p - q).abs().max()))
+
+
 def test_step_folds_equal_per_op_folds():
     """StepFolds (student/resnet.py: w * scale of every trainable 1x1 ConvBN in ONE launch per step) against the fold inside each op:
     the folded filters are bit-identical, the trainer uses them for every trainable 1x1 ConvBN in every phase (losses and the parameters
