@@ -467,7 +467,9 @@ int lgd_wino_filter_images_h2(const float* w, const float* scale, int Co, int Ci
 
 /* dx = dy where the bit is set, for rows of HW elements with ceil(HW / 32) mask words each */
 size_t lgd_relu_rowbits_words(long long rows, int HW);
-int lgd_relu_rowbits_bwd(const uint32_t* relu_bits, const float* dy, long long rows, int HW, float* dx, void* stream);
+int lgd_relu_rowbits_bwd(const uint32_t* relu_bits, const float* dy, long long rows, int HW, float* dx, uint32_t* amax_out, void* stream);
+/* (amax_out: NULL, or a word the caller zeroed that receives the float bits of max |dx|: the magnitude tag of the masked gradient, from which the
+ *  1x1 products that read it derive their f16x2 scales -- lgd_gemm2h, lgd_h2_pwdw) */
 
 /* ------------------------------------------------------------------ FCOS ground-truth assignment
  * [ref: models/customized_detectors/thirdparty_heads/fcos.py:177-284  FCOS.get_ground_truth]
@@ -505,11 +507,12 @@ int lgd_stem_bias_relu_maxpool(const float* y, const float* bias, int N, int C, 
  * v_mfma_f32_32x32x16_f16 from two-piece f16 operands (fp32-class: error vs fp64 ~5e-7 of the output scale); the conv output never reaches memory.
  * lgd_stem7_image: the filter as MFMA fragments (lgd_stem7_image_bytes() bytes, 16-byte aligned) scaled by the power of two that the bound *w_amax
  * (float bits of max |w|) prescribes, inverse scale in *w_inv -- once per (frozen) filter.  lgd_stem7_conv_pool: *x_amax = float bits of a bound of
- * max |x| (lgd_h2_amax_maps); Ho = (H - 1) / 2 + 1, Hp = (Ho - 1) / 2 + 1 (W alike). */
+ * max |x| (lgd_h2_amax_maps); Ho = (H - 1) / 2 + 1, Hp = (Ho - 1) / 2 + 1 (W alike); amax_out: NULL, or a word the caller zeroed that receives the
+ * float bits of max |out| (the tag res2's first 1x1 products take their f16x2 scale from). */
 size_t lgd_stem7_image_bytes(void);
 int lgd_stem7_image(const float* w, const uint32_t* w_amax, void* image, float* w_inv, void* stream);
 int lgd_stem7_conv_pool(const float* x, const void* image, const float* w_inv, const uint32_t* x_amax, const float* shift, int N, int H, int W, float* out,
-                        void* stream);
+                        uint32_t* amax_out, void* stream);
 int lgd_bias_act_fwd(const float* x, const float* bias, const float* residual, int N, int C, int HW, int relu, float* out,
                      uint32_t* relu_bits, void* stream);
 /* weight gradient of a pointwise convolution from per-image partial products: out[o][i] = scale[o] * sum_n part[n][o][i]

@@ -86,6 +86,31 @@ __global__ __launch_bounds__(256) void relu_rowbits_kernel(const uint32_t* __res
     vstore<VW>(dx + i, r);
 }
 
+// ... leaving max |dx| as well (float bits, atomic max onto a word the caller zeroed): the gradient that reaches a block's last ReLU is often a sum
+// autograd built, which carries no magnitude tag -- with the bound from here the 1x1 input- and weight-gradient products that read dx take their
+// f16x2 forms (csrc/gemm3.hip lgd_gemm2h, csrc/h2.hip lgd_h2_pwdw).  Four chunks per thread: a quarter of the workgroups, one report each.
+template <int VW>
+__global__ __launch_bounds__(256) void relu_rowbits_amax_kernel(const uint32_t* __restrict__ bits, const float* __restrict__ dy,
+                                                                float* __restrict__ dx, int HW, int wpr, unsigned* __restrict__ amax) {
+    __shared__ float slots[4];
+    const long long row = blockIdx.x;
+    float am = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int n = ((blockIdx.y * 4 + it) * 256 + threadIdx.x) * VW;
+        if (n < HW) {
+            const unsigned w = bits[row * wpr + (n >> 5)] >> (unsigned)(n & 31);
+            const long long i = row * HW + n;
+            const Vec<VW> g = vload<VW>(dy + i);
+            Vec<VW> r;
+#pragma unroll
+            for (int k = 0; k < VW; ++k) { r.v[k] = ((w >> k) & 1u) ? g.v[k] : 0.f; am = fmaxf(am, fabsf(r.v[k])); }
+            vstore<VW>(dx + i, r);
+        }
+    }
+    block_max_bits(amax, wave_max(am), slots);
+}
+
 template <int VW>
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                         float* __restrict__ dx, long long total) {
@@ -174,11 +199,19 @@ int lgd_relu_bits_bwd(const uint32_t* relu_bits, const float* dy, long long tota
 
 size_t lgd_relu_rowbits_words(long long rows, int HW) { return rows < 1 || HW < 1 ? 0 : (size_t)rows * (size_t)((HW + 31) / 32); }
 
-int lgd_relu_rowbits_bwd(const uint32_t* relu_bits, const float* dy, long long rows, int HW, float* dx, void* stream) {
+int lgd_relu_rowbits_bwd(const uint32_t* relu_bits, const float* dy, long long rows, int HW, float* dx, uint32_t* amax_out, void* stream) {
     if (!relu_bits || !dy || !dx || rows < 1 || rows >= (1LL << 31) || HW < 1) return LGD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool al = (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
     const int wpr = (HW + 31) / 32;
+    if (amax_out) {
+        if (HW % 4 == 0 && al) {
+            LGD_LAUNCH("relu_rowbits_kernel", lgd::relu_rowbits_amax_kernel<4>, dim3((unsigned)rows, (unsigned)((HW / 4 + 1023) / 1024)), dim3(256), 0, st, relu_bits, dy, dx, HW, wpr, amax_out);
+        } else {
+            LGD_LAUNCH("relu_rowbits_kernel", lgd::relu_rowbits_amax_kernel<1>, dim3((unsigned)rows, (unsigned)((HW + 1023) / 1024)), dim3(256), 0, st, relu_bits, dy, dx, HW, wpr, amax_out);
+        }
+        return lgd::check_launch();
+    }
     if (HW % 4 == 0 && al) {
         LGD_LAUNCH("relu_rowbits_kernel", lgd::relu_rowbits_kernel<4>, dim3((unsigned)rows, (unsigned)((HW / 4 + 255) / 256)), dim3(256), 0, st, relu_bits, dy, dx, HW, wpr);
     } else {

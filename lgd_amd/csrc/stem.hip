@@ -33,6 +33,7 @@ constexpr int kPoolR = 8, kPoolC = 15;           // pooled pixels per workgroup
 
 struct Stem7Args {
     const float* x; const char* img; const float* w_inv; const unsigned* x_amax; const float* shift; float* out;
+    unsigned* amax;   // optional: atomic max of the float bits of the pooled outputs (a word the caller zeroed): the magnitude tag of the stem's output
     int N, H, W, Ho, Wo, Hp, Wp;
 };
 
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_STEM7_W
     __syncthreads();
     const int cx = cx0 + n;
     const bool colok = cx >= 0 && cx < a.Wo;
-    float cur[16];
+    float cur[16], omax = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) cur[e] = 0.f;
 #pragma unroll 1
@@ -140,16 +141,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_STEM7_W
                 const float t = fmaxf(cur[e], v[e]);
                 const float t1 = __shfl_down(t, 1, 32), t2 = __shfl_down(t, 2, 32);
                 const int m = 32 * mb + (e & 3) + 8 * (e >> 2) + 4 * g;
+                const float o = fmaxf(t, fmaxf(t1, t2));
 #if LGD_STEM7_ABL == 3
                 if (st && t == 123456.f)
 #else
                 if (st)
 #endif
-                    a.out[(((size_t)n_img * 64 + m) * a.Hp + pr) * a.Wp + pc] = fmaxf(t, fmaxf(t1, t2));
+                    a.out[(((size_t)n_img * 64 + m) * a.Hp + pr) * a.Wp + pc] = o;
+                omax = fmaxf(omax, st ? o : 0.f);
             }
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) cur[e] = (r & 1) == 0 ? v[e] : fmaxf(cur[e], v[e]);
+    }
+    if (a.amax) {
+        __syncthreads();   // (the patch is dead: its first words serve as the four slots of the workgroup's maximum)
+        block_max_bits(a.amax, wave_max(omax), reinterpret_cast<float*>(ph));
     }
 }
 
@@ -191,10 +198,10 @@ int lgd_stem7_image(const float* w, const uint32_t* w_amax, void* image, float* 
 }
 
 int lgd_stem7_conv_pool(const float* x, const void* image, const float* w_inv, const uint32_t* x_amax, const float* shift, int N, int H, int W, float* out,
-                        void* stream) {
+                        uint32_t* amax_out, void* stream) {
     if (!x || !image || !w_inv || !x_amax || !shift || !out || N < 1 || H < 1 || W < 1 || (long long)H * W > (1LL << 27)) return LGD_EINVAL;
     lgd::Stem7Args a;
-    a.x = x; a.img = (const char*)image; a.w_inv = w_inv; a.x_amax = x_amax; a.shift = shift; a.out = out;
+    a.x = x; a.img = (const char*)image; a.w_inv = w_inv; a.x_amax = x_amax; a.shift = shift; a.out = out; a.amax = amax_out;
     a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1; a.Hp = (a.Ho - 1) / 2 + 1; a.Wp = (a.Wo - 1) / 2 + 1;
     if (N > 65535) return LGD_EINVAL;
     const dim3 grid((a.Wp + lgd::kPoolC - 1) / lgd::kPoolC, (a.Hp + lgd::kPoolR - 1) / lgd::kPoolR, N);

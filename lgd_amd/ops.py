@@ -1182,7 +1182,7 @@ def _wino_filter_grads(lib, dU, scales, Cos, need, Ci, tile):
 def _wino_out(lib, Mk, bias, hw, L, N, Co, tile, relu, ys, bits):
     """output transform of Co channels of M (+ bias, ReLU, mask bits); with the f16x2 pipeline on (tile 6) it also leaves max |y| for the
     next convolution's scale and tags the maps with it"""
-    if tile == 6 and _tags_wanted(sum(N * ((y.shape[2] + 5) // 6) * ((y.shape[3] + 5) // 6) for y in ys)):
+    if tile == 6 and _tags_wanted(sum(N * ((y.shape[2] + 5) // 6) * ((y.shape[3] + 5) // 6) for y in ys), ys):
         amax = _zero_words(ys[0].device)
         hip.check(lib.lgd_wino_out_amax(hip.ptr(Mk), hip.ptr(bias) if bias is not None else None, hw, L, N, Co, int(relu), hip.ptr_array(ys),
                                         hip.ptr(bits) if bits is not None else None, hip.ptr(amax), hip.stream_ptr()), "lgd_wino_out_amax")
@@ -1194,7 +1194,7 @@ def _wino_out(lib, Mk, bias, hw, L, N, Co, tile, relu, ys, bits):
 
 def _wino_in_t(lib, dV, hw, L, N, Ci, tile, dxs, pre_bits):
     """adjoint input transform (+ activation mask); tile 6 with the f16x2 pipeline on: also max |dx|, tagged on the gradient maps"""
-    if tile == 6 and _tags_wanted(sum(N * ((d.shape[2] + 5) // 6) * ((d.shape[3] + 5) // 6) for d in dxs)):
+    if tile == 6 and _tags_wanted(sum(N * ((d.shape[2] + 5) // 6) * ((d.shape[3] + 5) // 6) for d in dxs), dxs):
         amax = _zero_words(dxs[0].device)
         hip.check(lib.lgd_wino_in_t_amax(hip.ptr(dV), hw, L, N, Ci, hip.ptr_array(dxs), hip.ptr(pre_bits) if pre_bits is not None else None,
                                          hip.ptr(amax), hip.stream_ptr()), "lgd_wino_in_t_amax")
@@ -2154,8 +2154,11 @@ def stem_conv_pool(x, wf, shift):
     hip.check(lib.lgd_h2_amax_maps(hip.ptr_array([x]), hip.int_array([H, W]), 1, N, 3, None, None, hip.ptr(xa), 1, st), "lgd_h2_amax_maps")
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = torch.empty((N, 64, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1), dtype=torch.float32, device=x.device)
-    hip.check(lib.lgd_stem7_conv_pool(hip.ptr(x), hip.ptr(kept[0]), hip.ptr(kept[1]), hip.ptr(xa), hip.ptr(shift), N, H, W, hip.ptr(out), st),
-              "lgd_stem7_conv_pool")
+    tag = _zero_words(x.device) if (_GEMM2H_ON and _H2_TAGS) else None
+    hip.check(lib.lgd_stem7_conv_pool(hip.ptr(x), hip.ptr(kept[0]), hip.ptr(kept[1]), hip.ptr(xa), hip.ptr(shift), N, H, W, hip.ptr(out),
+                                      hip.ptr(tag) if tag is not None else None, st), "lgd_stem7_conv_pool")
+    if tag is not None:
+        _amax_tag([out], tag)
     return out
 
 
@@ -2240,13 +2243,24 @@ def _conv1x1_epilogue(ctx, x, wf, scale, shift, residual, relu):
 def _relu_bits_bwd(ctx, bits, dy):
     """dy where the forward output was > 0, from the flat bitmap bias_act wrote or the row-padded one of the gemm3 epilogue"""
     dz = torch.empty_like(dy)
+    tag = getattr(dy, "_lgd_amax", None)
+    tagged = tag is not None and tag[1] == dy._version
     if getattr(ctx, "rowbits", False):
+        # a gradient without a tag (a sum autograd built: the first block of a stage, the FPN laterals' sources): the mask kernel leaves max |dz|, so
+        # that the products reading dz keep their f16x2 forms
+        # (only where the input-gradient product that reads dz -- C -> C / 4, the block's last 1x1 convolution -- passes lgd_gemm2h's gate: at 2 images
+        #  per GPU it does not, and the weight gradient alone on lgd_h2_pwdw measured slower than the library there: config 4 27.6 against 27.4 ms)
+        word = None
+        if not tagged and _GEMM2H_ON and _H2_TAGS and _RELU_AMAX and _gemm3_shape_ok(dy.shape[0], max(dy.shape[1] // 4, 1), dy.shape[1],
+                                                                                    dy.shape[2] * dy.shape[3], dy.device, shared=True):
+            word = _zero_words(dy.device)
         hip.check(hip.load().lgd_relu_rowbits_bwd(hip.ptr(bits), hip.ptr(dy), dy.shape[0] * dy.shape[1], dy.shape[2] * dy.shape[3], hip.ptr(dz),
-                                                  hip.stream_ptr()), "lgd_relu_rowbits_bwd")
+                                                  hip.ptr(word) if word is not None else None, hip.stream_ptr()), "lgd_relu_rowbits_bwd")
+        if word is not None:
+            _amax_tag([dz], word)
     else:
         hip.check(hip.load().lgd_relu_bits_bwd(hip.ptr(bits), hip.ptr(dy), dy.numel(), hip.ptr(dz), hip.stream_ptr()), "lgd_relu_bits_bwd")
-    tag = getattr(dy, "_lgd_amax", None)
-    if tag is not None and tag[1] == dy._version:   # (a mask only removes elements: the bound of dy holds for dz)
+    if tagged:   # (a mask only removes elements: the bound of dy holds for dz)
         _amax_tag([dz], tag[0])
     return dz
 
@@ -2534,6 +2548,7 @@ def gemm3_bmm(a, b, out=None, accumulate=False, residual=None, shift=None, relu=
 _GEMM2H_ON = os.environ.get("LGD_GEMM2H", "1") != "0"
 _PW_MIN_FILL = float(os.environ.get("LGD_PW_MIN_FILL", "1.0"))   # fraction of "two rounds of workgroups" a product must fill to leave the library (experiments)
 _PW_ONE_ROUND_FILL = float(os.environ.get("LGD_PW_ONE_ROUND_FILL", "1.0"))   # workgroups per CU a long-K product must reach (experiments)
+_RELU_AMAX = os.environ.get("LGD_RELU_AMAX", "1") != "0"   # 0: the ReLU-mask kernel leaves no maximum for untagged gradients (A/B runs)
 _PW_TAGS_ALWAYS = os.environ.get("LGD_PW_TAGS_ALWAYS", "0") != "0"   # 1: every output transform leaves its maximum, whatever the map's size (experiments)
 
 
@@ -2657,6 +2672,11 @@ def _pw_product(name, a, b, bmap, out=None, accumulate=False, **epi):
         fn = lambda: gemm2h_bmm(a, b, b_amax, out, accumulate, amax_out=amax, **epi)   # noqa: E731
         name = name.replace("_gemm3_", "_gemm2h_")
     else:
+        if _H2_DEBUG:
+            import traceback
+            fr = [f for f in traceback.extract_stack()[:-1] if "ops.py" not in f.filename and "torch" not in f.filename][-2:]
+            print("[1x1 product without a tag -> bf16x3] %s M=%d K=%d N=%d x %d  <- %s" % (name, a.shape[1], a.shape[2], b.shape[2], b.shape[0],
+                  " / ".join("%s:%d %s" % (f.filename.split("/")[-1], f.lineno, f.name) for f in fr)))
         fn = lambda: gemm3_bmm(a, b, out, accumulate, amax_out=amax, **epi)   # noqa: E731
     if not _TIMER_ON:
         return fn(), amax
@@ -2745,10 +2765,18 @@ def _zero_words(dev, n=1):
     return w
 
 
-def _tags_wanted(n_tiles):
+def _tags_wanted(n_tiles, maps=None):
     """whether a kernel that writes maps of n_tiles 6x6 tiles should leave their maximum: only where a consumer could take the f16x2 pipeline (the
-    one-pass head runs over two pyramids: twice the tiles of the maps it reads)"""
-    return _H2_ON and _H2_TAGS and (_H2_FORCE or _PW_TAGS_ALWAYS or 2 * n_tiles >= _H2_MIN_T)
+    one-pass head runs over two pyramids: twice the tiles of the maps it reads) -- or, for a single map of C channels (a bottleneck's 3x3
+    convolution), where the 1x1 product that reads it (C -> 4 C) passes lgd_gemm2h's gate (res5 at 8 images: 280 tiles, but 1152 workgroups)"""
+    if not (_H2_ON and _H2_TAGS):
+        return False
+    if _H2_FORCE or _PW_TAGS_ALWAYS or 2 * n_tiles >= _H2_MIN_T:
+        return True
+    if maps is not None and len(maps) == 1 and _GEMM2H_ON:
+        m = maps[0]
+        return _gemm3_shape_ok(m.shape[0], 4 * m.shape[1], m.shape[1], m.shape[2] * m.shape[3], m.device, shared=True)
+    return False
 
 
 def _amax_tag(maps, amax):

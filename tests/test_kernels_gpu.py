@@ -1050,7 +1050,11 @@ def test_gemm3_epilogue_residual_shift_relu_and_mask(Co, Ci, HW, res, sh, relu, 
         assert float(pre.abs()[flips].max() if flips.any() else 0.0) <= 1e-5 * float(pre.abs().max())
         dy = torch.randn(N, Co, HW, device=DEV, generator=g)
         dz = torch.empty_like(dy)
-        hip.check(lib.lgd_relu_rowbits_bwd(hip.ptr(bits), hip.ptr(dy), N * Co, HW, hip.ptr(dz), hip.stream_ptr()), "lgd_relu_rowbits_bwd")
+        word = torch.zeros(1, dtype=torch.int32, device=DEV)
+        hip.check(lib.lgd_relu_rowbits_bwd(hip.ptr(bits), hip.ptr(dy), N * Co, HW, hip.ptr(dz), None, hip.stream_ptr()), "lgd_relu_rowbits_bwd")
+        dz2 = torch.full_like(dz, float("nan"))
+        hip.check(lib.lgd_relu_rowbits_bwd(hip.ptr(bits), hip.ptr(dy), N * Co, HW, hip.ptr(dz2), hip.ptr(word), hip.stream_ptr()), "lgd_relu_rowbits_bwd")
+        assert torch.equal(dz, dz2) and float(word.view(torch.float32)) == float(dz.abs().max())   # (the form that also leaves max |dz|)
         assert torch.equal(dz, torch.where(got, dy, torch.zeros_like(dy)))
     print("gemm3 epilogue %d -> %d over %d px (residual %s, shift %s, relu %s): %.2e" % (Ci, Co, HW, res, sh, relu, e))
 
@@ -1096,8 +1100,9 @@ def test_pointwise_conv_bn_fused_epilogue_equals_product_plus_bias_act(residual,
     for a, b, name in zip(out[True][1:], out[False][1:], ("dx", "dw", "d residual")):
         if a is None:
             continue
-        if flips == 0:   # the same mask -> the same masked gradient through the same kernels
-            assert torch.equal(a, b), name
+        if flips == 0:   # the same mask -> the same masked gradient; the fused form's mask kernel also leaves max |dz|, so its products take
+            # the f16x2 form where the two-launch form's run bf16x3: equal to fp32 rounding, not bit for bit
+            assert float((a - b).abs().max() / b.abs().max()) <= 2e-6, name
         else:
             assert float((a - b).abs().max() / b.abs().max()) <= 5e-2, name
 
@@ -2217,6 +2222,7 @@ def test_stem_conv_pool_vs_fp64(N, H, W):
     wd = w.to(DEV)
     out = ops.stem_conv_pool(x.to(DEV), wd, shift.to(DEV))
     assert tuple(out.shape) == tuple(ref.shape)
+    assert float(out._lgd_amax[0].view(torch.float32)) == float(out.abs().max())   # (the output's magnitude tag)
     err = (out.double().cpu() - ref).abs().max().item() / pre.abs().max().item()
     assert err < 2e-6, err
     # the library convolution + the pooling pass it replaces: the same to fp32 rounding

@@ -7,7 +7,7 @@ ops.stem_conv_pool(x, w, sh)
 img, winv, _ = w._lgd_stem7
 xa = x.abs().max().reshape(1).view(torch.int32)
 out = torch.empty(8, 64, 200, 336, device='cuda')
-def k(): hip.check(lib.lgd_stem7_conv_pool(hip.ptr(x), hip.ptr(img), hip.ptr(winv), hip.ptr(xa), hip.ptr(sh), 8, 800, 1344, hip.ptr(out), hip.stream_ptr()), "k")
+def k(): hip.check(lib.lgd_stem7_conv_pool(hip.ptr(x), hip.ptr(img), hip.ptr(winv), hip.ptr(xa), hip.ptr(sh), 8, 800, 1344, hip.ptr(out), None, hip.stream_ptr()), "k")
 for _ in range(3): k()
 torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
 for _ in range(20): k()
