@@ -2832,8 +2832,10 @@ def _amax_bits(lib, xs, hw_levels, pre=None, affine=False):
     if _H2_DEBUG:
         import traceback
         fr = [f for f in traceback.extract_stack()[:-1] if "ops.py" not in f.filename and "torch" not in f.filename][-2:]
-        print("[h2 amax pass] L=%d of %d N=%d C=%d hw=%s pre=%s <- %s" % (L, len(xs), N, C, [tuple(xs[i].shape[2:]) for i in rest][:2], None if pre is None else ("affine" if affine else "bias"),
-                                                                         " / ".join("%s:%d %s" % (f.filename.split("/")[-1], f.lineno, f.name) for f in fr)))
+        node = torch._C._current_autograd_node()
+        print("[h2 amax pass] L=%d of %d N=%d C=%d hw=%s pre=%s <- %s%s" % (L, len(xs), N, C, [tuple(xs[i].shape[2:]) for i in rest][:2], None if pre is None else ("affine" if affine else "bias"),
+                                                                           " / ".join("%s:%d %s" % (f.filename.split("/")[-1], f.lineno, f.name) for f in fr),
+                                                                           "" if node is None else " [backward of %s; maps from %s]" % (node.name(), ", ".join(sorted({type(getattr(xs[i], "grad_fn", None)).__name__ for i in rest})))))
     hw_rest = hw_levels if len(rest) == len(xs) else hip.int_array([v for i in rest for v in xs[i].shape[-2:]])
     hip.check(lib.lgd_h2_amax_maps(hip.ptr_array([xs[i] for i in rest]), hw_rest, L, N, C, hip.ptr(pre) if pre is not None and not affine else None,
                                    hip.ptr(pre) if pre is not None and affine else None, hip.ptr(out), 1, hip.stream_ptr()), "lgd_h2_amax_maps")
