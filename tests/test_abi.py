@@ -96,15 +96,18 @@ def _kernels(asm, pattern):
 
 
 def _mfma_loops(lines):
-    """bodies (lists of lines) of the loops that contain MFMAs: a conditional branch back to a label seen earlier"""
+    """bodies (lists of lines) of the loops that contain MFMAs: from a label to the LAST branch (conditional or not) back to it"""
     pos = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
-    loops = []
+    last = {}
     for i, l in enumerate(lines):
-        m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        m = re.match(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
         if m and m.group(1) in pos and pos[m.group(1)] < i:
-            body = lines[pos[m.group(1)]:i]
-            if any("v_mfma" in b for b in body):
-                loops.append(body)
+            last[m.group(1)] = i
+    loops = []
+    for lab, i in sorted(last.items(), key=lambda kv: pos[kv[0]]):
+        body = lines[pos[lab]:i]
+        if any("v_mfma" in b for b in body) and not any(pos[o] <= pos[lab] and last[o] >= i and o != lab for o in last):
+            loops.append(body)
     return loops
 
 
