@@ -14,6 +14,7 @@ The third value returned by forward() is the BoxGeometry (the reference returns 
 masks there; nothing downstream reads them -- base_distillator.py:34-64 ignores the argument).
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -150,6 +151,9 @@ class LabelEncoder(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------- teacher
+_RUNTIME = weakref.WeakKeyDictionary()   # DynamicTeacher -> side-stream state (DynamicTeacher._rt)
+
+
 @CUSTOMIZED_DETECTORS_REGISTRY.register()
 class DynamicTeacher(nn.Module):
     def __init__(self, cfg):
@@ -224,22 +228,50 @@ class DynamicTeacher(nn.Module):
     # autograd runs its backward on the same stream, under the backbone's backward.  LGD_TEACHER_STREAM=0: in line, on the caller's stream.
     side_stream = os.environ.get("LGD_TEACHER_STREAM", "1") != "0"
 
+    def _rt(self):
+        """runtime state of the side stream (stream objects, hook handles, the result in flight), kept OUTSIDE the module's attributes: a
+        copy.deepcopy / pickle of the model must not meet a stream"""
+        st = _RUNTIME.get(self)
+        if st is None:
+            st = _RUNTIME[self] = {}
+        return st
+
     def encode_ahead(self, batched_inputs, images):
         """label encoder + canonical projection of this mini-batch on the side stream (a no-op off the GPU or when switched off); forward()
         picks the result up.  Called by the distillator between the student's preprocessing and its backbone."""
-        self._ahead = None
+        rt = self._rt()
+        rt["ahead"] = None
         dev = images.tensor.device
         if not (self.side_stream and dev.type == "cuda"):
             return
-        main = torch.cuda.current_stream(dev)
-        side = getattr(self, "_side", None)
+        main = rt["main"] = torch.cuda.current_stream(dev)
+        side = rt.get("side")
         if side is None or side.device != dev:
-            side = self._side = torch.cuda.Stream(dev)
+            side = rt["side"] = torch.cuda.Stream(dev)
+            self._join_hooks()
         side.wait_stream(main)   # the weights last step's optimizer wrote, the annotations the loader copied
         with torch.cuda.stream(side):
             enc = self.label_encoder_((batched_inputs, images, None, dev))
             canoni = _lin_ln_relu(self.canoni_proj_1D[0][0], enc[0])
-        self._ahead = (id(batched_inputs), enc, canoni, side)
+        rt["ahead"] = (id(batched_inputs), enc, canoni, side)
+
+    def _join_hooks(self):
+        """Data-parallel runs: DistributedDataParallel starts a bucket's all-reduce from the gradient hook of the bucket's LAST parameter and orders it
+        behind the stream THAT hook runs on.  The encoder's parameter gradients are written on the side stream, those of the other parameters of
+        the same bucket on the main one: as each encoder gradient is accumulated the two streams are joined (each waits for the other's work so
+        far), so whichever hook comes last, its stream has seen every gradient of the bucket.  The encoder's backward is the last thing the engine
+        issues, so the joins cost no overlap.  Single-process runs need none of this (the engine joins the streams when backward() returns)."""
+        def join(_param):
+            import torch.distributed as dist
+            rt = _RUNTIME.get(self) or {}
+            side, main = rt.get("side"), rt.get("main")
+            if side is not None and main is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                side.wait_stream(main)
+                main.wait_stream(side)
+        rt = self._rt()
+        if rt.get("handles"):
+            return
+        rt["handles"] = [p.register_post_accumulate_grad_hook(join) for m in (self.label_encoder_, self.canoni_proj_1D) for p in m.parameters()]
 
     def interactive_remapping(self, label_embed, boxes, counts, feats, img_size_dict, canoni=None):
         """[ref: dynamic_teacher.py:209-283]"""
@@ -269,7 +301,8 @@ class DynamicTeacher(nn.Module):
         return tea, geom
 
     def forward(self, info_list):
-        ahead, self._ahead = getattr(self, "_ahead", None), None
+        rt = _RUNTIME.get(self)
+        ahead = rt.pop("ahead", None) if rt else None
         canoni = None
         if ahead is not None and ahead[0] == id(info_list[0]):
             _, enc, canoni, side = ahead

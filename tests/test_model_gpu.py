@@ -826,7 +826,9 @@ def test_label_encoder_on_the_side_stream_equals_in_line():
             va, vb = float(la[k].detach()), float(lb[k].detach())
             assert abs(va - vb) <= 1e-5 * max(1.0, abs(vb)), (it, k, va, vb)
     assert seen == [True, True, True]
-    assert getattr(twin.teacher, "_side", None) is None
+    from lgd_amd import dynamic_teacher
+    assert dynamic_teacher._RUNTIME.get(twin.teacher, {}).get("side") is None and dynamic_teacher._RUNTIME[base.teacher].get("side") is not None
+    copy.deepcopy(base)   # (the stream lives outside the module: the model still copies)
     for (n, p), (_, q) in zip(base.named_parameters(), twin.named_parameters()):
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), (n, float((p - q).abs().max()))
 
