@@ -148,11 +148,11 @@ def test_gemm3_kernels_keep_their_counted_waits_and_no_scratch():
     test_gemm3_and_h2_products_under_load.)"""
     asm = _asm_of("gemm3.hip")
     ks = _kernels(asm, r"gemm3_kernel")
-    assert len(ks) == 25, sorted(ks)   # {256, 128 rows} x 5 epilogues x {bf16x3, f16x2} + the f16x2 form's 64-row tile x 5
+    assert len(ks) == 20, sorted(ks)   # {256, 128 rows} x 5 epilogues x {bf16x3, f16x2}
     for name, (lines, scratch) in ks.items():
         assert scratch == 0, (name, scratch)
         pcs = 2 if name.endswith("ELi2EEEvNS0_6ParamsE") else 3
-        ch = pcs * (8 if "ILi256E" in name else 4 if "ILi128E" in name else 2) // 4   # LDS-DMA instructions per wave and k-step (pieces x BM / 32 row blocks / 4 waves)
+        ch = pcs * (8 if "ILi256E" in name else 4) // 4   # LDS-DMA instructions per wave and k-step (pieces x BM / 32 row blocks / 4 waves)
         dma = [i for i, l in enumerate(lines) if re.match(r"buffer_load_dwordx4 .* lds$", l)]
         assert dma and len(dma) % ch == 0, (name, len(dma))
         def to_barrier(i):   # the wait reaches a barrier within a few instructions, none of them a vector-memory one
