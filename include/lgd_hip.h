@@ -396,7 +396,10 @@ typedef struct lgd_split_task { unsigned long long a, img, amax, inv; int M, K, 
 int lgd_gemm2h_split_multi(const void* tasks_dev, const int32_t* blk0_dev, int n, int nblocks, void* stream);
 int lgd_gemm2h(const void* image, int image_shared, const float* a_inv, const float* B, const uint32_t* b_amax, long long b_sb, long long b_sk, float* C,
                long long c_sb, long long c_sm, const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits,
-               uint32_t* amax_out, int nb, int M, int N, int K, void* stream);
+               uint32_t* amax_out, float* splitk_ws, int splits, int nb, int M, int N, int K, void* stream);
+/* (splits > 1: split-K for plain products -- no R / shift / relu / mask, C dense -- whose tiles do not fill the chip and whose k-loop is long (the
+ *  1024 -> 256 convolutions of res4 at 2 images per GPU: 132 tiles of 64 k-steps): the grid's S row blocks take K / S each and leave partials in
+ *  splitk_ws (S * nb * M * N floats), a second launch adds them in fixed order into C and leaves max |C| in amax_out.  splits <= 1: splitk_ws unused.) */
 
 /* ---- K10: the Winograd channel products from f16x2 operands that are split in HBM (csrc/h2.hip; round 5).
  * Replaces, like lgd_gemm3, the arithmetic of every nn.Conv2d(C, C', 3, padding=1) of the path (dynamic_teacher.py:57,61,67-73,145,280;

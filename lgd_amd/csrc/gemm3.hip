@@ -81,15 +81,16 @@ struct Params {
     uint32_t* bits; int wpr;                     // ReLU mask: bit n % 32 of word (b * M + m) * wpr + n / 32 = (C(m, n) > 0)
     int relu;
     const float* a_inv; const unsigned* b_amax;  // PCS == 2: inverse scale of the image (one per image), bound of |B| (float bits): B is scaled by 2^eb in the kernel
+    int kper; long part_stride;                  // split-K (gridDim.y > 1): k-steps per split; split s writes its partial product to C + s * part_stride
     unsigned* amax;                              // optional: atomic max of the float bits of |C| as stored (one word, zeroed by the caller): the bound
                                                  // the NEXT convolution's f16x2 scale is derived from (csrc/h2.hip)
 };
 
 // EPI: 0 the plain product; otherwise the epilogue kernel with bit 0: R present, bit 1: shift present
 // waves per SIMD the register allocator is held to: three workgroups per CU for the 128-row tile (left alone the epilogue forms take 172-180
-// registers -- two workgroups; tools/gemm2h_probe.py: res3's 512 -> 128 convolution with its epilogue 124 -> 101 us).  One instance
-// (bf16x3, shift only) would spill at 168.
-template <int BM, int EPI, int PCS> constexpr int gemm3_waves() { return BM == 128 && !(PCS == 3 && EPI == 2) ? 3 : 2; }
+// registers -- two workgroups; tools/gemm2h_probe.py: res3's 512 -> 128 convolution with its epilogue 124 -> 101 us).  The f16x2 form only:
+// two of the bf16x3 instances would spill at 168, and nothing large runs on them any more.
+template <int BM, int EPI, int PCS> constexpr int gemm3_waves() { return BM == 128 && PCS == 2 ? 3 : 2; }
 template <int BM, int EPI, int PCS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm3_waves<BM, EPI, PCS>()))) void gemm3_kernel(const Params p) {
     typedef Tile<BM, PCS> TL;
@@ -122,14 +123,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm3_waves<
         b = rest / p.nt; tn = rest % p.nt;
     }
     const int m0 = sub * BM, n0 = tn * BN, rb0 = sub * RB;
-    const int ksteps = p.K / BK;                       // K % 16 == 0 (host-checked)
-    const char* Ai = p.Aimg + (long)b * p.a_sb;
+    // split-K: workgroup row blockIdx.y takes the k-steps [ks0, ks0 + ksteps) and leaves a PARTIAL product (plain launches only: host-checked)
+    // (the epilogue kernels are never split: the code is compiled out of them)
+    const int ks0 = EPI == 0 ? (int)blockIdx.y * p.kper : 0;
+    const int ksteps = EPI == 0 ? min(p.kper, p.K / BK - ks0) : p.K / BK;    // K % 16 == 0 (host-checked)
+    const char* Ai = p.Aimg + (long)b * p.a_sb + (long)ks0 * ((long)PCS * p.rbp * 1024);
     // B staging: thread <-> (k-group kg = t >> 7, column n = t & 127): 8 dwords down the k axis, a wave's load covers 256 contiguous
     // bytes.  Columns >= N are read from column N - 1 and rows >= M come as zeros from the image: both only reach elements of C that are
     // never stored (rows and columns of a product are independent), so nothing is zeroed here.
     const int kg = t >> 7, nl = t & 127;
     const int ncol = n0 + nl < p.N ? n0 + nl : p.N - 1;
-    const float* Bb = p.B + (long)b * p.b_sb;
+    const float* Bb = p.B + (long)b * p.b_sb + (long)ks0 * BK * p.b_ld;
     uint32_t boff[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) boff[e] = (uint32_t)((kg * 8 + e) * (int)p.b_ld + ncol) * 4u;   // bytes
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm3_waves<
         uint32_t* bwl = p.bits + ((long)b * p.M + wrow + brow) * p.wpr + (wcol >> 5);
         // C by buffer stores: the wave's origin in the descriptor, ONE running per-lane offset (+ 1 or + 5 rows per step; as scalar offsets
         // hipcc precomputes all of them at kernel entry, spills them into VGPR lanes and pays a v_readlane per store)
-        const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(p.C + (long)b * p.c_sb + (long)wrow * ld + wcol, 0, 0xffffffffu, 0x00020000);
+        const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(p.C + (EPI == 0 ? (long)blockIdx.y * p.part_stride : 0L) + (long)b * p.c_sb + (long)wrow * ld + wcol, 0, 0xffffffffu, 0x00020000);
         const int c1 = ld * 4, c5 = ld * 20, mrem = p.M - mw;
         const bool colok[2] = {nw < p.N, nw + 32 < p.N};
         const bool want_max = p.amax != nullptr;
@@ -445,6 +449,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm3_waves<
         if constexpr ((EPI & 2) != 0) __syncthreads();   // the next tile's prologue writes the LDS the shift values were read from
     }
     }   // tiles of this workgroup
+}
+
+// out = sum of the S split-K partials in fixed order (bit-reproducible), leaving max |out| like the product's own epilogue would
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ P, float* __restrict__ out, long n4, int S, unsigned* __restrict__ amax) {
+    __shared__ float slots[4];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float am = 0.f;
+    if (i < n4) {
+        float4 a = reinterpret_cast<const float4*>(P)[i];
+        for (int s_ = 1; s_ < S; ++s_) {
+            const float4 v = reinterpret_cast<const float4*>(P)[(long)s_ * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = a;
+        am = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+    }
+    if (amax) block_max_bits(amax, wave_max(am), slots);
 }
 
 // A (M x K per batch, element (m, k) at A[b * a_sb + m * sm + k * sk]) -> the image.  Thread per 16-byte fragment slot; rows >= M and
@@ -556,7 +577,7 @@ int lgd_gemm3_split(const float* A, long long a_sb, long long a_sm, long long a_
 template <int PCS>
 static int gemm3_launch(const void* image, int image_shared, const float* a_inv, const float* B, const uint32_t* b_amax, long long b_sb, long long b_sk,
                         float* C, long long c_sb, long long c_sm, const float* R, long long r_sb, long long r_sm, const float* shift, int relu,
-                        uint32_t* relu_bits, uint32_t* amax_out, int nb, int M, int N, int K, void* stream) {
+                        uint32_t* relu_bits, uint32_t* amax_out, int nb, int M, int N, int K, void* stream, float* splitk_ws = nullptr, int splits = 1) {
     if (!image || !B || !C || nb <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 15) || ((uintptr_t)image & 15)) return LGD_EINVAL;
     // 256-row tiles unless that leaves more than a quarter of the rows of the last tile empty and 128-row tiles do not
     const bool epi = R || shift || relu || relu_bits;
@@ -575,6 +596,19 @@ static int gemm3_launch(const void* image, int image_shared, const float* a_inv,
     p.C = C; p.c_sb = (long)c_sb; p.c_ld = (long)c_sm;
     p.R = R; p.r_sb = (long)r_sb; p.r_ld = (long)r_sm; p.r_bytes = (((long)nb - 1) * r_sb + ((long)M - 1) * r_sm + N) * 4; p.shift = shift; p.bits = relu_bits; p.amax = amax_out; p.wpr = (N + 31) / 32; p.relu = relu ? 1 : 0;
     p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + bm - 1) / bm; p.nt = (N + lgd::BN - 1) / lgd::BN;
+    // split-K: S row blocks of the grid take K / S each and leave partials in the workspace [S][nb][M][N]; splitk_reduce_kernel adds them in fixed
+    // order into C.  Plain products with a dense C only (an epilogue would have to move into the reduction).
+    const int ksteps_all = K / 16;
+    if (splits > 1) {
+        if (!splitk_ws || epi || splits > ksteps_all || c_sm != N || c_sb != (long long)M * N || (((long long)nb * M * N) & 3)) return LGD_EINVAL;
+        p.kper = (ksteps_all + splits - 1) / splits;
+        splits = (ksteps_all + p.kper - 1) / p.kper;   // (no empty split)
+        p.part_stride = (long)nb * M * N;
+        p.C = splitk_ws;
+        p.amax = nullptr;
+    } else {
+        splits = 1; p.kper = ksteps_all; p.part_stride = 0;
+    }
     // 32-bit BYTE offsets from the descriptors' origins inside the kernel: one k-step of B rows, one tile of C / R rows
     if ((long)(lgd::BK + 1) * b_sk + N >= (1L << 30) || 256L * c_sm >= (1L << 30) || c_sm < 0 || (R && (r_sb < 0 || r_sm < 0 || 256L * r_sm >= (1L << 30))))
         return LGD_EINVAL;
@@ -605,7 +639,7 @@ static int gemm3_launch(const void* image, int image_shared, const float* a_inv,
     const char* pe = getenv("LGD_GEMM3_PERSIST");
     const int slots = (cus * (small ? 3 : 2)) & ~7;
     const int gridn = (pe && pe[0] == '1') && p.total > slots ? slots : p.total;
-    const dim3 grid((unsigned)gridn), block(lgd::NT);
+    const dim3 grid((unsigned)(splits > 1 ? p.total : gridn), (unsigned)splits), block(lgd::NT);
     hipStream_t st = (hipStream_t)stream;
     const int kind = !epi ? 0 : (R ? 1 : 0) | (shift ? 2 : 0) ? (R ? 1 : 0) | (shift ? 2 : 0) : 4;
 #define LGD_GEMM3_CASE(BM_, E_) \
@@ -616,6 +650,10 @@ static int gemm3_launch(const void* image, int image_shared, const float* a_inv,
         switch (kind) { LGD_GEMM3_CASE(256, 0) LGD_GEMM3_CASE(256, 1) LGD_GEMM3_CASE(256, 2) LGD_GEMM3_CASE(256, 3) LGD_GEMM3_CASE(256, 4) }
     }
 #undef LGD_GEMM3_CASE
+    if (splits > 1) {
+        const long n4 = (long)nb * M * N / 4;
+        LGD_LAUNCH("gemm3_splitk_reduce_kernel", lgd::splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, splitk_ws, C, n4, splits, amax_out);
+    }
     return lgd::check_launch();
 }
 
@@ -648,10 +686,10 @@ int lgd_gemm2h_split(const float* A, long long a_sb, long long a_sm, long long a
 
 int lgd_gemm2h(const void* image, int image_shared, const float* a_inv, const float* B, const uint32_t* b_amax, long long b_sb, long long b_sk, float* C,
                long long c_sb, long long c_sm, const float* R, long long r_sb, long long r_sm, const float* shift, int relu, uint32_t* relu_bits,
-               uint32_t* amax_out, int nb, int M, int N, int K, void* stream) {
+               uint32_t* amax_out, float* splitk_ws, int splits, int nb, int M, int N, int K, void* stream) {
     if (!a_inv || !b_amax || !image_shared) return LGD_EINVAL;   // (one image and one scale for all batches: the student's 1x1 convolutions)
     return gemm3_launch<2>(image, image_shared, a_inv, B, b_amax, b_sb, b_sk, C, c_sb, c_sm, R, r_sb, r_sm, shift, relu, relu_bits, amax_out, nb, M, N, K,
-                           stream);
+                           stream, splitk_ws, splits);
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.environ.get("LGD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")   # LGD_HIP_LIB: a lab build
 _lib = None
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -104,7 +104,7 @@ SIGNATURES = {
     "lgd_gemm2h_image_bytes": (c_sz, [c_i, c_i, c_i]),
     "lgd_gemm2h_split_multi": (c_i, [c_fp, c_fp, c_i, c_i, c_fp]),
     "lgd_gemm2h_split": (c_i, [c_fp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
-    "lgd_gemm2h": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "lgd_gemm2h": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, ctypes.c_longlong, ctypes.c_longlong, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "lgd_relu_rowbits_words": (c_sz, [ctypes.c_longlong, c_i]),
     "lgd_relu_rowbits_bwd": (c_i, [c_fp, c_fp, ctypes.c_longlong, c_i, c_fp, c_fp, c_fp]),
     "lgd_relu_bits_words": (c_sz, [ctypes.c_longlong]),

@@ -2477,7 +2477,7 @@ def _cu_count(device):
     return _CU_COUNT[i]
 
 
-def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False, shared=False):
+def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False, shared=False, splitk_ok=False):
     """the speed policy of csrc/gemm3.hip on plain sizes (tile choice as in lgd_gemm3 / lgd_gemm2h); shared: one filter for the whole batch (the
     student's 1x1 convolutions, which take the f16x2 form and its 128-row tiles)"""
     if not _GEMM3_ON:
@@ -2498,13 +2498,30 @@ def _gemm3_shape_ok(nb, M, K, N, device, accumulate=False, shared=False):
         return True
     # one workgroup per CU is enough when the k-loop is long (64+ steps amortise a tile's prologue and epilogue): the 1024 -> 256
     # convolutions of res4 and the 1024-channel lateral at 8 images, x1.05-1.10 (profiles/r04_gemm3_probe_buffer_addressing.log)
-    return _GEMM3_ONE_ROUND and wgs >= cus * _PW_ONE_ROUND_FILL and K >= 1024
+    if _GEMM3_ONE_ROUND and wgs >= cus * _PW_ONE_ROUND_FILL and K >= 1024:
+        return True
+    # plain products of the f16x2 form below that: split-K brings them to two workgroups per CU (_splitk) -- the caller says whether it is one
+    return bool(splitk_ok) and shared and _GEMM2H_ON and not accumulate and K >= 1024 and wgs * _splitk(nb, M, K, N, device) >= cus
 
 
-def _gemm3_ok(a, b, out, accumulate=False):
+_SPLITK = os.environ.get("LGD_GEMM2H_SPLITK", "1") != "0"   # 0: no split-K (A/B runs)
+
+
+def _splitk(nb, M, K, N, device):
+    """number of K splits of a plain lgd_gemm2h product (1 = none): the 128-row tiles fill less than one workgroup per CU and the k-loop has at least
+    16 steps per split -- a workgroup's time is its k-steps (a latency chain each), so S splits take 1 / S of it plus the partials' round trip"""
+    if not (_SPLITK and _GEMM2H_ON) or (nb * M * N) % 4:
+        return 1
+    wgs, cus = nb * ((N + 127) // 128) * ((M + 127) // 128), _cu_count(device)
+    if wgs >= cus:
+        return 1
+    return max(1, min(4, (K // 16) // 16, (2 * cus + wgs - 1) // wgs))
+
+
+def _gemm3_ok(a, b, out, accumulate=False, plain=False):
     if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 3 and b.dim() == 3):
         return False
-    if not _gemm3_shape_ok(a.shape[0], a.shape[1], a.shape[2], b.shape[2], a.device, accumulate, shared=a.stride(0) == 0):
+    if not _gemm3_shape_ok(a.shape[0], a.shape[1], a.shape[2], b.shape[2], a.device, accumulate, shared=a.stride(0) == 0, splitk_ok=plain and out is None):
         return False
     if b.stride(2) != 1 or 17 * b.stride(1) + b.shape[2] >= 1 << 30:   # the kernel's 32-bit byte offsets (lgd_gemm3 returns LGD_EINVAL beyond)
         return False
@@ -2611,11 +2628,14 @@ def gemm2h_bmm(a, b, b_amax, out=None, accumulate=False, residual=None, shift=No
             if kept is None:
                 kept = root._lgd_w_img = {}
             kept[key] = (img, a_inv, root._version, tuple(a0.shape) + tuple(a0.stride()))
+    # split-K where a plain product's tiles leave most of the chip idle behind a long k-loop (_splitk)
+    S = _splitk(nb, M, K, N, a.device) if (residual is None and shift is None and not relu and relu_bits is None and out.is_contiguous()) else 1
+    ws = torch.empty((S, nb, M, N), dtype=torch.float32, device=a.device) if S > 1 else None
     hip.check(lib.lgd_gemm2h(hip.ptr(img), 1, hip.ptr(a_inv), hip.ptr(b), hip.ptr(b_amax), b.stride(0), b.stride(1), hip.ptr(out), out.stride(0), out.stride(1),
                              hip.ptr(residual) if residual is not None else None, residual.stride(0) if residual is not None else 0,
                              residual.stride(1) if residual is not None else 0, hip.ptr(shift) if shift is not None else None, 1 if relu else 0,
-                             hip.ptr(relu_bits) if relu_bits is not None else None, hip.ptr(amax_out) if amax_out is not None else None, nb, M, N, K, st),
-              "lgd_gemm2h")
+                             hip.ptr(relu_bits) if relu_bits is not None else None, hip.ptr(amax_out) if amax_out is not None else None,
+                             hip.ptr(ws) if ws is not None else None, S, nb, M, N, K, st), "lgd_gemm2h")
     return out
 
 
@@ -2957,7 +2977,7 @@ def _conv1x1_fwd(x, wf):
     N, Ci, H, W = x.shape
     Co = wf.shape[0]
     a, b = wf.view(1, Co, Ci).expand(N, Co, Ci), x.view(N, Ci, H * W)
-    if _gemm3_ok(a, b, None):   # csrc/gemm3.hip: one bf16x3 image of the filter for the whole batch
+    if _gemm3_ok(a, b, None, plain=_valid_tag(x) is not None):   # csrc/gemm3.hip: one image of the filter for the whole batch (split-K only in the f16x2 form: the map must carry its bound)
         return _tagged_gemm3("pw_gemm3_fwd", a, b, x).view(N, Co, H, W)
     return _timed_gemm("pw_gemm_fwd", _pw_flops(x, Co), torch.bmm, a, b).view(N, Co, H, W)
 
@@ -2967,7 +2987,7 @@ def _conv1x1_dx(dz, x, wf):
     N, Ci, H, W = x.shape
     Co = wf.shape[0]
     a, b = wf.view(1, Co, Ci).transpose(1, 2).expand(N, Ci, Co), dz.view(N, Co, H * W)
-    if _gemm3_ok(a, b, None):
+    if _gemm3_ok(a, b, None, plain=_valid_tag(dz) is not None):
         return _tagged_gemm3("pw_gemm3_dx", a, b, dz).view(N, Ci, H, W)
     return _timed_gemm("pw_gemm_dx", _pw_flops(x, Co), torch.bmm, a, b).view(N, Ci, H, W)
 

@@ -618,3 +618,42 @@ def test_words_max():
     hip.check(lib.lgd_h2_words_max(hip.ptr_array(words), 5, hip.ptr(out), hip.stream_ptr()), "lgd_h2_words_max")
     assert float(out.view(torch.float32)) == 7.5
     assert lib.lgd_h2_words_max(hip.ptr_array(words), 17, hip.ptr(out), hip.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("nb,M,K,N,S", [(2, 256, 1024, 4200, 4), (2, 512, 2048, 1050, 3), (1, 128, 512, 300, 2), (3, 200, 1040, 132, 5)])
+def test_gemm2h_split_k(nb, M, K, N, S):
+    """lgd_gemm2h with split-K (plain products whose tiles leave the chip idle behind a long k-loop: res4's 1024 -> 256 convolutions at 2 images per
+    GPU): S row blocks of the grid take K / S k-steps each, a second launch adds the partials in fixed order -- against the fp64 product, against the
+    unsplit launch (equal to fp32 rounding: another summation order) and bit-reproducible run to run; max |C| is left by the reduction"""
+    hip, lib = _lib()
+    g = torch.Generator(device=DEV).manual_seed(K + N)
+    w = torch.randn(M, K, device=DEV, generator=g) * 0.05
+    x = torch.randn(nb, K, N, device=DEV, generator=g)
+    wa, xa = w.abs().max().reshape(1).view(torch.int32), x.abs().max().reshape(1).view(torch.int32)
+    img = torch.empty(lib.lgd_gemm2h_image_bytes(1, M, K), dtype=torch.uint8, device=DEV)
+    winv = torch.empty(1, device=DEV)
+    st = hip.stream_ptr()
+    hip.check(lib.lgd_gemm2h_split(hip.ptr(w), 0, K, 1, 1, M, K, hip.ptr(wa), hip.ptr(img), hip.ptr(winv), st), "split")
+
+    def run(splits):
+        out = torch.full((nb, M, N), float("nan"), device=DEV)
+        word = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ws = torch.empty((max(splits, 1), nb, M, N), device=DEV) if splits > 1 else None
+        hip.check(lib.lgd_gemm2h(hip.ptr(img), 1, hip.ptr(winv), hip.ptr(x), hip.ptr(xa), K * N, N, hip.ptr(out), M * N, N, None, 0, 0, None, 0, None,
+                                 hip.ptr(word), hip.ptr(ws) if ws is not None else None, splits, nb, M, N, K, st), "lgd_gemm2h")
+        return out, float(word.view(torch.float32))
+    ref = torch.matmul(w.double(), x.double())
+    one, a1 = run(1)
+    if (nb * M * N) % 4 == 0:
+        sk, a2 = run(S)
+        sk2, _ = run(S)
+        assert torch.equal(sk, sk2)
+        assert ((sk.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+        assert ((sk - one).abs().max() / ref.abs().max()).item() < 2e-6
+        assert a2 == float(sk.abs().max()) and a1 == float(one.abs().max())
+    # an epilogue cannot be split
+    ws = torch.empty((2, nb, M, N), device=DEV)
+    out = torch.empty((nb, M, N), device=DEV)
+    sh = torch.zeros(M, device=DEV)
+    assert lib.lgd_gemm2h(hip.ptr(img), 1, hip.ptr(winv), hip.ptr(x), hip.ptr(xa), K * N, N, hip.ptr(out), M * N, N, None, 0, 0, hip.ptr(sh), 0, None,
+                          None, hip.ptr(ws), 2, nb, M, N, K, st) != 0
