@@ -5,6 +5,7 @@ reference's surface: `forward` returns (losses, raw_features, features, images, 
 `predict(features)`, `losses(...)`, `inference(...)`, attributes `fpn/backbone/raw_backbone/head/
 head_in_features`.  The loss path is free of host syncs (d2 calls `.item()` on the positive count)."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -20,6 +21,10 @@ def permute_to_N_HWA_K(t, K):
     """(N, A*K, H, W) -> (N, H*W*A, K)  [ref: retinanet.py:13-22]"""
     N, _, H, W = t.shape
     return t.view(N, -1, K, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, K)
+
+
+_HEAD_STREAMS = os.environ.get("LGD_HEAD_STREAMS", "0") != "0"
+_SIDE = {}
 
 
 class RetinaNetHead(nn.Module):
@@ -49,6 +54,23 @@ class RetinaNetHead(nn.Module):
         cl = [self.cls_subnet[i] for i in range(2, len(self.cls_subnet), 2)] + [self.cls_score]
         bl = [self.bbox_subnet[i] for i in range(2, len(self.bbox_subnet), 2)] + [self.bbox_pred]
         relus = [True] * (len(cl) - 1) + [False]
+        if _HEAD_STREAMS and c[0].is_cuda:
+            # (experiment, LGD_HEAD_STREAMS=1: the box tower on a second stream beside the class tower -- the two chains are independent)
+            dev = c[0].device
+            main = torch.cuda.current_stream(dev)
+            side = _SIDE.get(dev)
+            if side is None:
+                side = _SIDE[dev] = torch.cuda.Stream(dev)
+            side.wait_stream(main)
+            for t in b:
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                bout = ops.conv3x3_chain(b, [(m.weight, m.bias) for m in bl], relus)
+            cout = ops.conv3x3_chain(c, [(m.weight, m.bias) for m in cl], relus)
+            main.wait_stream(side)
+            for t in bout:
+                t.record_stream(main)
+            return cout, bout
         return (ops.conv3x3_chain(c, [(m.weight, m.bias) for m in cl], relus),
                 ops.conv3x3_chain(b, [(m.weight, m.bias) for m in bl], relus))
 
