@@ -11,9 +11,10 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import ops, streams
 from ..registry import CUSTOMIZED_DETECTORS_REGISTRY
 from ..structures import ImageList
+from . import retinanet as _rn
 from .retinanet import batched_nms, build_resnet_fpn
 
 
@@ -60,6 +61,45 @@ class FCOSHead(nn.Module):
         self.fold_group_norm = True
         self.fold_group_norm_bwd = True   # False: the GroupNorm backward as its own statistics + apply passes (A/B: bench.py --no-gn-bwd-fold)
 
+    def _forward_two_streams(self, feats, raw_reg):
+        """forward() with the two towers on two streams (the shipped fold path): after the first layer, which reads the shared input, the box tower
+        (with bbox_pred, and centerness where it hangs off it) runs on a second stream beside the class tower -- see RetinaNetHead.forward"""
+        nl = len(self.fpn_strides)
+        gc, gb = self.cls_subnet[1], self.bbox_subnet[1]
+        wc, wb = self.cls_subnet[0], self.bbox_subnet[0]
+        (pc, c), (pb, b) = ops.conv3x3_gn(feats, [(wc.weight, wc.bias, gc.weight, gc.bias), (wb.weight, wb.bias, gb.weight, gb.bias)], gc.num_groups)
+
+        def tower(sub, x, p):
+            for i in range(3, len(sub), 3):
+                w, g = sub[i], sub[i + 1]
+                (p, x), = ops.conv3x3_gn(x, [(w.weight, w.bias, g.weight, g.bias)], g.num_groups, pre=p)
+            return x, p
+        side_mods = [self.bbox_subnet[i] for i in range(3, len(self.bbox_subnet)) if not isinstance(self.bbox_subnet[i], nn.ReLU)] + [self.bbox_pred]
+        if self.centerness_on_reg:
+            side_mods.append(self.centerness)
+        main, side = streams.fork(c[0].device, "head", inputs=list(b) + [pb])
+        streams.join_on_grad([q for m in side_mods for q in m.parameters()], "head")
+        with torch.cuda.stream(side):
+            b, pb = tower(self.bbox_subnet, b, pb)
+            if self.centerness_on_reg:
+                regs, ctr = ops.conv3x3_shared_input(b, [(self.bbox_pred.weight, self.bbox_pred.bias), (self.centerness.weight, self.centerness.bias)], pre=pb)
+            else:
+                regs, ctr = self.bbox_pred.levels(b, pre=pb), None
+        c, pc = tower(self.cls_subnet, c, pc)
+        if self.centerness_on_reg:
+            logits = self.cls_score.levels(c, pre=pc)
+        else:
+            logits, ctr = ops.conv3x3_shared_input(c, [(self.cls_score.weight, self.cls_score.bias), (self.centerness.weight, self.centerness.bias)], pre=pc)
+        streams.join(main, side, outputs=list(regs) + (list(ctr) if self.centerness_on_reg else []))
+        if raw_reg:
+            return logits, RawRegMaps(regs), ctr
+        reg = []
+        for i, r in enumerate(regs):
+            lvl = i % nl
+            r = self.scales[lvl](r)
+            reg.append(F.relu(r) * self.fpn_strides[lvl] if self.norm_reg_targets else torch.exp(r))
+        return logits, reg, ctr
+
     def forward(self, features, raw_reg=False):
         """features: the L pyramid levels, or 2L maps (student + teacher pyramids, one pass).  raw_reg: return the bbox_pred maps without
         the per-level Scale / ReLU * stride epilogue (the training losses apply it inside their kernel, ops.fcos_reg_ctr_loss).  Every tower layer is ONE
@@ -68,6 +108,8 @@ class FCOSHead(nn.Module):
         nl = len(self.fpn_strides)
         c = b = list(features)
         pc = pb = None   # (scale, shift) of the previous layer's GroupNorm + ReLU, applied by the next convolution's input transform
+        if _rn._HEAD_STREAMS and c[0].is_cuda and self.fold_group_norm and self.fold_group_norm_bwd:
+            return self._forward_two_streams(c, raw_reg)
         for i in range(0, len(self.cls_subnet), 3):
             gc, gb = self.cls_subnet[i + 1], self.bbox_subnet[i + 1]
             wc, wb = self.cls_subnet[i], self.bbox_subnet[i]
