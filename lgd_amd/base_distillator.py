@@ -1,11 +1,12 @@
 """BaseDistillator: student + dynamic teacher + adapter and the feature-distillation loss
 [ref: models/base_distillator.py:11-77, models/customized_detectors/build.py:14-17,40-43]."""
+import os
 from abc import abstractmethod
 
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, streams
 from .adapters import build_adapter
 from .registry import CUSTOMIZED_DETECTORS_REGISTRY
 
@@ -33,10 +34,29 @@ class BaseDistillator(nn.Module):
         # the reference leaves distill_flag to the training loop (train.py:266); default = OFF like there
         self.distill_flag = cfg.MODEL.DISTILLATOR.DISTILL_OFF
 
-    def distill_loss(self, features, images, batched_inputs, batchified_inside_masks, inst_labels):
-        return {"loss_distill": self.distill(features, images, batched_inputs, batchified_inside_masks, inst_labels)}
+    def distill_loss(self, features, images, batched_inputs, batchified_inside_masks, inst_labels, adapted=None):
+        return {"loss_distill": self.distill(features, images, batched_inputs, batchified_inside_masks, inst_labels, adapted=adapted)}
 
-    def distill(self, features, images, batched_inputs, batchified_inside_masks, fg_labels):
+    # the adapter reads the student's features only: issued on a second stream as soon as they exist (adapt_ahead), it runs beside the teacher's
+    # kernels, and its backward beside the head's (lgd_amd/streams.py).  LGD_ADAPTER_STREAM=0: inside distill(), on the caller's stream.
+    adapter_stream = os.environ.get("LGD_ADAPTER_STREAM", "1") != "0"
+
+    def adapt_ahead(self, features_stu):
+        """the adapter over the student's pyramid on the side stream; distill(adapted=...) picks the result up.  None where it does not apply."""
+        adapter = self.adapter["distill"]
+        keys = sorted(features_stu.keys())
+        stu = [features_stu[k] for k in keys]
+        if not (self.adapter_stream and hasattr(adapter, "levels") and stu and stu[0].is_cuda):
+            return None
+        if self.distill_flag == 0:
+            stu = [f.detach() for f in stu]
+        main, side = streams.fork(stu[0].device, "adapter", inputs=stu)
+        streams.join_on_grad(list(adapter.parameters()), "adapter")
+        with torch.cuda.stream(side):
+            out = adapter.levels(stu)
+        return keys, out, main, side, self.distill_flag
+
+    def distill(self, features, images, batched_inputs, batchified_inside_masks, fg_labels, adapted=None):
         """coef * mse(IN(tea), IN(adapter(stu))) over all shared levels; teacher always detached,
         student detached while distill_flag == 0 (the adapter still trains).  `images`,
         `batched_inputs`, masks and labels are accepted and unused, as in the reference
@@ -46,8 +66,12 @@ class BaseDistillator(nn.Module):
         tea = [features["tea"][k].detach() for k in keys]
         if self.distill_flag == 0:
             stu = [f.detach() for f in stu]
-        adapter = self.adapter["distill"]
-        stu = adapter.levels(stu) if hasattr(adapter, "levels") else [adapter(f) for f in stu]
+        if adapted is not None and adapted[0] == keys and adapted[4] == self.distill_flag:
+            _, stu, main, side, _ = adapted
+            streams.join(main, side, outputs=stu)
+        else:
+            adapter = self.adapter["distill"]
+            stu = adapter.levels(stu) if hasattr(adapter, "levels") else [adapter(f) for f in stu]
         return ops.distill_in_mse(stu, tea, self.coef)
 
     @abstractmethod

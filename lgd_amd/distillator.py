@@ -24,11 +24,12 @@ class _Distillator(BaseDistillator):
             s = self.student
             r_features, features, images, gt_instances = s.backbone_features(
                 batched_inputs, after_preprocess=lambda images: self.teacher.encode_ahead(batched_inputs, images))
+            adapted = self.adapt_ahead(features)   # (on its side stream, beside the teacher)
             features_tea, inst_labels, geom = self.teacher((batched_inputs, images, r_features, features))
             losses, losses_tea = self._pair_losses([features[f] for f in s.head_in_features],
                                                    [features_tea[f] for f in s.head_in_features], gt_instances)
             losses.update({k + ".tea": v for k, v in losses_tea.items()})
-            losses.update(self.distill_loss({"stu": features, "tea": features_tea}, images, batched_inputs, geom, inst_labels))
+            losses.update(self.distill_loss({"stu": features, "tea": features_tea}, images, batched_inputs, geom, inst_labels, adapted=adapted))
             return losses
         if self.training:
             losses, r_features, features, images, gt = self.forward_student(batched_inputs)

@@ -835,8 +835,8 @@ def test_label_encoder_on_the_side_stream_equals_in_line():
 
 @pytest.mark.parametrize("yaml_name", ["lgd_retinanet_r50.yaml", "lgd_fcos_r50.yaml"])
 def test_head_towers_on_two_streams_equal_one_stream(yaml_name):
-    """the head's box tower on a second stream beside the class tower (lgd_amd/streams.py; autograd runs its backward there too) against both towers
-    on one stream, from the same weights: losses and parameters after three trainer steps across the phase switches equal to the run-to-run noise"""
+    """the head's box tower on a second stream beside the class tower and the adapter on its own stream beside the teacher (lgd_amd/streams.py;
+    autograd runs their backward there too) against everything on one stream, from the same weights: losses and parameters after three trainer steps across the phase switches equal to the run-to-run noise"""
     import copy
     from lgd_amd import config, streams
     from lgd_amd.data import synthetic_batch
@@ -851,7 +851,8 @@ def test_head_towers_on_two_streams_equal_one_stream(yaml_name):
     data = synthetic_batch(2, 256, 320, 5, seed=6)
     a = Trainer(cfg, base, distributed=False)
     b = Trainer(cfg, twin, distributed=False)
-    assert retinanet._HEAD_STREAMS
+    assert retinanet._HEAD_STREAMS and base.adapter_stream
+    twin.adapter_stream = False          # (the adapter beside the teacher on ITS side stream: switched off in the twin as well)
     forks = []
     real_fork = streams.fork
     streams.fork = lambda dev, name, inputs=(): (forks.append(name), real_fork(dev, name, inputs))[1]
@@ -864,7 +865,7 @@ def test_head_towers_on_two_streams_equal_one_stream(yaml_name):
                 lb = b.step(data, it)
             finally:
                 retinanet._HEAD_STREAMS = True
-            assert len(forks) == n_forks and "head" in forks
+            assert len(forks) == n_forks and "head" in forks and "adapter" in forks
             for k in la:
                 va, vb = float(la[k].detach()), float(lb[k].detach())
                 assert abs(va - vb) <= 1e-5 * max(1.0, abs(vb)), (it, k, va, vb)
