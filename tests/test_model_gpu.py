@@ -1261,6 +1261,8 @@ def test_fcos_head_gradients_fp64_under_product_masks(tile):
         return out
     prev = ops.conv3x3_backend(winograd=True, min_tiles=0, tile=tile)
     ops.conv3x3_gn = conv_gn
+    from lgd_amd.student import retinanet
+    streams_on, retinanet._HEAD_STREAMS = retinanet._HEAD_STREAMS, False   # (one stream: the masks are recorded in the interleaved call order below)
     try:
         outs = dict(zip(("logits", "reg", "ctr"), head(feats)))
         total = sum((t * torch.from_numpy(probes[kind][i]).to(DEV)).sum() for kind, maps in outs.items() for i, t in enumerate(maps))
@@ -1268,6 +1270,7 @@ def test_fcos_head_gradients_fp64_under_product_masks(tile):
     finally:
         ops.conv3x3_gn = real_conv_gn
         ops.conv3x3_backend(*prev)
+        retinanet._HEAD_STREAMS = streams_on
     assert len(gn_masks) == 8   # per tower layer: the cls tower's call, then the bbox tower's
     reg_masks = [(t.detach() > 0).cpu() for t in outs["reg"]]
     # the oracle's ReLU sites in its call order: per level -- cls tower (4), bbox tower (4), then the regression branch
