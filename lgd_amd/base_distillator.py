@@ -46,7 +46,7 @@ class BaseDistillator(nn.Module):
         adapter = self.adapter["distill"]
         keys = sorted(features_stu.keys())
         stu = [features_stu[k] for k in keys]
-        if not (self.adapter_stream and hasattr(adapter, "levels") and stu and stu[0].is_cuda):
+        if not (self.adapter_stream and hasattr(adapter, "levels") and stu and stu[0].is_cuda and ops.side_streams_ok()):
             return None
         if self.distill_flag == 0:
             stu = [f.detach() for f in stu]

@@ -1814,6 +1814,14 @@ def conv3x3_folds_pre(N, C, H, W, Cout, device, dtype=torch.float32):
             and C >= _WINO_MIN_CH and Cout >= _WINO_MIN_CH)
 
 
+def side_streams_ok():
+    """whether the independent chains of the step may fork onto second streams (lgd_amd/streams.py): on the shipped convolution path only -- F(6x6,3x3)
+    with its products on this library's kernels.  The A/B variants (F(4x4), library convolutions, library GEMMs) run on one stream: a two-stream step
+    on the F(4x4) variant stopped making progress on the GPU inside the full test suite (never in isolation, never on the shipped path), and the
+    variants exist to be compared, not to be fast."""
+    return _WINO_ON and _WINO_TILE == 6 and _H2_ON and _GEMM3_ON
+
+
 def conv3x3_stride2(x, w, b=None):
     """3x3 / stride 2 / padding 1 convolution (the FPN's extra levels p6 / p7 [d2-memory: LastLevelP6P7]).  Output pixel (i, j) of the
     strided convolution is output pixel (2i, 2j) of the stride-1 one, and F(4x4,3x3) spends 36 / 16 = 2.25 (F(6x6,3x3): 1.78) multiplies

@@ -108,7 +108,7 @@ class FCOSHead(nn.Module):
         nl = len(self.fpn_strides)
         c = b = list(features)
         pc = pb = None   # (scale, shift) of the previous layer's GroupNorm + ReLU, applied by the next convolution's input transform
-        if _rn._HEAD_STREAMS and c[0].is_cuda and self.fold_group_norm and self.fold_group_norm_bwd:
+        if _rn._HEAD_STREAMS and c[0].is_cuda and ops.side_streams_ok() and self.fold_group_norm and self.fold_group_norm_bwd:
             return self._forward_two_streams(c, raw_reg)
         for i in range(0, len(self.cls_subnet), 3):
             gc, gb = self.cls_subnet[i + 1], self.bbox_subnet[i + 1]

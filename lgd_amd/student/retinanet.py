@@ -53,7 +53,7 @@ class RetinaNetHead(nn.Module):
         cl = [self.cls_subnet[i] for i in range(2, len(self.cls_subnet), 2)] + [self.cls_score]
         bl = [self.bbox_subnet[i] for i in range(2, len(self.bbox_subnet), 2)] + [self.bbox_pred]
         relus = [True] * (len(cl) - 1) + [False]
-        if _HEAD_STREAMS and c[0].is_cuda:
+        if _HEAD_STREAMS and c[0].is_cuda and ops.side_streams_ok():
             # the two chains do not depend on each other: the box tower runs on a second stream beside the class tower (tails and small launches of
             # one under the other's kernels; config 2, same call: 52.32 / 52.11 -> 51.60 / 51.53 ms, losses identical; LGD_HEAD_STREAMS=0: one stream)
             main, side = streams.fork(c[0].device, "head", inputs=b)
