@@ -37,6 +37,13 @@ if [[ $what == all || $what == profile ]]; then
      cp $(ls /tmp/prof_$n/*/*kernel_stats.csv | head -1) $R/$O/kernel_stats_steps$n.csv
    done)
   python tools/prof_diff.py $O/kernel_stats_steps5.csv $O/kernel_stats_steps25.csv 20 $O/bench_rocprofv3_steady_state.csv
+  # ... and the same with the step's side streams off (bench.py --one-stream): a kernel's OWN duration, what bench.py's roofline objects are priced on
+  (cd /tmp && export TMPDIR=/tmp
+   for n in 5 25; do rm -rf /tmp/prof1_$n
+     timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1_$n -- python $R/bench.py --one-stream --steps $n --warmup 3 --no-cpu-baseline --no-kernel-timing --no-host-pass > /dev/null 2>&1
+     cp $(ls /tmp/prof1_$n/*/*kernel_stats.csv | head -1) $R/$O/kernel_stats_one_stream_steps$n.csv
+   done)
+  python tools/prof_diff.py $O/kernel_stats_one_stream_steps5.csv $O/kernel_stats_one_stream_steps25.csv 20 $O/bench_rocprofv3_steady_state_one_stream.csv
 fi
 if [[ $what == all || $what == pmc ]]; then bash tools/pmc_bench.sh > $O/pmc.log 2>&1; tail -3 $O/pmc.log; fi
 if [[ $what == all || $what == traject ]]; then bash tools/trajectory_check.sh; fi
