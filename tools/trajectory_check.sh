@@ -16,7 +16,7 @@ EXTRA="" run "shipped: F(6x6,3x3), products on h2.hip / gemm2h (f16x2)" LGD_X=0
 EXTRA="" run "round-4 path: gemm3.hip bf16x3 + library dW" LGD_H2=0 LGD_GEMM2H=0
 EXTRA="" run "f16x2 with every bound by its own pass (no tags)" LGD_H2_TAGS=0
 EXTRA="" run "stem on the library convolution + pooling pass" LGD_STEM7=0
-EXTRA="" run "label encoder in line (no side stream)" LGD_TEACHER_STREAM=0
+EXTRA="--one-stream" run "everything on one stream (no forks)" LGD_X=0
 EXTRA="" run "1x1 products: bf16x3 / library (no gemm2h)" LGD_GEMM2H=0
 EXTRA="--library-gemms" run "3x3 products h2 off, all on the library fp32 GEMMs" LGD_H2=0 LGD_GEMM2H=0
 EXTRA="--no-teacher-fold" run "teacher activations as their own passes" LGD_X=0
