@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--no-teacher-fold", action="store_true", help="DynamicTeacher: rendering's + ctx / ReLU and the refinement GroupNorm(1) + ReLU pairs as their own passes instead of inside the next convolution's input transform (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented second pass")
-    ap.add_argument("--one-stream", action="store_true", help="no side streams: the teacher's label encoder, the head's box tower and the adapter run in line on the step's stream (A/B runs; the rocprof summary the per-kernel roofline numbers are checked against)")
+    ap.add_argument("--one-stream", action="store_true", help="no side streams: the teacher's label encoder, the head's box tower, the adapter and the FPN's small levels run in line on the step's stream (A/B runs; the rocprof summary the per-kernel roofline numbers are checked against)")
     ap.add_argument("--no-gn-bwd-fold", action="store_true", help="FCOS towers: the GroupNorm backward as its own statistics + apply passes instead of inside the producing convolution's adjoint output transform (A/B runs)")
     ap.add_argument("--no-gn-fold", action="store_true", help="FCOS towers: GroupNorm(32) + ReLU as its own passes instead of inside the next convolution's input transform (A/B runs)")
     ap.add_argument("--no-fcos-fused-loss", action="store_true", help="FCOS: GIoU / centerness losses as the composed torch form instead of one kernel on the raw head outputs (A/B runs)")
@@ -253,13 +253,15 @@ def main():
     if args.no_gn_bwd_fold and hasattr(model.student.head, "fold_group_norm_bwd"):
         model.student.head.fold_group_norm_bwd = False
     from lgd_amd.student import retinanet as _rn
-    streams_shipped = (bool(getattr(model.teacher, "side_stream", False)), bool(_rn._HEAD_STREAMS), bool(getattr(model, "adapter_stream", False)))
+    from lgd_amd.student import fpn as _fpn
+    streams_shipped = (bool(getattr(model.teacher, "side_stream", False)), bool(_rn._HEAD_STREAMS), bool(getattr(model, "adapter_stream", False)), bool(_fpn._FPN_STREAM))
 
     def side_streams(on):
         """the step's three forks (lgd_amd/streams.py) as shipped, or all off: everything on the step's own stream"""
         model.teacher.side_stream = streams_shipped[0] and on
         _rn._HEAD_STREAMS = streams_shipped[1] and on
         model.adapter_stream = streams_shipped[2] and on
+        _fpn._FPN_STREAM = streams_shipped[3] and on
     side_streams(not args.one_stream)
     trainer = Trainer(cfg, model, device=dev, distributed=True if force_ddp else None, fused_sgd=not args.torch_optimizers)
     d = cfg.MODEL.DISTILLATOR
@@ -335,7 +337,7 @@ def main():
         dt_host_inline = time.perf_counter() - t0
         trainer.fetch_metrics()
     # second pass, instrumented: an event pair around every launch of the library and around the Winograd GEMMs
-    # The per-kernel numbers are a kernel's OWN durations: the shipped step forks three chains onto side streams, and launches that share the chip
+    # The per-kernel numbers are a kernel's OWN durations: the shipped step forks four chains onto side streams, and launches that share the chip
     # stretch each other (the two head towers run their products side by side: each takes ~1.6x as long, the step is 2 % shorter) -- so this pass
     # runs with the forks off, everything on the step's stream, and a third pass as shipped leaves the overlapped durations of the dominant
     # kernel next to them (`roofline.as_shipped`).
@@ -563,7 +565,7 @@ def main():
             "hbm_peak_alloc_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,
             "side_streams": {"teacher_label_encoder": streams_shipped[0] and not args.one_stream, "head_box_tower": streams_shipped[1] and not args.one_stream,
-                             "adapter": streams_shipped[2] and not args.one_stream,
+                             "adapter": streams_shipped[2] and not args.one_stream, "fpn_small_levels": streams_shipped[3] and not args.one_stream,
                              "note": "`value` / `ms_per_step` are the step as shipped (the forks on); the per-kernel durations behind every roofline object are taken in a pass "
                                      "with the forks OFF (one stream: a kernel's own duration -- launches that share the chip stretch each other); `roofline.as_shipped` "
                                      "carries the dominant kernel's overlapped durations from a third pass; --one-stream runs everything without the forks"},

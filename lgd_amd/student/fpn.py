@@ -2,11 +2,16 @@
 [d2-memory: detectron2/modeling/backbone/fpn.py @ v0.3].  `forward` takes the bottom-up feature
 dict: the reference replaces `fpn.bottom_up` by an identity nn.Sequential() and feeds it the raw
 ResNet features (models/customized_detectors/retinanet.py:29-34,52-53)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import ops, streams
+
+
+_FPN_STREAM = os.environ.get("LGD_FPN_STREAM", "1") != "0"   # 0: the whole FPN on one stream (A/B runs)
 
 
 class LastLevelP6P7(nn.Module):
@@ -50,6 +55,17 @@ class FPN(nn.Module):
         feats = self.bottom_up(x)
         results = []
         prev = None
+        # the extra levels (p6 / p7) and the output convolutions of the small levels do not feed the top-down path: on a second stream they run beside
+        # the laterals and the large level's output convolution (lgd_amd/streams.py; same call, config 2: 51.17 / 50.92 -> 50.73 / 50.50 ms)
+        two = _FPN_STREAM and ops.side_streams_ok() and all(v.is_cuda and v.dtype == torch.float32 for v in feats.values())
+        top = None
+        forked = None
+        if two and self.top_block is not None and self.top_block.in_feature in feats:
+            src = feats[self.top_block.in_feature]
+            forked = streams.fork(src.device, "fpn", inputs=[src])
+            streams.join_on_grad(list(self.top_block.parameters()), "fpn")
+            with torch.cuda.stream(forked[1]):
+                top = self.top_block(src)
         for f, idx in zip(reversed(self.in_features), reversed(self.stages)):
             m, x = getattr(self, "fpn_lateral%d" % idx), feats[f]
             up = F.interpolate(prev, scale_factor=2.0, mode="nearest") if prev is not None else None
@@ -63,7 +79,20 @@ class FPN(nn.Module):
                 if up is not None:
                     lat = lat + up
             prev = lat
-            results.insert(0, getattr(self, "fpn_output%d" % idx)(prev))
+            out = getattr(self, "fpn_output%d" % idx)
+            if two and idx != self.stages[0]:   # (every level but the largest)
+                if forked is None:
+                    forked = streams.fork(prev.device, "fpn", inputs=[prev])
+                else:
+                    forked[1].wait_stream(forked[0])
+                    prev.record_stream(forked[1])
+                streams.join_on_grad(list(out.parameters()), "fpn")
+                with torch.cuda.stream(forked[1]):
+                    results.insert(0, out(prev))
+            else:
+                results.insert(0, out(prev))
         if self.top_block is not None:
-            results.extend(self.top_block(feats[self.top_block.in_feature]))
+            results.extend(top if top is not None else self.top_block(feats[self.top_block.in_feature]))
+        if forked is not None:
+            streams.join(forked[0], forked[1], outputs=results[1:])
         return dict(zip(self.out_features, results))

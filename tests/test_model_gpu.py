@@ -863,12 +863,13 @@ def test_head_towers_on_two_streams_equal_one_stream(yaml_name):
         for it in (0, 25000, 40000):
             la = a.step(data, it)
             n_forks = len(forks)
-            retinanet._HEAD_STREAMS = False
+            from lgd_amd.student import fpn
+            retinanet._HEAD_STREAMS = fpn._FPN_STREAM = False
             try:
                 lb = b.step(data, it)
             finally:
-                retinanet._HEAD_STREAMS = True
-            assert len(forks) == n_forks and "head" in forks and "adapter" in forks
+                retinanet._HEAD_STREAMS = fpn._FPN_STREAM = True
+            assert len(forks) == n_forks and "head" in forks and "adapter" in forks and "fpn" in forks
             for k in la:
                 va, vb = float(la[k].detach()), float(lb[k].detach())
                 assert abs(va - vb) <= 1e-5 * max(1.0, abs(vb)), (it, k, va, vb)
