@@ -616,6 +616,10 @@ int lgd_timing_collect(char* names, size_t names_len, double* total_ms, int32_t*
 /* same, plus the shortest / longest launch of every kernel name (ms) */
 int lgd_timing_collect_ex(char* names, size_t names_len, double* total_ms, double* min_ms, double* max_ms, int32_t* launches,
                           int max_entries);
+/* Stall diagnosis (round 6): the recorded launches whose end event has not completed yet, oldest first, one text line each --
+ * "RUNNING <stream> <kernel>" (start event done) or "QUEUED <stream> <kernel>"; never blocks; returns their number.  There is no
+ * counterpart in the reference (it has no kernels of its own: SURVEY.md section 2a); the step it watches is train.py:182-215. */
+int lgd_timing_pending(char* out, size_t out_len);
 
 #ifdef __cplusplus
 }

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void box_prep_kernel(PrepArgs a) {
 
 extern "C" {
 
-int lgd_abi_version(void) { return 25; }
+int lgd_abi_version(void) { return 26; }
 const char* lgd_arch(void) { return "gfx950"; }
 const char* lgd_last_error(void) {
     return lgd::g_last_err == hipSuccess ? "" : hipGetErrorString(lgd::g_last_err);

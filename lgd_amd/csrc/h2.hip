@@ -49,10 +49,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
     const uint32_t n = bytes_left <= 0 ? 0u : bytes_left > 0xffffffffL ? 0xffffffffu : (uint32_t)bytes_left;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
 }
-// 16 bytes per lane, global -> LDS (lane-linear: LDS byte address lds_addr + 16 lane)
+// 16 bytes per lane, global -> LDS (lane-linear: LDS byte address lds_addr + 16 lane).  The statement WRITES m0 (the LDS base of the DMA) and says
+// so: without the clobber the compiler may keep a value of its own in m0 across it (its LDS-DMA builtins, v_movrel, s_sendmsg, ds_gws / readlane
+// forms all set m0 up ahead of use) or move such a set-up across it -- ADVICE r5; tests/test_abi.py::test_h2_dma_statements_own_m0 checks the object.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // "clobber list contains reserved registers: m0": reserved = never allocated, which is why it has to be said
 __device__ __forceinline__ void glds16(const __amdgpu_buffer_rsrc_t rs, uint32_t lds_addr, uint32_t voff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 
 // ------------------------------------------------------------------------------------------------------------------ forward / dx product
@@ -640,6 +645,19 @@ int ensure_attrs() {
     return LGD_OK;
 }
 
+// CUs of the current device, asked once per device (hipGetDeviceProperties is slow on ROCm and the split helpers sit on the host's launch path:
+// once per 3x3 and 1x1 weight-gradient product, ~80 calls per step -- ADVICE r5)
+int cu_count() {
+    static int cus_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus_dev[dev]) {
+        hipDeviceProp_t prop;
+        cus_dev[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus_dev[dev];
+}
+
 }  // namespace
 }  // namespace lgd
 
@@ -681,9 +699,7 @@ int lgd_h2_fwd(const void* image, const void* B, long long b_sb, long long b_sk,
 
 int lgd_h2_dw_splits(int nb, int M, int N, int T) {
     if (nb <= 0 || M <= 0 || N <= 0 || T < 16) return 1;
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const int cus = lgd::cu_count();
     const long tiles = (long)nb * ((M + 255) / 256) * ((N + 255) / 256);
     const int nstage = T / 16;
     // one workgroup per CU: as many splits as fill the chip once (measured: 64 batches x 4 on 256 CUs 184 us, x 2 246, x 8 224), at least 8 stages each
@@ -719,9 +735,7 @@ int lgd_h2_dw(const void* A, long long a_rs, long long a_sb, long long a_bytes, 
 
 int lgd_h2_pwdw_splits(int nimg, int M, int N, int HW) {
     if (nimg <= 0 || M <= 0 || N <= 0 || HW <= 0) return 1;
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const int cus = lgd::cu_count();
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256), nstage = (long)nimg * ((HW + 31) / 32);
     long S = (cus + tiles - 1) / tiles;           // one workgroup per CU
     while (S > 1 && nstage / S < 8) --S;

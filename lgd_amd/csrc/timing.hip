@@ -1,5 +1,6 @@
 // Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for
 // the live roofline numbers).  Disabled by default: a launch then costs one relaxed flag read.
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -10,7 +11,7 @@
 
 namespace lgd {
 
-struct Rec { const char* name; hipEvent_t a, b; };
+struct Rec { const char* name; hipEvent_t a, b; hipStream_t s; };
 static bool g_on = false;
 static std::mutex g_mu;
 static std::vector<Rec> g_recs;
@@ -24,7 +25,7 @@ KTimer::~KTimer() {
     if (!a_) return;
     (void)hipEventRecord(b_, s_);
     std::lock_guard<std::mutex> lk(g_mu);
-    g_recs.push_back({name_, a_, b_});
+    g_recs.push_back({name_, a_, b_, s_});
 }
 
 }  // namespace lgd
@@ -70,6 +71,26 @@ static int collect(char* names, size_t names_len, double* total_ms, double* min_
         launches[n] = kv.second.n;
         ++n;
     }
+    return n;
+}
+
+// Stall diagnosis (tools/stall_repro.py): the launches recorded since the last collect whose END event has not completed, oldest first, as text
+// lines "<RUNNING|QUEUED> <stream> <kernel>" -- RUNNING: its start event has completed (the kernel, or something in front of it on that stream that
+// is not one of this library's launches, is what the stream is executing), QUEUED: not even that.  Never blocks.  Returns the number of pending
+// launches (the text holds as many as fit).
+int lgd_timing_pending(char* out, size_t out_len) {
+    std::lock_guard<std::mutex> lk(lgd::g_mu);
+    int n = 0;
+    size_t off = 0;
+    if (out && out_len) out[0] = 0;
+    for (auto& r : lgd::g_recs) {
+        if (hipEventQuery(r.b) == hipSuccess) continue;
+        ++n;
+        char line[160];
+        const int len = snprintf(line, sizeof line, "%s %p %s\n", hipEventQuery(r.a) == hipSuccess ? "RUNNING" : "QUEUED", (void*)r.s, r.name);
+        if (out && len > 0 && off + (size_t)len + 1 <= out_len) { std::memcpy(out + off, line, (size_t)len + 1); off += (size_t)len; }
+    }
+    (void)hipGetLastError();   // (hipErrorNotReady from the queries is not a launch failure)
     return n;
 }
 

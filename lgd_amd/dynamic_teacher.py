@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import hip, ops
+from . import hip, ops, streams
 from .registry import CUSTOMIZED_DETECTORS_REGISTRY
 
 
@@ -248,7 +248,7 @@ class DynamicTeacher(nn.Module):
         side = rt.get("side")
         if side is None or side.device != dev:
             side = rt["side"] = torch.cuda.Stream(dev)
-            self._join_hooks()
+        self._join_hooks()
         side.wait_stream(main)   # the weights last step's optimizer wrote, the annotations the loader copied
         with torch.cuda.stream(side):
             enc = self.label_encoder_((batched_inputs, images, None, dev))
@@ -261,16 +261,18 @@ class DynamicTeacher(nn.Module):
         the same bucket on the main one: as each encoder gradient is accumulated the two streams are joined (each waits for the other's work so
         far), so whichever hook comes last, its stream has seen every gradient of the bucket.  The encoder's backward is the last thing the engine
         issues, so the joins cost no overlap.  Single-process runs need none of this (the engine joins the streams when backward() returns)."""
+        rt = self._rt()
+        if rt.get("handles") or not streams._multi_rank():   # (asked on every forward: registered on the first one that runs in a process group of > 1 ranks)
+            return
+        ref = weakref.ref(self)
+
         def join(_param):
-            import torch.distributed as dist
-            rt = _RUNTIME.get(self) or {}
+            me = ref()
+            rt = (_RUNTIME.get(me) if me is not None else None) or {}
             side, main = rt.get("side"), rt.get("main")
-            if side is not None and main is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if side is not None and main is not None:
                 side.wait_stream(main)
                 main.wait_stream(side)
-        rt = self._rt()
-        if rt.get("handles"):
-            return
         rt["handles"] = [p.register_post_accumulate_grad_hook(join) for m in (self.label_encoder_, self.canoni_proj_1D) for p in m.parameters()]
 
     def interactive_remapping(self, label_embed, boxes, counts, feats, img_size_dict, canoni=None):
@@ -308,8 +310,7 @@ class DynamicTeacher(nn.Module):
             _, enc, canoni, side = ahead
             main = torch.cuda.current_stream(canoni.device)
             main.wait_stream(side)
-            for t in (canoni, enc[0], enc[3]):   # made on the side stream, read on this one: keep their memory until this stream is done with it
-                t.record_stream(main)
+            streams.record_all((canoni, enc), main)   # made on the side stream (uploads and magnitude tags included), read on this one from here on
         else:
             enc = self.label_encoder_(info_list)
         x, _, _, boxes, img_size_dict, inst_labels, counts = enc

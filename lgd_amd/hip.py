@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.environ.get("LGD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liblgd_hip.so")   # LGD_HIP_LIB: a lab build
 _lib = None
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -133,6 +133,7 @@ SIGNATURES = {
     "lgd_timing_enable": (c_i, [c_i]),
     "lgd_timing_collect": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_i]),
     "lgd_timing_collect_ex": (c_i, [ctypes.c_char_p, c_sz, c_fp, c_fp, c_fp, c_fp, c_i]),
+    "lgd_timing_pending": (c_i, [ctypes.c_char_p, c_sz]),
 }
 
 
@@ -211,33 +212,44 @@ class _PinnedRing:
     """Small host -> device uploads (per-image offsets, index lists: a few dozen bytes, several per step) through a ring of PINNED
     staging slots: `torch.tensor(list).to(device)` reads pageable memory, which the runtime copies synchronously with the host and
     only after the stream has drained -- every such call let the GPU run dry for 0.2-0.7 ms (tools/gap_profile.sh).  The ring is cut
-    into SEGMENTS of slots; the last upload of a segment records an event on its stream and the first upload of the ring's next pass
-    over that segment waits for it -- a slot is never rewritten before the copy that read it has executed (in practice the event is
-    hundreds of steps old and the wait is a flag test)."""
+    into SEGMENTS of slots; the last upload of a segment records an event on EVERY stream that issued a copy out of the segment (the step uploads
+    from its main stream and from side streams alike: lgd_amd/streams.py) and the first upload of the ring's next pass over that segment waits
+    for all of them -- a slot is never rewritten before the copy that read it has executed (in practice the events are hundreds of steps old and
+    the wait is a flag test)."""
     SLOTS, SLOT_BYTES, SEGMENT = 1024, 1024, 128
 
     def __init__(self):
         self.buf = torch.empty(self.SLOTS * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
         self.i = 0
-        self.events = [None] * (self.SLOTS // self.SEGMENT)
-        self.waits = 0   # how many segment re-entries found an event to wait for (tests)
+        self.events = [None] * (self.SLOTS // self.SEGMENT)   # per segment: list of events, one per stream that copied out of it
+        self.used = {}    # raw stream handle -> torch stream object: the streams that copied out of the current segment
+        self.waits = 0    # how many segment re-entries found events to wait for (tests)
 
     def upload(self, t, device):
         n = t.numel() * t.element_size()
         if n == 0 or n > self.SLOT_BYTES:
             return t.to(device, non_blocking=True)
         seg, first = divmod(self.i, self.SEGMENT)
-        if first == 0 and self.events[seg] is not None:
-            self.events[seg].synchronize()
-            self.waits += 1
+        if first == 0:
+            if self.events[seg]:
+                for e in self.events[seg]:
+                    e.synchronize()
+                self.waits += 1
+            self.used = {}
         o = self.i * self.SLOT_BYTES
         slot = self.buf[o:o + n].view(t.dtype).view(t.shape)
         slot.copy_(t)
         out = slot.to(device, non_blocking=True)
+        raw = torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch._C._cuda_getDevice())
+        if raw not in self.used:
+            self.used[raw] = torch.cuda.current_stream(device)
         if first == self.SEGMENT - 1:
-            if self.events[seg] is None:
-                self.events[seg] = torch.cuda.Event()
-            self.events[seg].record()   # the current stream: the one the copy above was issued on
+            evs = []
+            for st in self.used.values():   # every stream that read a slot of this segment, not only the one of the last upload (ADVICE r5)
+                e = torch.cuda.Event()
+                e.record(st)
+                evs.append(e)
+            self.events[seg] = evs
         self.i = (self.i + 1) % self.SLOTS
         return out
 

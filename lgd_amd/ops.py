@@ -1819,6 +1819,8 @@ def side_streams_ok():
     with its products on this library's kernels.  The A/B variants (F(4x4), library convolutions, library GEMMs) run on one stream: a two-stream step
     on the F(4x4) variant stopped making progress on the GPU inside the full test suite (never in isolation, never on the shipped path), and the
     variants exist to be compared, not to be fast."""
+    if os.environ.get("LGD_SIDE_STREAMS_ANY") == "1":   # tools/stall_repro.sh: the forks on every variant, to reproduce that stall
+        return True
     return _WINO_ON and _WINO_TILE == 6 and _H2_ON and _GEMM3_ON
 
 

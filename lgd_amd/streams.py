@@ -3,6 +3,8 @@ the head beside the class tower): one process per GPU still, the streams overlap
 Autograd runs every backward node on the stream of its forward, so the overlap carries over to the backward pass.
 [ref: the reference issues everything on one stream -- train.py:182-215; the chains themselves: thirdparty_heads/fcos.py:520-546,
  detectron2 RetinaNetHead.forward]"""
+import weakref
+
 import torch
 
 _SIDE = {}   # (device index, name) -> torch.cuda.Stream
@@ -30,30 +32,58 @@ def fork(device, name, inputs=()):
     return main, s
 
 
+def record_all(obj, stream):
+    """record_stream on every device tensor reachable from obj (tensors, nested lists / tuples / dicts) AND on the magnitude-tag word a tensor
+    carries (ops._amax_tag: a slice of the zero-word pool of the stream that PRODUCED the tensor): all of them were allocated on one stream and are
+    about to be read on `stream` -- the caching allocator must not hand their memory out again under it"""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+            tag = getattr(obj, "_lgd_amax", None)
+            if tag is not None and isinstance(tag[0], torch.Tensor) and tag[0].is_cuda:
+                tag[0].record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            record_all(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            record_all(o, stream)
+
+
 def join(main, s, outputs=()):
-    """the current stream waits for the side stream; `outputs` (made on the side stream, read on the current one from here on) are recorded on it"""
+    """the current stream waits for the side stream; `outputs` (made on the side stream, read on the current one from here on: tensors or nested
+    containers of them) are recorded on it together with their magnitude tags"""
     main.wait_stream(s)
-    for t in outputs:
-        t.record_stream(main)
+    record_all(outputs, main)
+
+
+_HOOKED = {}   # id(parameter) -> (weak reference to it, names of the streams it is joined to): kept OUTSIDE the Parameter, whose __dict__ a
+               # whole-model pickle / deepcopy carries along while the hooks themselves stay behind (ADVICE r5)
+
+
+def _multi_rank():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def join_on_grad(params, name):
     """Data-parallel runs: DistributedDataParallel starts a bucket's all-reduce from the gradient hook of the bucket's LAST parameter and orders it
     behind the stream THAT hook runs on.  Parameters whose gradients are written on a side stream get a post-accumulate hook that joins the two
-    streams (each waits for the other's work so far) when the process group has more than one rank, so whichever hook of a bucket comes last,
-    its stream has seen every gradient of the bucket.  Registered once per parameter and stream name."""
+    streams (each waits for the other's work so far), so whichever hook of a bucket comes last, its stream has seen every gradient of the bucket.
+    Registered once per (parameter object, stream name), and only once the process group has more than one rank (called on every forward pass: a
+    single-process run never pays for the hooks, a model that was copied or unpickled gets them on its first multi-rank forward)."""
+    if not _multi_rank():
+        return
+
     def hook(p):
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            return
         s, m = _SIDE.get((p.device.index, name)), _MAIN.get(p.device.index)
         if s is not None and m is not None:
             s.wait_stream(m)
             m.wait_stream(s)
     for p in params:
-        done = getattr(p, "_lgd_join_streams", None)
-        if done is None:
-            done = p._lgd_join_streams = set()
-        if name not in done:
+        ent = _HOOKED.get(id(p))
+        if ent is None or ent[0]() is not p:
+            ent = _HOOKED[id(p)] = (weakref.ref(p, lambda _r, k=id(p): _HOOKED.pop(k, None)), set())
+        if name not in ent[1]:
             p.register_post_accumulate_grad_hook(hook)
-            done.add(name)
+            ent[1].add(name)

@@ -140,6 +140,34 @@ def test_h2_kloop_has_only_counted_waits():
             assert sum("ds_read_b64_tr_b16" in l for l in body) == 8, name
 
 
+def test_h2_dma_statements_own_m0():
+    """the inline-asm LDS-DMA of csrc/h2.hip writes m0.  (1) Source: every asm statement under csrc/ whose text names m0 lists
+    it among its clobbers.  (2) Object: in the product kernels every LDS-DMA instruction has its own `s_mov_b32 m0` directly in front of it (at most
+    the hazard nop between), and nothing else in those kernels writes or implicitly reads m0 (no other `... lds` form, v_movrel, s_sendmsg,
+    ds_gws): the compiler keeps no value of its own in m0 across the statements."""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "lgd_amd", "csrc", "*.h*")):
+        src = open(path).read()
+        for m in re.finditer(r"asm\s*(?:volatile)?\s*\((.*?)\);", src, flags=re.S):
+            body = m.group(1)
+            if re.search(r"\bm0\b", body.split(":")[0]):
+                clobbers = body.rsplit(":", 1)[1]
+                assert '"m0"' in clobbers, (os.path.basename(path), body[:80])
+    asm = _asm_of("h2.hip")
+    ks = _kernels(asm, r"h2_fwd_kernel|h2_dw_kernel")
+    assert len(ks) == 5
+    for name, (lines, _) in ks.items():
+        dma = [i for i, l in enumerate(lines) if re.match(r"buffer_load_dwordx4 .* lds$", l)]
+        assert dma, name
+        for i in dma:
+            prev = [l for l in lines[max(0, i - 2):i]]
+            assert any(l.startswith("s_mov_b32 m0,") for l in prev), (name, lines[max(0, i - 3):i + 1])
+        writes = [l for l in lines if re.match(r"s_\w+ m0,", l)]
+        assert len(writes) == len(dma) and all(l.startswith("s_mov_b32 m0,") for l in writes), (name, len(writes), len(dma))
+        others = [l for l in lines if re.match(r"(v_movrel|s_sendmsg|ds_gws|ds_\w+_gs_reg|global_load_lds|buffer_load_(dword|ubyte|ushort) .* lds$)", l)]
+        assert not others, (name, others[:3])
+
+
 def test_gemm3_kernels_keep_their_counted_waits_and_no_scratch():
     """csrc/gemm3.hip: the k-loop waits `vmcnt(8)` for the image DMA of the next k-step, relying on exactly 8 B loads having been issued behind
     it.  Build-time guard on every instance: no scratch (a spill would put extra loads into the counted window), the counted

