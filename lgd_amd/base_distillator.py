@@ -48,6 +48,9 @@ class BaseDistillator(nn.Module):
         stu = [features_stu[k] for k in keys]
         if not (self.adapter_stream and hasattr(adapter, "levels") and stu and stu[0].is_cuda and ops.side_streams_ok()):
             return None
+        convs = [m for m in adapter.modules() if isinstance(m, torch.nn.Conv2d)]
+        if not ops.convs_on_own_kernels(stu, [[m.weight] for m in convs]):   # (a side stream carries this library's kernels only: streams.library_call)
+            return None
         if self.distill_flag == 0:
             stu = [f.detach() for f in stu]
         main, side = streams.fork(stu[0].device, "adapter", inputs=stu)

@@ -10,7 +10,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import hip
+from . import hip, streams
 
 
 class BoxGeometry:
@@ -1696,6 +1696,44 @@ _WINO_MIN_CO = 16   # single-map convolutions with fewer output channels stay on
 _WINO_ON = True
 
 
+class _LibConv2d(torch.autograd.Function):
+    """the vendor library's convolution (MIOpen through torch) as ONE autograd node whose forward AND backward run inside
+    streams.library_call: what stays on the library -- tiny maps under the Winograd threshold, strided / 7x7 / grouped convolutions -- is
+    never in flight on two streams at once, also when autograd runs the backward on a side stream (a plain F.conv2d's backward is issued
+    by the engine, outside anybody's guard)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, dilation, groups):
+        ctx.save_for_backward(x, w)
+        ctx.geom = (stride, padding, dilation, groups, b is not None)
+        with streams.library_call(x.device):
+            return F.conv2d(x, w, b, stride, padding, dilation, groups)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, groups, has_b = ctx.geom
+        mask = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2])
+        with streams.library_call(x.device):
+            dx, dw, db = torch.ops.aten.convolution_backward(dy, x, w, [w.shape[0]] if has_b else None, list(stride), list(padding), list(dilation),
+                                                             False, [0, 0], groups, list(mask))
+        return dx, dw, (db if mask[2] else None), None, None, None, None
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else tuple(int(e) for e in v)
+
+
+def lib_conv2d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+    """F.conv2d on the vendor library, ordered against every other library call of the step (see _LibConv2d / streams.library_call)"""
+    if not x.is_cuda:
+        return F.conv2d(x, w, b, stride, padding, dilation, groups)
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+        return _LibConv2d.apply(x, w, b, _pair(stride), _pair(padding), _pair(dilation), int(groups))
+    with streams.library_call(x.device):
+        return F.conv2d(x, w, b, stride, padding, dilation, groups)
+
+
 def conv3x3_backend(winograd=None, min_tiles=None, tile=None):
     """which implementation the 3x3 convolutions take: tests force the Winograd kernels onto problems below the production
     threshold (min_tiles = 0), or the library's convolutions onto large ones (winograd = False) to compare the two; tile selects
@@ -1734,7 +1772,7 @@ def conv3x3_levels(xs, w, b=None, relu=False, scale=None, pre=None):
         xs = _apply_pre(xs, pre)
     if scale is not None:
         w = w * scale.view(-1, 1, 1, 1)
-    ys = [F.conv2d(x, w, b, 1, 1) for x in xs]
+    ys = [lib_conv2d(x, w, b, 1, 1) for x in xs]
     return [F.relu_(y) for y in ys] if relu else ys
 
 
@@ -1815,13 +1853,37 @@ def conv3x3_folds_pre(N, C, H, W, Cout, device, dtype=torch.float32):
 
 
 def side_streams_ok():
-    """whether the independent chains of the step may fork onto second streams (lgd_amd/streams.py): on the shipped convolution path only -- F(6x6,3x3)
-    with its products on this library's kernels.  The A/B variants (F(4x4), library convolutions, library GEMMs) run on one stream: a two-stream step
-    on the F(4x4) variant stopped making progress on the GPU inside the full test suite (never in isolation, never on the shipped path), and the
-    variants exist to be compared, not to be fast."""
-    if os.environ.get("LGD_SIDE_STREAMS_ANY") == "1":   # tools/stall_repro.sh: the forks on every variant, to reproduce that stall
+    """whether the independent chains of the step may fork onto second streams at all (lgd_amd/streams.py); LGD_SIDE_STREAMS=0 switches every fork off
+    (A/B runs).  WHICH chain may go to a side stream is decided per call by convs_on_own_kernels()."""
+    return os.environ.get("LGD_SIDE_STREAMS", "1") != "0"
+
+
+def convs_on_own_kernels(xs, filter_groups):
+    """True if every 3x3 convolution over the maps xs -- filter_groups: one list of weights per convolution call, several weights = filters stacked on
+    one input (conv3x3_shared_input / conv3x3_gn) -- runs on THIS library's kernels only: F(6x6) transforms and the f16x2 products of csrc/h2.hip,
+    forward, input AND weight gradient.  The per-call gate of the step's forks: a chain goes to a side stream only then.
+
+    Why: round 5's two-stream stall, reproduced and named in round 6 (profiles/r06_stall_root_cause.txt) -- two rocBLAS GEMMs in flight on two streams
+    share the single workspace of torch's per-thread handle, and the split-K kernel of one spins for ever on flags the other reset.  Chains that
+    contain calls of the vendor library (problems under the size gates, C' = 36 / 80 score convolutions, the F(4x4) and library A/B variants) stay on
+    the step's main stream, where stream order serialises them; streams.library_call additionally ORDERS any library call that does reach a side
+    stream, so nothing depends on this predicate for correctness -- only for speed (an ordered call on a side stream waits for the main stream).
+    LGD_SIDE_STREAMS_ANY=1: every chain may fork (tools/stall_repro.sh: with LGD_LIBRARY_ORDER=0 the stall reproduces)."""
+    if os.environ.get("LGD_SIDE_STREAMS_ANY") == "1":
         return True
-    return _WINO_ON and _WINO_TILE == 6 and _H2_ON and _GEMM3_ON
+    xs = list(xs)
+    if not xs or not xs[0].is_cuda or _WINO_TILE != 6:
+        return False
+    hw = hip.int_array([d for x in xs for d in x.shape[2:]])
+    T = hip.load().lgd_wino_tiles(hw, len(xs), xs[0].shape[0], 6)
+    Ci = xs[0].shape[1]
+    for ws in filter_groups:
+        if not all(_wino_ok(xs, w) and w.shape[1] == Ci for w in ws):
+            return False
+        if not _h2_ok(6, Ci, [w.shape[0] for w in ws], T, xs[0].device):
+            return False
+        Ci = ws[0].shape[0] if len(ws) == 1 else Ci   # (a chain: the next convolution reads this one's output; stacked filters end a chain)
+    return True
 
 
 def conv3x3_stride2(x, w, b=None):
@@ -1838,7 +1900,7 @@ def conv3x3_stride2(x, w, b=None):
         if tag is not None and tag[1] == y._version:   # (a subset of the pixels: the bound of the whole map holds)
             _amax_tag([z], tag[0])
         return z
-    return F.conv2d(x, w, b, 2, 1)
+    return lib_conv2d(x, w, b, 2, 1)
 
 
 class Conv3x3(torch.nn.Conv2d):
@@ -1936,7 +1998,8 @@ class _DeformConv(torch.autograd.Function):
                                          stride, padding, dilation, hip.ptr(col), hip.stream_ptr()), "lgd_dcn_im2col")
         # batched GEMM with the filter as a stride-0 batch: torch.matmul(2-D, 3-D) folds the batch by transposing + copying the whole
         # column matrix (and the result back): 135 strided copies = 8 of config 5's 58 ms of kernels per step (rocprofv3)
-        out = torch.bmm(weight.view(1, O, C * 9).expand(N, O, C * 9), col).view(N, O, Ho, Wo)
+        with streams.library_call(x.device):
+            out = torch.bmm(weight.view(1, O, C * 9).expand(N, O, C * 9), col).view(N, O, Ho, Wo)
         if bias is not None:
             out = out + bias.view(1, -1, 1, 1)
         ctx.save_for_backward(x, offset, mask, weight, col)
@@ -1953,7 +2016,8 @@ class _DeformConv(torch.autograd.Function):
         dy = hip.dense_f32(dy).view(N, O, -1)
         dx = doff = dmask = dw = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
-            dcol = torch.bmm(weight.view(1, O, C * 9).transpose(1, 2).expand(N, C * 9, O), dy)
+            with streams.library_call(x.device):
+                dcol = torch.bmm(weight.view(1, O, C * 9).transpose(1, 2).expand(N, C * 9, O), dy)
             # dx | d offset | d mask | per-cell contribution lists (dx by gather instead of the L2's float atomics, csrc/dcn.hip; _DCN_GATHER =
             # False: atomic scatter) carved out of ONE allocation in the order the entry point zeroes them: one fill instead of four
             def r4(n):
@@ -1979,7 +2043,8 @@ class _DeformConv(torch.autograd.Function):
                                              hip.ptr(dmask) if dmask is not None else None, hip.ptr(ws) if ws is not None else None,
                                              hip.stream_ptr()), "lgd_dcn_col2im")
         if ctx.needs_input_grad[3]:
-            dw = torch.bmm(dy, col.transpose(1, 2)).sum(0).view_as(weight)
+            with streams.library_call(x.device):
+                dw = torch.bmm(dy, col.transpose(1, 2)).sum(0).view_as(weight)
         if has_bias and ctx.needs_input_grad[4]:
             db = dy.sum((0, 2))
         return dx, doff, dmask, dw, db, None, None, None, None
@@ -2379,7 +2444,7 @@ def conv1x1(x, w):
     """bias-free pointwise convolution (see _Conv1x1); stride 1 only."""
     if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and torch.is_grad_enabled() and w.requires_grad:
         return _Conv1x1.apply(x, w)
-    return F.conv2d(x, w)
+    return lib_conv2d(x, w)
 
 
 _TIMER_ON = False
@@ -2444,11 +2509,13 @@ _GEMM_FLOPS = {}
 def _timed_bmm(name, a, b, out=None):
     """torch.bmm, bracketed by an event pair on the current stream while the kernel timer is on (bench.py's MFMA roofline)."""
     if not _TIMER_ON:
-        return torch.bmm(a, b, out=out) if out is not None else torch.bmm(a, b)
+        with streams.library_call(a.device):   # (one rocBLAS handle and workspace per host thread: never two library GEMMs at once -- streams.py)
+            return torch.bmm(a, b, out=out) if out is not None else torch.bmm(a, b)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = torch.bmm(a, b, out=out) if out is not None else torch.bmm(a, b)
-    e1.record()
+    with streams.library_call(a.device):
+        e0.record()
+        r = torch.bmm(a, b, out=out) if out is not None else torch.bmm(a, b)
+        e1.record()
     _GEMM_EVENTS.append((name, e0, e1))
     _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + 2 * a.shape[0] * a.shape[1] * a.shape[2] * b.shape[2]
     return r
@@ -2965,11 +3032,13 @@ def _timed_gemm(name, flops, fn, *args, **kw):
     """fn(*args, **kw) -- a library GEMM (or a convolution the library runs as one) -- bracketed by an event pair on the current
     stream while the kernel timer is on: the student's pointwise convolutions in bench.py's second MFMA roofline object."""
     if not _TIMER_ON:
-        return fn(*args, **kw)
+        with streams.library_call(args[0].device):
+            return fn(*args, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = fn(*args, **kw)
-    e1.record()
+    with streams.library_call(args[0].device):
+        e0.record()
+        r = fn(*args, **kw)
+        e1.record()
     _GEMM_EVENTS.append((name, e0, e1))
     _GEMM_FLOPS[name] = _GEMM_FLOPS.get(name, 0) + int(flops)
     return r

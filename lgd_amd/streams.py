@@ -3,6 +3,7 @@ the head beside the class tower): one process per GPU still, the streams overlap
 Autograd runs every backward node on the stream of its forward, so the overlap carries over to the backward pass.
 [ref: the reference issues everything on one stream -- train.py:182-215; the chains themselves: thirdparty_heads/fcos.py:520-546,
  detectron2 RetinaNetHead.forward]"""
+import os
 import weakref
 
 import torch
@@ -11,13 +12,78 @@ _SIDE = {}   # (device index, name) -> torch.cuda.Stream
 _MAIN = {}   # device index -> the stream the step runs on (the one a fork was last taken from)
 
 
+_SIDE_RAW = {}  # device index -> {raw handle of a side stream: the stream object}
+_LIB_LAST = {}  # device index -> {raw handle of a side stream: event behind its last library call}
+_LIB_SEEN = {}  # (device index, raw handle of a waiting stream, raw handle of a side stream) -> the event that stream has already waited for
+
+
 def side(device, name):
     """the side stream `name` of a device (created on first use)"""
     key = (device.index if device.index is not None else torch.cuda.current_device(), name)
     s = _SIDE.get(key)
     if s is None:
         s = _SIDE[key] = torch.cuda.Stream(device)
+        _SIDE_RAW.setdefault(key[0], {})[s.cuda_stream] = s
     return s
+
+
+_ORDER_LIBRARY = os.environ.get("LGD_LIBRARY_ORDER", "1") != "0"   # 0: the round-5 behaviour (tools/stall_repro.sh reproduces the stall with it)
+
+
+class library_call:
+    """`with streams.library_call(device):` around EVERY rocBLAS / MIOpen call this package issues (torch.bmm, baddbmm, F.conv2d and the
+    convolution backward): calls on different streams are ORDERED, never concurrent.
+
+    Root cause of round 5's two-stream stall (tools/stall_repro.sh, profiles/r06_stall_root_cause.txt): torch keeps ONE rocBLAS handle per host
+    thread and points it at whatever stream is current (at::cuda::getCurrentCUDABlasHandle -> rocblas_set_stream); the handle owns ONE device
+    workspace, which the library's split-K kernels (the long-K weight-gradient products dU = dM V^T of the F(4x4) variant, 36 batches) use for
+    partial tiles and for the flags their workgroups spin on.  Two such GEMMs issued from two streams overlap on the device, one resets the other's
+    flags, and its workgroups spin for ever: GPU 100 % busy, memory idle, every later launch of that stream queued behind it -- reproduced in
+    isolation on the second step of the F(4x4) variant with only the head fork on, with and without the tuning table.  (CUDA builds of torch give
+    every (handle, stream) pair its own workspace -- cublasSetWorkspace; the ROCm build does not.)  The shipped F(6x6) path keeps its large
+    products on this library's own kernels (no workspace, no inter-workgroup waits), but bbox_pred's C' = 36 products, everything under the size
+    gates at 2 images per GPU and the small FPN levels ARE library calls on side streams: the same hazard with better odds.
+    Ordering costs nothing where it matters: the forks exist to overlap this library's launches, tails and small kernels, not two GEMMs of the
+    vendor library (measured slower in round 3).  Calls on the step's main stream cost one dictionary probe; a call on a side stream waits for
+    the main stream's work so far and for the other side streams' last library call, and leaves an event the others wait for."""
+    __slots__ = ("idx", "cur", "raw")
+
+    def __init__(self, device):
+        self.idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.cur = None
+
+    def __enter__(self):
+        sides = _SIDE_RAW.get(self.idx)
+        if not sides or not _ORDER_LIBRARY:   # no fork has ever been taken on this device: one stream, stream order
+            return self
+        raw = self.raw = torch._C._cuda_getCurrentRawStream(self.idx)
+        last = _LIB_LAST.get(self.idx)
+        cur = sides.get(raw)
+        if cur is not None:    # on a side stream
+            self.cur = cur
+            m = _MAIN.get(self.idx)
+            if m is not None:
+                cur.wait_stream(m)
+            if last:
+                for r2, ev in last.items():
+                    if r2 != raw:
+                        cur.wait_event(ev)
+        elif last:             # on the main stream (or any other): behind the side streams' last library calls, each waited for once
+            st = None
+            for r2, ev in last.items():
+                if _LIB_SEEN.get((self.idx, raw, r2)) is not ev:
+                    if st is None:
+                        st = torch.cuda.current_stream(self.idx)
+                    st.wait_event(ev)
+                    _LIB_SEEN[(self.idx, raw, r2)] = ev
+        return self
+
+    def __exit__(self, *exc):
+        if self.cur is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.cur)
+            _LIB_LAST.setdefault(self.idx, {})[self.raw] = ev
+        return False
 
 
 def fork(device, name, inputs=()):

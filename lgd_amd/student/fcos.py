@@ -62,8 +62,8 @@ class FCOSHead(nn.Module):
         self.fold_group_norm_bwd = True   # False: the GroupNorm backward as its own statistics + apply passes (A/B: bench.py --no-gn-bwd-fold)
 
     def _forward_two_streams(self, feats, raw_reg):
-        """forward() with the two towers on two streams (the shipped fold path): after the first layer, which reads the shared input, the box tower
-        (with bbox_pred, and centerness where it hangs off it) runs on a second stream beside the class tower -- see RetinaNetHead.forward"""
+        """forward() with the two towers on two streams (the shipped fold path): after the first layer, which reads the shared input, the class
+        tower runs on a second stream beside the box tower -- see RetinaNetHead.forward"""
         nl = len(self.fpn_strides)
         gc, gb = self.cls_subnet[1], self.bbox_subnet[1]
         wc, wb = self.cls_subnet[0], self.bbox_subnet[0]
@@ -74,23 +74,24 @@ class FCOSHead(nn.Module):
                 w, g = sub[i], sub[i + 1]
                 (p, x), = ops.conv3x3_gn(x, [(w.weight, w.bias, g.weight, g.bias)], g.num_groups, pre=p)
             return x, p
-        side_mods = [self.bbox_subnet[i] for i in range(3, len(self.bbox_subnet)) if not isinstance(self.bbox_subnet[i], nn.ReLU)] + [self.bbox_pred]
-        if self.centerness_on_reg:
-            side_mods.append(self.centerness)
-        main, side = streams.fork(c[0].device, "head", inputs=list(b) + [pb])
+        # the CLASS tower's convolution + GroupNorm layers go to the side stream: 256 -> 256 convolutions on this library's kernels only (the gate of
+        # forward(): ops.convs_on_own_kernels).  The score convolutions (C' = 80 / 4 + 1: products of the vendor library) run on the main stream, the
+        # class one behind the join -- a side stream never carries a library call (round 6: the root cause of round 5's stall, lgd_amd/streams.py)
+        side_mods = [self.cls_subnet[i] for i in range(3, len(self.cls_subnet)) if not isinstance(self.cls_subnet[i], nn.ReLU)]
+        main, side = streams.fork(c[0].device, "head", inputs=list(c) + [pc])
         streams.join_on_grad([q for m in side_mods for q in m.parameters()], "head")
         with torch.cuda.stream(side):
-            b, pb = tower(self.bbox_subnet, b, pb)
-            if self.centerness_on_reg:
-                regs, ctr = ops.conv3x3_shared_input(b, [(self.bbox_pred.weight, self.bbox_pred.bias), (self.centerness.weight, self.centerness.bias)], pre=pb)
-            else:
-                regs, ctr = self.bbox_pred.levels(b, pre=pb), None
-        c, pc = tower(self.cls_subnet, c, pc)
+            c, pc = tower(self.cls_subnet, c, pc)
+        b, pb = tower(self.bbox_subnet, b, pb)
+        if self.centerness_on_reg:
+            regs, ctr = ops.conv3x3_shared_input(b, [(self.bbox_pred.weight, self.bbox_pred.bias), (self.centerness.weight, self.centerness.bias)], pre=pb)
+        else:
+            regs, ctr = self.bbox_pred.levels(b, pre=pb), None
+        streams.join(main, side, outputs=list(c) + [pc])
         if self.centerness_on_reg:
             logits = self.cls_score.levels(c, pre=pc)
         else:
             logits, ctr = ops.conv3x3_shared_input(c, [(self.cls_score.weight, self.cls_score.bias), (self.centerness.weight, self.centerness.bias)], pre=pc)
-        streams.join(main, side, outputs=list(regs) + (list(ctr) if self.centerness_on_reg else []))
         if raw_reg:
             return logits, RawRegMaps(regs), ctr
         reg = []
@@ -108,7 +109,8 @@ class FCOSHead(nn.Module):
         nl = len(self.fpn_strides)
         c = b = list(features)
         pc = pb = None   # (scale, shift) of the previous layer's GroupNorm + ReLU, applied by the next convolution's input transform
-        if _rn._HEAD_STREAMS and c[0].is_cuda and ops.side_streams_ok() and self.fold_group_norm and self.fold_group_norm_bwd:
+        if (_rn._HEAD_STREAMS and c[0].is_cuda and ops.side_streams_ok() and self.fold_group_norm and self.fold_group_norm_bwd
+                and ops.convs_on_own_kernels(c, [[self.cls_subnet[i].weight] for i in range(3, len(self.cls_subnet), 3)])):
             return self._forward_two_streams(c, raw_reg)
         for i in range(0, len(self.cls_subnet), 3):
             gc, gb = self.cls_subnet[i + 1], self.bbox_subnet[i + 1]

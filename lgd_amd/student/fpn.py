@@ -53,19 +53,8 @@ class FPN(nn.Module):
 
     def forward(self, x):
         feats = self.bottom_up(x)
-        results = []
-        prev = None
-        # the extra levels (p6 / p7) and the output convolutions of the small levels do not feed the top-down path: on a second stream they run beside
-        # the laterals and the large level's output convolution (lgd_amd/streams.py; same call, config 2: 51.17 / 50.92 -> 50.73 / 50.50 ms)
-        two = _FPN_STREAM and ops.side_streams_ok() and all(v.is_cuda and v.dtype == torch.float32 for v in feats.values())
-        top = None
-        forked = None
-        if two and self.top_block is not None and self.top_block.in_feature in feats:
-            src = feats[self.top_block.in_feature]
-            forked = streams.fork(src.device, "fpn", inputs=[src])
-            streams.join_on_grad(list(self.top_block.parameters()), "fpn")
-            with torch.cuda.stream(forked[1]):
-                top = self.top_block(src)
+        # top-down path first: lateral 1x1 convolutions + the upsampled sum, smallest level first
+        lats, prev = {}, None
         for f, idx in zip(reversed(self.in_features), reversed(self.stages)):
             m, x = getattr(self, "fpn_lateral%d" % idx), feats[f]
             up = F.interpolate(prev, scale_factor=2.0, mode="nearest") if prev is not None else None
@@ -78,21 +67,29 @@ class FPN(nn.Module):
                 lat = m(x)
                 if up is not None:
                     lat = lat + up
-            prev = lat
-            out = getattr(self, "fpn_output%d" % idx)
-            if two and idx != self.stages[0]:   # (every level but the largest)
-                if forked is None:
-                    forked = streams.fork(prev.device, "fpn", inputs=[prev])
-                else:
-                    forked[1].wait_stream(forked[0])
-                    prev.record_stream(forked[1])
-                streams.join_on_grad(list(out.parameters()), "fpn")
-                with torch.cuda.stream(forked[1]):
-                    results.insert(0, out(prev))
-            else:
-                results.insert(0, out(prev))
+            lats[idx] = prev = lat
+        # The output convolution of the LARGEST level (p3: 3/4 of the pyramid's pixels, this library's kernels only) goes to a second stream, where
+        # it runs beside the small levels' output convolutions and the extra levels p6 / p7 (lgd_amd/streams.py; round 5, the roles the other way
+        # round, same call at config 2: 51.17 / 50.92 -> 50.73 / 50.50 ms).  Round 6 turned the roles round: the small levels and p6 / p7 are problems
+        # under the size gates -- calls of the vendor library -- and a side stream carries this library's kernels only (ops.convs_on_own_kernels;
+        # the root cause of round 5's stall: streams.library_call).  LGD_FPN_STREAM=0: everything on one stream.
+        big = self.stages[0]
+        out_big = getattr(self, "fpn_output%d" % big)
+        two = (_FPN_STREAM and ops.side_streams_ok() and len(self.stages) > 1 and lats[big].is_cuda and lats[big].dtype == torch.float32
+               and ops.convs_on_own_kernels([lats[big]], [[out_big.weight]]))
+        results = {}
+        forked = None
+        if two:
+            forked = streams.fork(lats[big].device, "fpn", inputs=[lats[big]])
+            streams.join_on_grad(list(out_big.parameters()), "fpn")
+            with torch.cuda.stream(forked[1]):
+                results[big] = out_big(lats[big])
+        for idx in reversed(self.stages):
+            if idx not in results:
+                results[idx] = getattr(self, "fpn_output%d" % idx)(lats[idx])
+        results = [results[idx] for idx in self.stages]
         if self.top_block is not None:
-            results.extend(top if top is not None else self.top_block(feats[self.top_block.in_feature]))
+            results.extend(self.top_block(feats[self.top_block.in_feature]))
         if forked is not None:
-            streams.join(forked[0], forked[1], outputs=results[1:])
+            streams.join(forked[0], forked[1], outputs=[results[0]])
         return dict(zip(self.out_features, results))

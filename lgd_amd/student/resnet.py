@@ -94,7 +94,7 @@ class ConvBN(nn.Conv2d):
             w = self._frozen_fold(scale)
         if self._plain3x3 and residual is None:  # 3x3 / stride 1: Winograd transforms + GEMMs (bias + ReLU fused in the output transform)
             return ops.conv3x3(x, w, shift, relu=relu, pre=pre)
-        y = F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
+        y = ops.lib_conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups)
         return ops.bias_act(y, shift, residual, relu)
 
 
@@ -195,7 +195,7 @@ class Stem(nn.Module):
                 wf = c._frozen_fold(scale)
                 if ops.stem_conv_pool_ok(x, wf) and c.stride == (2, 2) and c.padding == (3, 3):
                     return ops.stem_conv_pool(x, wf, shift)   # csrc/stem.hip: convolution, shift, ReLU and the pool in one kernel
-                return ops.stem_bias_relu_maxpool(F.conv2d(x, wf, None, c.stride, c.padding), shift)
+                return ops.stem_bias_relu_maxpool(ops.lib_conv2d(x, wf, None, c.stride, c.padding), shift)
         return F.max_pool2d(self.conv1(x, relu=True), 3, 2, 1)
 
 

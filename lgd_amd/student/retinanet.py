@@ -53,15 +53,17 @@ class RetinaNetHead(nn.Module):
         cl = [self.cls_subnet[i] for i in range(2, len(self.cls_subnet), 2)] + [self.cls_score]
         bl = [self.bbox_subnet[i] for i in range(2, len(self.bbox_subnet), 2)] + [self.bbox_pred]
         relus = [True] * (len(cl) - 1) + [False]
-        if _HEAD_STREAMS and c[0].is_cuda and ops.side_streams_ok():
-            # the two chains do not depend on each other: the box tower runs on a second stream beside the class tower (tails and small launches of
-            # one under the other's kernels; config 2, same call: 52.32 / 52.11 -> 51.60 / 51.53 ms, losses identical; LGD_HEAD_STREAMS=0: one stream)
-            main, side = streams.fork(c[0].device, "head", inputs=b)
-            streams.join_on_grad([q for m in bl for q in (m.weight, m.bias)], "head")
+        if _HEAD_STREAMS and c[0].is_cuda and ops.side_streams_ok() and ops.convs_on_own_kernels(c, [[m.weight] for m in cl]):
+            # the two chains do not depend on each other: the CLASS tower runs on a second stream beside the box tower (tails and small launches of
+            # one under the other's kernels; config 2, same call: 52.32 / 52.11 -> 51.60 / 51.53 ms, losses identical; LGD_HEAD_STREAMS=0: one stream).
+            # Which one goes aside is not a matter of taste: a side stream carries this library's kernels only (ops.convs_on_own_kernels) -- bbox_pred's
+            # C' = 36 products are calls of the vendor library and stay on the main stream (round 6: the root cause of round 5's stall, streams.py)
+            main, side = streams.fork(c[0].device, "head", inputs=c)
+            streams.join_on_grad([q for m in cl for q in (m.weight, m.bias)], "head")
             with torch.cuda.stream(side):
-                bout = ops.conv3x3_chain(b, [(m.weight, m.bias) for m in bl], relus)
-            cout = ops.conv3x3_chain(c, [(m.weight, m.bias) for m in cl], relus)
-            streams.join(main, side, outputs=bout)
+                cout = ops.conv3x3_chain(c, [(m.weight, m.bias) for m in cl], relus)
+            bout = ops.conv3x3_chain(b, [(m.weight, m.bias) for m in bl], relus)
+            streams.join(main, side, outputs=cout)
             return cout, bout
         return (ops.conv3x3_chain(c, [(m.weight, m.bias) for m in cl], relus),
                 ops.conv3x3_chain(b, [(m.weight, m.bias) for m in bl], relus))

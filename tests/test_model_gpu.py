@@ -948,8 +948,11 @@ def test_head_towers_on_two_streams_equal_one_stream(yaml_name):
     real_fork = streams.fork
     streams.fork = lambda dev, name, inputs=(): (forks.append(name), real_fork(dev, name, inputs))[1]
     from lgd_amd import ops
-    prev_conv = ops.conv3x3_backend(winograd=True, tile=6)   # (a module-scoped golden fixture may still hold the library back-end: the forks are taken
-    assert ops.side_streams_ok()                             #  on the shipped convolution path only)
+    prev_conv = ops.conv3x3_backend(winograd=True, tile=6)   # (a module-scoped golden fixture may still hold the library back-end)
+    # the maps of this test are far below the size gates: the per-call gate of the forks (ops.convs_on_own_kernels) would keep every chain on one
+    # stream.  Forced on, the side chains run on the vendor library's GEMMs -- ordered against the main stream's by streams.library_call
+    os.environ["LGD_SIDE_STREAMS_ANY"] = "1"
+    assert ops.side_streams_ok()
     try:
         for it in (0, 25000, 40000):
             la = a.step(data, it)
@@ -967,19 +970,35 @@ def test_head_towers_on_two_streams_equal_one_stream(yaml_name):
     finally:
         streams.fork = real_fork
         ops.conv3x3_backend(*prev_conv)
+        del os.environ["LGD_SIDE_STREAMS_ANY"]
     for (n, p), (_, q) in zip(base.named_parameters(), twin.named_parameters()):
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), (n, float((p - q).abs().max()))
 
 
+@pytest.mark.timeout(600)
+def test_f4x4_variant_with_forks_makes_progress():
+    """Regression test of round 5's two-stream stall (profiles/r06_stall_root_cause.txt): BASELINE config 5 (R-101-DCNv2, 2 multi-scale images) on the
+    F(4x4) A/B variant with EVERY fork forced on -- two long-K rocBLAS products of the vendor library side by side on two streams, which stopped
+    making progress on the second step when nothing ordered them -- now runs through (streams.library_call orders every library call of this
+    package).  A subprocess with its own watchdog: a stall is exit code 3 after 60 s, not a hung suite."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LGD_")}
+    env["LGD_SIDE_STREAMS_ANY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stall_repro.py"), "--steps", "12", "--tile", "4"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and "12 steps done" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+
+
 @pytest.mark.timeout(1800)
 def test_step_forks_under_a_competing_stream():
-    """VERDICT r5 item 2c / ADVICE r5: 300 optimizer steps of the shipped path (RetinaNet R-50 + LGD, 2 images of 800 x 1333: BASELINE config 4's
-    per-rank workload on the R-50) with ALL forks of the step on, while a further stream saturates HBM with 256 MB copies -- the place RCCL's
-    kernels take in a data-parallel job -- against the same steps on ONE stream with nothing beside them (tools/stream_stress.py, run as a
-    subprocess with a deadline: a stall fails the test instead of hanging the suite).  Progress: every step returns its losses.  Results: the
-    first step's losses (same weights, before any update) equal to 1e-6, the first 20 steps to 1e-5, all 300 finite and within the drift two
-    identical runs of this step show (the library's small-level convolutions are not bit-reproducible run to run: DESIGN section 2).
-    [ref: the step is train.py:182-215]"""
+    """VERDICT r5 item 2c / ADVICE r5: 300 optimizer steps of the shipped path at BASELINE config 2 (RetinaNet R-50 + LGD, 8 images of 800 x 1333)
+    with ALL forks of the step on, while a further stream saturates HBM with 256 MB copies -- the place RCCL's kernels take in a data-parallel job
+    -- against the same steps on ONE stream with nothing beside them (tools/stream_stress.py, run as a subprocess with a deadline: a stall fails the
+    test instead of hanging the suite).  Progress: every step returns its losses.  Results: the first two steps BIT-equal (the forks change no
+    arithmetic), the first 20 to 1e-5; from there on two IDENTICAL one-stream runs drift apart themselves (the vendor library's small-level kernels
+    are not bit-reproducible run to run and 300 SGD steps amplify the last bit: 5e-4 after 50 steps, tens of per cent after 150), so the forked run
+    is held to 10x the drift the tool measures between two one-stream runs up to the same step.  [ref: the step is train.py:182-215]"""
     import json
     import subprocess
     import sys
@@ -989,21 +1008,21 @@ def test_step_forks_under_a_competing_stream():
                        text=True, timeout=1500)
     assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    fa, fb = rec["forked"], rec["one_stream"]
-    assert len(fa) == len(fb) == 300 and rec["competitor_copies"] == 300 * 24
+    fa, fb, fc = rec["forked"], rec["one_stream"], rec["one_stream_again"]
+    assert len(fa) == len(fb) == len(fc) == 300 and rec["competitor_copies"] == 300 * 24
     assert {"head", "adapter", "fpn"} <= set(rec["forks_per_step"]) and all(v >= 1.0 for v in rec["forks_per_step"].values()), rec["forks_per_step"]
-    worst = [0.0, 0.0]
-    for i, (x, y) in enumerate(zip(fa, fb)):
-        assert set(x) == set(y)
-        for k in x:
-            assert np.isfinite(x[k]) and np.isfinite(y[k]), (i, k)
-            e = abs(x[k] - y[k]) / max(abs(y[k]), 1e-6)
-            if i < 20:
-                worst[0] = max(worst[0], e)
-            worst[1] = max(worst[1], e)
-            assert e <= (1e-6 if i == 0 else 1e-5 if i < 20 else 5e-3), (i, k, x[k], y[k])
-    print("300 steps, forks on + competing stream %.1f ms/step, one stream %.1f ms/step; worst loss deviation: first 20 steps %.1e, all %.1e"
-          % (rec["ms_per_step_forked_under_load"], rec["ms_per_step_one_stream"], worst[0], worst[1]))
+
+    def dev(x, y):
+        assert all(set(p) == set(q) and all(np.isfinite(v) for v in list(p.values()) + list(q.values())) for p, q in zip(x, y))
+        return [max(abs(p[k] - q[k]) / max(abs(q[k]), 1e-6) for k in p) for p, q in zip(x, y)]
+    dab, dbc = dev(fa, fb), dev(fb, fc)
+    assert max(dab[:2]) == 0.0, dab[:2]
+    assert max(dab[:20]) <= 1e-5, max(dab[:20])
+    for i in range(20, 300):
+        assert max(dab[:i + 1]) <= 10.0 * max(max(dbc[:i + 1]), 1e-6), (i, max(dab[:i + 1]), max(dbc[:i + 1]))
+    print("300 steps at config 2: forks on + competing stream %.1f ms/step, one stream %.1f ms/step; worst loss deviation over the first 20 steps %.1e "
+          "(two one-stream runs: %.1e), over the first 50 %.1e (%.1e)" % (rec["ms_per_step_forked_under_load"], rec["ms_per_step_one_stream"], max(dab[:20]),
+                                                                          max(dbc[:20]), max(dab[:50]), max(dbc[:50])))
 
 
 def test_step_folds_equal_per_op_folds():
@@ -1165,10 +1184,14 @@ def test_config2_step_shipped_vs_library_b8():
         assert {"head", "adapter", "fpn"} <= set(forks), forks     # the step as shipped: every fork taken
         nf = len(forks)
         ops.conv3x3_backend(winograd=False)
-        assert not ops.side_streams_ok()
-        twin.teacher.side_stream = False                             # (the label encoder's own side stream: an instance switch, as bench.py --one-stream)
-        b = Trainer(cfg, twin, distributed=False, fused_sgd=False)
-        lb = [{k: float(v) for k, v in b.step(data, it0 + i).items()} for i in range(2)]
+        os.environ["LGD_SIDE_STREAMS"] = "0"                         # every fork off ...
+        twin.teacher.side_stream = False                             # (... and the label encoder's own side stream: an instance switch, as bench.py --one-stream)
+        try:
+            assert not ops.side_streams_ok()
+            b = Trainer(cfg, twin, distributed=False, fused_sgd=False)
+            lb = [{k: float(v) for k, v in b.step(data, it0 + i).items()} for i in range(2)]
+        finally:
+            del os.environ["LGD_SIDE_STREAMS"]
         assert len(forks) == nf, forks[nf:]                          # ... against ONE stream
     finally:
         streams.fork = real_fork
