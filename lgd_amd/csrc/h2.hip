@@ -36,6 +36,10 @@
 
 #include "winograd.h"
 
+#ifndef LGD_H2_ABL
+#define LGD_H2_ABL 0   // lab ablations of h2_fwd_kernel (tools/h2_ablate.sh; results are garbage): 1 no C stores, 2 no DMA of B, 3 no DMA of the image,
+#endif                 // 4 no MFMAs, 5 no DMA at all and no stores (fragment reads, MFMAs and barriers only)
+
 namespace lgd {
 namespace {
 
@@ -114,11 +118,15 @@ __global__ __launch_bounds__(256) void h2_fwd_kernel(const FwdP p) {
     auto dma = [&](int ks, int buf) {
         char* dst = lds + buf * BUF;
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ai + ks * astep, 0x7fffffff);
+#if LGD_H2_ABL != 3 && LGD_H2_ABL != 5
 #pragma unroll
         for (int c = 0; c < ACH; ++c) glds16(ra, lds_addr_of(dst + (w * ACH + c) * 1024), aoff[c]);
+#endif
         const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(Bb + ks * bstep, b_left0 - ks * bstep);
+#if LGD_H2_ABL != 2 && LGD_H2_ABL != 5
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) glds16(rb_, lds_addr_of(dst + A_BYTES + (2 * w + jj) * 1024), boff[jj]);
+#endif
     };
     f32x16 acc[MI][2];
 #pragma unroll
@@ -170,6 +178,12 @@ __global__ __launch_bounds__(256) void h2_fwd_kernel(const FwdP p) {
             dma(nx, (ks + 2) % ST);
         }
         // smallest terms first
+#if LGD_H2_ABL == 4   // (lab: the fragments stay live through one cheap use)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[i][jn][0] += (float)fa[1][i][0] + (float)fb[0][jn][0] + (float)fa[0][i][1] + (float)fb[1][jn][1];
+#else
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -182,6 +196,7 @@ __global__ __launch_bounds__(256) void h2_fwd_kernel(const FwdP p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][jn], acc[i][jn], 0, 0, 0);
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
         __syncthreads();
     }
@@ -211,7 +226,11 @@ __global__ __launch_bounds__(256) void h2_fwd_kernel(const FwdP p) {
                 for (int e = 0; e < 16; ++e) {
                     const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
                     const float v = acc[i][jn][e] * inv;
+#if LGD_H2_ABL == 1 || LGD_H2_ABL == 5   // lab: no C stores (a never-true condition keeps the accumulators alive)
+                    const bool ok = v == 123456.789f;
+#else
                     const bool ok = hf || (dm < mrem && colok[jn]);
+#endif
                     if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
                     if constexpr (AMAX) { const uint32_t ab = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu; bm = max(bm, ok ? ab : 0u); }
                     co += (e & 3) == 3 ? c5 : c1;
