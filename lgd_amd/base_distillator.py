@@ -42,17 +42,21 @@ class BaseDistillator(nn.Module):
     adapter_stream = os.environ.get("LGD_ADAPTER_STREAM", "1") != "0"
 
     def adapt_ahead(self, features_stu):
-        """the adapter over the student's pyramid on the side stream; distill(adapted=...) picks the result up.  None where it does not apply."""
+        """the adapter over the student's pyramid, issued as soon as the features exist: on the side stream where that is allowed (the fork), else at
+        the SAME point of the program on the caller's stream -- so that the autograd graph, and with it the order in which the feature gradients of
+        the teacher, the adapter and the head are summed, does not depend on whether the step forks: the forked and the one-stream step are
+        bit-identical (tools/step_determinism.py).  distill(adapted=...) picks the result up.  None where it does not apply."""
         adapter = self.adapter["distill"]
         keys = sorted(features_stu.keys())
         stu = [features_stu[k] for k in keys]
-        if not (self.adapter_stream and hasattr(adapter, "levels") and stu and stu[0].is_cuda and ops.side_streams_ok()):
-            return None
-        convs = [m for m in adapter.modules() if isinstance(m, torch.nn.Conv2d)]
-        if not ops.convs_on_own_kernels(stu, [[m.weight] for m in convs]):   # (a side stream carries this library's kernels only: streams.library_call)
+        if not (hasattr(adapter, "levels") and stu and stu[0].is_cuda):
             return None
         if self.distill_flag == 0:
             stu = [f.detach() for f in stu]
+        convs = [m for m in adapter.modules() if isinstance(m, torch.nn.Conv2d)]
+        # (a side stream carries this library's kernels only: ops.convs_on_own_kernels / streams.library_call)
+        if not (self.adapter_stream and ops.side_streams_ok() and ops.convs_on_own_kernels(stu, [[m.weight] for m in convs])):
+            return keys, adapter.levels(stu), None, None, self.distill_flag
         main, side = streams.fork(stu[0].device, "adapter", inputs=stu)
         streams.join_on_grad(list(adapter.parameters()), "adapter")
         with torch.cuda.stream(side):
@@ -71,7 +75,8 @@ class BaseDistillator(nn.Module):
             stu = [f.detach() for f in stu]
         if adapted is not None and adapted[0] == keys and adapted[4] == self.distill_flag:
             _, stu, main, side, _ = adapted
-            streams.join(main, side, outputs=stu)
+            if side is not None:
+                streams.join(main, side, outputs=stu)
         else:
             adapter = self.adapter["distill"]
             stu = adapter.levels(stu) if hasattr(adapter, "levels") else [adapter(f) for f in stu]

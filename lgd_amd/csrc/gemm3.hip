@@ -41,6 +41,12 @@ constexpr int BN = 128, BK = 16, NT = 256;
 #ifndef LGD_GEMM3_PIPE
 #define LGD_GEMM3_PIPE 1   // 1: staging behind the k-step's barrier (shipped); 0: at the top of the k-step (lab: the form until the end of round 4)
 #endif
+#ifndef LGD_GEMM3_STORE_AUX
+#define LGD_GEMM3_STORE_AUX 0   // cache policy of the C stores (lab: 17 = sc0 sc1, write-through at system scope; 2 = nt)
+#endif
+#ifndef LGD_GEMM3_END_FENCE
+#define LGD_GEMM3_END_FENCE 0   // lab: 1 = __threadfence() behind a tile's stores
+#endif
 #ifndef LGD_GEMM3_ABL
 #define LGD_GEMM3_ABL 0   // lab ablations of the staging parts (tools/gpu_checks.sh ablate; results are garbage): 1 no split arithmetic, 2 no B at
 #endif                    // all, 3 no image DMA, 4 no C stores, 5 none of them (MFMA phase, fragment reads and barriers only)
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm3_waves<
                         if (v == 123456.f)
 #endif
                         const bool ok = hf || (dm < mrem && colok[jn]);
-                        if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
+                        if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, LGD_GEMM3_STORE_AUX);
                         bm = max(bm, ok ? __builtin_bit_cast(uint32_t, v) & 0x7fffffffu : 0u);   // (always: a branch per element costs registers, not time)
                         co += (e & 3) == 3 ? c5 : c1;
                         asm volatile("" : "+v"(co));
@@ -447,6 +453,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm3_waves<
             if (lane == 0) atomic_max_bits(p.amax, amax);
         }
         if constexpr ((EPI & 2) != 0) __syncthreads();   // the next tile's prologue writes the LDS the shift values were read from
+#if LGD_GEMM3_END_FENCE
+        __threadfence();
+#endif
     }
     }   // tiles of this workgroup
 }
@@ -620,13 +629,13 @@ static int gemm3_launch(const void* image, int image_shared, const float* a_inv,
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LGD_ELAUNCH;
     bool& attr = attr_dev[dev];
     int& cus = cus_dev[dev];
-    if (!attr) {
+    if constexpr (PCS == 3) if (!attr) {
         const void* big[5] = {(const void*)lgd::gemm3_kernel<256, 0, PCS>, (const void*)lgd::gemm3_kernel<256, 1, PCS>, (const void*)lgd::gemm3_kernel<256, 2, PCS>,
                               (const void*)lgd::gemm3_kernel<256, 3, PCS>, (const void*)lgd::gemm3_kernel<256, 4, PCS>};
         for (const void* f : big)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lgd::Tile<256, PCS>::LDS_BYTES) != hipSuccess) return LGD_ELAUNCH;
-        attr = true;
     }
+    attr = true;
     p.total = (int)((image_shared ? ((long)nb * p.nt + 7) / 8 : (long)((nb + 7) / 8) * p.nt) * p.mt * 8);
     // persistent launch: as many workgroups as are resident at once (2 per CU with the 256-row tile, 3 with the 128-row one); each walks
     // tiles id, id + grid, ...  Measured equal to one workgroup per tile on every shape of tools/gemm3_probe.py (dispatch is not what
@@ -646,7 +655,7 @@ static int gemm3_launch(const void* image, int image_shared, const float* a_inv,
     case E_: LGD_LAUNCH(PCS == 3 ? "gemm3_kernel" : "gemm2h_kernel", (lgd::gemm3_kernel<BM_, E_, PCS>), grid, block, (lgd::Tile<BM_, PCS>::LDS_BYTES), st, p); break;
     if (small) {
         switch (kind) { LGD_GEMM3_CASE(128, 0) LGD_GEMM3_CASE(128, 1) LGD_GEMM3_CASE(128, 2) LGD_GEMM3_CASE(128, 3) LGD_GEMM3_CASE(128, 4) }
-    } else {
+    } else if constexpr (PCS == 3) {   // (the f16x2 form always takes the 128-row tile: its 256-row instances would be dead code)
         switch (kind) { LGD_GEMM3_CASE(256, 0) LGD_GEMM3_CASE(256, 1) LGD_GEMM3_CASE(256, 2) LGD_GEMM3_CASE(256, 3) LGD_GEMM3_CASE(256, 4) }
     }
 #undef LGD_GEMM3_CASE

@@ -69,6 +69,21 @@ def test_product_path_fails_loudly_without_gpu(lib):
         ops.distill_in_mse([torch.zeros(1, 4, 8, 8)], [torch.zeros(1, 4, 8, 8)], 1.0)
 
 
+def test_no_packed_fp32_in_the_library(lib):
+    """Round 6: a wave's packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) return wrong low bits while a wave of ANOTHER kernel
+    on the same CU issues f16 MFMAs -- found as wino6_out changing a few hundred elements per step beside h2_fwd on a side stream
+    (profiles/r06_packed_fp32_beside_mfma.txt; tools/conv_stage_probe.py: 59 of 60 runs differ from the quiet run with the packed forms, 0 of 100
+    without).  The library is built with `-target-feature -packed-fp32-ops` (__graft_entry__.FLAGS): the gfx950 code of the BUILT .so must not
+    hold a single one of them, whatever a later edit or compiler picks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scan_packed_fp32", os.path.join(ROOT, "tools", "scan_packed_fp32.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    found, n = mod.scan(os.path.join(ROOT, "lgd_amd", "_lib", "liblgd_hip.so"))
+    assert n > 100000, n          # (every translation unit's code object was scanned)
+    assert not found, sorted(found.items(), key=lambda kv: -kv[1])[:5]
+
+
 # ---- the counted waits of the LDS-DMA pipelines (ADVICE r4: "nothing enforces this at build time")
 def _asm_of(src):
     """hipcc -S of one csrc file with the library's flags (cached under build/asm while the source is older)"""
@@ -77,7 +92,8 @@ def _asm_of(src):
     out_dir = os.path.join(ROOT, "build", "asm")
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(ROOT, "lgd_amd", "csrc", src)
-    out = os.path.join(out_dir, src.replace(".hip", ".s"))
+    import hashlib
+    out = os.path.join(out_dir, src.replace(".hip", "") + "." + hashlib.sha1(" ".join(g.FLAGS).encode()).hexdigest()[:8] + ".s")   # (the flags are part of the cache key)
     deps = [path, os.path.join(ROOT, "lgd_amd", "csrc", "common.h"), os.path.join(ROOT, "lgd_amd", "csrc", "winograd.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         flags = [f for f in g.FLAGS if f not in ("-shared", "-fPIC")]
@@ -170,15 +186,14 @@ def test_h2_dma_statements_own_m0():
 
 def test_gemm3_kernels_keep_their_counted_waits_and_no_scratch():
     """csrc/gemm3.hip: the k-loop waits `vmcnt(8)` for the image DMA of the next k-step, relying on exactly 8 B loads having been issued behind
-    it.  Build-time guard on every instance: no scratch (a spill would put extra loads into the counted window), the counted
+    it.  Build-time guard on every instance: no scratch traffic inside the counted window (a spill reloaded there would be an extra load), the counted
     wait still stands directly in front of the k-loop's barriers, the LDS-DMA and the 8-load groups are there in the expected numbers.  (The
     run-time side -- products under memory pressure from a second stream, bit-equal to the quiet run -- is tests/test_kernels_gpu.py::
     test_gemm3_and_h2_products_under_load.)"""
     asm = _asm_of("gemm3.hip")
     ks = _kernels(asm, r"gemm3_kernel")
-    assert len(ks) == 20, sorted(ks)   # {256, 128 rows} x 5 epilogues x {bf16x3, f16x2}
+    assert len(ks) == 15, sorted(ks)   # bf16x3: {256, 128 rows} x 5 epilogues; f16x2: 128 rows x 5 epilogues (it never takes the 256-row tile)
     for name, (lines, scratch) in ks.items():
-        assert scratch == 0, (name, scratch)
         pcs = 2 if name.endswith("ELi2EEEvNS0_6ParamsE") else 3
         ch = pcs * (8 if "ILi256E" in name else 4) // 4   # LDS-DMA instructions per wave and k-step (pieces x BM / 32 row blocks / 4 waves)
         dma = [i for i, l in enumerate(lines) if re.match(r"buffer_load_dwordx4 .* lds$", l)]
@@ -192,6 +207,12 @@ def test_gemm3_kernels_keep_their_counted_waits_and_no_scratch():
             return False
         counted = [i for i, l in enumerate(lines) if l.startswith("s_waitcnt vmcnt(8)") and to_barrier(i)]
         assert len(counted) >= 2, (name, len(counted))   # prologue + k-loop
+        # no scratch traffic inside the counted window (first LDS-DMA .. the k-loop's last counted wait): a spill reloaded there would be one more load
+        # in the memory pipe than the waits count.  (Round 6: without packed fp32 instructions one epilogue instance -- <128, residual, f16x2>, held to
+        # 168 registers -- spills 28 bytes in its residual prologue and its epilogue; that is outside the window and stays allowed, but small.)
+        spills = [i for i, l in enumerate(lines) if l.startswith("scratch_")]
+        assert all(i < dma[0] or i > counted[-1] for i in spills), (name, [i for i in spills if dma[0] <= i <= counted[-1]][:4], dma[0], counted[-1])
+        assert scratch <= 64, (name, scratch)
         # every DMA group is followed by exactly 8 dword loads of B before anything else enters the memory pipe or a wait is taken
         groups = [dma[j] for j in range(ch - 1, len(dma), ch)]
         ok = 0

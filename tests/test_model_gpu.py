@@ -995,10 +995,11 @@ def test_step_forks_under_a_competing_stream():
     """VERDICT r5 item 2c / ADVICE r5: 300 optimizer steps of the shipped path at BASELINE config 2 (RetinaNet R-50 + LGD, 8 images of 800 x 1333)
     with ALL forks of the step on, while a further stream saturates HBM with 256 MB copies -- the place RCCL's kernels take in a data-parallel job
     -- against the same steps on ONE stream with nothing beside them (tools/stream_stress.py, run as a subprocess with a deadline: a stall fails the
-    test instead of hanging the suite).  Progress: every step returns its losses.  Results: the first 20 steps equal to 1e-5 (measured: 0 to 2e-6,
-    the last bits of fp32 sums); from there on two IDENTICAL one-stream runs drift apart themselves (the vendor library's small-level kernels
-    are not bit-reproducible run to run and 300 SGD steps amplify the last bit: 5e-4 after 50 steps, tens of per cent after 150), so the forked run
-    is held to 10x the drift the tool measures between two one-stream runs up to the same step.  [ref: the step is train.py:182-215]"""
+    test instead of hanging the suite).  Progress: every step returns its losses.  Results: the forked run is held to the drift the tool measures
+    between two IDENTICAL one-stream runs up to the same step (x10) -- at this size the one-stream step is bit-reproducible, so that means
+    BIT-EQUAL losses over all 300 steps, which is what round 6 measures since the library holds no packed-fp32 instruction any more (they return
+    wrong low bits beside another kernel's f16 MFMAs: test_abi.py::test_no_packed_fp32_in_the_library) and the adapter is issued at the same point
+    of the program whether it forks or not (same gradient summation order).  [ref: the step is train.py:182-215]"""
     import json
     import subprocess
     import sys
@@ -1018,8 +1019,8 @@ def test_step_forks_under_a_competing_stream():
     dab, dbc = dev(fa, fb), dev(fb, fc)
     table = r.stderr[r.stderr.find("step:"):][:700]
     assert max(dab[:20]) <= 1e-5, (max(dab[:20]), table)   # (measured 0 .. 2e-6: equal to the last bits of fp32 sums; the forks change no arithmetic)
-    for i in range(20, 300):
-        assert max(dab[:i + 1]) <= 10.0 * max(max(dbc[:i + 1]), 1e-6), (i, max(dab[:i + 1]), max(dbc[:i + 1]), table)
+    for i in range(300):   # (where the one-stream step is bit-reproducible -- measured at this size: all 300 steps -- this demands BIT-equal losses of the forked run)
+        assert max(dab[:i + 1]) <= 10.0 * max(dbc[:i + 1]), (i, max(dab[:i + 1]), max(dbc[:i + 1]), table)
     print("300 steps at config 2: forks on + competing stream %.1f ms/step, one stream %.1f ms/step; worst loss deviation over the first 20 steps %.1e "
           "(two one-stream runs: %.1e), over the first 50 %.1e (%.1e)" % (rec["ms_per_step_forked_under_load"], rec["ms_per_step_one_stream"], max(dab[:20]),
                                                                           max(dbc[:20]), max(dab[:50]), max(dbc[:50])))
