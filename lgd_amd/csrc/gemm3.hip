@@ -41,12 +41,6 @@ constexpr int BN = 128, BK = 16, NT = 256;
 #ifndef LGD_GEMM3_PIPE
 #define LGD_GEMM3_PIPE 1   // 1: staging behind the k-step's barrier (shipped); 0: at the top of the k-step (lab: the form until the end of round 4)
 #endif
-#ifndef LGD_GEMM3_STORE_AUX
-#define LGD_GEMM3_STORE_AUX 0   // cache policy of the C stores (lab: 17 = sc0 sc1, write-through at system scope; 2 = nt)
-#endif
-#ifndef LGD_GEMM3_END_FENCE
-#define LGD_GEMM3_END_FENCE 0   // lab: 1 = __threadfence() behind a tile's stores
-#endif
 #ifndef LGD_GEMM3_ABL
 #define LGD_GEMM3_ABL 0   // lab ablations of the staging parts (tools/gpu_checks.sh ablate; results are garbage): 1 no split arithmetic, 2 no B at
 #endif                    // all, 3 no image DMA, 4 no C stores, 5 none of them (MFMA phase, fragment reads and barriers only)
@@ -425,7 +419,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm3_waves<
                         if (v == 123456.f)
 #endif
                         const bool ok = hf || (dm < mrem && colok[jn]);
-                        if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, LGD_GEMM3_STORE_AUX);
+                        if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
                         bm = max(bm, ok ? __builtin_bit_cast(uint32_t, v) & 0x7fffffffu : 0u);   // (always: a branch per element costs registers, not time)
                         co += (e & 3) == 3 ? c5 : c1;
                         asm volatile("" : "+v"(co));
@@ -453,9 +447,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm3_waves<
             if (lane == 0) atomic_max_bits(p.amax, amax);
         }
         if constexpr ((EPI & 2) != 0) __syncthreads();   // the next tile's prologue writes the LDS the shift values were read from
-#if LGD_GEMM3_END_FENCE
-        __threadfence();
-#endif
     }
     }   // tiles of this workgroup
 }

@@ -39,9 +39,6 @@
 
 #include "winograd.h"
 
-#ifndef LGD_H2_STORE_AUX
-#define LGD_H2_STORE_AUX 0   // cache policy of the forward product's C stores (lab: 17 = sc0 sc1, write-through at system scope)
-#endif
 #ifndef LGD_H2_ABL
 #define LGD_H2_ABL 0   // lab ablations of h2_fwd_kernel (tools/h2_ablate.sh; results are garbage): 1 no C stores, 2 no DMA of B, 3 no DMA of the image,
 #endif                 // 4 no MFMAs, 5 no DMA at all and no stores (fragment reads, MFMAs and barriers only)
@@ -78,7 +75,6 @@ struct FwdP {
     const float* a_inv; const float* b_inv; int b_inv_stride;   // 2^-e per batch (stride 0: one scale for all batches)
     unsigned* amax_out;                              // AMAX kernels: per batch max |C| (float bits, atomicMax; pre-zeroed)
     int nb, M, N, K, mt, nt;
-    int skew, first;                                 // lab (LGD_H2_SKEW): workgroups first .. 2 first - 1 (the second residents of the first round) start `skew` x ~3.5 us late
 };
 
 template <int BM, bool AMAX>
@@ -96,8 +92,6 @@ __global__ __launch_bounds__(256) void h2_fwd_kernel(const FwdP p) {
     const int b = (j / per_b) * 8 + xcd;
     const int r = j % per_b;
     if (b >= p.nb) return;
-    if (p.skew > 0 && id >= p.first && id < 2 * p.first)   // (lab: de-phase the two workgroups of a CU -- one in its k-loop while the other stores)
-        for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
     const int tn = r / p.mt, sub = r % p.mt;
     const int m0 = sub * BM, n0 = tn * BN, rb0 = sub * RB;
     const int ksteps = p.K / 16;
@@ -245,7 +239,7 @@ __global__ __launch_bounds__(256) void h2_fwd_kernel(const FwdP p) {
 #else
                     const bool ok = hf || (dm < mrem && colok[jn]);
 #endif
-                    if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, LGD_H2_STORE_AUX);
+                    if (ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), cs, co + jn * 128, 0, 0);
                     if constexpr (AMAX) { const uint32_t ab = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu; bm = max(bm, ok ? ab : 0u); }
                     co += (e & 3) == 3 ? c5 : c1;
                     asm volatile("" : "+v"(co));
@@ -660,12 +654,6 @@ __global__ __launch_bounds__(64) void h2_words_max_kernel(WordsArgs a) {
 
 constexpr int kFwdLds256 = 3 * (2 * 8 * 1024 + 8192), kFwdLds128 = 3 * (2 * 4 * 1024 + 8192), kDwLds = 4 * 2 * 256 * 64, kPwDwLds = 2 * 2 * 256 * 128;
 
-// lab (LGD_H2_LDS_PAD=bytes): the 256-row forward product asks for more LDS than it uses, so that fewer workgroups -- of any kernel -- share its CU
-int lds_pad() {
-    static const int pad = getenv("LGD_H2_LDS_PAD") ? atoi(getenv("LGD_H2_LDS_PAD")) : 0;
-    return pad;
-}
-
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, device)
 int ensure_attrs() {
     static bool done[64] = {};
@@ -675,7 +663,7 @@ int ensure_attrs() {
     const void* f256[2] = {(const void*)h2_fwd_kernel<256, false>, (const void*)h2_fwd_kernel<256, true>};
     const void* f128[2] = {(const void*)h2_fwd_kernel<128, false>, (const void*)h2_fwd_kernel<128, true>};
     for (const void* f : f256)
-        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds256 + lds_pad()) != hipSuccess) return LGD_ELAUNCH;
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds256) != hipSuccess) return LGD_ELAUNCH;
     for (const void* f : f128)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds128) != hipSuccess) return LGD_ELAUNCH;
     if (hipFuncSetAttribute((const void*)h2_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLds) != hipSuccess) return LGD_ELAUNCH;
@@ -723,8 +711,6 @@ int lgd_h2_fwd(const void* image, const void* B, long long b_sb, long long b_sk,
     const bool small = ((M + 255) / 256 * 256 - M >= 64 && (M + 127) / 128 * 128 - M < 64);
     const int bm = small ? 128 : 256;
     p.nb = nb; p.M = M; p.N = N; p.K = K; p.mt = (M + bm - 1) / bm; p.nt = (N + 127) / 128;
-    static const int skew_env = getenv("LGD_H2_SKEW") ? atoi(getenv("LGD_H2_SKEW")) : 0;
-    p.skew = skew_env; p.first = lgd::cu_count();
     const unsigned total = (unsigned)(((nb + 7) / 8) * p.nt * p.mt * 8);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(total), block(256);
@@ -732,8 +718,8 @@ int lgd_h2_fwd(const void* image, const void* B, long long b_sb, long long b_sk,
         if (amax_out) { LGD_LAUNCH("h2_fwd_kernel", (lgd::h2_fwd_kernel<128, true>), grid, block, lgd::kFwdLds128, st, p); }
         else { LGD_LAUNCH("h2_fwd_kernel", (lgd::h2_fwd_kernel<128, false>), grid, block, lgd::kFwdLds128, st, p); }
     } else {
-        if (amax_out) { LGD_LAUNCH("h2_fwd_kernel", (lgd::h2_fwd_kernel<256, true>), grid, block, lgd::kFwdLds256 + lgd::lds_pad(), st, p); }
-        else { LGD_LAUNCH("h2_fwd_kernel", (lgd::h2_fwd_kernel<256, false>), grid, block, lgd::kFwdLds256 + lgd::lds_pad(), st, p); }
+        if (amax_out) { LGD_LAUNCH("h2_fwd_kernel", (lgd::h2_fwd_kernel<256, true>), grid, block, lgd::kFwdLds256, st, p); }
+        else { LGD_LAUNCH("h2_fwd_kernel", (lgd::h2_fwd_kernel<256, false>), grid, block, lgd::kFwdLds256, st, p); }
     }
     return lgd::check_launch();
 }

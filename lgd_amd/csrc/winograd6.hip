@@ -317,16 +317,7 @@ __device__ __forceinline__ Slab16 slab_issue(const float* m, size_t plane, int p
     for (int k = 0; k < 4; ++k) {
         const int idx = k * 256 + threadIdx.x, f = idx >> 6, q4 = idx & 63;
         s.q[k].x = s.q[k].y = s.q[k].z = s.q[k].w = 0.f;
-#if defined(LGD_W6_SLAB_PLAIN_LOADS)   // lab
-        if (q4 * 4 < valid) s.q[k] = *reinterpret_cast<const wino_vf4*>(m + (size_t)(16 * ph + f) * plane + q4 * 4);
-#elif defined(LGD_W6_SLAB_SYS_LOADS)   // lab: system-scope loads (sc0 sc1: past the XCD's L2)
-        if (q4 * 4 < valid) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m + (size_t)(16 * ph + f) * plane), 0, 0xffffffffu, 0x00020000);
-            s.q[k] = __builtin_bit_cast(wino_vf4, __builtin_amdgcn_raw_buffer_load_b128(rs, q4 * 16, 0, 17));
-        }
-#else
         if (q4 * 4 < valid) s.q[k] = __builtin_nontemporal_load(reinterpret_cast<const wino_vf4*>(m + (size_t)(16 * ph + f) * plane + q4 * 4));
-#endif
     }
     return s;
 }
@@ -334,15 +325,7 @@ __device__ __forceinline__ void slab_park(const Slab16& s, float* lds) {
     #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = k * 256 + threadIdx.x, f = idx >> 6, q4 = idx & 63;
-#if defined(LGD_W6_PARK_B32)   // lab: four 4-byte LDS writes instead of one 16-byte write
-        volatile float* d = &lds[f * 256 + q4 * 4];
-        d[0] = s.q[k].x; d[1] = s.q[k].y; d[2] = s.q[k].z; d[3] = s.q[k].w;
-#elif defined(LGD_W6_PARK_B64)   // lab: two 8-byte writes
-        *reinterpret_cast<volatile float2*>(&lds[f * 256 + q4 * 4]) = make_float2(s.q[k].x, s.q[k].y);
-        *reinterpret_cast<volatile float2*>(&lds[f * 256 + q4 * 4 + 2]) = make_float2(s.q[k].z, s.q[k].w);
-#else
         *reinterpret_cast<float4*>(&lds[f * 256 + q4 * 4]) = make_float4(s.q[k].x, s.q[k].y, s.q[k].z, s.q[k].w);
-#endif
     }
 }
 
@@ -438,13 +421,7 @@ __device__ __forceinline__ void wino6_out_body(const WinoArgs& a, int l, float* 
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LGD_W6_OUT_WAVES, 8))) void wino6_out_kernel(WinoArgs a) {
-#ifdef LGD_W6_OUT_LDS_SKIP   // lab: the slab starts LGD_W6_OUT_LDS_SKIP floats into the workgroup's LDS (is it the allocation's first KB that goes wrong?)
-    __shared__ __attribute__((aligned(16))) float lds_[16 * 256 + LGD_W6_OUT_LDS_SKIP];
-    float* lds = lds_ + LGD_W6_OUT_LDS_SKIP;
-    if (threadIdx.x == 9999) lds_[0] = 1.f;
-#else
     __shared__ __attribute__((aligned(16))) float lds[16 * 256];
-#endif
     const int l = wino_level(a);
     if (a.pair[l]) wino6_out_body<true>(a, l, lds);
     else wino6_out_body<false>(a, l, lds);
