@@ -414,7 +414,7 @@ def main():
         hbm_bound = [k for k in kernels if k in alg and not k.startswith("focal") and k != "gemm3_kernel" and "amax" not in k]  # focal is exp/log bound, gemm3 MFMA bound
         dom = max(hbm_bound, key=lambda k: kernels[k]["total_ms"], default=None)
         roofline = roofline_mfma = None
-        PMC = "r05_pmc_traffic.json"
+        PMC = "r06_pmc_traffic.json"
 
         def pmc_traffic(name):
             """HBM bytes per launch of `name` from the tracked counter summary (tools/pmc_bench.sh collects the CSV and this JSON in ONE command)

@@ -13,5 +13,5 @@ done
 F=$(ls /tmp/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1)
 W=$(ls /tmp/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
 mkdir -p $R/gpurun_out
-STEPS_PROFILED=4 python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r05_bench_pmc_fetch_write.csv $R/gpurun_out/r05_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing --no-host-pass (BASELINE configs[1], B=8 800x1333; round 5 launch mix: F(6x6,3x3), 3x3 channel products on h2.hip, 1x1 on gemm3.hip)"
-cat $R/gpurun_out/r05_bench_pmc_fetch_write.csv
+STEPS_PROFILED=4 python $R/tools/pmc_summary.py $F $W $R/gpurun_out/r06_bench_pmc_fetch_write.csv $R/gpurun_out/r06_pmc_traffic.json "python bench.py --steps 2 --warmup 2 --no-kernel-timing --no-host-pass (BASELINE configs[1], B=8 800x1333; round 6 launch mix: F(6x6,3x3), 3x3 channel products on h2.hip, 1x1 on gemm2h, no packed fp32)"
+cat $R/gpurun_out/r06_bench_pmc_fetch_write.csv

@@ -2,7 +2,7 @@
 # same seed / synthetic batch, 42 optimizer steps from the same initial weights: mean losses of the last 40 for the shipped path,
 # the two-pass head, the library convolutions (round 1's file: profiles/r01_training_trajectory_check.txt)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-out=gpurun_out/r05_training_trajectory_check.txt
+out=gpurun_out/r06_training_trajectory_check.txt
 echo "# python bench.py --steps 40 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-host-pass --batches 1 (BASELINE configs[1], same seed / synthetic batch), MI355X" > $out
 echo "# mean losses over the 40 timed optimizer steps (42 steps from the same initial weights)" >> $out
 run() {
