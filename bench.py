@@ -56,6 +56,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0      # what a float4 copy kernel reaches on this part (same guide: "6.29 TB/s measured, 79 %"): reported beside `frac`, never instead of it
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), same guide
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), same guide; the bf16x3 products issue 6 bf16 MFMA flops per fp32 flop
 
@@ -434,7 +435,7 @@ def main():
             traffic, tsrc = pmc_traffic(dom)
             k = kernels[dom]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
+                        "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBPS, "frac_of_measured_copy_rate": k["GBps"] / HBM_COPY_GBPS, "traffic": traffic,
                         "traffic_source": tsrc,
                         "alg_bytes_per_launch": alg[dom], "avg_launch_us": k["avg_us"], "min_launch_us": k["min_us"],
                         "max_launch_us": k["max_us"], "ms_per_step": k["total_ms"] / args.steps,
@@ -574,7 +575,7 @@ def main():
             "gemm_solution_table_loaded": bool(trainer.tuned_gemms), "conv3x3": "winograd F(%dx%d,3x3)" % (ops._WINO_TILE, ops._WINO_TILE) if ops._WINO_ON else "library",
             "hbm_peak_alloc_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "ms_per_step_instrumented": None if dt_instr is None else 1e3 * dt_instr / args.steps,
-            "side_streams": {"teacher_label_encoder": streams_shipped[0] and not args.one_stream, "head_box_tower": streams_shipped[1] and not args.one_stream,
+            "side_streams": {"teacher_label_encoder": streams_shipped[0] and not args.one_stream, "head_class_tower": streams_shipped[1] and not args.one_stream,
                              "adapter": streams_shipped[2] and not args.one_stream, "fpn_small_levels": streams_shipped[3] and not args.one_stream,
                              "note": "`value` / `ms_per_step` are the step as shipped (the forks on); the per-kernel durations behind every roofline object are taken in a pass "
                                      "with the forks OFF (one stream: a kernel's own duration -- launches that share the chip stretch each other); `roofline.as_shipped` "

@@ -56,12 +56,12 @@ class BaseDistillator(nn.Module):
         convs = [m for m in adapter.modules() if isinstance(m, torch.nn.Conv2d)]
         # (a side stream carries this library's kernels only: ops.convs_on_own_kernels / streams.library_call)
         if not (self.adapter_stream and ops.side_streams_ok() and ops.convs_on_own_kernels(stu, [[m.weight] for m in convs])):
-            return keys, adapter.levels(stu), None, None, self.distill_flag
+            return keys, adapter.levels(stu), None, None, self.distill_flag, None
         main, side = streams.fork(stu[0].device, "adapter", inputs=stu)
         streams.join_on_grad(list(adapter.parameters()), "adapter")
         with torch.cuda.stream(side):
             out = adapter.levels(stu)
-        return keys, out, main, side, self.distill_flag
+        return keys, out, main, side, self.distill_flag, streams.done(side)
 
     def distill(self, features, images, batched_inputs, batchified_inside_masks, fg_labels, adapted=None):
         """coef * mse(IN(tea), IN(adapter(stu))) over all shared levels; teacher always detached,
@@ -74,9 +74,9 @@ class BaseDistillator(nn.Module):
         if self.distill_flag == 0:
             stu = [f.detach() for f in stu]
         if adapted is not None and adapted[0] == keys and adapted[4] == self.distill_flag:
-            _, stu, main, side, _ = adapted
+            _, stu, main, side, _, ev = adapted
             if side is not None:
-                streams.join(main, side, outputs=stu)
+                streams.join(main, side, outputs=stu, event=ev)
         else:
             adapter = self.adapter["distill"]
             stu = adapter.levels(stu) if hasattr(adapter, "levels") else [adapter(f) for f in stu]

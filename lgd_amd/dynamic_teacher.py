@@ -242,18 +242,16 @@ class DynamicTeacher(nn.Module):
         rt = self._rt()
         rt["ahead"] = None
         dev = images.tensor.device
-        if not (self.side_stream and dev.type == "cuda"):
+        if not (self.side_stream and dev.type == "cuda" and ops.side_streams_ok()):
             return
         main = rt["main"] = torch.cuda.current_stream(dev)
-        side = rt.get("side")
-        if side is None or side.device != dev:
-            side = rt["side"] = torch.cuda.Stream(dev)
+        side = rt["side"] = streams.side(dev, "teacher")
         self._join_hooks()
         side.wait_stream(main)   # the weights last step's optimizer wrote, the annotations the loader copied
         with torch.cuda.stream(side):
             enc = self.label_encoder_((batched_inputs, images, None, dev))
             canoni = _lin_ln_relu(self.canoni_proj_1D[0][0], enc[0])
-        rt["ahead"] = (id(batched_inputs), enc, canoni, side)
+        rt["ahead"] = (id(batched_inputs), enc, canoni, side, streams.done(side))
 
     def _join_hooks(self):
         """Data-parallel runs: DistributedDataParallel starts a bucket's all-reduce from the gradient hook of the bucket's LAST parameter and orders it
@@ -307,10 +305,9 @@ class DynamicTeacher(nn.Module):
         ahead = rt.pop("ahead", None) if rt else None
         canoni = None
         if ahead is not None and ahead[0] == id(info_list[0]):
-            _, enc, canoni, side = ahead
+            _, enc, canoni, side, ev = ahead
             main = torch.cuda.current_stream(canoni.device)
-            main.wait_stream(side)
-            streams.record_all((canoni, enc), main)   # made on the side stream (uploads and magnitude tags included), read on this one from here on
+            streams.join(main, side, (canoni, enc), event=ev)   # made on the side stream (uploads and magnitude tags included), read on this one from here on
         else:
             enc = self.label_encoder_(info_list)
         x, _, _, boxes, img_size_dict, inst_labels, counts = enc

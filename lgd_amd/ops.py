@@ -1853,9 +1853,23 @@ def conv3x3_folds_pre(N, C, H, W, Cout, device, dtype=torch.float32):
 
 
 def side_streams_ok():
-    """whether the independent chains of the step may fork onto second streams at all (lgd_amd/streams.py); LGD_SIDE_STREAMS=0 switches every fork off
-    (A/B runs).  WHICH chain may go to a side stream is decided per call by convs_on_own_kernels()."""
-    return os.environ.get("LGD_SIDE_STREAMS", "1") != "0"
+    """whether the independent chains of the step may fork onto the side stream at all (lgd_amd/streams.py); LGD_SIDE_STREAMS=0 switches every fork
+    off (A/B runs).  WHICH chain may fork is decided per call by convs_on_own_kernels().
+    With a stream PER fork (LGD_ONE_SIDE_STREAM=0, the round-5 form) the forks are also off when the process asks HIP for more than its default 4
+    hardware queues (GPU_MAX_HW_QUEUES > 4): a fork whose two chains wait for each other then costs 19-22 ms per step (config 2: 71 ms against 52)
+    -- not in the kernels (two streams of lgd_h2_fwd overlap 5 % FASTER than one under any queue count, tools/queue_probe.py) and not under
+    rocprofv3 (every dispatch carries a completion signal there): the cross-queue waits themselves stall (profiles/r06_hw_queues_and_forks.txt).
+    The shipped form -- ONE side stream for all forks, two streams in the process -- measures the same under 4 and 8 queues.
+    LGD_SIDE_STREAMS=force overrides."""
+    v = os.environ.get("LGD_SIDE_STREAMS", "1")
+    if v == "0":
+        return False
+    if v == "force" or streams._ONE_SIDE:
+        return True
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) <= 4
+    except ValueError:
+        return True
 
 
 def convs_on_own_kernels(xs, filter_groups):

@@ -17,9 +17,21 @@ _LIB_LAST = {}  # device index -> {raw handle of a side stream: event behind its
 _LIB_SEEN = {}  # (device index, raw handle of a waiting stream, raw handle of a side stream) -> the event that stream has already waited for
 
 
+# All forks of the step share ONE physical side stream per device (LGD_ONE_SIDE_STREAM=0: one per name, the round-5 form).  The forks are active in
+# different phases of the step (label encoder under the backbone, FPN output convolution inside the FPN, adapter beside the teacher, class tower
+# beside the box tower; the backward visits them in reverse), so one stream loses no overlap -- and the process then holds TWO streams, which HIP
+# maps onto two of its 4 hardware queues whatever else the process created: with a stream per fork the fourth one shared the main stream's queue
+# (its fork serialised: whichever fork came last gained nothing) and more than 4 queues stalled (profiles/r06_hw_queues_and_forks.txt).
+_ONE_SIDE = os.environ.get("LGD_ONE_SIDE_STREAM", "1") != "0"
+
+
+def _key(idx, name):
+    return (idx, "side" if _ONE_SIDE else name)
+
+
 def side(device, name):
-    """the side stream `name` of a device (created on first use)"""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), name)
+    """the side stream a fork called `name` runs on (created on first use)"""
+    key = _key(device.index if device.index is not None else torch.cuda.current_device(), name)
     s = _SIDE.get(key)
     if s is None:
         s = _SIDE[key] = torch.cuda.Stream(device)
@@ -116,10 +128,23 @@ def record_all(obj, stream):
             record_all(o, stream)
 
 
-def join(main, s, outputs=()):
-    """the current stream waits for the side stream; `outputs` (made on the side stream, read on the current one from here on: tensors or nested
-    containers of them) are recorded on it together with their magnitude tags"""
-    main.wait_stream(s)
+def done(s):
+    """an event behind what the side stream has been given so far: recorded where a fork's work ENDS, so that its join waits for that work only
+    (the forks share one side stream: a later fork issued on it before this one is joined -- the adapter between the label encoder's fork and
+    its join -- must not be waited for)"""
+    ev = torch.cuda.Event()
+    ev.record(s)
+    return ev
+
+
+def join(main, s, outputs=(), event=None):
+    """the current stream waits for the side stream -- for `event` (done(s)) if given, else for everything issued on it so far; `outputs` (made on
+    the side stream, read on the current one from here on: tensors or nested containers of them) are recorded on it together with their
+    magnitude tags"""
+    if event is not None:
+        main.wait_event(event)
+    else:
+        main.wait_stream(s)
     record_all(outputs, main)
 
 
@@ -142,7 +167,7 @@ def join_on_grad(params, name):
         return
 
     def hook(p):
-        s, m = _SIDE.get((p.device.index, name)), _MAIN.get(p.device.index)
+        s, m = _SIDE.get(_key(p.device.index, name)), _MAIN.get(p.device.index)
         if s is not None and m is not None:
             s.wait_stream(m)
             m.wait_stream(s)

@@ -11,7 +11,10 @@ import torch.nn.functional as F
 from .. import ops, streams
 
 
-_FPN_STREAM = os.environ.get("LGD_FPN_STREAM", "1") != "0"   # 0: the whole FPN on one stream (A/B runs)
+# p3's output convolution on the side stream beside the small levels: OFF since all forks share one side stream (round 6,
+# profiles/r06_hw_queues_and_forks.txt: alone +0.2 ms at config 2, with the other three forks +0.2 / +0.4 at configs 2 / 3; it was worth
+# -0.2 ms on a stream of its own, which the shared stream's robustness is not traded for).  LGD_FPN_STREAM=1 switches it on; under test.
+_FPN_STREAM = os.environ.get("LGD_FPN_STREAM", "0") == "1"
 
 
 class LastLevelP6P7(nn.Module):
@@ -72,7 +75,7 @@ class FPN(nn.Module):
         # it runs beside the small levels' output convolutions and the extra levels p6 / p7 (lgd_amd/streams.py; round 5, the roles the other way
         # round, same call at config 2: 51.17 / 50.92 -> 50.73 / 50.50 ms).  Round 6 turned the roles round: the small levels and p6 / p7 are problems
         # under the size gates -- calls of the vendor library -- and a side stream carries this library's kernels only (ops.convs_on_own_kernels;
-        # the root cause of round 5's stall: streams.library_call).  LGD_FPN_STREAM=0: everything on one stream.
+        # the root cause of round 5's stall: streams.library_call).  Opt-in since round 6: see _FPN_STREAM.
         big = self.stages[0]
         out_big = getattr(self, "fpn_output%d" % big)
         two = (_FPN_STREAM and ops.side_streams_ok() and len(self.stages) > 1 and lats[big].is_cuda and lats[big].dtype == torch.float32

@@ -23,7 +23,11 @@ def permute_to_N_HWA_K(t, K):
     return t.view(N, -1, K, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, K)
 
 
-_HEAD_STREAMS = os.environ.get("LGD_HEAD_STREAMS", "1") != "0"   # 0: both towers of the head on one stream (A/B runs)
+# The class tower of the head on the step's side stream beside the box tower (LGD_HEAD_STREAMS=0: one stream).  Round 6
+# (profiles/r06_hw_queues_and_forks.txt): with a stream PER fork this one gained nothing under HIP's default 4 hardware queues (its stream shared the
+# main stream's queue) and cost 19-22 ms per step under more (71 ms against 52: cross-queue waits stalling, not the kernels); on the ONE side stream
+# all forks now share (streams._ONE_SIDE) it is worth 0.5-0.6 ms at config 2, 0.8-1.1 at config 3, the same under 4 and 8 queues.
+_HEAD_STREAMS = os.environ.get("LGD_HEAD_STREAMS", "1") != "0"
 
 
 class RetinaNetHead(nn.Module):
@@ -55,7 +59,7 @@ class RetinaNetHead(nn.Module):
         relus = [True] * (len(cl) - 1) + [False]
         if _HEAD_STREAMS and c[0].is_cuda and ops.side_streams_ok() and ops.convs_on_own_kernels(c, [[m.weight] for m in cl]):
             # the two chains do not depend on each other: the CLASS tower runs on a second stream beside the box tower (tails and small launches of
-            # one under the other's kernels; config 2, same call: 52.32 / 52.11 -> 51.60 / 51.53 ms, losses identical; LGD_HEAD_STREAMS=0: one stream).
+            # one under the other's kernels; round 5, same call: 52.32 / 52.11 -> 51.60 / 51.53 ms, losses identical; round 6: see _HEAD_STREAMS above).
             # Which one goes aside is not a matter of taste: a side stream carries this library's kernels only (ops.convs_on_own_kernels) -- bbox_pred's
             # C' = 36 products are calls of the vendor library and stay on the main stream (round 6: the root cause of round 5's stall, streams.py)
             main, side = streams.fork(c[0].device, "head", inputs=c)

@@ -43,7 +43,8 @@ def main():
     data = [synthetic_batch(a.batch, 800, 1333, 10, seed=3 + j, device=dev) for j in range(2)]
     d = cfg.MODEL.DISTILLATOR
     it0 = max(d.PRE_NONDISTILL_ITERS, d.PRE_FREEZE_STUDENT_BACKBONE_ITERS)
-    assert ops.side_streams_ok() and base.teacher.side_stream and _rn._HEAD_STREAMS and base.adapter_stream and _fpn._FPN_STREAM
+    _rn._HEAD_STREAMS = _fpn._FPN_STREAM = True   # (the FPN fork ships off since round 6 -- student/fpn.py -- the stress run keeps it on: every fork the code has)
+    assert ops.side_streams_ok() and base.teacher.side_stream and base.adapter_stream
     forks = []
     real_fork = streams.fork
     streams.fork = lambda dv, name, inputs=(): (forks.append(name), real_fork(dv, name, inputs))[1]
