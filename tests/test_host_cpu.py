@@ -614,3 +614,27 @@ def test_bench_and_train_self_launch_command(monkeypatch):
         spec.loader.exec_module(mod)     # not __main__: importing must not launch anything
         f = getattr(mod, fn)
         assert f([flag, "8", "--x"]) == 8 and f([flag + "=2"]) == 2 and f(["--steps", "3"]) == 1
+
+
+def test_side_streams_switches(monkeypatch):
+    """ops.side_streams_ok(): LGD_SIDE_STREAMS=0 switches every fork off; with a stream PER fork (LGD_ONE_SIDE_STREAM=0) the forks are also off above HIP's
+    default 4 hardware queues (round 6: cross-queue waits stall there, profiles/r06_hw_queues_and_forks.txt), LGD_SIDE_STREAMS=force overrides; the shipped form
+    -- one shared side stream -- does not depend on the queue count."""
+    from lgd_amd import ops, streams
+    for k in ("LGD_SIDE_STREAMS", "GPU_MAX_HW_QUEUES"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(streams, "_ONE_SIDE", True)
+    assert ops.side_streams_ok()
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert ops.side_streams_ok()
+    monkeypatch.setattr(streams, "_ONE_SIDE", False)
+    assert not ops.side_streams_ok()
+    monkeypatch.setenv("LGD_SIDE_STREAMS", "force")
+    assert ops.side_streams_ok()
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    monkeypatch.setenv("LGD_SIDE_STREAMS", "1")
+    assert ops.side_streams_ok()
+    monkeypatch.setenv("LGD_SIDE_STREAMS", "0")
+    assert not ops.side_streams_ok()
+    monkeypatch.setattr(streams, "_ONE_SIDE", True)
+    assert not ops.side_streams_ok()

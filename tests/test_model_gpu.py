@@ -1,6 +1,7 @@
 """GPU parity of the PRODUCT modules (lgd_amd.DynamicTeacher / BaseDistillator.distill / meta-archs) against
 the reference golden vectors and the CPU oracle.  Bar: 1e-4 relative (BASELINE.json north_star)."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -766,6 +767,35 @@ def test_small_uploads_through_the_pinned_ring():
     big = list(range(1000))   # larger than a slot: plain copy
     assert hip.to_device(big, torch.int64, DEV).tolist() == big
     assert hip.to_device([[1, 2], [3, 4]], torch.int32, DEV).tolist() == [[1, 2], [3, 4]]
+
+
+def test_forks_share_one_side_stream():
+    """round 6 (profiles/r06_hw_queues_and_forks.txt): every fork of the step runs on ONE physical side stream per device -- two compute streams in the
+    process, two hardware queues whatever else it created -- and a fork's join waits for the event recorded where ITS work ends, not for whatever a later
+    fork put on the shared stream (the adapter is issued between the label encoder's fork and its join)."""
+    from lgd_amd import streams
+    dev = torch.device(DEV)
+    assert streams._ONE_SIDE
+    names = ("teacher", "head", "adapter", "fpn")
+    assert len({id(streams.side(dev, n)) for n in names}) == 1
+    prev, streams._ONE_SIDE = streams._ONE_SIDE, False
+    try:
+        assert len({id(streams.side(dev, n)) for n in names}) == 4      # (the round-5 form, behind LGD_ONE_SIDE_STREAM=0)
+    finally:
+        streams._ONE_SIDE = prev
+    main, s = streams.fork(dev, "teacher")
+    with torch.cuda.stream(s):
+        a = torch.full((1 << 20,), 3.0, device=dev)
+        ev = streams.done(s)
+        torch.cuda._sleep(200_000_000)                                  # "a later fork": ~0.1 s of work behind the event on the same stream
+        late = torch.full((4,), 1.0, device=dev)
+    streams.join(main, s, [a], event=ev)
+    t0 = time.time()
+    assert float(a.sum()) == 3.0 * (1 << 20)                            # the first fork's result is there ...
+    assert not s.query()                                                # ... while the shared stream is still busy with the later one
+    assert time.time() - t0 < 0.05
+    streams.join(main, s, [late])
+    assert float(late.sum()) == 4.0
 
 
 def test_pinned_ring_records_every_stream_of_a_segment():
