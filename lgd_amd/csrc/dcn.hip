@@ -105,6 +105,7 @@ __device__ __forceinline__ void dcn_append(const DcnArgs& a, int n, int k, int p
             if (y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
             const int cell = y * a.W + x;
             const float w = m * wy[dy] * wx[dx];
+            if (w == 0.f) continue;   // (a corner without weight -- three of four on the regular grid of zero offsets -- contributes nothing: no list entry, no atomic)
             const int slot = atomicAdd(cnt + cell, 1);
             if (slot < kDcnSlots) ent[(size_t)slot * HW + cell] = make_int2(pix, __float_as_int(w));
             else {   // list full: this contribution goes the atomic way, channel by channel

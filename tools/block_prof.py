@@ -9,6 +9,10 @@ C, mid, H, W, N = (int(v) for v in (sys.argv[2:7] if len(sys.argv) > 6 else (102
 ops.enable_tuned_gemms()
 torch.manual_seed(0)
 blk = (DeformBottleneck if kind == "dcn" else Bottleneck)(C, C, mid, 1).cuda()
+import os
+sigma = float(os.environ.get("LGD_DCN_OFFSET_SIGMA", "0"))   # > 0: LEARNED offsets -- the zero-initialised offset convolution's weights drawn from N(0, sigma^2): fractional sampling positions
+if kind == "dcn" and sigma > 0:
+    torch.nn.init.normal_(blk.conv2_offset.weight, std=sigma)
 for p in blk.parameters():
     p.requires_grad_(True)
 x = torch.randn(N, C, H, W, device='cuda', requires_grad=True)
@@ -27,6 +31,6 @@ for e in prof.events():
         a[0] += 1
         a[1] += e.device_time
 tot = sum(t for _, t in agg.values()) / 5
-print("%s block C=%d mid=%d %dx%d N=%d: %.1f us of kernels per fwd+bwd, %d launches" % (kind, C, mid, H, W, N, tot, sum(n for n, _ in agg.values()) / 5))
+print("%s block C=%d mid=%d %dx%d N=%d%s: %.1f us of kernels per fwd+bwd, %d launches" % (kind, C, mid, H, W, N, " offset-conv weights N(0, %g^2)" % sigma if sigma > 0 else "", tot, sum(n for n, _ in agg.values()) / 5))
 for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print("%5.1f calls %8.1f us/call  %s" % (n / 5, t / n, k))
