@@ -19,7 +19,8 @@ def main():
     ap.add_argument("--config", default="configs/lgd_retinanet_r50.yaml")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--all-subsets", action="store_true", help="all 16 subsets instead of none / each alone / all / all but one")
+    ap.add_argument("--all-subsets", action="store_true", help="all subsets instead of none / each alone / all / all but one")
+    ap.add_argument("--sets", default="", help="explicit subsets, e.g. 'none;teacher+head+adapter;teacher+head+adapter+filters'")
     a = ap.parse_args()
     from lgd_amd import config
     from lgd_amd.data import synthetic_batch
@@ -51,8 +52,10 @@ def main():
             tr.step(data[i % 2], it0 + i)
         torch.cuda.synchronize()
         return 1e3 * (time.time() - t0) / n
-    if a.all_subsets:
-        subsets = [c for r in range(5) for c in itertools.combinations(names, r)]
+    if a.sets:
+        subsets = [tuple(n for n in names if n in spec.split("+")) for spec in a.sets.split(";")]
+    elif a.all_subsets:
+        subsets = [c for r in range(len(names) + 1) for c in itertools.combinations(names, r)]
     else:
         subsets = [()] + [(n,) for n in names] + [tuple(m for m in names if m != n) for n in names] + [names]
     setting(names)
